@@ -1,0 +1,191 @@
+/*
+ * scrooge_amd.h — C ABI of the MI355X-native GenASM/Scrooge aligner.
+ *
+ * This is the drop-in boundary for Scrooge's GPU library surface
+ * (reference: src/genasm_gpu.hpp:5-10, implemented in src/genasm_gpu.cu:890-1065):
+ *
+ *   genasm_gpu::align_all(vector<string>& texts, vector<string>& queries, long long* ns)
+ *       -> scrg_align_pairs()
+ *   genasm_gpu::align_all(Genome_t&, vector<Read_t>&, long long* ns)
+ *       -> scrg_align_mapping()
+ *   __global__ genasm_gpu::ascii_to_twobit_strings(count, lens, ascii, twobit)
+ *       -> scrg_ascii_to_twobit()          (same byte layout, src/genasm_gpu.cu:631-685)
+ *   genasm_gpu::enabled_algorithm_log
+ *       -> scrg_set_log()
+ *
+ * include/scrooge_amd.hpp rebuilds the reference's C++ signatures on top of
+ * these entry points.  Everything here is plain pointers and sizes; the
+ * library owns no torch/STL types at the boundary.  Unlike the reference
+ * (exit()/assert on every error) every entry point returns a
+ * status code.
+ *
+ * Algorithm contract: results (edit distance and CIGAR) are bit-identical to
+ * the reference CPU path src/genasm_cpu.cpp:178-438 at the same W and O with
+ * K = W; CIGAR runs are flushed per window and never merged across windows
+ * (src/genasm_cpu.cpp:304-305, 400-403).
+ */
+#ifndef SCROOGE_AMD_H
+#define SCROOGE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t scrg_status;
+enum {
+    SCRG_OK = 0,
+    SCRG_ERR_INVALID_ARG = 1,   /* null pointer, W/O out of range, ...              */
+    SCRG_ERR_BAD_BASE = 2,      /* non-ACGT/acgt input (reference: assert, genasm_cpu.cpp:487-489) */
+    SCRG_ERR_NO_DEVICE = 3,     /* no usable gfx950 device / HIP runtime failure at init */
+    SCRG_ERR_HIP = 4,           /* a HIP call failed; see scrg_last_error()         */
+    SCRG_ERR_OOM = 5,           /* host or device allocation failed                 */
+    SCRG_ERR_CIGAR_OVERFLOW = 6 /* a pair produced more runs than its arena slice   */
+};
+
+/* Tunables.  Zero-initialise and call scrg_params_default(). */
+typedef struct scrg_params {
+    int32_t W;               /* window length, 2..64; reference default 64 (genasm_cpu.cpp:7)   */
+    int32_t O;               /* window overlap; reference default 33 (genasm_cpu.cpp:9);
+                                the kernel stores W-O+1 <= 32 traceback columns, so 1 <= W-O <= 31 */
+    int32_t lanes_per_pair;  /* 64 = one pair per wavefront (lane = text column);
+                                4/8/16/32 pack 64/lanes pairs into one wavefront.  0 = default   */
+    int32_t lds_rows;        /* rows of the R table kept in LDS per pair (rest spills to HBM);
+                                0 = default                                                        */
+    int32_t waves_per_cu;    /* persistent wavefronts launched per CU; 0 = default                */
+    int32_t sort_by_length;  /* host entry points: issue pairs longest-read-first (the reference's
+                                callers do this themselves, src/tests.cu:375-377); results keep
+                                input order either way.  Default 1                                 */
+    int32_t reserved[2];
+} scrg_params;
+
+void scrg_params_default(scrg_params *p);
+
+/* One CIGAR run, layout-compatible with the reference's CigarEntry_t
+ * (src/util.hpp:43-46). */
+typedef struct scrg_run {
+    uint8_t count;
+    char    op;     /* one of '=', 'X', 'I', 'D' */
+} scrg_run;
+
+/* Per-device handle: owns a HIP stream, the work counter and scratch.  One
+ * handle may be used by one thread at a time; separate handles are independent
+ * (the reference's GPU path is not re-entrant at all, genasm_gpu.cu:582). */
+typedef struct scrg_ctx scrg_ctx;
+
+scrg_status scrg_ctx_create(int device, scrg_ctx **out);
+void        scrg_ctx_destroy(scrg_ctx *ctx);
+/* Use a caller-owned hipStream_t (e.g. torch's current stream) instead of the
+ * handle's own; pass NULL to go back. */
+scrg_status scrg_ctx_set_stream(scrg_ctx *ctx, void *hip_stream);
+const char *scrg_last_error(const scrg_ctx *ctx);
+const char *scrg_status_string(scrg_status s);
+/* mirrors genasm_gpu::enabled_algorithm_log (src/genasm_gpu.hpp:6) */
+void        scrg_set_log(int enabled);
+int         scrg_device_count(void);
+
+/* ---------------------------------------------------------------------------
+ * Host-pointer entry points (the drop-in path).
+ * ------------------------------------------------------------------------- */
+
+/* Library-owned result of one batch; release with scrg_result_free(). */
+typedef struct scrg_result {
+    uint64_t  n_pairs;
+    int64_t  *edit_distance;  /* [n_pairs]                                              */
+    uint32_t *pair_status;    /* [n_pairs] SCRG_OK or SCRG_ERR_CIGAR_OVERFLOW            */
+    uint64_t *run_offset;     /* [n_pairs+1] into runs                                   */
+    scrg_run *runs;           /* all runs, pair after pair                               */
+    uint64_t *cigar_offset;   /* [n_pairs+1] into cigar_text (each CIGAR NUL-terminated) */
+    char     *cigar_text;     /* "%d%c" rendering, as genasm_cpu.cpp:387-403             */
+    int64_t   kernel_ns;      /* align kernel only (reference: core_algorithm_ns)        */
+    int64_t   pack_ns;        /* H2D + ASCII->2-bit                                      */
+    int64_t   total_ns;       /* whole call                                              */
+} scrg_result;
+
+void scrg_result_free(scrg_result *r);
+
+/* Unstructured pairwise alignment: queries[i] is consumed completely against a
+ * prefix of texts[i] (reference: genasm_gpu.cu:982-1065; returns all n results,
+ * unlike the CPU overload's double increment at genasm_cpu.cpp:600-605). */
+scrg_status scrg_align_pairs(scrg_ctx *ctx, const scrg_params *params, uint64_t n_pairs,
+                             const char *const *texts, const uint64_t *text_lens,
+                             const char *const *queries, const uint64_t *query_lens,
+                             scrg_result **out);
+
+/* Read-mapping alignment: read r is aligned against the genome suffix starting
+ * at cand_start[c] for every c in [cand_offsets[r], cand_offsets[r+1])
+ * (reference: genasm_gpu.cu:890-980 / genasm_cpu.cpp:495-555, :512-514 for the
+ * suffix semantics).  Genome and reads are packed and stored once.  Results are
+ * in read-major, candidate-minor order. */
+scrg_status scrg_align_mapping(scrg_ctx *ctx, const scrg_params *params,
+                               const char *genome, uint64_t genome_len,
+                               uint64_t n_reads, const char *const *reads, const uint64_t *read_lens,
+                               const uint64_t *cand_offsets, const uint64_t *cand_start,
+                               scrg_result **out);
+
+/* ---------------------------------------------------------------------------
+ * Device-pointer entry points (inputs/outputs already resident in HBM; this is
+ * what bench.py times).  All pointers below are device pointers valid on the
+ * handle's device; work is enqueued on the handle's stream and NOT synchronised.
+ * ------------------------------------------------------------------------- */
+
+/* Sequence storage used by the align kernel: "planar 2-bit" — one uint64_t per
+ * 32 bases; bit k of the low word is bit 0 of base k's code, bit k of the high
+ * word is bit 1 (A=0 C=1 G=2 T=3, genasm_cpu.cpp:87-90).  Sequence arrays need
+ * SCRG_SEQ_PAD_WORDS readable words past the last base. */
+#define SCRG_SEQ_PAD_WORDS 4
+
+/* ASCII -> planar.  d_ascii holds n_words*32 bytes; bytes equal to 0 are
+ * padding and encode as A.  *d_bad_count is incremented for every other
+ * non-ACGTacgt byte. */
+scrg_status scrg_pack_planar(scrg_ctx *ctx, const char *d_ascii, uint64_t n_words,
+                             uint64_t *d_planar, uint32_t *d_bad_count);
+
+/* One alignment problem.  Offsets are in bases from the start of d_seq. */
+typedef struct scrg_pair_desc {
+    uint64_t text_off;
+    uint64_t text_len;
+    uint64_t read_off;
+    uint64_t read_len;
+    uint64_t cigar_off;   /* first run of this pair's slice, in scrg_run units */
+    uint64_t cigar_cap;   /* slice capacity in runs */
+} scrg_pair_desc;
+
+/* Aligns n_pairs problems.  Outputs: d_edit_distance[n], d_n_runs[n],
+ * d_pair_status[n], runs in d_runs at each pair's slice. */
+scrg_status scrg_align_device(scrg_ctx *ctx, const scrg_params *params, uint64_t n_pairs,
+                              const uint64_t *d_seq, const scrg_pair_desc *d_pairs,
+                              scrg_run *d_runs, int64_t *d_edit_distance,
+                              uint32_t *d_n_runs, uint32_t *d_pair_status);
+
+/* Gathers every pair's runs from its slice into one dense array:
+ * d_dense[d_dense_offset[p] + k] = d_runs[d_pairs[p].cigar_off + k]. */
+scrg_status scrg_compact_runs(scrg_ctx *ctx, uint64_t n_pairs, const scrg_pair_desc *d_pairs,
+                              const scrg_run *d_runs, const uint32_t *d_n_runs,
+                              const uint64_t *d_dense_offset, scrg_run *d_dense);
+
+/* Reference-layout 2-bit packer, mirrors the exported kernel
+ * genasm_gpu::ascii_to_twobit_strings (src/genasm_gpu.cu:631-685): 4 bases per
+ * byte, first base in bits 7..6, last byte zero-padded.  Each string occupies
+ * ceil(len/4) bytes at d_twobit + d_twobit_off[s]. */
+scrg_status scrg_ascii_to_twobit(scrg_ctx *ctx, uint64_t count, const uint64_t *d_lens,
+                                 const uint64_t *d_ascii_off, const char *d_ascii,
+                                 const uint64_t *d_twobit_off, uint8_t *d_twobit,
+                                 uint32_t *d_bad_count);
+
+/* Launch geometry actually used for params on this device (for the bench's
+ * roofline line): persistent wavefronts, pairs per wavefront, LDS bytes. */
+scrg_status scrg_query_launch(scrg_ctx *ctx, const scrg_params *params,
+                              int32_t *n_waves, int32_t *pairs_per_wave, int32_t *lds_bytes,
+                              int32_t *n_cus);
+
+/* Times the most recent scrg_align_device launch with HIP events recorded on
+ * the launch stream (milliseconds); blocks until that launch finished. */
+scrg_status scrg_last_kernel_ms(scrg_ctx *ctx, float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCROOGE_AMD_H */

@@ -1,0 +1,130 @@
+"""ctypes loaders for the two CPU checkers (TEST INFRASTRUCTURE ONLY).
+
+* ``Oracle``    — oracle/liboracle.so, this repo's C restatement of
+  /root/reference/src/genasm_cpu.cpp:178-460 (travels to the GPU box).
+* ``Reference`` — oracle/_ref/libgenasm_ref.so, the unmodified reference CPU
+  path compiled by oracle/Makefile (prebuilt file travels; sources do not).
+"""
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class GoStats(C.Structure):
+    _fields_ = [("windows", C.c_uint64), ("dc_cells", C.c_uint64),
+                ("tb_steps", C.c_uint64), ("runs", C.c_uint64),
+                ("text_used", C.c_uint64)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+def build(force=False):
+    """Compile liboracle.so (and _ref when /root/reference is present)."""
+    so = os.path.join(HERE, "liboracle.so")
+    if force or not os.path.exists(so) or \
+            os.path.getmtime(so) < os.path.getmtime(os.path.join(HERE, "genasm_oracle.c")):
+        subprocess.check_call(["make", "-C", HERE, "--no-print-directory"],
+                              stdout=subprocess.DEVNULL)
+    return so
+
+
+def _as_bytes_list(seqs):
+    return [s.encode() if isinstance(s, str) else bytes(s) for s in seqs]
+
+
+def _marshal(texts, reads):
+    texts = _as_bytes_list(texts)
+    reads = _as_bytes_list(reads)
+    n = len(texts)
+    assert n == len(reads)
+    tp = (C.c_char_p * n)(*texts)
+    rp = (C.c_char_p * n)(*reads)
+    tl = (C.c_uint64 * n)(*[len(t) for t in texts])
+    rl = (C.c_uint64 * n)(*[len(r) for r in reads])
+    bufs = [C.create_string_buffer(4 * len(r) + 1) for r in reads]
+    cp = (C.c_char_p * n)(*[C.cast(b, C.c_char_p) for b in bufs])
+    eds = (C.c_longlong * n)()
+    return n, tp, tl, rp, rl, bufs, cp, eds
+
+
+class Oracle:
+    def __init__(self):
+        self.lib = C.CDLL(build())
+        self.lib.go_align_batch_ascii.restype = C.c_int
+        self.lib.go_align_batch_ascii.argtypes = [
+            C.c_size_t, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64),
+            C.POINTER(C.c_char_p), C.POINTER(C.c_uint64), C.c_int, C.c_int, C.c_int,
+            C.POINTER(C.c_char_p), C.POINTER(C.c_longlong), C.POINTER(GoStats),
+            C.POINTER(C.c_longlong)]
+
+    def align(self, texts, reads, W=64, O=33, threads=1):
+        """-> (edit_distances, cigars, stats dict, kernel_ns)"""
+        n, tp, tl, rp, rl, bufs, cp, eds = _marshal(texts, reads)
+        st = GoStats()
+        ns = C.c_longlong(0)
+        rc = self.lib.go_align_batch_ascii(n, tp, tl, rp, rl, W, O, threads, cp, eds,
+                                           C.byref(st), C.byref(ns))
+        if rc != 0:
+            raise ValueError("oracle status %d" % rc)
+        return [int(e) for e in eds], [b.value.decode() for b in bufs], st.as_dict(), ns.value
+
+
+class Reference:
+    """The real reference CPU path at its default knobs (W=64, K=64, O=33)."""
+    PATH = os.path.join(HERE, "_ref", "libgenasm_ref.so")
+
+    @classmethod
+    def available(cls):
+        return os.path.exists(cls.PATH)
+
+    def __init__(self):
+        self.lib = C.CDLL(self.PATH)
+        self.lib.ref_align_pairs.restype = C.c_int
+        self.lib.ref_align_pairs.argtypes = [
+            C.c_size_t, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64),
+            C.POINTER(C.c_char_p), C.POINTER(C.c_uint64), C.c_int,
+            C.POINTER(C.c_char_p), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
+        self.lib.ref_align_mapping.restype = C.c_int
+        self.lib.ref_align_mapping.argtypes = [
+            C.c_char_p, C.c_uint64, C.c_size_t, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64),
+            C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int,
+            C.POINTER(C.c_char_p), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
+
+    def align(self, texts, reads, threads=1):
+        """-> (edit_distances, cigars, kernel_ns)"""
+        n, tp, tl, rp, rl, bufs, cp, eds = _marshal(texts, reads)
+        ns = C.c_longlong(0)
+        rc = self.lib.ref_align_pairs(n, tp, tl, rp, rl, threads, cp, eds, C.byref(ns))
+        if rc != 0:
+            raise RuntimeError("reference driver status %d" % rc)
+        return [int(e) for e in eds], [b.value.decode() for b in bufs], ns.value
+
+    def align_mapping(self, genome, reads, candidates, threads=1):
+        """candidates: list (per read) of lists of start_in_reference."""
+        genome = genome.encode() if isinstance(genome, str) else bytes(genome)
+        reads = _as_bytes_list(reads)
+        nr = len(reads)
+        offs = [0]
+        starts = []
+        for c in candidates:
+            starts.extend(int(x) for x in c)
+            offs.append(len(starts))
+        npairs = len(starts)
+        rp = (C.c_char_p * nr)(*reads)
+        rl = (C.c_uint64 * nr)(*[len(r) for r in reads])
+        co = (C.c_uint64 * (nr + 1))(*offs)
+        cs = (C.c_uint64 * max(npairs, 1))(*starts)
+        bufs = []
+        for r, c in zip(reads, candidates):
+            bufs.extend(C.create_string_buffer(4 * len(r) + 1) for _ in c)
+        cp = (C.c_char_p * max(npairs, 1))(*[C.cast(b, C.c_char_p) for b in bufs])
+        eds = (C.c_longlong * max(npairs, 1))()
+        ns = C.c_longlong(0)
+        rc = self.lib.ref_align_mapping(genome, len(genome), nr, rp, rl, co, cs, threads,
+                                        cp, eds, C.byref(ns))
+        if rc != 0:
+            raise RuntimeError("reference driver status %d" % rc)
+        return [int(e) for e in eds[:npairs]], [b.value.decode() for b in bufs], ns.value

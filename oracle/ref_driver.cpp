@@ -1,0 +1,96 @@
+/*
+ * ref_driver.cpp — TEST INFRASTRUCTURE ONLY.
+ *
+ * Thin extern "C" wrapper around the UNMODIFIED reference CPU path
+ * (/root/reference/src/genasm_cpu.cpp), compiled where it lies by
+ * oracle/Makefile into oracle/_ref/libgenasm_ref.so.  No reference source is
+ * copied into this repository; this file only calls the reference's public
+ * entry points (src/genasm_cpu.hpp:6-7) through its own headers.
+ *
+ * The reference's unstructured overload drops every odd-indexed result
+ * (src/genasm_cpu.cpp:600-605 increments pair_idx twice per iteration), so
+ * this wrapper interleaves an empty dummy pair after every real pair: real
+ * pairs land on even indices and all of them come back.  The timed kernel
+ * region (:589-591) still covers exactly the real work (an empty read costs
+ * zero windows).
+ */
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "genasm_cpu.hpp"
+
+extern "C" {
+
+int ref_align_pairs(size_t n_pairs,
+                    const char *const *texts, const uint64_t *text_lens,
+                    const char *const *reads, const uint64_t *read_lens,
+                    int threads,
+                    char *const *cigars, long long *edit_distances,
+                    long long *kernel_ns)
+{
+    genasm_cpu::enabled_algorithm_log = false;
+    std::vector<std::string> t, q;
+    t.reserve(2 * n_pairs);
+    q.reserve(2 * n_pairs);
+    for (size_t p = 0; p < n_pairs; p++) {
+        t.emplace_back(texts[p], text_lens[p]);
+        q.emplace_back(reads[p], read_lens[p]);
+        t.emplace_back();
+        q.emplace_back();
+    }
+    long long ns = 0;
+    std::vector<Alignment_t> res = genasm_cpu::align_all(t, q, threads, &ns);
+    if (res.size() != n_pairs)
+        return 1;
+    for (size_t p = 0; p < n_pairs; p++) {
+        std::memcpy(cigars[p], res[p].cigar.c_str(), res[p].cigar.size() + 1);
+        edit_distances[p] = res[p].edit_distance;
+    }
+    if (kernel_ns)
+        *kernel_ns = ns;
+    return 0;
+}
+
+/* Read-mapping overload (src/genasm_cpu.cpp:495-555): candidate k of read r
+ * aligns the read against the genome suffix starting at cand_starts[...]. */
+int ref_align_mapping(const char *genome, uint64_t genome_len,
+                      size_t n_reads,
+                      const char *const *reads, const uint64_t *read_lens,
+                      const uint64_t *cand_offsets, /* n_reads+1 */
+                      const uint64_t *cand_starts,
+                      int threads,
+                      char *const *cigars, long long *edit_distances,
+                      long long *kernel_ns)
+{
+    genasm_cpu::enabled_algorithm_log = false;
+    Genome_t g;
+    g.content.assign(genome, genome_len);
+    std::vector<Read_t> rs(n_reads);
+    for (size_t r = 0; r < n_reads; r++) {
+        rs[r].content.assign(reads[r], read_lens[r]);
+        for (uint64_t c = cand_offsets[r]; c < cand_offsets[r + 1]; c++) {
+            CandidateLocation_t loc;
+            loc.start_in_reference = (long long)cand_starts[c];
+            loc.start_in_chromosome = (long long)cand_starts[c];
+            loc.start_of_aligned_region = 0;
+            loc.size_of_aligned_region = 0;
+            loc.strand = true;
+            rs[r].locations.push_back(loc);
+        }
+    }
+    long long ns = 0;
+    std::vector<Alignment_t> res = genasm_cpu::align_all(g, rs, threads, &ns);
+    if (res.size() != cand_offsets[n_reads])
+        return 1;
+    for (size_t p = 0; p < res.size(); p++) {
+        std::memcpy(cigars[p], res[p].cigar.c_str(), res[p].cigar.size() + 1);
+        edit_distances[p] = res[p].edit_distance;
+    }
+    if (kernel_ns)
+        *kernel_ns = ns;
+    return 0;
+}
+
+}

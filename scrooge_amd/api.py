@@ -1,0 +1,272 @@
+"""ctypes binding of include/scrooge_amd.h."""
+import ctypes as C
+import os
+import subprocess
+from collections import namedtuple
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+# same two fields as the reference's Alignment_t (src/util.hpp:38-41)
+Alignment = namedtuple("Alignment", ["cigar", "edit_distance"])
+
+SCRG_OK = 0
+SCRG_ERR_INVALID_ARG = 1
+SCRG_ERR_BAD_BASE = 2
+SCRG_ERR_NO_DEVICE = 3
+SCRG_ERR_HIP = 4
+SCRG_ERR_OOM = 5
+SCRG_ERR_CIGAR_OVERFLOW = 6
+SEQ_PAD_WORDS = 4
+
+
+class ScroogeError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("scrooge_amd status %d: %s" % (status, message))
+        self.status = status
+
+
+class Params(C.Structure):
+    _fields_ = [("W", C.c_int32), ("O", C.c_int32), ("lanes_per_pair", C.c_int32),
+                ("lds_rows", C.c_int32), ("waves_per_cu", C.c_int32),
+                ("sort_by_length", C.c_int32), ("reserved", C.c_int32 * 2)]
+
+
+class PairDesc(C.Structure):
+    _fields_ = [("text_off", C.c_uint64), ("text_len", C.c_uint64), ("read_off", C.c_uint64),
+                ("read_len", C.c_uint64), ("cigar_off", C.c_uint64), ("cigar_cap", C.c_uint64)]
+
+
+class Run(C.Structure):
+    _fields_ = [("count", C.c_uint8), ("op", C.c_char)]
+
+
+class Result(C.Structure):
+    _fields_ = [("n_pairs", C.c_uint64),
+                ("edit_distance", C.POINTER(C.c_int64)),
+                ("pair_status", C.POINTER(C.c_uint32)),
+                ("run_offset", C.POINTER(C.c_uint64)),
+                ("runs", C.POINTER(Run)),
+                ("cigar_offset", C.POINTER(C.c_uint64)),
+                ("cigar_text", C.POINTER(C.c_char)),
+                ("kernel_ns", C.c_int64), ("pack_ns", C.c_int64), ("total_ns", C.c_int64)]
+
+
+def library_path():
+    return os.path.join(HERE, "libscrooge_amd.so")
+
+
+def build_library(force=False):
+    """Compile the HIP kernels + host code for gfx950 (hipcc cross-compiles without a GPU)."""
+    so = library_path()
+    src_dir = os.path.join(HERE, "csrc")
+    srcs = [os.path.join(src_dir, f) for f in os.listdir(src_dir)] + \
+        [os.path.join(HERE, "..", "include", "scrooge_amd.h")]
+    stale = (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", src_dir, "--no-print-directory"] + (["-B"] if force else []))
+    return so
+
+
+def load_library():
+    """Load libscrooge_amd.so; raises (never falls back) when it is missing."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    so = library_path()
+    if not os.path.exists(so):
+        raise ScroogeError(SCRG_ERR_NO_DEVICE,
+                           "%s not built; run scrooge_amd.build_library() (needs hipcc)" % so)
+    lib = C.CDLL(so)
+    vp, u64, i32p = C.c_void_p, C.c_uint64, C.POINTER(C.c_int32)
+    sigs = {
+        "scrg_params_default": (None, [C.POINTER(Params)]),
+        "scrg_ctx_create": (C.c_int32, [C.c_int, C.POINTER(vp)]),
+        "scrg_ctx_destroy": (None, [vp]),
+        "scrg_ctx_set_stream": (C.c_int32, [vp, vp]),
+        "scrg_last_error": (C.c_char_p, [vp]),
+        "scrg_status_string": (C.c_char_p, [C.c_int32]),
+        "scrg_set_log": (None, [C.c_int]),
+        "scrg_device_count": (C.c_int, []),
+        "scrg_result_free": (None, [C.POINTER(Result)]),
+        "scrg_align_pairs": (C.c_int32, [vp, C.POINTER(Params), u64, C.POINTER(C.c_char_p),
+                                         C.POINTER(u64), C.POINTER(C.c_char_p), C.POINTER(u64),
+                                         C.POINTER(C.POINTER(Result))]),
+        "scrg_align_mapping": (C.c_int32, [vp, C.POINTER(Params), C.c_char_p, u64, u64,
+                                           C.POINTER(C.c_char_p), C.POINTER(u64), C.POINTER(u64),
+                                           C.POINTER(u64), C.POINTER(C.POINTER(Result))]),
+        "scrg_pack_planar": (C.c_int32, [vp, vp, u64, vp, vp]),
+        "scrg_align_device": (C.c_int32, [vp, C.POINTER(Params), u64, vp, vp, vp, vp, vp, vp]),
+        "scrg_compact_runs": (C.c_int32, [vp, u64, vp, vp, vp, vp, vp]),
+        "scrg_ascii_to_twobit": (C.c_int32, [vp, u64, vp, vp, vp, vp, vp, vp]),
+        "scrg_query_launch": (C.c_int32, [vp, C.POINTER(Params), i32p, i32p, i32p, i32p]),
+        "scrg_last_kernel_ms": (C.c_int32, [vp, C.POINTER(C.c_float)]),
+    }
+    for name, (res, args) in sigs.items():
+        fn = getattr(lib, name)   # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = [
+    "scrg_params_default", "scrg_ctx_create", "scrg_ctx_destroy", "scrg_ctx_set_stream",
+    "scrg_last_error", "scrg_status_string", "scrg_set_log", "scrg_device_count",
+    "scrg_result_free", "scrg_align_pairs", "scrg_align_mapping", "scrg_pack_planar",
+    "scrg_align_device", "scrg_compact_runs", "scrg_ascii_to_twobit", "scrg_query_launch",
+    "scrg_last_kernel_ms"]
+
+
+def _bytes_list(seqs):
+    return [s.encode() if isinstance(s, str) else bytes(s) for s in seqs]
+
+
+def _ptr(t):
+    """device pointer of a torch tensor (or None)"""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class Aligner:
+    """One handle per GPU (scrg_ctx).
+
+    ``align_pairs`` / ``align_mapping`` mirror the two overloads of
+    genasm_gpu::align_all (src/genasm_gpu.hpp:7-8) and return a list of
+    ``Alignment(cigar, edit_distance)`` in the reference's result order.
+    """
+
+    def __init__(self, device=0, **params):
+        self.lib = load_library()
+        h = C.c_void_p()
+        st = self.lib.scrg_ctx_create(int(device), C.byref(h))
+        if st != SCRG_OK:
+            raise ScroogeError(st, self.lib.scrg_status_string(st).decode())
+        self.h = h
+        self.device = int(device)
+        self.params = self.make_params(**params)
+        self.last_timing = {}
+
+    def make_params(self, **kw):
+        p = Params()
+        self.lib.scrg_params_default(C.byref(p))
+        for k, v in kw.items():
+            if not hasattr(p, k):
+                raise TypeError("unknown parameter %r" % k)
+            setattr(p, k, int(v))
+        return p
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.scrg_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st, allow=()):
+        if st != SCRG_OK and st not in allow:
+            raise ScroogeError(st, (self.lib.scrg_last_error(self.h) or b"").decode() or
+                               self.lib.scrg_status_string(st).decode())
+
+    def _params(self, kw):
+        if not kw:
+            return self.params
+        p = Params()
+        C.memmove(C.byref(p), C.byref(self.params), C.sizeof(Params))
+        for k, v in kw.items():
+            if not hasattr(p, k):
+                raise TypeError("unknown parameter %r" % k)
+            setattr(p, k, int(v))
+        return p
+
+    def _collect(self, res_p, st):
+        try:
+            r = res_p.contents
+            n = int(r.n_pairs)
+            text = C.string_at(r.cigar_text, int(r.cigar_offset[n])) if n else b""
+            out = []
+            for i in range(n):
+                a, b = int(r.cigar_offset[i]), int(r.cigar_offset[i + 1])
+                out.append(Alignment(text[a:b - 1].decode(), int(r.edit_distance[i])))
+            self.last_timing = {"kernel_ns": int(r.kernel_ns), "pack_ns": int(r.pack_ns),
+                                "total_ns": int(r.total_ns)}
+            self.last_status = [int(r.pair_status[i]) for i in range(n)]
+        finally:
+            self.lib.scrg_result_free(res_p)
+        return out
+
+    # -- genasm_gpu::align_all(texts, queries)  (src/genasm_gpu.cu:982-1065) --------
+    def align_pairs(self, texts, queries, **kw):
+        texts, queries = _bytes_list(texts), _bytes_list(queries)
+        if len(texts) != len(queries):
+            raise ValueError("texts and queries differ in length")   # reference: assert, genasm_cpu.cpp:559
+        n = len(texts)
+        tp = (C.c_char_p * max(n, 1))(*texts)
+        qp = (C.c_char_p * max(n, 1))(*queries)
+        tl = (C.c_uint64 * max(n, 1))(*[len(t) for t in texts])
+        ql = (C.c_uint64 * max(n, 1))(*[len(q) for q in queries])
+        res = C.POINTER(Result)()
+        st = self.lib.scrg_align_pairs(self.h, C.byref(self._params(kw)), n, tp, tl, qp, ql,
+                                       C.byref(res))
+        self._check(st, allow=(SCRG_ERR_CIGAR_OVERFLOW,))
+        return self._collect(res, st)
+
+    # -- genasm_gpu::align_all(genome, reads)  (src/genasm_gpu.cu:890-980) ----------
+    def align_mapping(self, genome, reads, candidates, **kw):
+        """candidates[r] = list of start_in_reference for read r (forward strand)."""
+        genome = genome.encode() if isinstance(genome, str) else bytes(genome)
+        reads = _bytes_list(reads)
+        nr = len(reads)
+        if len(candidates) != nr:
+            raise ValueError("one candidate list per read expected")
+        offs, starts = [0], []
+        for c in candidates:
+            starts.extend(int(x) for x in c)
+            offs.append(len(starts))
+        rp = (C.c_char_p * max(nr, 1))(*reads)
+        rl = (C.c_uint64 * max(nr, 1))(*[len(r) for r in reads])
+        co = (C.c_uint64 * (nr + 1))(*offs)
+        cs = (C.c_uint64 * max(len(starts), 1))(*starts)
+        res = C.POINTER(Result)()
+        st = self.lib.scrg_align_mapping(self.h, C.byref(self._params(kw)), genome, len(genome),
+                                         nr, rp, rl, co, cs, C.byref(res))
+        self._check(st, allow=(SCRG_ERR_CIGAR_OVERFLOW,))
+        return self._collect(res, st)
+
+    # -- device-pointer layer (torch tensors as plain device memory) -----------
+    def set_stream(self, stream_handle):
+        self._check(self.lib.scrg_ctx_set_stream(self.h, C.c_void_p(stream_handle)))
+
+    def pack_planar(self, ascii_u8, planar_u64, bad_u32):
+        n_words = ascii_u8.numel() // 32
+        self._check(self.lib.scrg_pack_planar(self.h, _ptr(ascii_u8), n_words, _ptr(planar_u64),
+                                              _ptr(bad_u32)))
+
+    def align_device(self, n_pairs, seq, pairs, runs, ed, n_runs, status, **kw):
+        self._check(self.lib.scrg_align_device(self.h, C.byref(self._params(kw)), int(n_pairs),
+                                               _ptr(seq), _ptr(pairs), _ptr(runs), _ptr(ed),
+                                               _ptr(n_runs), _ptr(status)))
+
+    def compact_runs(self, n_pairs, pairs, runs, n_runs, dense_off, dense):
+        self._check(self.lib.scrg_compact_runs(self.h, int(n_pairs), _ptr(pairs), _ptr(runs),
+                                               _ptr(n_runs), _ptr(dense_off), _ptr(dense)))
+
+    def ascii_to_twobit(self, count, lens, ascii_off, ascii, twobit_off, twobit, bad):
+        self._check(self.lib.scrg_ascii_to_twobit(self.h, int(count), _ptr(lens), _ptr(ascii_off),
+                                                  _ptr(ascii), _ptr(twobit_off), _ptr(twobit),
+                                                  _ptr(bad)))
+
+    def last_kernel_ms(self):
+        ms = C.c_float(0)
+        self._check(self.lib.scrg_last_kernel_ms(self.h, C.byref(ms)))
+        return float(ms.value)
+
+    def query_launch(self, **kw):
+        a, b, c, d = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        self._check(self.lib.scrg_query_launch(self.h, C.byref(self._params(kw)), C.byref(a),
+                                               C.byref(b), C.byref(c), C.byref(d)))
+        return {"n_waves": a.value, "pairs_per_wave": b.value, "lds_bytes": c.value,
+                "n_cus": d.value}

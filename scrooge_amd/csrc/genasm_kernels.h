@@ -1,0 +1,41 @@
+// genasm_kernels.h — launch interface between the C-ABI host code
+// (scrg_api.cpp) and the gfx950 kernels (genasm_kernels.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/scrooge_amd.h"
+
+namespace scrg {
+
+// rows of the HBM spill area per pair slot: K+1 = 65 rows of R can exist, plus
+// the rows lanes ahead of the slot leader run past the final row
+constexpr int SPILL_ROWS = 72;
+
+struct AlignArgs {
+    const uint64_t* seq;          // planar 2-bit words
+    const scrg_pair_desc* pairs;
+    uint16_t* runs;               // scrg_run as count | op << 8
+    int64_t* ed;
+    uint32_t* n_runs;
+    uint32_t* status;
+    uint32_t* counter;            // work queue head, zeroed before launch
+    uint32_t* spill;              // grid * slots * SPILL_ROWS * 32 words
+    uint32_t n_pairs;
+    int32_t W;
+    int32_t tb_limit;             // W - O
+    int32_t lds_rows;
+};
+
+hipError_t launch_align(int lanes_per_pair, const AlignArgs& a, int grid, size_t lds_bytes, hipStream_t s);
+hipError_t launch_pack_planar(const char* d_ascii, uint64_t n_words, uint64_t* d_planar, uint32_t* d_bad,
+                              int n_cus, hipStream_t s);
+hipError_t launch_ascii_to_twobit(uint64_t count, const uint64_t* d_lens, const uint64_t* d_ascii_off,
+                                  const char* d_ascii, const uint64_t* d_twobit_off, uint8_t* d_twobit,
+                                  uint32_t* d_bad, uint64_t max_len, hipStream_t s);
+hipError_t launch_compact_runs(uint64_t n_pairs, const scrg_pair_desc* d_pairs, const uint16_t* d_runs,
+                               const uint32_t* d_n_runs, const uint64_t* d_dense_off, uint16_t* d_dense,
+                               int n_cus, hipStream_t s);
+
+}  // namespace scrg

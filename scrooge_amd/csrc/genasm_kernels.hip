@@ -1,0 +1,486 @@
+// genasm_kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels for the
+// GenASM/Scrooge hot path.  No MFMA: this is 64-bit logic/shift work on the
+// VALU with the traceback table in LDS.
+//
+// What is computed (reference semantics, src/genasm_cpu.cpp):
+//   window loop            :411-438
+//   GenASM-DC (distance)   :210-288   R[i][d] = mat & sub & ins & del
+//   GenASM-TB (traceback)  :290-409   priority I > D > X > =, per-window run flush
+//   pattern masks          :178-198
+// and Scrooge's three optimisations:
+//   SENE  only the centre entry R[i][d] is stored (:63-78)
+//   DENT  only W-O+1 columns and the top min(W-O+1, m) bits are stored (:200-208, :258-267)
+//   ET    the sweep stops at the first row that reaches the goal bit (:278-283)
+//
+// Mapping onto a wavefront: a wave holds 64/G independent pairs
+// ("slots"), G lanes each.  Lane t of a slot owns text columns
+// [t*CPL, (t+1)*CPL), CPL = 64/G, keeps row d-1 of those columns and their
+// match masks in VGPRs, and sweeps rows skewed by one step per lane (lane t is
+// at row step-(G-1-t)): the only cross-lane traffic is one 64-bit DPP shift per
+// row.  G = 64 is the "one pair per wavefront, one lane per bitvector word"
+// mapping; G = 8 packs 8 pairs per wave and is the default.  Rows of R
+// needed by the traceback go to LDS (rows >= lds_rows spill to an HBM scratch).
+// The traceback itself is lane-parallel: lane l of a slot tests the cell l steps
+// down the current diagonal, a ballot finds the first non-match.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "genasm_kernels.h"
+
+namespace scrg {
+
+// ----------------------------------------------------------------------------
+// small device helpers
+// ----------------------------------------------------------------------------
+
+// lane i <- lane i+1 across the whole wave (DPP wave_shl:1, full rate, no LDS)
+__device__ __forceinline__ uint32_t dpp_from_next(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+}
+__device__ __forceinline__ uint64_t dpp_from_next64(uint64_t v)
+{
+    uint32_t lo = dpp_from_next((uint32_t)v);
+    uint32_t hi = dpp_from_next((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+__device__ __forceinline__ uint64_t ones_shl(int d)
+{
+    // bitvector::ones() << d with the reference's ">= width gives zero" rule
+    // (src/bitvector.hpp:116-122)
+    return d >= 64 ? 0ull : (~0ull << d);
+}
+
+// 64 bases starting at base offset p of a planar array: returns the low-bit
+// plane in .x and the high-bit plane in .y (bit k <-> base p+k)
+struct Planes { uint64_t lo, hi; };
+__device__ __forceinline__ Planes load_window(const uint64_t* __restrict__ seq, uint64_t p)
+{
+    const uint64_t w = p >> 5;
+    const uint32_t s = (uint32_t)p & 31u;
+    const uint64_t a = seq[w], b = seq[w + 1], c = seq[w + 2];
+    const uint32_t l0 = (uint32_t)a, l1 = (uint32_t)b, l2 = (uint32_t)c;
+    const uint32_t h0 = (uint32_t)(a >> 32), h1 = (uint32_t)(b >> 32), h2 = (uint32_t)(c >> 32);
+    Planes r;
+    r.lo = (uint64_t)__builtin_amdgcn_alignbit(l1, l0, s) | ((uint64_t)__builtin_amdgcn_alignbit(l2, l1, s) << 32);
+    r.hi = (uint64_t)__builtin_amdgcn_alignbit(h1, h0, s) | ((uint64_t)__builtin_amdgcn_alignbit(h2, h1, s) << 32);
+    return r;
+}
+
+__device__ __forceinline__ uint64_t brev64(uint64_t v)
+{
+    return ((uint64_t)__builtin_bitreverse32((uint32_t)v) << 32) | __builtin_bitreverse32((uint32_t)(v >> 32));
+}
+
+// ----------------------------------------------------------------------------
+// the aligner
+// ----------------------------------------------------------------------------
+
+template <int G>
+__global__ __launch_bounds__(64) void genasm_align_kernel(AlignArgs a)
+{
+    constexpr int CPL = 64 / G;          // text columns per lane
+    constexpr int SLOTS = 64 / G;        // pairs per wavefront
+    constexpr uint32_t GMASK = (G == 32) ? 0xffffffffu : ((G == 64) ? 0xffffffffu : ((1u << (G & 31)) - 1u));
+
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+
+    const int lane = threadIdx.x;
+    const int t = lane % G;              // lane within slot
+    const int gbase = lane - t;          // first lane of my slot
+    const int slot = lane / G;
+    const bool leader = (t == 0);
+
+    const int W = a.W;
+    const int TBL = a.tb_limit;          // W - O
+    const int RB = a.lds_rows;
+    const uint32_t slot_stride = (uint32_t)RB * 32u + 1u;          // +1 word: conflict-free slot banks
+    uint32_t* const Rl = lds + slot * slot_stride;                  // R[d][i] at Rl[d*32+i], d < RB
+    uint32_t* const Rs = a.spill + ((size_t)blockIdx.x * SLOTS + slot) * (size_t)(SPILL_ROWS * 32);
+
+    // mask with bit (first lane of slot s) set for every slot
+    uint64_t leaders = 0;
+#pragma unroll
+    for (int s = 0; s < SLOTS; s++) leaders |= 1ull << (s * G);
+
+    // ---- per-slot state (replicated in the slot's G lanes) ----
+    bool has_pair = false;
+    uint32_t pair = 0;
+    uint64_t text_off = 0, read_off = 0, cigar_off = 0;
+    uint32_t text_len = 0, read_len = 0, cigar_cap = 0;
+    uint32_t ref_idx = 0, read_idx = 0, n_runs = 0, edits = 0;
+    bool overflow = false;
+    bool queue_empty = false;            // wave-uniform
+
+    for (;;) {
+        // ---------------- retire finished pairs, fetch new ones ----------------
+        for (;;) {
+            const bool fin = has_pair && read_idx >= read_len;
+            if (fin && leader) {
+                a.ed[pair] = (int64_t)edits;
+                a.n_runs[pair] = n_runs;
+                a.status[pair] = overflow ? 1u : 0u;
+            }
+            has_pair = has_pair && !fin;
+            const bool want = !has_pair && !queue_empty;
+            if (!__any(want)) break;
+
+            uint32_t idx = 0xffffffffu;
+            if (want && leader) idx = atomicAdd(a.counter, 1u);
+            idx = (uint32_t)__shfl((int)idx, gbase);
+            const bool got = want && idx < a.n_pairs;
+            if (__any(want && idx >= a.n_pairs)) queue_empty = true;
+            if (got) {
+                const scrg_pair_desc pd = a.pairs[idx];
+                pair = idx;
+                text_off = pd.text_off;
+                read_off = pd.read_off;
+                text_len = pd.text_len > 0xffffffffull ? 0xffffffffu : (uint32_t)pd.text_len;
+                read_len = (uint32_t)pd.read_len;
+                cigar_off = pd.cigar_off;
+                cigar_cap = pd.cigar_cap > 0xffffffffull ? 0xffffffffu : (uint32_t)pd.cigar_cap;
+                ref_idx = read_idx = n_runs = edits = 0;
+                overflow = false;
+                has_pair = true;
+            }
+        }
+        if (!__any(has_pair)) break;
+
+        // ---------------- window setup (genasm_cpu.cpp:417-420) ----------------
+        const uint32_t n = (has_pair && ref_idx < text_len) ? min((uint32_t)W, text_len - ref_idx) : 0u;
+        const uint32_t m = has_pair ? min((uint32_t)W, read_len - read_idx) : 1u;   // >= 1 for live pairs
+
+        uint64_t M[CPL];      // match mask of my columns: bit b == 0 <=> pattern[m-1-b] == text[col]
+        {
+            Planes tw = {0, 0}, pw = {0, 0};
+            if (has_pair) {
+                tw = load_window(a.seq, text_off + ref_idx);
+                pw = load_window(a.seq, read_off + read_idx);
+            }
+            // pattern, reversed so that bit b <-> pattern[m-1-b] (genasm_cpu.cpp:185-189)
+            const uint32_t rs = 64u - m;
+            const uint64_t plo = brev64(pw.lo) >> rs;
+            const uint64_t phi = brev64(pw.hi) >> rs;
+            const uint64_t inval = (m >= 64u) ? 0ull : (~0ull << m);   // bits >= m stay 1 (:180-183)
+            const uint32_t tlo = (uint32_t)(tw.lo >> (t * CPL));
+            const uint32_t thi = (uint32_t)(tw.hi >> (t * CPL));
+#pragma unroll
+            for (int k = 0; k < CPL; k++) {
+                const uint64_t sl = (uint64_t)(int64_t)(-(int32_t)((tlo >> k) & 1u));
+                const uint64_t sh = (uint64_t)(int64_t)(-(int32_t)((thi >> k) & 1u));
+                const uint64_t mk = (plo ^ sl) | (phi ^ sh) | inval;
+                // columns at or past n behave as the all-insertions boundary column
+                // (genasm_cpu.cpp:239-245): with an all-ones mask the recurrence
+                // reproduces ones<<d there by itself
+                M[k] = ((uint32_t)(t * CPL + k) < n) ? mk : ~0ull;
+            }
+        }
+
+        // ---------------- GenASM-DC, skewed row sweep (genasm_cpu.cpp:210-288) ----------------
+        uint64_t prev[CPL];   // row d-1 of my columns
+#pragma unroll
+        for (int k = 0; k < CPL; k++) prev[k] = ~0ull;
+        uint64_t rn_prev = ~0ull;                 // R[my last column + 1][d-1]
+        int d = -(G - 1 - t);                      // my row at step 0
+        uint32_t dw = 0;                           // window edit distance once found
+        bool gdone = !has_pair;                    // slot finished its sweep
+        uint64_t done_mask = __ballot(!has_pair);  // wave-uniform copy of gdone per slot
+        const uint32_t goal_bit = m - 1u;
+        const uint32_t tb_shift = m > 32u ? m - 32u : 0u;   // DENT: keep the top min(m,32) bits
+        const uint32_t col0 = (uint32_t)(t * CPL);
+
+        for (int step = 0;; step++) {
+            // right neighbour's first column at my row: it finished that row one step ago
+            uint64_t rn_cur = dpp_from_next64(prev[0]);
+            if (t == G - 1) rn_cur = ones_shl(d);  // virtual column 64 (always >= n)
+            const uint64_t d0mask = (d == 0) ? ~0ull : 0ull;
+
+            uint64_t right = rn_cur, tr = rn_prev;
+            const bool st_ok = (d >= 0) && !gdone && (col0 < 32u);
+            const int dr = d < 0 ? 0 : (d < SPILL_ROWS ? d : SPILL_ROWS - 1);
+            uint32_t* const rowp = (dr < RB) ? (Rl + dr * 32 + col0) : (Rs + (size_t)dr * 32 + col0);
+#pragma unroll
+            for (int k = CPL - 1; k >= 0; k--) {
+                const uint64_t top = prev[k];
+                const uint64_t mat = (right << 1) | M[k];
+                // sub & ins & del = ((tr & top) << 1) & tr ; row 0 has no predecessors
+                const uint64_t x = (((tr & top) << 1) & tr) | d0mask;
+                const uint64_t c = mat & x;
+                tr = top;
+                right = c;
+                prev[k] = c;
+                if (st_ok) rowp[k] = (uint32_t)(c >> tb_shift);
+            }
+            rn_prev = rn_cur;
+
+            // early termination: column 0 reaches bit m-1 (genasm_cpu.cpp:278-283)
+            const bool hit = leader && (d >= 0) && !gdone && (((prev[0] >> goal_bit) & 1ull) == 0ull);
+            const uint64_t hits = __ballot(hit);
+            if (!gdone && ((hits >> gbase) & 1ull)) {
+                gdone = true;
+                dw = (uint32_t)(step - (G - 1));
+            }
+            done_mask |= hits;
+            d++;
+            if ((done_mask & leaders) == leaders) break;
+        }
+
+        // ---------------- GenASM-TB, lane-parallel diagonal scan (genasm_cpu.cpp:290-409) ----------------
+        {
+            uint32_t i = 0, j = 0, dd = dw;
+            uint32_t cur_op = 0, cur_cnt = 0;
+            bool act = has_pair;
+            const uint32_t mtb = m < 32u ? m : 32u;       // stored bits per entry
+
+            auto push_run = [&](uint32_t op, uint32_t cnt) {
+                if (n_runs < cigar_cap) {
+                    if (leader) a.runs[cigar_off + n_runs] = (uint16_t)(cnt | (op << 8));
+                } else {
+                    overflow = true;
+                }
+                n_runs++;
+            };
+            auto emit = [&](uint32_t op, uint32_t cnt) {
+                if (op == cur_op) {
+                    cur_cnt += cnt;
+                } else {
+                    if (cur_cnt) push_run(cur_op, cur_cnt);
+                    cur_op = op;
+                    cur_cnt = cnt;
+                }
+            };
+
+            while (__any(act)) {
+                const uint32_t il = i + t, jl = j + t;
+                const bool pos_ok = (jl < m) && (il < (uint32_t)TBL) && (jl < (uint32_t)TBL);
+                uint32_t ev = 0;          // 0 '=', 1 'I', 2 'D', 3 'X', 4 stop
+                if (act) {
+                    if (!pos_ok) {
+                        ev = 4;
+                    } else if (dd > 0) {
+                        const bool text_left = il < n;
+                        bool ins, del, sub;
+                        if (jl + 1 < m) {
+                            const uint32_t r = dd - 1;
+                            const uint32_t* rp = (r < (uint32_t)RB) ? (Rl + r * 32 + il) : (Rs + (size_t)r * 32 + il);
+                            const uint32_t w0 = rp[0], w1 = rp[1];
+                            const uint32_t bj = mtb - 1 - jl;      // TB_BIT(j), genasm_cpu.cpp:57
+                            ins = ((w0 >> (bj - 1)) & 1u) == 0u;
+                            del = text_left && (((w1 >> bj) & 1u) == 0u);
+                            sub = text_left && (((w1 >> (bj - 1)) & 1u) == 0u);
+                        } else {                                   // last pattern character (:336-343)
+                            ins = true;
+                            del = false;
+                            sub = text_left;
+                        }
+                        ev = ins ? 1u : (del ? 2u : (sub ? 3u : 0u));
+                    }
+                }
+                const uint64_t nm = __ballot(ev != 0);
+                const uint32_t gm = (uint32_t)(nm >> gbase) & GMASK;
+                uint32_t first;
+                if (G == 64) {
+                    first = nm ? (uint32_t)__builtin_ctzll(nm) : (uint32_t)G;
+                } else {
+                    first = gm ? (uint32_t)__builtin_ctz(gm) : (uint32_t)G;
+                }
+                uint32_t evf = (uint32_t)__shfl((int)ev, gbase + (int)(first < (uint32_t)G ? first : 0u));
+                if (first == (uint32_t)G) evf = 0;
+                if (act) {
+                    if (first) emit('=', first);
+                    i += first;
+                    j += first;
+                    if (evf == 1) { emit('I', 1); j++; dd--; }
+                    else if (evf == 2) { emit('D', 1); i++; dd--; }
+                    else if (evf == 3) { emit('X', 1); i++; j++; dd--; }
+                    else if (evf == 4) { act = false; }
+                }
+            }
+            if (has_pair) {
+                if (cur_cnt) push_run(cur_op, cur_cnt);      // per-window flush (:400-403)
+                edits += dw - dd;
+                ref_idx += i;
+                read_idx += j;
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------
+// ASCII -> planar 2-bit.  One thread per 32 bases: two 16-byte loads, one
+// 8-byte store; a wave reads 2 KiB contiguous and writes 512 B contiguous.
+// ----------------------------------------------------------------------------
+__device__ __forceinline__ void pack4(uint32_t v, uint32_t& lo, uint32_t& hi, uint32_t& bad)
+{
+    // per byte: x = (c>>1)&3 gives A0 C1 T2 G3; code = x ^ (x>>1) gives A0 C1 G2 T3
+    const uint32_t b1 = (v >> 1) & 0x01010101u;
+    const uint32_t b2 = (v >> 2) & 0x01010101u;
+    const uint32_t l = b1 ^ b2;
+    const uint32_t h = b2;
+    // gather the four byte-lsbs into a nibble
+    lo = ((l * 0x01020408u) >> 24) & 0xfu;
+    hi = ((h * 0x01020408u) >> 24) & 0xfu;
+    // validity: upper-cased byte must be one of A C G T, or the byte is 0 (padding)
+    const uint32_t u = v & 0xdfdfdfdfu;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t c = (u >> (8 * k)) & 0xffu;
+        const uint32_t raw = (v >> (8 * k)) & 0xffu;
+        const bool ok = (c == 'A') || (c == 'C') || (c == 'G') || (c == 'T') || (raw == 0u);
+        bad += ok ? 0u : 1u;
+    }
+}
+
+__global__ __launch_bounds__(256) void pack_planar_kernel(const uint4* __restrict__ ascii, uint64_t n_words,
+                                                          uint64_t* __restrict__ planar, uint32_t* __restrict__ bad_count)
+{
+    uint32_t bad = 0;
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words;
+         w += (uint64_t)gridDim.x * blockDim.x) {
+        const uint4 q0 = ascii[2 * w], q1 = ascii[2 * w + 1];
+        const uint32_t v[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            uint32_t l, h;
+            pack4(v[k], l, h, bad);
+            lo |= l << (4 * k);
+            hi |= h << (4 * k);
+        }
+        planar[w] = ((uint64_t)hi << 32) | lo;
+    }
+    if (bad) atomicAdd(bad_count, bad);
+}
+
+// ----------------------------------------------------------------------------
+// Reference-layout packer (src/genasm_gpu.cu:631-685): 4 bases per byte, the
+// first base of each quad in bits 7..6; one thread per output byte, strings
+// concatenated.  (The reference launches every block over the whole buffer;
+// here each output byte is produced exactly once.)
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ascii_to_twobit_kernel(uint64_t count, const uint64_t* __restrict__ lens,
+                                                              const uint64_t* __restrict__ ascii_off,
+                                                              const char* __restrict__ ascii,
+                                                              const uint64_t* __restrict__ twobit_off,
+                                                              uint8_t* __restrict__ twobit,
+                                                              uint32_t* __restrict__ bad_count)
+{
+    // grid.y strides over strings, grid.x*block over bytes of a string
+    uint32_t bad = 0;
+    for (uint64_t s = blockIdx.y; s < count; s += gridDim.y) {
+        const uint64_t len = lens[s];
+        const uint64_t nbytes = (len + 3) / 4;
+        const char* src = ascii + ascii_off[s];
+        uint8_t* dst = twobit + twobit_off[s];
+        for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < nbytes;
+             b += (uint64_t)gridDim.x * blockDim.x) {
+            uint32_t out = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint64_t p = 4 * b + k;
+                uint32_t code = 0;
+                if (p < len) {
+                    const uint32_t c = (uint8_t)src[p];
+                    const uint32_t u = c & 0xdfu;
+                    if (!(u == 'A' || u == 'C' || u == 'G' || u == 'T')) bad++;
+                    const uint32_t x = (c >> 1) & 3u;
+                    code = x ^ (x >> 1);
+                }
+                out |= code << (6 - 2 * k);
+            }
+            dst[b] = (uint8_t)out;
+        }
+    }
+    if (bad) atomicAdd(bad_count, bad);
+}
+
+// ----------------------------------------------------------------------------
+// Run compaction: one wavefront per pair copies its runs from the pair's
+// arena slice into the dense output.
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void compact_runs_kernel(uint64_t n_pairs, const scrg_pair_desc* __restrict__ pairs,
+                                                           const uint16_t* __restrict__ runs,
+                                                           const uint32_t* __restrict__ n_runs,
+                                                           const uint64_t* __restrict__ dense_off,
+                                                           uint16_t* __restrict__ dense)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t p = wave; p < n_pairs; p += n_waves) {
+        const uint64_t src = pairs[p].cigar_off;
+        const uint64_t cap = pairs[p].cigar_cap;
+        uint64_t cnt = n_runs[p];
+        if (cnt > cap) cnt = cap;
+        const uint64_t dst = dense_off[p];
+        for (uint64_t k = lane; k < cnt; k += 64) dense[dst + k] = runs[src + k];
+    }
+}
+
+// ----------------------------------------------------------------------------
+// host-side launchers
+// ----------------------------------------------------------------------------
+template <int G>
+static hipError_t launch_align_t(const AlignArgs& a, int grid, size_t lds_bytes, hipStream_t s)
+{
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&genasm_align_kernel<G>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(genasm_align_kernel<G>, dim3(grid), dim3(64), lds_bytes, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_align(int lanes_per_pair, const AlignArgs& a, int grid, size_t lds_bytes, hipStream_t s)
+{
+    switch (lanes_per_pair) {
+    case 4:  return launch_align_t<4>(a, grid, lds_bytes, s);
+    case 8:  return launch_align_t<8>(a, grid, lds_bytes, s);
+    case 16: return launch_align_t<16>(a, grid, lds_bytes, s);
+    case 32: return launch_align_t<32>(a, grid, lds_bytes, s);
+    case 64: return launch_align_t<64>(a, grid, lds_bytes, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_pack_planar(const char* d_ascii, uint64_t n_words, uint64_t* d_planar, uint32_t* d_bad,
+                              int n_cus, hipStream_t s)
+{
+    if (n_words == 0) return hipSuccess;
+    uint64_t blocks = (n_words + 255) / 256;
+    const uint64_t cap = (uint64_t)n_cus * 8;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(pack_planar_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
+                       reinterpret_cast<const uint4*>(d_ascii), n_words, d_planar, d_bad);
+    return hipGetLastError();
+}
+
+hipError_t launch_ascii_to_twobit(uint64_t count, const uint64_t* d_lens, const uint64_t* d_ascii_off,
+                                  const char* d_ascii, const uint64_t* d_twobit_off, uint8_t* d_twobit,
+                                  uint32_t* d_bad, uint64_t max_len, hipStream_t s)
+{
+    if (count == 0) return hipSuccess;
+    uint64_t bx = ((max_len + 3) / 4 + 255) / 256;
+    if (bx < 1) bx = 1;
+    if (bx > 64) bx = 64;
+    uint64_t by = count < 4096 ? count : 4096;
+    hipLaunchKernelGGL(ascii_to_twobit_kernel, dim3((unsigned)bx, (unsigned)by), dim3(256), 0, s,
+                       count, d_lens, d_ascii_off, d_ascii, d_twobit_off, d_twobit, d_bad);
+    return hipGetLastError();
+}
+
+hipError_t launch_compact_runs(uint64_t n_pairs, const scrg_pair_desc* d_pairs, const uint16_t* d_runs,
+                               const uint32_t* d_n_runs, const uint64_t* d_dense_off, uint16_t* d_dense,
+                               int n_cus, hipStream_t s)
+{
+    if (n_pairs == 0) return hipSuccess;
+    uint64_t blocks = (n_pairs + 3) / 4;
+    const uint64_t cap = (uint64_t)n_cus * 8;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(compact_runs_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
+                       n_pairs, d_pairs, d_runs, d_n_runs, d_dense_off, d_dense);
+    return hipGetLastError();
+}
+
+}  // namespace scrg

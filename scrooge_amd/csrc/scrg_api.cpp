@@ -1,0 +1,671 @@
+// scrg_api.cpp — host side of the C ABI declared in include/scrooge_amd.h.
+//
+// Mirrors the staging the reference does around its kernel
+// (src/genasm_gpu.cu:890-1065: concatenate + pack sequences, size the CIGAR
+// storage, launch, read CIGARs back) with explicit device memory instead of
+// managed memory, status codes instead of exit(), and one handle per device
+// instead of __managed__ globals.  There is no CPU fallback anywhere in this
+// file: without a HIP device every entry point fails with SCRG_ERR_NO_DEVICE.
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "genasm_kernels.h"
+
+namespace {
+
+std::atomic<int> g_log{0};
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            e = hipMalloc(&p, bytes);
+            want = bytes;
+        }
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <typename T> T* as() const { return static_cast<T*>(p); }
+};
+
+struct HostPinned {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+        if (e == hipSuccess) cap = bytes;
+        return e;
+    }
+    void release()
+    {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+int64_t now_ns()
+{
+    return std::chrono::duration_cast<std::chrono::nanoseconds>(
+               std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+template <typename F> void parallel_for(uint64_t n, F f)
+{
+    unsigned hw = std::thread::hardware_concurrency();
+    unsigned nt = hw ? std::min(hw, 16u) : 4u;
+    if (n < 64 || nt <= 1) {
+        for (uint64_t i = 0; i < n; i++) f(i);
+        return;
+    }
+    std::atomic<uint64_t> next{0};
+    const uint64_t chunk = std::max<uint64_t>(1, n / (nt * 16));
+    std::vector<std::thread> th;
+    for (unsigned k = 0; k < nt; k++)
+        th.emplace_back([&]() {
+            for (;;) {
+                uint64_t b = next.fetch_add(chunk);
+                if (b >= n) break;
+                uint64_t e = std::min(n, b + chunk);
+                for (uint64_t i = b; i < e; i++) f(i);
+            }
+        });
+    for (auto& t : th) t.join();
+}
+
+}  // namespace
+
+struct scrg_ctx {
+    int device = 0;
+    int n_cus = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool have_timing = false;
+    std::string last_error;
+
+    DevBuf counter;     // work queue head
+    DevBuf spill;       // HBM overflow rows of R
+    // staging used by the host-pointer entry points
+    HostPinned h_ascii;
+    DevBuf d_ascii, d_seq, d_pairs, d_runs, d_ed, d_nruns, d_status, d_bad, d_dense_off, d_dense;
+
+    scrg_status fail(scrg_status s, const char* what, hipError_t e = hipSuccess)
+    {
+        last_error = what;
+        if (e != hipSuccess) {
+            last_error += ": ";
+            last_error += hipGetErrorString(e);
+            (void)hipGetLastError();
+        }
+        if (g_log.load()) fprintf(stderr, "[scrooge_amd] error: %s\n", last_error.c_str());
+        return s;
+    }
+};
+
+#define HIP_TRY(ctx, call)                                                     \
+    do {                                                                       \
+        hipError_t e__ = (call);                                               \
+        if (e__ != hipSuccess)                                                 \
+            return (ctx)->fail(e__ == hipErrorOutOfMemory ? SCRG_ERR_OOM : SCRG_ERR_HIP, #call, e__); \
+    } while (0)
+
+extern "C" {
+
+void scrg_params_default(scrg_params* p)
+{
+    if (!p) return;
+    memset(p, 0, sizeof(*p));
+    p->W = 64;                // src/genasm_cpu.cpp:7
+    p->O = 33;                // src/genasm_cpu.cpp:9
+    p->lanes_per_pair = 8;
+    p->lds_rows = 16;
+    p->waves_per_cu = 8;
+    p->sort_by_length = 1;
+}
+
+const char* scrg_status_string(scrg_status s)
+{
+    switch (s) {
+    case SCRG_OK: return "ok";
+    case SCRG_ERR_INVALID_ARG: return "invalid argument";
+    case SCRG_ERR_BAD_BASE: return "sequence contains a character other than ACGTacgt";
+    case SCRG_ERR_NO_DEVICE: return "no usable HIP device";
+    case SCRG_ERR_HIP: return "HIP runtime error";
+    case SCRG_ERR_OOM: return "out of memory";
+    case SCRG_ERR_CIGAR_OVERFLOW: return "CIGAR arena slice too small";
+    default: return "unknown status";
+    }
+}
+
+void scrg_set_log(int enabled) { g_log.store(enabled ? 1 : 0); }
+
+int scrg_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+scrg_status scrg_ctx_create(int device, scrg_ctx** out)
+{
+    if (!out) return SCRG_ERR_INVALID_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) {
+        (void)hipGetLastError();
+        return SCRG_ERR_NO_DEVICE;
+    }
+    if (hipSetDevice(device) != hipSuccess) return SCRG_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return SCRG_ERR_NO_DEVICE;
+    scrg_ctx* c = new (std::nothrow) scrg_ctx();
+    if (!c) return SCRG_ERR_OOM;
+    c->device = device;
+    c->n_cus = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&c->ev_start) != hipSuccess || hipEventCreate(&c->ev_stop) != hipSuccess) {
+        delete c;
+        return SCRG_ERR_HIP;
+    }
+    c->stream = c->own_stream;
+    if (g_log.load())
+        fprintf(stderr, "[scrooge_amd] device %d: %s, %d CUs, arch %s\n", device, prop.name, c->n_cus,
+                prop.gcnArchName);
+    *out = c;
+    return SCRG_OK;
+}
+
+void scrg_ctx_destroy(scrg_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    c->counter.release();
+    c->spill.release();
+    c->h_ascii.release();
+    for (DevBuf* b : {&c->d_ascii, &c->d_seq, &c->d_pairs, &c->d_runs, &c->d_ed, &c->d_nruns, &c->d_status,
+                      &c->d_bad, &c->d_dense_off, &c->d_dense})
+        b->release();
+    if (c->ev_start) (void)hipEventDestroy(c->ev_start);
+    if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+scrg_status scrg_ctx_set_stream(scrg_ctx* c, void* hip_stream)
+{
+    if (!c) return SCRG_ERR_INVALID_ARG;
+    c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+    return SCRG_OK;
+}
+
+const char* scrg_last_error(const scrg_ctx* c) { return c ? c->last_error.c_str() : "null context"; }
+
+// ---------------------------------------------------------------------------
+// launch geometry
+// ---------------------------------------------------------------------------
+static bool resolve_params(const scrg_params* in, scrg_params* p)
+{
+    scrg_params_default(p);
+    if (in) {
+        if (in->W) p->W = in->W;
+        if (in->O || in->W) p->O = in->O;
+        if (in->lanes_per_pair) p->lanes_per_pair = in->lanes_per_pair;
+        if (in->lds_rows) p->lds_rows = in->lds_rows;
+        if (in->waves_per_cu) p->waves_per_cu = in->waves_per_cu;
+        p->sort_by_length = in->sort_by_length;
+    }
+    const int g = p->lanes_per_pair;
+    if (!(g == 4 || g == 8 || g == 16 || g == 32 || g == 64)) return false;
+    if (p->W < 2 || p->W > 64) return false;
+    const int tbl = p->W - p->O;
+    if (tbl < 1 || tbl > 31) return false;
+    if (p->lds_rows < 1) return false;
+    if (p->lds_rows > 65) p->lds_rows = 65;
+    if (p->waves_per_cu < 1 || p->waves_per_cu > 32) return false;
+    return true;
+}
+
+static size_t lds_bytes_for(const scrg_params& p)
+{
+    const size_t slots = 64 / p.lanes_per_pair;
+    return slots * ((size_t)p.lds_rows * 32 + 1) * sizeof(uint32_t);
+}
+
+scrg_status scrg_query_launch(scrg_ctx* c, const scrg_params* params, int32_t* n_waves, int32_t* pairs_per_wave,
+                              int32_t* lds_bytes, int32_t* n_cus)
+{
+    if (!c) return SCRG_ERR_INVALID_ARG;
+    scrg_params p;
+    if (!resolve_params(params, &p)) return c->fail(SCRG_ERR_INVALID_ARG, "bad scrg_params");
+    size_t lds = lds_bytes_for(p);
+    int wpc = p.waves_per_cu;
+    const size_t lds_cap = 160 * 1024;
+    if (lds * wpc > lds_cap) wpc = (int)std::max<size_t>(1, lds_cap / lds);
+    if (n_waves) *n_waves = c->n_cus * wpc;
+    if (pairs_per_wave) *pairs_per_wave = 64 / p.lanes_per_pair;
+    if (lds_bytes) *lds_bytes = (int32_t)lds;
+    if (n_cus) *n_cus = c->n_cus;
+    return SCRG_OK;
+}
+
+// ---------------------------------------------------------------------------
+// device-pointer entry points
+// ---------------------------------------------------------------------------
+scrg_status scrg_pack_planar(scrg_ctx* c, const char* d_ascii, uint64_t n_words, uint64_t* d_planar,
+                             uint32_t* d_bad_count)
+{
+    if (!c || (n_words && (!d_ascii || !d_planar)) || !d_bad_count) return SCRG_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, scrg::launch_pack_planar(d_ascii, n_words, d_planar, d_bad_count, c->n_cus, c->stream));
+    return SCRG_OK;
+}
+
+scrg_status scrg_align_device(scrg_ctx* c, const scrg_params* params, uint64_t n_pairs, const uint64_t* d_seq,
+                              const scrg_pair_desc* d_pairs, scrg_run* d_runs, int64_t* d_edit_distance,
+                              uint32_t* d_n_runs, uint32_t* d_pair_status)
+{
+    if (!c) return SCRG_ERR_INVALID_ARG;
+    scrg_params p;
+    if (!resolve_params(params, &p)) return c->fail(SCRG_ERR_INVALID_ARG, "bad scrg_params");
+    if (n_pairs > 0xfffffff0ull) return c->fail(SCRG_ERR_INVALID_ARG, "too many pairs for one launch");
+    if (n_pairs && (!d_seq || !d_pairs || !d_runs || !d_edit_distance || !d_n_runs || !d_pair_status))
+        return c->fail(SCRG_ERR_INVALID_ARG, "null device pointer");
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->have_timing = false;
+    if (n_pairs == 0) return SCRG_OK;
+
+    int32_t n_waves = 0, ppw = 0, lds = 0;
+    scrg_status s = scrg_query_launch(c, &p, &n_waves, &ppw, &lds, nullptr);
+    if (s != SCRG_OK) return s;
+    // no point in launching more slots than pairs
+    const uint64_t need_waves = (n_pairs + ppw - 1) / ppw;
+    if ((uint64_t)n_waves > need_waves) n_waves = (int32_t)need_waves;
+
+    HIP_TRY(c, c->counter.ensure(sizeof(uint32_t)));
+    HIP_TRY(c, c->spill.ensure((size_t)n_waves * ppw * scrg::SPILL_ROWS * 32 * sizeof(uint32_t)));
+    HIP_TRY(c, hipMemsetAsync(c->counter.p, 0, sizeof(uint32_t), c->stream));
+
+    scrg::AlignArgs a;
+    a.seq = d_seq;
+    a.pairs = d_pairs;
+    a.runs = reinterpret_cast<uint16_t*>(d_runs);
+    a.ed = d_edit_distance;
+    a.n_runs = d_n_runs;
+    a.status = d_pair_status;
+    a.counter = c->counter.as<uint32_t>();
+    a.spill = c->spill.as<uint32_t>();
+    a.n_pairs = (uint32_t)n_pairs;
+    a.W = p.W;
+    a.tb_limit = p.W - p.O;
+    a.lds_rows = p.lds_rows;
+
+    HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));
+    HIP_TRY(c, scrg::launch_align(p.lanes_per_pair, a, n_waves, (size_t)lds, c->stream));
+    HIP_TRY(c, hipEventRecord(c->ev_stop, c->stream));
+    c->have_timing = true;
+    return SCRG_OK;
+}
+
+scrg_status scrg_last_kernel_ms(scrg_ctx* c, float* ms)
+{
+    if (!c || !ms) return SCRG_ERR_INVALID_ARG;
+    *ms = 0.f;
+    if (!c->have_timing) return SCRG_OK;
+    HIP_TRY(c, hipEventSynchronize(c->ev_stop));
+    HIP_TRY(c, hipEventElapsedTime(ms, c->ev_start, c->ev_stop));
+    return SCRG_OK;
+}
+
+scrg_status scrg_compact_runs(scrg_ctx* c, uint64_t n_pairs, const scrg_pair_desc* d_pairs, const scrg_run* d_runs,
+                              const uint32_t* d_n_runs, const uint64_t* d_dense_offset, scrg_run* d_dense)
+{
+    if (!c) return SCRG_ERR_INVALID_ARG;
+    if (n_pairs && (!d_pairs || !d_runs || !d_n_runs || !d_dense_offset || !d_dense))
+        return c->fail(SCRG_ERR_INVALID_ARG, "null device pointer");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, scrg::launch_compact_runs(n_pairs, d_pairs, reinterpret_cast<const uint16_t*>(d_runs), d_n_runs,
+                                         d_dense_offset, reinterpret_cast<uint16_t*>(d_dense), c->n_cus, c->stream));
+    return SCRG_OK;
+}
+
+scrg_status scrg_ascii_to_twobit(scrg_ctx* c, uint64_t count, const uint64_t* d_lens, const uint64_t* d_ascii_off,
+                                 const char* d_ascii, const uint64_t* d_twobit_off, uint8_t* d_twobit,
+                                 uint32_t* d_bad_count)
+{
+    if (!c || !d_bad_count) return SCRG_ERR_INVALID_ARG;
+    if (count && (!d_lens || !d_ascii_off || !d_ascii || !d_twobit_off || !d_twobit))
+        return c->fail(SCRG_ERR_INVALID_ARG, "null device pointer");
+    HIP_TRY(c, hipSetDevice(c->device));
+    // the grid's x extent only needs an upper bound on the string length; take it from the
+    // device array without a sync by assuming long strings (extra blocks exit immediately)
+    HIP_TRY(c, scrg::launch_ascii_to_twobit(count, d_lens, d_ascii_off, d_ascii, d_twobit_off, d_twobit, d_bad_count,
+                                            1 << 16, c->stream));
+    return SCRG_OK;
+}
+
+// ---------------------------------------------------------------------------
+// host-pointer entry points
+// ---------------------------------------------------------------------------
+void scrg_result_free(scrg_result* r)
+{
+    if (!r) return;
+    free(r->edit_distance);
+    free(r->pair_status);
+    free(r->run_offset);
+    free(r->runs);
+    free(r->cigar_offset);
+    free(r->cigar_text);
+    free(r);
+}
+
+namespace {
+
+struct SeqRef {
+    const char* p;
+    uint64_t len;
+    uint64_t word_off;   // first planar word of this sequence
+};
+
+struct Problem {         // one (text, read) problem in caller order
+    uint64_t text_off, text_len, read_off, read_len;   // base offsets into the planar array
+};
+
+// Shared tail of both host entry points: sequences are described by `seqs`
+// (each packed once, 32-base aligned), problems by `probs`.
+scrg_status run_batch(scrg_ctx* c, const scrg_params& p, std::vector<SeqRef>& seqs, uint64_t total_words,
+                      const std::vector<Problem>& probs, scrg_result** out)
+{
+    const int64_t t_begin = now_ns();
+    const uint64_t n = probs.size();
+    HIP_TRY(c, hipSetDevice(c->device));
+
+    scrg_result* r = static_cast<scrg_result*>(calloc(1, sizeof(scrg_result)));
+    if (!r) return c->fail(SCRG_ERR_OOM, "result header");
+    r->n_pairs = n;
+    auto bail = [&](scrg_status s) {
+        scrg_result_free(r);
+        return s;
+    };
+    r->edit_distance = static_cast<int64_t*>(calloc(n + 1, sizeof(int64_t)));
+    r->pair_status = static_cast<uint32_t*>(calloc(n + 1, sizeof(uint32_t)));
+    r->run_offset = static_cast<uint64_t*>(calloc(n + 1, sizeof(uint64_t)));
+    r->cigar_offset = static_cast<uint64_t*>(calloc(n + 1, sizeof(uint64_t)));
+    if (!r->edit_distance || !r->pair_status || !r->run_offset || !r->cigar_offset)
+        return bail(c->fail(SCRG_ERR_OOM, "result arrays"));
+
+    // ---- stage ASCII (32 bytes per planar word, zero padded), H2D, pack ----
+    const uint64_t seq_words = total_words + SCRG_SEQ_PAD_WORDS;
+    const size_t ascii_bytes = (size_t)total_words * 32;
+    if (ascii_bytes) {
+        hipError_t e = c->h_ascii.ensure(ascii_bytes);
+        if (e != hipSuccess) return bail(c->fail(SCRG_ERR_OOM, "pinned staging buffer", e));
+        char* h = static_cast<char*>(c->h_ascii.p);
+        parallel_for(seqs.size(), [&](uint64_t s) {
+            const SeqRef& q = seqs[s];
+            char* dst = h + q.word_off * 32;
+            const uint64_t span = ((q.len + 31) / 32) * 32;
+            if (q.len) memcpy(dst, q.p, q.len);
+            if (span > q.len) memset(dst + q.len, 0, span - q.len);
+        });
+    }
+    hipError_t e;
+    if ((e = c->d_ascii.ensure(ascii_bytes + 32)) != hipSuccess || (e = c->d_seq.ensure(seq_words * 8)) != hipSuccess ||
+        (e = c->d_bad.ensure(4)) != hipSuccess)
+        return bail(c->fail(SCRG_ERR_OOM, "device sequence buffers", e));
+    const int64_t t_pack0 = now_ns();
+    if ((e = hipMemsetAsync(c->d_bad.p, 0, 4, c->stream)) != hipSuccess ||
+        (e = hipMemsetAsync(c->d_seq.as<uint64_t>() + total_words, 0, SCRG_SEQ_PAD_WORDS * 8, c->stream)) != hipSuccess)
+        return bail(c->fail(SCRG_ERR_HIP, "memset", e));
+    if (ascii_bytes) {
+        if ((e = hipMemcpyAsync(c->d_ascii.p, c->h_ascii.p, ascii_bytes, hipMemcpyHostToDevice, c->stream)) != hipSuccess)
+            return bail(c->fail(SCRG_ERR_HIP, "H2D ascii", e));
+        scrg_status s = scrg_pack_planar(c, c->d_ascii.as<char>(), total_words, c->d_seq.as<uint64_t>(),
+                                         c->d_bad.as<uint32_t>());
+        if (s != SCRG_OK) return bail(s);
+    }
+    uint32_t bad = 0;
+    if ((e = hipMemcpyAsync(&bad, c->d_bad.p, 4, hipMemcpyDeviceToHost, c->stream)) != hipSuccess ||
+        (e = hipStreamSynchronize(c->stream)) != hipSuccess)
+        return bail(c->fail(SCRG_ERR_HIP, "pack", e));
+    r->pack_ns = now_ns() - t_pack0;
+    if (bad) return bail(c->fail(SCRG_ERR_BAD_BASE, "input contains characters other than ACGTacgt"));
+
+    // ---- problem descriptors, longest read first (src/tests.cu:375-377) ----
+    std::vector<uint32_t> order(n);
+    std::iota(order.begin(), order.end(), 0u);
+    if (p.sort_by_length)
+        std::stable_sort(order.begin(), order.end(),
+                         [&](uint32_t x, uint32_t y) { return probs[x].read_len > probs[y].read_len; });
+    std::vector<scrg_pair_desc> desc(n);
+    uint64_t arena = 0;
+    for (uint64_t k = 0; k < n; k++) {
+        const Problem& q = probs[order[k]];
+        scrg_pair_desc& d = desc[k];
+        d.text_off = q.text_off;
+        d.text_len = q.text_len;
+        d.read_off = q.read_off;
+        d.read_len = q.read_len;
+        d.cigar_off = arena;
+        // same bound as the reference's GPU list sizing (2*read_len, genasm_gpu.cu:906-911)
+        d.cigar_cap = 2 * q.read_len + 8;
+        arena += d.cigar_cap;
+    }
+    if (n == 0) {
+        r->runs = static_cast<scrg_run*>(calloc(1, sizeof(scrg_run)));
+        r->cigar_text = static_cast<char*>(calloc(1, 1));
+        r->total_ns = now_ns() - t_begin;
+        *out = r;
+        return SCRG_OK;
+    }
+    if ((e = c->d_pairs.ensure(n * sizeof(scrg_pair_desc))) != hipSuccess ||
+        (e = c->d_runs.ensure(arena * sizeof(scrg_run))) != hipSuccess || (e = c->d_ed.ensure(n * 8)) != hipSuccess ||
+        (e = c->d_nruns.ensure(n * 4)) != hipSuccess || (e = c->d_status.ensure(n * 4)) != hipSuccess ||
+        (e = c->d_dense_off.ensure(n * 8)) != hipSuccess)
+        return bail(c->fail(SCRG_ERR_OOM, "device result buffers", e));
+    if ((e = hipMemcpyAsync(c->d_pairs.p, desc.data(), n * sizeof(scrg_pair_desc), hipMemcpyHostToDevice, c->stream)) !=
+        hipSuccess)
+        return bail(c->fail(SCRG_ERR_HIP, "H2D descriptors", e));
+
+    // ---- the timed region of the reference: kernel + sync (genasm_gpu.cu:939-944) ----
+    scrg_status s = scrg_align_device(c, &p, n, c->d_seq.as<uint64_t>(), c->d_pairs.as<scrg_pair_desc>(),
+                                      c->d_runs.as<scrg_run>(), c->d_ed.as<int64_t>(), c->d_nruns.as<uint32_t>(),
+                                      c->d_status.as<uint32_t>());
+    if (s != SCRG_OK) return bail(s);
+    float ms = 0.f;
+    s = scrg_last_kernel_ms(c, &ms);
+    if (s != SCRG_OK) return bail(s);
+    r->kernel_ns = (int64_t)((double)ms * 1e6);
+    if (g_log.load() && ms > 0.f)   // the reference's log line, genasm_gpu.cu:949-951
+        fprintf(stderr, "core algorithm ran at %lld aligns/second\n", (long long)((double)n * 1000.0 / ms));
+
+    // ---- read back: per-pair scalars, then the compacted runs ----
+    std::vector<int64_t> ed(n);
+    std::vector<uint32_t> nr(n), st(n);
+    if ((e = hipMemcpyAsync(ed.data(), c->d_ed.p, n * 8, hipMemcpyDeviceToHost, c->stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(nr.data(), c->d_nruns.p, n * 4, hipMemcpyDeviceToHost, c->stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(st.data(), c->d_status.p, n * 4, hipMemcpyDeviceToHost, c->stream)) != hipSuccess ||
+        (e = hipStreamSynchronize(c->stream)) != hipSuccess)
+        return bail(c->fail(SCRG_ERR_HIP, "D2H scalars", e));
+
+    // dense layout in caller order
+    std::vector<uint64_t> dense_off_sorted(n);
+    {
+        std::vector<uint32_t> cnt_by_caller(n);
+        for (uint64_t k = 0; k < n; k++) {
+            uint64_t cnt = std::min<uint64_t>(nr[k], desc[k].cigar_cap);
+            cnt_by_caller[order[k]] = (uint32_t)cnt;
+        }
+        uint64_t acc = 0;
+        for (uint64_t i = 0; i < n; i++) {
+            r->run_offset[i] = acc;
+            acc += cnt_by_caller[i];
+        }
+        r->run_offset[n] = acc;
+        for (uint64_t k = 0; k < n; k++) dense_off_sorted[k] = r->run_offset[order[k]];
+    }
+    const uint64_t total_runs = r->run_offset[n];
+    r->runs = static_cast<scrg_run*>(malloc((total_runs + 1) * sizeof(scrg_run)));
+    if (!r->runs) return bail(c->fail(SCRG_ERR_OOM, "runs"));
+    if (total_runs) {
+        if ((e = c->d_dense.ensure(total_runs * sizeof(scrg_run))) != hipSuccess)
+            return bail(c->fail(SCRG_ERR_OOM, "dense runs", e));
+        if ((e = hipMemcpyAsync(c->d_dense_off.p, dense_off_sorted.data(), n * 8, hipMemcpyHostToDevice, c->stream)) !=
+            hipSuccess)
+            return bail(c->fail(SCRG_ERR_HIP, "H2D offsets", e));
+        s = scrg_compact_runs(c, n, c->d_pairs.as<scrg_pair_desc>(), c->d_runs.as<scrg_run>(), c->d_nruns.as<uint32_t>(),
+                              c->d_dense_off.as<uint64_t>(), c->d_dense.as<scrg_run>());
+        if (s != SCRG_OK) return bail(s);
+        if ((e = hipMemcpyAsync(r->runs, c->d_dense.p, total_runs * sizeof(scrg_run), hipMemcpyDeviceToHost, c->stream)) !=
+                hipSuccess ||
+            (e = hipStreamSynchronize(c->stream)) != hipSuccess)
+            return bail(c->fail(SCRG_ERR_HIP, "D2H runs", e));
+    }
+
+    scrg_status worst = SCRG_OK;
+    for (uint64_t k = 0; k < n; k++) {
+        r->edit_distance[order[k]] = ed[k];
+        r->pair_status[order[k]] = st[k] ? (uint32_t)SCRG_ERR_CIGAR_OVERFLOW : (uint32_t)SCRG_OK;
+        if (st[k]) worst = SCRG_ERR_CIGAR_OVERFLOW;
+    }
+
+    // ---- "%d%c" text, as genasm_cpu.cpp:387-403 ----
+    {
+        uint64_t acc = 0;
+        for (uint64_t i = 0; i < n; i++) {
+            r->cigar_offset[i] = acc;
+            uint64_t chars = 0;
+            for (uint64_t k = r->run_offset[i]; k < r->run_offset[i + 1]; k++) {
+                const unsigned cnt = r->runs[k].count;
+                chars += (cnt >= 100 ? 4 : (cnt >= 10 ? 3 : 2));
+            }
+            acc += chars + 1;
+        }
+        r->cigar_offset[n] = acc;
+        r->cigar_text = static_cast<char*>(malloc(acc + 1));
+        if (!r->cigar_text) return bail(c->fail(SCRG_ERR_OOM, "cigar text"));
+        parallel_for(n, [&](uint64_t i) {
+            char* w = r->cigar_text + r->cigar_offset[i];
+            for (uint64_t k = r->run_offset[i]; k < r->run_offset[i + 1]; k++) {
+                unsigned cnt = r->runs[k].count;
+                if (cnt >= 100) *w++ = (char)('0' + cnt / 100);
+                if (cnt >= 10) *w++ = (char)('0' + (cnt / 10) % 10);
+                *w++ = (char)('0' + cnt % 10);
+                *w++ = r->runs[k].op;
+            }
+            *w = '\0';
+        });
+    }
+    r->total_ns = now_ns() - t_begin;
+    *out = r;
+    if (worst != SCRG_OK) c->fail(worst, "at least one pair overflowed its CIGAR slice (see pair_status)");
+    return worst;
+}
+
+}  // namespace
+
+scrg_status scrg_align_pairs(scrg_ctx* c, const scrg_params* params, uint64_t n_pairs, const char* const* texts,
+                             const uint64_t* text_lens, const char* const* queries, const uint64_t* query_lens,
+                             scrg_result** out)
+{
+    if (!c || !out) return SCRG_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (n_pairs && (!texts || !text_lens || !queries || !query_lens))
+        return c->fail(SCRG_ERR_INVALID_ARG, "null input array");
+    scrg_params p;
+    if (!resolve_params(params, &p)) return c->fail(SCRG_ERR_INVALID_ARG, "bad scrg_params");
+    if (n_pairs > 0xfffffff0ull) return c->fail(SCRG_ERR_INVALID_ARG, "too many pairs");
+
+    std::vector<SeqRef> seqs(2 * n_pairs);
+    std::vector<Problem> probs(n_pairs);
+    uint64_t w = 0;
+    for (uint64_t i = 0; i < n_pairs; i++) {
+        if ((text_lens[i] && !texts[i]) || (query_lens[i] && !queries[i]))
+            return c->fail(SCRG_ERR_INVALID_ARG, "null sequence pointer");
+        if (query_lens[i] > 0x7fffffffull) return c->fail(SCRG_ERR_INVALID_ARG, "read longer than 2^31-1");
+        seqs[2 * i] = {texts[i], text_lens[i], w};
+        probs[i].text_off = w * 32;
+        probs[i].text_len = text_lens[i];
+        w += (text_lens[i] + 31) / 32;
+        seqs[2 * i + 1] = {queries[i], query_lens[i], w};
+        probs[i].read_off = w * 32;
+        probs[i].read_len = query_lens[i];
+        w += (query_lens[i] + 31) / 32;
+    }
+    return run_batch(c, p, seqs, w, probs, out);
+}
+
+scrg_status scrg_align_mapping(scrg_ctx* c, const scrg_params* params, const char* genome, uint64_t genome_len,
+                               uint64_t n_reads, const char* const* reads, const uint64_t* read_lens,
+                               const uint64_t* cand_offsets, const uint64_t* cand_start, scrg_result** out)
+{
+    if (!c || !out) return SCRG_ERR_INVALID_ARG;
+    *out = nullptr;
+    if ((genome_len && !genome) || (n_reads && (!reads || !read_lens)) || !cand_offsets)
+        return c->fail(SCRG_ERR_INVALID_ARG, "null input array");
+    scrg_params p;
+    if (!resolve_params(params, &p)) return c->fail(SCRG_ERR_INVALID_ARG, "bad scrg_params");
+    const uint64_t n_pairs = cand_offsets[n_reads];
+    if (n_pairs > 0xfffffff0ull) return c->fail(SCRG_ERR_INVALID_ARG, "too many pairs");
+    if (n_pairs && !cand_start) return c->fail(SCRG_ERR_INVALID_ARG, "null candidate array");
+
+    // genome and every read are packed exactly once (README.md:83 of the reference asks for this)
+    std::vector<SeqRef> seqs(1 + n_reads);
+    std::vector<Problem> probs(n_pairs);
+    uint64_t w = 0;
+    seqs[0] = {genome, genome_len, 0};
+    w += (genome_len + 31) / 32;
+    for (uint64_t r = 0; r < n_reads; r++) {
+        if (read_lens[r] && !reads[r]) return c->fail(SCRG_ERR_INVALID_ARG, "null read pointer");
+        if (read_lens[r] > 0x7fffffffull) return c->fail(SCRG_ERR_INVALID_ARG, "read longer than 2^31-1");
+        if (cand_offsets[r + 1] < cand_offsets[r]) return c->fail(SCRG_ERR_INVALID_ARG, "cand_offsets not monotone");
+        seqs[1 + r] = {reads[r], read_lens[r], w};
+        for (uint64_t k = cand_offsets[r]; k < cand_offsets[r + 1]; k++) {
+            if (cand_start[k] > genome_len) return c->fail(SCRG_ERR_INVALID_ARG, "candidate past end of genome");
+            // text = genome suffix from start_in_reference (genasm_cpu.cpp:512-514)
+            probs[k].text_off = cand_start[k];
+            probs[k].text_len = genome_len - cand_start[k];
+            probs[k].read_off = w * 32;
+            probs[k].read_len = read_lens[r];
+        }
+        w += (read_lens[r] + 31) / 32;
+    }
+    return run_batch(c, p, seqs, w, probs, out);
+}
+
+}  // extern "C"

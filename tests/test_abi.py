@@ -1,0 +1,68 @@
+"""CPU tests of the C-ABI boundary: the library builds for gfx950, loads, and
+exports every symbol include/scrooge_amd.h declares.  No compute calls here."""
+import os
+import re
+
+import pytest
+
+import scrooge_amd
+from scrooge_amd import api
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    scrooge_amd.build_library()
+    return scrooge_amd.load_library()
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "scrooge_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(scrg_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_symbols_exported(lib):
+    names = declared_symbols()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), n
+    assert sorted(api.EXPORTED_SYMBOLS) == names
+
+
+def test_defaults_match_reference_knobs(lib):
+    p = api.Params()
+    lib.scrg_params_default(p)
+    assert (p.W, p.O) == (64, 33)        # src/genasm_cpu.cpp:7-9
+    assert p.lanes_per_pair in (4, 8, 16, 32, 64)
+
+
+def test_struct_layouts():
+    import ctypes as C
+    assert C.sizeof(api.Run) == 2        # CigarEntry_t, src/util.hpp:43-46
+    assert C.sizeof(api.PairDesc) == 48
+    assert C.sizeof(api.Params) == 32
+
+
+def test_status_strings(lib):
+    for s in range(0, 7):
+        assert lib.scrg_status_string(s)
+
+
+def test_no_device_is_an_error_not_a_fallback(lib):
+    if lib.scrg_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(scrooge_amd.ScroogeError) as e:
+        scrooge_amd.Aligner(0)
+    assert e.value.status == api.SCRG_ERR_NO_DEVICE
+
+
+def test_product_does_not_reference_oracle():
+    """The shipped path must never import, link or load anything under oracle/."""
+    pkg = os.path.join(ROOT, "scrooge_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", "Makefile")):
+                txt = open(os.path.join(d, f), errors="ignore").read()
+                assert "oracle" not in txt.lower(), os.path.join(d, f)

@@ -1,0 +1,116 @@
+"""GPU parity: the HIP path, called through the C ABI, against the committed
+reference fixtures and against the oracle on seeded random inputs.  Bit-exact:
+edit distance and CIGAR text must be identical."""
+import numpy as np
+import pytest
+
+from scrooge_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+MAPPINGS = [8, 64, 16, 4, 32]     # lanes per pair; 64 = one pair per wavefront
+
+
+def _check(alns, eds, cigars, tag=""):
+    assert len(alns) == len(eds)
+    bad = [k for k, (a, e, c) in enumerate(zip(alns, eds, cigars))
+           if a.edit_distance != e or a.cigar != c]
+    assert not bad, "%s: %d/%d pairs differ, first %d: got (%d,%s) want (%d,%s)" % (
+        tag, len(bad), len(eds), bad[0], alns[bad[0]].edit_distance, alns[bad[0]].cigar[:80],
+        eds[bad[0]], cigars[bad[0]][:80])
+
+
+@pytest.mark.parametrize("g", MAPPINGS)
+def test_golden_pairs(aligner, golden_pairs, g):
+    cases = golden_pairs["cases"]
+    alns = aligner.align_pairs([c["text"] for c in cases], [c["read"] for c in cases],
+                               lanes_per_pair=g)
+    _check(alns, [c["ed"] for c in cases], [c["cigar"] for c in cases], "golden g=%d" % g)
+
+
+@pytest.mark.parametrize("g", [8, 64])
+def test_golden_mapping(aligner, golden_mapping, g):
+    gm = golden_mapping
+    alns = aligner.align_mapping(gm["genome"], gm["reads"], gm["candidates"], lanes_per_pair=g)
+    _check(alns, gm["ed"], gm["cigar"], "mapping g=%d" % g)
+
+
+def test_known_edit_distances(aligner):
+    """src/tests.cu:224-271 (cpu/gpu_algorithm_correctness_test)"""
+    ref = "AAAACCCCGGGGTTTT"
+    reads = ["CCCCGGGGTTTTAAAA", "AAAACCCCGGGGTTTT", "ACCCCGG", "AAAAGGGGAAAATTTT",
+             "AAAAAAAAAAAAAAAA", "ATTAACGCCTTT", "TTTTAAAACCCCGGGGTTTTAAAA", "",
+             "T" * 44 + "AAAACCCCGGGGTTTTAAAA"]
+    alns = aligner.align_mapping(ref, reads, [[0]] * len(reads))
+    assert [a.edit_distance for a in alns] == [8, 0, 3, 8, 12, 6, 8, 0, 48]
+
+
+def test_library_example(aligner):
+    """src/library_example.cu:11-31"""
+    alns = aligner.align_pairs(["ACGTACGT"], ["ACGTACG"])
+    assert alns == [("7=", 0)]
+
+
+def test_empty_batch_and_empty_reads(aligner):
+    assert aligner.align_pairs([], []) == []
+    alns = aligner.align_pairs(["ACGT", "", ""], ["", "", "ACG"])
+    assert alns[0] == ("", 0) and alns[1] == ("", 0)
+    assert alns[2] == ("3I", 3)
+
+
+def test_non_acgt_is_an_error(aligner):
+    import scrooge_amd
+    with pytest.raises(scrooge_amd.ScroogeError) as e:
+        aligner.align_pairs(["ACGTN"], ["ACGT"])
+    assert e.value.status == 2
+
+
+@pytest.mark.parametrize("g", MAPPINGS)
+@pytest.mark.parametrize("lds_rows", [16, 3])
+def test_random_vs_oracle(aligner, oracle, g, lds_rows):
+    """Seeded random pairs incl. unrelated sequences (window distances up to 64, which
+    exercises the HBM spill rows when lds_rows is small)."""
+    rng = np.random.Generator(np.random.PCG64(1000 + g))
+    T, Q = [], []
+    for _ in range(300):
+        T.append(synth.random_seq(int(rng.integers(0, 260)), rng))
+        Q.append(synth.random_seq(int(rng.integers(0, 260)), rng))
+    for prof, L, n in [("ont", 1500, 40), ("pacbio15", 3000, 12), ("illumina", 150, 200)]:
+        t, q = synth.make_pairs(n, L, prof, seed=g + L)
+        T += t
+        Q += q
+    eds, cigars, _, _ = oracle.align(T, Q, threads=8)
+    alns = aligner.align_pairs(T, Q, lanes_per_pair=g, lds_rows=lds_rows)
+    _check(alns, eds, cigars, "random g=%d rows=%d" % (g, lds_rows))
+
+
+@pytest.mark.parametrize("sort", [0, 1])
+def test_result_order_is_input_order(aligner, oracle, sort):
+    t, q = [], []
+    for L in [50, 900, 10, 400, 0, 77, 1300]:
+        a, b = synth.make_pairs(3, max(L, 1), "ont", seed=L + 1)
+        t += a
+        q += [x[:L] for x in b]
+    eds, cigars, _, _ = oracle.align(t, q)
+    _check(aligner.align_pairs(t, q, sort_by_length=sort), eds, cigars, "order sort=%d" % sort)
+
+
+@pytest.mark.parametrize("w,o", [(32, 17), (64, 40), (48, 24), (17, 3)])
+def test_other_window_settings(aligner, oracle, w, o):
+    """W/O are runtime parameters here (compile-time macros in the reference,
+    src/genasm_cpu.cpp:22-35); the short-read setting of the paper is W=32, O=17."""
+    t, q = synth.make_pairs(60, 200, "ont", seed=w * 100 + o)
+    rng = np.random.Generator(np.random.PCG64(w))
+    for _ in range(60):
+        t.append(synth.random_seq(int(rng.integers(0, 120)), rng))
+        q.append(synth.random_seq(int(rng.integers(0, 120)), rng))
+    eds, cigars, _, _ = oracle.align(t, q, W=w, O=o)
+    _check(aligner.align_pairs(t, q, W=w, O=o), eds, cigars, "W=%d O=%d" % (w, o))
+    _check(aligner.align_pairs(t, q, W=w, O=o, lanes_per_pair=64), eds, cigars, "W=%d O=%d g64" % (w, o))
+
+
+def test_long_reads_10kb(aligner, oracle):
+    t, q = synth.make_pairs(64, 10000, "ont", seed=42)
+    eds, cigars, st, _ = oracle.align(t, q, threads=8)
+    _check(aligner.align_pairs(t, q), eds, cigars, "10kb")
+    _check(aligner.align_pairs(t, q, lanes_per_pair=64), eds, cigars, "10kb g64")
