@@ -1,0 +1,329 @@
+#!/usr/bin/env python3
+"""bench.py — aligned pairs/s of the GenASM-DC + GenASM-TB hot path on MI355X.
+
+One "step" = one pass of the align kernel over one batch of synthetic
+PBSIM2-shaped pairs that is already packed and resident in HBM, followed by
+the run compaction and (N > 1) the RCCL gather of edit distances + CIGAR runs
+to rank 0.  Workload at N=1 = BASELINE.json configs[1]: 100k x 10 kb ONT-error
+pairs, W=64, O=33.  N > 1 is weak scaling (every rank aligns its own 100k
+pairs; no data-path collective other than the result gather).
+
+    python bench.py --gpus 1 --steps 5 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        --master-port 29500 bench.py --gpus 8 --steps 5 --warmup 1
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: HBM3E 8 TB/s
+VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9   # 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6 T int32 lane-ops/s
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pairs", type=int, default=100000, help="pairs per GPU")
+    ap.add_argument("--read-len", type=int, default=10000)
+    ap.add_argument("--profile", default="ont", help="error profile (scrooge_amd.synth.PROFILES)")
+    ap.add_argument("--lanes", type=int, default=0, help="lanes per pair (0 = library default)")
+    ap.add_argument("--lds-rows", type=int, default=0)
+    ap.add_argument("--waves-per-cu", type=int, default=0)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
+    ap.add_argument("--seed", type=int, default=42)
+    return ap.parse_args()
+
+
+def usable_cores():
+    """CPUs this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return n
+
+
+def device_pairs(torch, n, read_len, err, ratio, seed, device, slack=0.15, chunk=8192):
+    """Synthetic pairs built on the GPU: uniform random text; read = text prefix with
+    i.i.d. per-base errors split sub:ins:del by `ratio` (scrooge_amd.synth.mutate, on device).
+
+    Returns (ascii uint8 [n, row_bytes], text_words, read_words, text_len): every row holds
+    the text in a 32-byte-aligned slot followed by the read in a 32-byte-aligned slot,
+    zero padded — the staging layout scrg_pack_planar expects."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    text_len = int(read_len * (1.0 + slack) + 0.999999)
+    src_len = max(text_len, int(read_len * 1.08) + 64)
+    tw, rw = (text_len + 31) // 32, (read_len + 31) // 32
+    out = torch.zeros((n, (tw + rw) * 32), dtype=torch.uint8, device=device)
+    lut = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=device)
+    r = torch.tensor(ratio, dtype=torch.float64)
+    r = (r / r.sum()).cumsum(0)
+    for b0 in range(0, n, chunk):
+        b = min(chunk, n - b0)
+        src = torch.randint(0, 4, (b, src_len), generator=g, device=device, dtype=torch.uint8)
+        u = torch.rand((b, src_len), generator=g, device=device)
+        v = torch.rand((b, src_len), generator=g, device=device)
+        is_err = u < err
+        sub = is_err & (v < float(r[0]))
+        ins = is_err & (v >= float(r[0])) & (v < float(r[1]))
+        dele = is_err & (v >= float(r[1]))
+        base = src.clone()
+        delta = torch.randint(1, 4, (b, src_len), generator=g, device=device, dtype=torch.uint8)
+        base = torch.where(sub, (base + delta) & 3, base)
+        emit = torch.ones((b, src_len), dtype=torch.int64, device=device)
+        emit[ins] = 2
+        emit[dele] = 0
+        pos = emit.cumsum(1) - emit
+        read = torch.zeros((b, read_len + 1), dtype=torch.uint8, device=device)   # last column = dump
+        # inserted random base first, then the (possibly substituted) source base
+        ins_base = torch.randint(0, 4, (b, src_len), generator=g, device=device, dtype=torch.uint8)
+        p_ins = torch.where(ins, pos, torch.full_like(pos, read_len)).clamp_(max=read_len)
+        read.scatter_(1, p_ins, ins_base)
+        p_keep = torch.where(emit > 0, pos + emit - 1, torch.full_like(pos, read_len)).clamp_(max=read_len)
+        read.scatter_(1, p_keep, base)
+        total = emit.sum(1)
+        assert int(total.min()) >= read_len, "source segment too short for the requested read length"
+        out[b0:b0 + b, :text_len] = lut[src[:, :text_len].long()]
+        out[b0:b0 + b, tw * 32: tw * 32 + read_len] = lut[read[:, :read_len].long()]
+        del src, u, v, emit, pos, read, p_ins, p_keep, base, delta, ins_base
+    return out, tw, rw, text_len
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    import scrooge_amd
+    from scrooge_amd import synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)    # nccl == RCCL on ROCm
+
+    scrooge_amd.build_library()
+    al = scrooge_amd.Aligner(local_rank)
+    al.set_stream(torch.cuda.current_stream().cuda_stream)
+    kw = {}
+    if args.lanes:
+        kw["lanes_per_pair"] = args.lanes
+    if args.lds_rows:
+        kw["lds_rows"] = args.lds_rows
+    if args.waves_per_cu:
+        kw["waves_per_cu"] = args.waves_per_cu
+    p = al._params(kw)
+    geom = al.query_launch(**kw)
+
+    # ---------------- synthetic batch, generated and packed on the GPU ----------------
+    n = args.pairs
+    L = args.read_len
+    err, ratio = synth.PROFILES[args.profile]
+    t_gen = time.time()
+    ascii_rows, tw, rw, text_len = device_pairs(torch, n, L, err, ratio, args.seed + 1000 * rank, device)
+    row_words = tw + rw
+    n_words = n * row_words
+    seq = torch.zeros(n_words + scrooge_amd.api.SEQ_PAD_WORDS, dtype=torch.int64, device=device)
+    bad = torch.zeros(1, dtype=torch.int32, device=device)
+    al.pack_planar(ascii_rows.view(-1), seq, bad)
+    torch.cuda.synchronize()
+    assert int(bad.item()) == 0
+    cap = 2 * L + 8                                   # runs per pair slice (genasm_gpu.cu:906-911)
+    idx = torch.arange(n, dtype=torch.int64, device=device)
+    desc = torch.stack([idx * row_words * 32, torch.full_like(idx, text_len),
+                        (idx * row_words + tw) * 32, torch.full_like(idx, L),
+                        idx * cap, torch.full_like(idx, cap)], dim=1).contiguous()
+    runs = torch.empty(n * cap * 2, dtype=torch.uint8, device=device)       # scrg_run = 2 bytes
+    ed = torch.empty(n, dtype=torch.int64, device=device)
+    n_runs = torch.empty(n, dtype=torch.int32, device=device)
+    status = torch.empty(n, dtype=torch.int32, device=device)
+    # keep a host copy of a sample for the CPU leg before freeing the ASCII staging
+    sample_cap = min(n, 20000)
+    sample_rows = ascii_rows[:sample_cap].cpu() if (rank == 0 and world == 1 and args.cpu_seconds > 0) else None
+    del ascii_rows
+    torch.cuda.empty_cache()
+    gen_s = time.time() - t_gen
+
+    # one untimed pass fixes the (deterministic) output sizes
+    al.align_device(n, seq, desc, runs, ed, n_runs, status, **kw)
+    torch.cuda.synchronize()
+    assert int(status.max().item()) == 0, "CIGAR slice overflow"
+    total_runs = int(n_runs.sum().item())
+    dense = torch.empty(total_runs * 2, dtype=torch.uint8, device=device)
+    max_total = total_runs
+    if world > 1:
+        tt = torch.tensor([total_runs], dtype=torch.int64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        max_total = int(tt.item())
+        send_runs = torch.zeros(max_total * 2, dtype=torch.uint8, device=device)
+        if rank == 0:
+            recv_runs = [torch.empty(max_total * 2, dtype=torch.uint8, device=device) for _ in range(world)]
+            recv_ed = [torch.empty(n, dtype=torch.int64, device=device) for _ in range(world)]
+            recv_cnt = [torch.empty(n, dtype=torch.int32, device=device) for _ in range(world)]
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(args.steps)]
+
+    def step(k=None):
+        if k is not None:
+            ev[k][0].record()
+        al.align_device(n, seq, desc, runs, ed, n_runs, status, **kw)
+        if k is not None:
+            ev[k][1].record()
+        cnt64 = n_runs.to(torch.int64)
+        dense_off = torch.cumsum(cnt64, 0) - cnt64
+        if world > 1:
+            al.compact_runs(n, desc, runs, n_runs, dense_off, send_runs)
+            # RCCL gather of scores + CIGAR runs to rank 0 over xGMI
+            dist.gather(ed, recv_ed if rank == 0 else None, dst=0)
+            dist.gather(n_runs, recv_cnt if rank == 0 else None, dst=0)
+            dist.gather(send_runs, recv_runs if rank == 0 else None, dst=0)
+        else:
+            al.compact_runs(n, desc, runs, n_runs, dense_off, dense)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # ---------------- work model for the roofline line ----------------
+    runs_per_pair = total_runs / n
+    # CPU leg: bounded sample, also the source of dc_cells / text_used per pair and a parity check
+    cpu = None
+    dc_cells = tb_steps = text_used = None
+    parity = None
+    if sample_rows is not None:
+        from oracle.pyoracle import Oracle, Reference
+        rows = sample_rows.numpy()
+        texts_all = [rows[i, :text_len].tobytes() for i in range(sample_cap)]
+        reads_all = [rows[i, tw * 32: tw * 32 + L].tobytes() for i in range(sample_cap)]
+        cores = usable_cores()
+        orc = Oracle()
+        cal = min(sample_cap, max(2 * cores, 16))
+        _, _, st, ns = orc.align(texts_all[:cal], reads_all[:cal], threads=cores)
+        dc_cells, tb_steps, text_used = (st["dc_cells"] / cal, st["tb_steps"] / cal, st["text_used"] / cal)
+        rate = cal / (ns * 1e-9)
+        m = int(min(sample_cap, max(cal, rate * args.cpu_seconds)))
+        use_ref = Reference.available()
+        if use_ref:
+            e_cpu, c_cpu, ns = Reference().align(texts_all[:m], reads_all[:m], threads=cores)
+        else:
+            e_cpu, c_cpu, _, ns = orc.align(texts_all[:m], reads_all[:m], threads=cores)
+        cpu = {"value": m / (ns * 1e-9), "unit": "pairs/s", "cores": cores,
+               "kind": "reference" if use_ref else "port",
+               "sample": "first %d of the %d pairs of this workload, kernel-only time (%s), %d OpenMP threads"
+                         % (m, n, "genasm_cpu.cpp:589-591 via oracle/_ref" if use_ref else "oracle/liboracle.so", cores)}
+        # parity of the timed GPU results on the same sample
+        k = min(m, 2000)
+        cnt = n_runs[:k].cpu().tolist()
+        off = (torch.cumsum(n_runs[:k].to(torch.int64), 0) - n_runs[:k].to(torch.int64)).cpu().tolist()
+        d = dense[: 2 * (off[-1] + cnt[-1])].cpu().numpy()
+        ed_h = ed[:k].cpu().tolist()
+        ok = True
+        for i in range(k):
+            seg = d[2 * off[i]: 2 * (off[i] + cnt[i])]
+            cig = "".join("%d%s" % (seg[2 * j], chr(seg[2 * j + 1])) for j in range(cnt[i]))
+            if cig != c_cpu[i] or ed_h[i] != e_cpu[i]:
+                ok = False
+                break
+        parity = {"checked_pairs": k, "bit_exact": ok}
+        assert ok, "GPU result differs from the CPU checker on the bench sample"
+
+    pairs_total = world * n * args.steps
+    value = pairs_total / dt
+    if text_used is None:
+        text_used = L * 1.015
+    bytes_per_pair = (L + 3) // 4 + int(text_used + 3) // 4 + 48 + 8 + 4 + 4 + 2 * runs_per_pair
+    launch_bytes = bytes_per_pair * n
+    achieved = launch_bytes / (kernel_ms * 1e-3) / 1e9
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tf):
+        try:
+            t = json.load(open(tf))
+            if t.get("pairs") == n and t.get("read_len") == L and t.get("profile") == args.profile:
+                traffic = t.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "aligned pairs/s (+ GCUPS) at W=64, 10kb reads; 1/2/4/8 MI355X",
+        "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": "unstructured pairwise: %d x %d bp %s-error pairs per GPU, W=%d O=%d"
+                               % (n, L, args.profile, p.W, p.O),
+                   "pairs_per_gpu": n, "read_len": L, "text_len": text_len, "error_profile": args.profile,
+                   "W": p.W, "O": p.O, "lanes_per_pair": p.lanes_per_pair, "lds_rows": p.lds_rows,
+                   "launch": geom, "step": "align kernel + run compaction" + (" + RCCL gather to rank 0" if world > 1 else "")},
+        "gcups": value * L * L / 1e9,
+        "kernel_ms": kernel_ms,
+        "kernel_pairs_per_s_per_gpu": n / (kernel_ms * 1e-3),
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "kernel": "genasm_align_kernel<%d>" % p.lanes_per_pair,
+                     "algorithmic_bytes_per_pair": bytes_per_pair,
+                     "note": "path is VALU/LDS-bound, not HBM-bound (SURVEY.md §8d); see 'valu'"},
+        "cpu_baseline": cpu,
+        "parity": parity,
+        "gen_seconds": gen_s,
+    }
+    if dc_cells is not None:
+        lane_ops = 14 * dc_cells      # 7 64-bit logic ops per DC cell = 14 int32 lane-ops (genasm_cpu.cpp:247-251)
+        out["valu"] = {"algorithmic_lane_ops_per_pair": lane_ops, "dc_cells_per_pair": dc_cells,
+                       "tb_steps_per_pair": tb_steps,
+                       "achieved": lane_ops * n / (kernel_ms * 1e-3), "peak": VALU_PEAK_LANE_OPS,
+                       "frac": lane_ops * n / (kernel_ms * 1e-3) / VALU_PEAK_LANE_OPS, "unit": "int32 lane-ops/s"}
+        out["bit_cell_gcups"] = value * dc_cells * 64 / 1e9
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -77,9 +77,11 @@ typedef struct scrg_ctx scrg_ctx;
 
 scrg_status scrg_ctx_create(int device, scrg_ctx **out);
 void        scrg_ctx_destroy(scrg_ctx *ctx);
-/* Use a caller-owned hipStream_t (e.g. torch's current stream) instead of the
- * handle's own; pass NULL to go back. */
+/* Enqueue on a caller-owned hipStream_t (e.g. torch's current stream) instead of
+ * the handle's own.  NULL is a valid value: the device's default (null) stream.
+ * scrg_ctx_use_own_stream() goes back to the handle's private stream. */
 scrg_status scrg_ctx_set_stream(scrg_ctx *ctx, void *hip_stream);
+scrg_status scrg_ctx_use_own_stream(scrg_ctx *ctx);
 const char *scrg_last_error(const scrg_ctx *ctx);
 const char *scrg_status_string(scrg_status s);
 /* mirrors genasm_gpu::enabled_algorithm_log (src/genasm_gpu.hpp:6) */

@@ -84,6 +84,7 @@ def load_library():
         "scrg_ctx_create": (C.c_int32, [C.c_int, C.POINTER(vp)]),
         "scrg_ctx_destroy": (None, [vp]),
         "scrg_ctx_set_stream": (C.c_int32, [vp, vp]),
+        "scrg_ctx_use_own_stream": (C.c_int32, [vp]),
         "scrg_last_error": (C.c_char_p, [vp]),
         "scrg_status_string": (C.c_char_p, [C.c_int32]),
         "scrg_set_log": (None, [C.c_int]),
@@ -112,6 +113,7 @@ def load_library():
 
 EXPORTED_SYMBOLS = [
     "scrg_params_default", "scrg_ctx_create", "scrg_ctx_destroy", "scrg_ctx_set_stream",
+    "scrg_ctx_use_own_stream",
     "scrg_last_error", "scrg_status_string", "scrg_set_log", "scrg_device_count",
     "scrg_result_free", "scrg_align_pairs", "scrg_align_mapping", "scrg_pack_planar",
     "scrg_align_device", "scrg_compact_runs", "scrg_ascii_to_twobit", "scrg_query_launch",
@@ -238,7 +240,11 @@ class Aligner:
 
     # -- device-pointer layer (torch tensors as plain device memory) -----------
     def set_stream(self, stream_handle):
+        """stream_handle: a hipStream_t as an integer (0 = the device's null stream)."""
         self._check(self.lib.scrg_ctx_set_stream(self.h, C.c_void_p(stream_handle)))
+
+    def use_own_stream(self):
+        self._check(self.lib.scrg_ctx_use_own_stream(self.h))
 
     def pack_planar(self, ascii_u8, planar_u64, bad_u32):
         n_words = ascii_u8.numel() // 32

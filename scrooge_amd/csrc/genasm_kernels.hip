@@ -97,7 +97,7 @@ __global__ __launch_bounds__(64) void genasm_align_kernel(AlignArgs a)
     const int TBL = a.tb_limit;          // W - O
     const int RB = a.lds_rows;
     const uint32_t slot_stride = (uint32_t)RB * 32u + 1u;          // +1 word: conflict-free slot banks
-    uint32_t* const Rl = lds + slot * slot_stride;                  // R[d][i] at Rl[d*32+i], d < RB
+    const uint32_t lds_slot = slot * slot_stride;                   // R[d][i] at lds[lds_slot + d*32 + i], d < RB
     uint32_t* const Rs = a.spill + ((size_t)blockIdx.x * SLOTS + slot) * (size_t)(SPILL_ROWS * 32);
 
     // mask with bit (first lane of slot s) set for every slot
@@ -190,6 +190,7 @@ __global__ __launch_bounds__(64) void genasm_align_kernel(AlignArgs a)
         const uint32_t goal_bit = m - 1u;
         const uint32_t tb_shift = m > 32u ? m - 32u : 0u;   // DENT: keep the top min(m,32) bits
         const uint32_t col0 = (uint32_t)(t * CPL);
+        bool spilled = false;                      // wave-uniform: some row went to HBM this window
 
         for (int step = 0;; step++) {
             // right neighbour's first column at my row: it finished that row one step ago
@@ -198,9 +199,6 @@ __global__ __launch_bounds__(64) void genasm_align_kernel(AlignArgs a)
             const uint64_t d0mask = (d == 0) ? ~0ull : 0ull;
 
             uint64_t right = rn_cur, tr = rn_prev;
-            const bool st_ok = (d >= 0) && !gdone && (col0 < 32u);
-            const int dr = d < 0 ? 0 : (d < SPILL_ROWS ? d : SPILL_ROWS - 1);
-            uint32_t* const rowp = (dr < RB) ? (Rl + dr * 32 + col0) : (Rs + (size_t)dr * 32 + col0);
 #pragma unroll
             for (int k = CPL - 1; k >= 0; k--) {
                 const uint64_t top = prev[k];
@@ -211,9 +209,28 @@ __global__ __launch_bounds__(64) void genasm_align_kernel(AlignArgs a)
                 tr = top;
                 right = c;
                 prev[k] = c;
-                if (st_ok) rowp[k] = (uint32_t)(c >> tb_shift);
             }
             rn_prev = rn_cur;
+
+            // SENE + DENT store of the row just computed (genasm_cpu.cpp:258-267): columns < 32,
+            // top min(m,32) bits.  Rows < RB live in LDS (plain ds_write, never a flat access);
+            // later rows go to the HBM spill area with L1-bypassing agent-scope stores.
+            const bool st_ok = (d >= 0) && !gdone && (col0 < 32u);
+            if (st_ok && d < RB) {
+                const uint32_t base = lds_slot + (uint32_t)d * 32u + col0;
+#pragma unroll
+                for (int k = 0; k < CPL; k++) lds[base + k] = (uint32_t)(prev[k] >> tb_shift);
+            }
+            if (__any(st_ok && d >= RB)) {
+                if (st_ok && d >= RB) {
+                    uint32_t* const rowp = Rs + (size_t)(d < SPILL_ROWS ? d : SPILL_ROWS - 1) * 32 + col0;
+#pragma unroll
+                    for (int k = 0; k < CPL; k++)
+                        __hip_atomic_store(rowp + k, (uint32_t)(prev[k] >> tb_shift), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                }
+                spilled = true;
+            }
 
             // early termination: column 0 reaches bit m-1 (genasm_cpu.cpp:278-283)
             const bool hit = leader && (d >= 0) && !gdone && (((prev[0] >> goal_bit) & 1ull) == 0ull);
@@ -226,6 +243,10 @@ __global__ __launch_bounds__(64) void genasm_align_kernel(AlignArgs a)
             d++;
             if ((done_mask & leaders) == leaders) break;
         }
+
+        // spilled rows were written by other lanes of this wave: make sure they reached L2
+        // before the traceback reads them back (it reads them with L1-bypassing loads)
+        if (spilled) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
         // ---------------- GenASM-TB, lane-parallel diagonal scan (genasm_cpu.cpp:290-409) ----------------
         {
@@ -264,8 +285,16 @@ __global__ __launch_bounds__(64) void genasm_align_kernel(AlignArgs a)
                         bool ins, del, sub;
                         if (jl + 1 < m) {
                             const uint32_t r = dd - 1;
-                            const uint32_t* rp = (r < (uint32_t)RB) ? (Rl + r * 32 + il) : (Rs + (size_t)r * 32 + il);
-                            const uint32_t w0 = rp[0], w1 = rp[1];
+                            uint32_t w0, w1;
+                            if (r < (uint32_t)RB) {
+                                const uint32_t base = lds_slot + r * 32u + il;
+                                w0 = lds[base];
+                                w1 = lds[base + 1];
+                            } else {
+                                uint32_t* rp = Rs + (size_t)r * 32 + il;
+                                w0 = __hip_atomic_load(rp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                w1 = __hip_atomic_load(rp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
                             const uint32_t bj = mtb - 1 - jl;      // TB_BIT(j), genasm_cpu.cpp:57
                             ins = ((w0 >> (bj - 1)) & 1u) == 0u;
                             del = text_left && (((w1 >> bj) & 1u) == 0u);

@@ -214,7 +214,7 @@ void scrg_ctx_destroy(scrg_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    (void)hipDeviceSynchronize();
     c->counter.release();
     c->spill.release();
     c->h_ascii.release();
@@ -230,7 +230,14 @@ void scrg_ctx_destroy(scrg_ctx* c)
 scrg_status scrg_ctx_set_stream(scrg_ctx* c, void* hip_stream)
 {
     if (!c) return SCRG_ERR_INVALID_ARG;
-    c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+    c->stream = static_cast<hipStream_t>(hip_stream);
+    return SCRG_OK;
+}
+
+scrg_status scrg_ctx_use_own_stream(scrg_ctx* c)
+{
+    if (!c) return SCRG_ERR_INVALID_ARG;
+    c->stream = c->own_stream;
     return SCRG_OK;
 }
 
