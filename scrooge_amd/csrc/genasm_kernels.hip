@@ -69,6 +69,15 @@ __device__ __forceinline__ Planes load_window(const uint64_t* __restrict__ seq, 
     return r;
 }
 
+// 64-bit shift left by one as ONE v_lshlrev_b64 (quarter-rate class, like any 32-bit shift on
+// gfx950); written as asm so the compiler does not split it into lshl + alignbit (two of them)
+__device__ __forceinline__ uint64_t shl1(uint64_t v)
+{
+    uint64_t r;
+    asm("v_lshlrev_b64 %0, 1, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+
 __device__ __forceinline__ uint64_t brev64(uint64_t v)
 {
     return ((uint64_t)__builtin_bitreverse32((uint32_t)v) << 32) | __builtin_bitreverse32((uint32_t)(v >> 32));
@@ -152,96 +161,135 @@ __global__ __launch_bounds__(64) void genasm_align_kernel(AlignArgs a)
         const uint32_t n = (has_pair && ref_idx < text_len) ? min((uint32_t)W, text_len - ref_idx) : 0u;
         const uint32_t m = has_pair ? min((uint32_t)W, read_len - read_idx) : 1u;   // >= 1 for live pairs
 
-        uint64_t M[CPL];      // match mask of my columns: bit b == 0 <=> pattern[m-1-b] == text[col]
+        // Bit layout inside a window ("left-aligned"): pattern character j lives at bit 63-j,
+        // i.e. every bitvector is the reference's (genasm_cpu.cpp:178-198, bit b <-> pattern[m-1-b])
+        // shifted left by s = 64-m with zeros below.  The recurrence is shift-invariant as long as
+        // the low s bits stay zero, the goal bit is always bit 63, and the DENT word (top
+        // min(m,32) bits, genasm_cpu.cpp:200-208) is always the high dword.
+        const uint64_t V = ~0ull << (64u - m);          // valid bits (m >= 1)
+        uint64_t M[CPL];      // match mask of my columns: bit 63-j == 0 <=> pattern[j] == text[col]
         {
             Planes tw = {0, 0}, pw = {0, 0};
             if (has_pair) {
                 tw = load_window(a.seq, text_off + ref_idx);
                 pw = load_window(a.seq, read_off + read_idx);
             }
-            // pattern, reversed so that bit b <-> pattern[m-1-b] (genasm_cpu.cpp:185-189)
-            const uint32_t rs = 64u - m;
-            const uint64_t plo = brev64(pw.lo) >> rs;
-            const uint64_t phi = brev64(pw.hi) >> rs;
-            const uint64_t inval = (m >= 64u) ? 0ull : (~0ull << m);   // bits >= m stay 1 (:180-183)
+            const uint64_t plo = brev64(pw.lo);        // char k of the window -> bit 63-k
+            const uint64_t phi = brev64(pw.hi);
             const uint32_t tlo = (uint32_t)(tw.lo >> (t * CPL));
             const uint32_t thi = (uint32_t)(tw.hi >> (t * CPL));
 #pragma unroll
             for (int k = 0; k < CPL; k++) {
                 const uint64_t sl = (uint64_t)(int64_t)(-(int32_t)((tlo >> k) & 1u));
                 const uint64_t sh = (uint64_t)(int64_t)(-(int32_t)((thi >> k) & 1u));
-                const uint64_t mk = (plo ^ sl) | (phi ^ sh) | inval;
-                // columns at or past n behave as the all-insertions boundary column
-                // (genasm_cpu.cpp:239-245): with an all-ones mask the recurrence
-                // reproduces ones<<d there by itself
-                M[k] = ((uint32_t)(t * CPL + k) < n) ? mk : ~0ull;
+                M[k] = ((plo ^ sl) | (phi ^ sh)) & V;
+            }
+            // columns at or past n behave as the all-insertions boundary column
+            // (genasm_cpu.cpp:239-245): with mask V the recurrence reproduces V<<d there by itself
+            if (__any(n < 64u)) {
+#pragma unroll
+                for (int k = 0; k < CPL; k++)
+                    if ((uint32_t)(t * CPL + k) >= n) M[k] = V;
             }
         }
 
         // ---------------- GenASM-DC, skewed row sweep (genasm_cpu.cpp:210-288) ----------------
-        uint64_t prev[CPL];   // row d-1 of my columns
+        // Lane t runs row d = step-(G-1-t).  Per cell (column k, row d), with the previous row's
+        // entries kept both plain (prev) and pre-shifted (prevs = prev<<1):
+        //   ins & sub & del = prevs[k] & prevs[k+1] & prev[k+1]      (genasm_cpu.cpp:248-250)
+        //   c   = ((R[k+1][d] << 1) | M[k]) & ins & sub & del          (:247, :251)
+        // = two 3-input logic ops per dword (v_bitop3_b32, full rate) + one 64-bit shift.
+        // Row 0 (:232-238) falls out by starting from all-ones stand-ins for "row -1".
+        // Two register sets (A/B) alternate as "previous row" and "current row" so that no
+        // register copies are needed between steps.
+        uint64_t pA[CPL], psA[CPL], pB[CPL], psB[CPL];
 #pragma unroll
-        for (int k = 0; k < CPL; k++) prev[k] = ~0ull;
-        uint64_t rn_prev = ~0ull;                 // R[my last column + 1][d-1]
+        for (int k = 0; k < CPL; k++) pA[k] = psA[k] = pB[k] = psB[k] = ~0ull;
+        uint64_t rnA = ~0ull, rnsA = ~0ull, rnB = ~0ull, rnsB = ~0ull;   // right neighbour column, per set
+        uint64_t bnd = V;                          // virtual column 64 at the current row: V << d
         int d = -(G - 1 - t);                      // my row at step 0
         uint32_t dw = 0;                           // window edit distance once found
         bool gdone = !has_pair;                    // slot finished its sweep
-        uint64_t done_mask = __ballot(!has_pair);  // wave-uniform copy of gdone per slot
-        const uint32_t goal_bit = m - 1u;
-        const uint32_t tb_shift = m > 32u ? m - 32u : 0u;   // DENT: keep the top min(m,32) bits
+        uint64_t done_mask = __ballot(!has_pair);  // wave-uniform: lanes of finished slots
         const uint32_t col0 = (uint32_t)(t * CPL);
+        const bool storer = col0 < 32u;            // DENT: only columns 0..31 are kept (:258-259)
         bool spilled = false;                      // wave-uniform: some row went to HBM this window
+        int step = 0;
 
-        for (int step = 0;; step++) {
+        // one skewed step: reads the row in (pi, psi, rni, rnsi), writes the next one to (po, pso, rno, rnso)
+        auto dc_step = [&](const uint64_t (&pi)[CPL], const uint64_t (&psi)[CPL], const uint64_t rni,
+                           const uint64_t rnsi, uint64_t (&po)[CPL], uint64_t (&pso)[CPL], uint64_t& rno,
+                           uint64_t& rnso) -> bool {
             // right neighbour's first column at my row: it finished that row one step ago
-            uint64_t rn_cur = dpp_from_next64(prev[0]);
-            if (t == G - 1) rn_cur = ones_shl(d);  // virtual column 64 (always >= n)
-            const uint64_t d0mask = (d == 0) ? ~0ull : 0ull;
+            uint64_t rn = dpp_from_next64(pi[0]);
+            const uint64_t bnds = shl1(bnd);
+            if (t == G - 1) rn = bnd;              // last lane: column 64 (always >= n)
+            const uint64_t rns = shl1(rn);
+            bnd = bnds;
 
-            uint64_t right = rn_cur, tr = rn_prev;
+            if (d >= 0) {
+                uint32_t rs_lo = (uint32_t)rns, rs_hi = (uint32_t)(rns >> 32);        // (R[k+1][d]) << 1
+                uint32_t tr_lo = (uint32_t)rni, tr_hi = (uint32_t)(rni >> 32);        // R[k+1][d-1]
+                uint32_t ts_lo = (uint32_t)rnsi, ts_hi = (uint32_t)(rnsi >> 32);      // R[k+1][d-1] << 1
 #pragma unroll
-            for (int k = CPL - 1; k >= 0; k--) {
-                const uint64_t top = prev[k];
-                const uint64_t mat = (right << 1) | M[k];
-                // sub & ins & del = ((tr & top) << 1) & tr ; row 0 has no predecessors
-                const uint64_t x = (((tr & top) << 1) & tr) | d0mask;
-                const uint64_t c = mat & x;
-                tr = top;
-                right = c;
-                prev[k] = c;
-            }
-            rn_prev = rn_cur;
-
-            // SENE + DENT store of the row just computed (genasm_cpu.cpp:258-267): columns < 32,
-            // top min(m,32) bits.  Rows < RB live in LDS (plain ds_write, never a flat access);
-            // later rows go to the HBM spill area with L1-bypassing agent-scope stores.
-            const bool st_ok = (d >= 0) && !gdone && (col0 < 32u);
-            if (st_ok && d < RB) {
-                const uint32_t base = lds_slot + (uint32_t)d * 32u + col0;
-#pragma unroll
-                for (int k = 0; k < CPL; k++) lds[base + k] = (uint32_t)(prev[k] >> tb_shift);
-            }
-            if (__any(st_ok && d >= RB)) {
-                if (st_ok && d >= RB) {
-                    uint32_t* const rowp = Rs + (size_t)(d < SPILL_ROWS ? d : SPILL_ROWS - 1) * 32 + col0;
-#pragma unroll
-                    for (int k = 0; k < CPL; k++)
-                        __hip_atomic_store(rowp + k, (uint32_t)(prev[k] >> tb_shift), __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
+                for (int k = CPL - 1; k >= 0; k--) {
+                    const uint32_t p_lo = (uint32_t)pi[k], p_hi = (uint32_t)(pi[k] >> 32);
+                    const uint32_t q_lo = (uint32_t)psi[k], q_hi = (uint32_t)(psi[k] >> 32);
+                    // ins & sub & del, then (match) & that: 2 x v_bitop3_b32 per dword
+                    const uint32_t x_lo = __builtin_amdgcn_bitop3_b32(q_lo, ts_lo, tr_lo, 0x80);
+                    const uint32_t x_hi = __builtin_amdgcn_bitop3_b32(q_hi, ts_hi, tr_hi, 0x80);
+                    const uint32_t c_lo = __builtin_amdgcn_bitop3_b32(rs_lo, (uint32_t)M[k], x_lo, 0xA8);
+                    const uint32_t c_hi = __builtin_amdgcn_bitop3_b32(rs_hi, (uint32_t)(M[k] >> 32), x_hi, 0xA8);
+                    const uint64_t c = ((uint64_t)c_hi << 32) | c_lo;
+                    const uint64_t cs = shl1(c);
+                    tr_lo = p_lo; tr_hi = p_hi;
+                    ts_lo = q_lo; ts_hi = q_hi;
+                    po[k] = c;
+                    pso[k] = cs;
+                    rs_lo = (uint32_t)cs; rs_hi = (uint32_t)(cs >> 32);
                 }
-                spilled = true;
-            }
+                rno = rn;
+                rnso = rns;
 
-            // early termination: column 0 reaches bit m-1 (genasm_cpu.cpp:278-283)
-            const bool hit = leader && (d >= 0) && !gdone && (((prev[0] >> goal_bit) & 1ull) == 0ull);
-            const uint64_t hits = __ballot(hit);
-            if (!gdone && ((hits >> gbase) & 1ull)) {
-                gdone = true;
-                dw = (uint32_t)(step - (G - 1));
+                // SENE + DENT store of the row just computed (genasm_cpu.cpp:258-267).  Rows < RB
+                // live in LDS (plain ds_write, never a flat access); later rows go to the HBM
+                // spill area with L1-bypassing agent-scope stores.
+                if (storer && !gdone) {
+                    if (d < RB) {
+                        const uint32_t base = lds_slot + (uint32_t)d * 32u + col0;
+#pragma unroll
+                        for (int k = 0; k < CPL; k++) lds[base + k] = (uint32_t)(po[k] >> 32);
+                    } else {
+                        uint32_t* const rowp = Rs + (size_t)(d < SPILL_ROWS ? d : SPILL_ROWS - 1) * 32 + col0;
+#pragma unroll
+                        for (int k = 0; k < CPL; k++)
+                            __hip_atomic_store(rowp + k, (uint32_t)(po[k] >> 32), __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
             }
-            done_mask |= hits;
+            if (__any(storer && !gdone && d >= RB)) spilled = true;
+
+            // early termination: column 0 reaches the goal bit (genasm_cpu.cpp:278-283)
+            const bool hit = leader && (d >= 0) && !gdone && ((int32_t)(po[0] >> 32) >= 0);
+            const uint64_t hits = __ballot(hit);
+            if (hits) {
+                // expand each hit leader bit to its slot's G lanes
+                const uint64_t newly = (G == 64) ? ~0ull
+                    : (((uint64_t)((uint32_t)hits * GMASK)) | ((uint64_t)((uint32_t)(hits >> 32) * GMASK) << 32));
+                if ((newly >> lane) & 1ull) {
+                    gdone = true;
+                    dw = (uint32_t)(step - (G - 1));
+                }
+                done_mask |= newly;
+            }
             d++;
-            if ((done_mask & leaders) == leaders) break;
+            step++;
+            return (done_mask & leaders) == leaders;
+        };
+        for (;;) {
+            if (dc_step(pA, psA, rnA, rnsA, pB, psB, rnB, rnsB)) break;
+            if (dc_step(pB, psB, rnB, rnsB, pA, psA, rnA, rnsA)) break;
         }
 
         // spilled rows were written by other lanes of this wave: make sure they reached L2
@@ -253,7 +301,6 @@ __global__ __launch_bounds__(64) void genasm_align_kernel(AlignArgs a)
             uint32_t i = 0, j = 0, dd = dw;
             uint32_t cur_op = 0, cur_cnt = 0;
             bool act = has_pair;
-            const uint32_t mtb = m < 32u ? m : 32u;       // stored bits per entry
 
             auto push_run = [&](uint32_t op, uint32_t cnt) {
                 if (n_runs < cigar_cap) {
@@ -295,7 +342,7 @@ __global__ __launch_bounds__(64) void genasm_align_kernel(AlignArgs a)
                                 w0 = __hip_atomic_load(rp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 w1 = __hip_atomic_load(rp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             }
-                            const uint32_t bj = mtb - 1 - jl;      // TB_BIT(j), genasm_cpu.cpp:57
+                            const uint32_t bj = 31u - jl;          // TB_BIT(j) (genasm_cpu.cpp:57) in the stored dword
                             ins = ((w0 >> (bj - 1)) & 1u) == 0u;
                             del = text_left && (((w1 >> bj) & 1u) == 0u);
                             sub = text_left && (((w1 >> (bj - 1)) & 1u) == 0u);
