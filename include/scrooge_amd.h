@@ -187,6 +187,13 @@ scrg_status scrg_query_launch(scrg_ctx *ctx, const scrg_params *params,
  * the launch stream (milliseconds); blocks until that launch finished. */
 scrg_status scrg_last_kernel_ms(scrg_ctx *ctx, float *ms);
 
+/* Profiling aid: when params.reserved[1] != 0 the align kernel accumulates
+ * {window rounds, DC sweep steps, TB macro-steps, and shader cycles summed over
+ * wavefronts for fetch / window setup / DC / TB, 0} per launch; this reads them
+ * back (blocks on the stream).  params.reserved[0] holds ablation switches and
+ * must be 0 for correct results. */
+scrg_status scrg_debug_stats(scrg_ctx *ctx, uint64_t out[8]);
+
 #ifdef __cplusplus
 }
 #endif

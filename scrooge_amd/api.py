@@ -102,6 +102,7 @@ def load_library():
         "scrg_ascii_to_twobit": (C.c_int32, [vp, u64, vp, vp, vp, vp, vp, vp]),
         "scrg_query_launch": (C.c_int32, [vp, C.POINTER(Params), i32p, i32p, i32p, i32p]),
         "scrg_last_kernel_ms": (C.c_int32, [vp, C.POINTER(C.c_float)]),
+        "scrg_debug_stats": (C.c_int32, [vp, C.POINTER(C.c_uint64)]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)   # AttributeError if the library lacks a declared symbol
@@ -117,7 +118,7 @@ EXPORTED_SYMBOLS = [
     "scrg_last_error", "scrg_status_string", "scrg_set_log", "scrg_device_count",
     "scrg_result_free", "scrg_align_pairs", "scrg_align_mapping", "scrg_pack_planar",
     "scrg_align_device", "scrg_compact_runs", "scrg_ascii_to_twobit", "scrg_query_launch",
-    "scrg_last_kernel_ms"]
+    "scrg_last_kernel_ms", "scrg_debug_stats"]
 
 
 def _bytes_list(seqs):
@@ -269,6 +270,13 @@ class Aligner:
         ms = C.c_float(0)
         self._check(self.lib.scrg_last_kernel_ms(self.h, C.byref(ms)))
         return float(ms.value)
+
+    def debug_stats(self):
+        out = (C.c_uint64 * 8)()
+        self._check(self.lib.scrg_debug_stats(self.h, out))
+        return {"rounds": int(out[0]), "dc_steps": int(out[1]), "tb_macro_steps": int(out[2]),
+                "cycles_fetch": int(out[3]), "cycles_setup": int(out[4]), "cycles_dc": int(out[5]),
+                "cycles_tb": int(out[6])}
 
     def query_launch(self, **kw):
         a, b, c, d = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()

@@ -26,6 +26,8 @@ struct AlignArgs {
     int32_t W;
     int32_t tb_limit;             // W - O
     int32_t lds_rows;
+    uint64_t* stats;              // optional profiling counters {rounds, DC steps, TB macro-steps}; may be null
+    int32_t debug;                // ablation switches for profiling only (params.reserved[0]); 0 in production
 };
 
 hipError_t launch_align(int lanes_per_pair, const AlignArgs& a, int grid, size_t lds_bytes, hipStream_t s);

@@ -25,6 +25,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "genasm_kernels.h"
 
@@ -67,6 +68,24 @@ __device__ __forceinline__ Planes load_window(const uint64_t* __restrict__ seq, 
     r.lo = (uint64_t)__builtin_amdgcn_alignbit(l1, l0, s) | ((uint64_t)__builtin_amdgcn_alignbit(l2, l1, s) << 32);
     r.hi = (uint64_t)__builtin_amdgcn_alignbit(h1, h0, s) | ((uint64_t)__builtin_amdgcn_alignbit(h2, h1, s) << 32);
     return r;
+}
+
+// minimum of v over the G lanes of a slot, returned in every lane.  G <= 16: butterfly of
+// DPP-modified v_min_u32 (no LDS traffic, no SALU); wider slots finish with xor-shuffles.
+template <int CTRL> __device__ __forceinline__ uint32_t dpp_min(uint32_t v)
+{
+    const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
+    return o < v ? o : v;
+}
+template <int G> __device__ __forceinline__ uint32_t slot_min(uint32_t v)
+{
+    v = dpp_min<0xB1>(v);                    // quad_perm:[1,0,3,2]
+    v = dpp_min<0x4E>(v);                    // quad_perm:[2,3,0,1]
+    if (G >= 8) v = dpp_min<0x141>(v);       // row_half_mirror
+    if (G >= 16) v = dpp_min<0x140>(v);      // row_mirror
+    if (G >= 32) { const uint32_t o = (uint32_t)__shfl_xor((int)v, 16); v = o < v ? o : v; }
+    if (G >= 64) { const uint32_t o = (uint32_t)__shfl_xor((int)v, 32); v = o < v ? o : v; }
+    return v;
 }
 
 // 64-bit shift left by one as ONE v_lshlrev_b64 (quarter-rate class, like any 32-bit shift on
@@ -122,8 +141,12 @@ __global__ __launch_bounds__(64) void genasm_align_kernel(AlignArgs a)
     uint32_t ref_idx = 0, read_idx = 0, n_runs = 0, edits = 0;
     bool overflow = false;
     bool queue_empty = false;            // wave-uniform
+    uint32_t st_rounds = 0, st_steps = 0, st_macro = 0;   // profiling counters (a.stats != nullptr)
+    uint64_t cy_fetch = 0, cy_setup = 0, cy_dc = 0, cy_tb = 0;
+    const bool timing = a.stats != nullptr;
 
     for (;;) {
+        const uint64_t tm0 = timing ? __builtin_readcyclecounter() : 0;
         // ---------------- retire finished pairs, fetch new ones ----------------
         for (;;) {
             const bool fin = has_pair && read_idx >= read_len;
@@ -157,6 +180,7 @@ __global__ __launch_bounds__(64) void genasm_align_kernel(AlignArgs a)
         }
         if (!__any(has_pair)) break;
 
+        const uint64_t tm1 = timing ? __builtin_readcyclecounter() : 0;
         // ---------------- window setup (genasm_cpu.cpp:417-420) ----------------
         const uint32_t n = (has_pair && ref_idx < text_len) ? min((uint32_t)W, text_len - ref_idx) : 0u;
         const uint32_t m = has_pair ? min((uint32_t)W, read_len - read_idx) : 1u;   // >= 1 for live pairs
@@ -209,17 +233,23 @@ __global__ __launch_bounds__(64) void genasm_align_kernel(AlignArgs a)
         uint64_t bnd = V;                          // virtual column 64 at the current row: V << d
         int d = -(G - 1 - t);                      // my row at step 0
         uint32_t dw = 0;                           // window edit distance once found
-        bool gdone = !has_pair;                    // slot finished its sweep
         uint64_t done_mask = __ballot(!has_pair);  // wave-uniform: lanes of finished slots
+        bool all_done = (done_mask & leaders) == leaders;
         const uint32_t col0 = (uint32_t)(t * CPL);
-        const bool storer = col0 < 32u;            // DENT: only columns 0..31 are kept (:258-259)
-        bool spilled = false;                      // wave-uniform: some row went to HBM this window
+        constexpr int ST = (32 + CPL - 1) / CPL;   // lanes 0..ST-1 of a slot own the DENT columns 0..31 (:258-259)
+        // Per-lane thresholds keep the per-step control flow to one compare each:
+        //   rows d < st_limit of a live slot's storer lanes go to LDS,
+        //   a live slot's leader reports a hit when the high dword of column 0 is > hit_thr (= bit 63 clear).
+        int32_t st_limit = (has_pair && t < ST) ? RB : INT32_MIN;
+        int32_t hit_thr = (has_pair && leader) ? -1 : INT32_MAX;
+        uint32_t saddr = lds_slot + col0;          // LDS word index of my columns in row d (once d >= 0)
         int step = 0;
+        const uint64_t tm2 = timing ? __builtin_readcyclecounter() : 0;
 
         // one skewed step: reads the row in (pi, psi, rni, rnsi), writes the next one to (po, pso, rno, rnso)
         auto dc_step = [&](const uint64_t (&pi)[CPL], const uint64_t (&psi)[CPL], const uint64_t rni,
                            const uint64_t rnsi, uint64_t (&po)[CPL], uint64_t (&pso)[CPL], uint64_t& rno,
-                           uint64_t& rnso) -> bool {
+                           uint64_t& rnso) {
             // right neighbour's first column at my row: it finished that row one step ago
             uint64_t rn = dpp_from_next64(pi[0]);
             const uint64_t bnds = shl1(bnd);
@@ -250,137 +280,154 @@ __global__ __launch_bounds__(64) void genasm_align_kernel(AlignArgs a)
                 }
                 rno = rn;
                 rnso = rns;
-
-                // SENE + DENT store of the row just computed (genasm_cpu.cpp:258-267).  Rows < RB
-                // live in LDS (plain ds_write, never a flat access); later rows go to the HBM
-                // spill area with L1-bypassing agent-scope stores.
-                if (storer && !gdone) {
-                    if (d < RB) {
-                        const uint32_t base = lds_slot + (uint32_t)d * 32u + col0;
+                // SENE + DENT store of the row just computed (genasm_cpu.cpp:258-267): plain
+                // ds_write of the high dwords (never a flat access)
+                if (d < st_limit) {
 #pragma unroll
-                        for (int k = 0; k < CPL; k++) lds[base + k] = (uint32_t)(po[k] >> 32);
-                    } else {
-                        uint32_t* const rowp = Rs + (size_t)(d < SPILL_ROWS ? d : SPILL_ROWS - 1) * 32 + col0;
+                    for (int k = 0; k < CPL; k++) lds[saddr + k] = (uint32_t)(po[k] >> 32);
+                }
+                saddr += 32u;
+            }
+            // rows >= RB of a live slot go to the HBM spill area (rare; L1-bypassing agent-scope stores)
+            if (step >= RB + (G - ST)) {
+                if (d >= RB && st_limit > 0) {
+                    uint32_t* const rowp = Rs + (size_t)(d < SPILL_ROWS ? d : SPILL_ROWS - 1) * 32 + col0;
 #pragma unroll
-                        for (int k = 0; k < CPL; k++)
-                            __hip_atomic_store(rowp + k, (uint32_t)(po[k] >> 32), __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_AGENT);
-                    }
+                    for (int k = 0; k < CPL; k++)
+                        __hip_atomic_store(rowp + k, (uint32_t)(po[k] >> 32), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
-            if (__any(storer && !gdone && d >= RB)) spilled = true;
 
             // early termination: column 0 reaches the goal bit (genasm_cpu.cpp:278-283)
-            const bool hit = leader && (d >= 0) && !gdone && ((int32_t)(po[0] >> 32) >= 0);
-            const uint64_t hits = __ballot(hit);
+            const uint64_t hits = __ballot((int32_t)(po[0] >> 32) > hit_thr);
             if (hits) {
                 // expand each hit leader bit to its slot's G lanes
                 const uint64_t newly = (G == 64) ? ~0ull
                     : (((uint64_t)((uint32_t)hits * GMASK)) | ((uint64_t)((uint32_t)(hits >> 32) * GMASK) << 32));
                 if ((newly >> lane) & 1ull) {
-                    gdone = true;
+                    st_limit = INT32_MIN;
+                    hit_thr = INT32_MAX;
                     dw = (uint32_t)(step - (G - 1));
                 }
                 done_mask |= newly;
+                all_done = (done_mask & leaders) == leaders;
             }
             d++;
             step++;
-            return (done_mask & leaders) == leaders;
         };
-        for (;;) {
-            if (dc_step(pA, psA, rnA, rnsA, pB, psB, rnB, rnsB)) break;
-            if (dc_step(pB, psB, rnB, rnsB, pA, psA, rnA, rnsA)) break;
+        if (!(a.debug & 2)) {
+            while (!all_done) {
+                dc_step(pA, psA, rnA, rnsA, pB, psB, rnB, rnsB);
+                if (all_done) break;
+                dc_step(pB, psB, rnB, rnsB, pA, psA, rnA, rnsA);
+            }
         }
+        const uint64_t tm3 = timing ? __builtin_readcyclecounter() : 0;
+        st_rounds++;
+        st_steps += (uint32_t)step;
+        // some row of a live slot was spilled if the sweep ran past row RB on a storer lane
+        const bool spilled = step > RB + (G - ST);
 
         // spilled rows were written by other lanes of this wave: make sure they reached L2
         // before the traceback reads them back (it reads them with L1-bypassing loads)
         if (spilled) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
         // ---------------- GenASM-TB, lane-parallel diagonal scan (genasm_cpu.cpp:290-409) ----------------
-        {
+        // The walk (i,j,d) is replicated in the slot's lanes.  In one macro-step lane l evaluates the
+        // reference's per-step decision (:319-370) for the cell l steps down the current diagonal,
+        // assuming every earlier step was a match; a DPP min-reduction over the slot finds the first
+        // lane whose cell is not a plain match, so a whole '=' run plus the edit that ends it retire
+        // per macro-step.  The common variant touches only LDS (no vmcnt waits in the loop); the
+        // variant that may read spilled rows from HBM is a separate instantiation.
+        auto traceback = [&](auto spill_tag) {
+            constexpr bool SPILL = decltype(spill_tag)::value;
             uint32_t i = 0, j = 0, dd = dw;
             uint32_t cur_op = 0, cur_cnt = 0;
             bool act = has_pair;
+            const uint32_t jlim = min(m, (uint32_t)TBL);       // j < m && j < W-O  (:307-310)
 
-            auto push_run = [&](uint32_t op, uint32_t cnt) {
-                if (n_runs < cigar_cap) {
-                    if (leader) a.runs[cigar_off + n_runs] = (uint16_t)(cnt | (op << 8));
-                } else {
-                    overflow = true;
+            auto emit = [&](bool en, uint32_t op, uint32_t cnt) {
+                const bool same = (op == cur_op);
+                if (en && !same && cur_cnt != 0) {             // run ended: write {count, op}
+                    if (n_runs < cigar_cap) {
+                        if (leader) a.runs[cigar_off + n_runs] = (uint16_t)(cur_cnt | (cur_op << 8));
+                    } else {
+                        overflow = true;
+                    }
+                    n_runs++;
                 }
-                n_runs++;
-            };
-            auto emit = [&](uint32_t op, uint32_t cnt) {
-                if (op == cur_op) {
-                    cur_cnt += cnt;
-                } else {
-                    if (cur_cnt) push_run(cur_op, cur_cnt);
-                    cur_op = op;
-                    cur_cnt = cnt;
-                }
+                cur_cnt = en ? (same ? cur_cnt + cnt : cnt) : cur_cnt;
+                cur_op = en ? op : cur_op;
             };
 
             while (__any(act)) {
+                st_macro++;
                 const uint32_t il = i + t, jl = j + t;
-                const bool pos_ok = (jl < m) && (il < (uint32_t)TBL) && (jl < (uint32_t)TBL);
-                uint32_t ev = 0;          // 0 '=', 1 'I', 2 'D', 3 'X', 4 stop
-                if (act) {
-                    if (!pos_ok) {
-                        ev = 4;
-                    } else if (dd > 0) {
-                        const bool text_left = il < n;
-                        bool ins, del, sub;
-                        if (jl + 1 < m) {
-                            const uint32_t r = dd - 1;
-                            uint32_t w0, w1;
-                            if (r < (uint32_t)RB) {
-                                const uint32_t base = lds_slot + r * 32u + il;
-                                w0 = lds[base];
-                                w1 = lds[base + 1];
-                            } else {
-                                uint32_t* rp = Rs + (size_t)r * 32 + il;
-                                w0 = __hip_atomic_load(rp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                w1 = __hip_atomic_load(rp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            }
-                            const uint32_t bj = 31u - jl;          // TB_BIT(j) (genasm_cpu.cpp:57) in the stored dword
-                            ins = ((w0 >> (bj - 1)) & 1u) == 0u;
-                            del = text_left && (((w1 >> bj) & 1u) == 0u);
-                            sub = text_left && (((w1 >> (bj - 1)) & 1u) == 0u);
-                        } else {                                   // last pattern character (:336-343)
-                            ins = true;
-                            del = false;
-                            sub = text_left;
-                        }
-                        ev = ins ? 1u : (del ? 2u : (sub ? 3u : 0u));
-                    }
-                }
-                const uint64_t nm = __ballot(ev != 0);
-                const uint32_t gm = (uint32_t)(nm >> gbase) & GMASK;
-                uint32_t first;
-                if (G == 64) {
-                    first = nm ? (uint32_t)__builtin_ctzll(nm) : (uint32_t)G;
+                const bool pos_ok = (jl < jlim) && (il < (uint32_t)TBL);
+                const bool room = dd > 0;                       // d_limit, :313
+                const uint32_t r = room ? dd - 1 : 0u;
+                const uint32_t ic = il < 30u ? il : 30u;
+                uint32_t w0, w1;                                // R[i][d-1], R[i+1][d-1] (DENT dwords)
+                if (SPILL && r >= (uint32_t)RB) {
+                    uint32_t* rp = Rs + (size_t)r * 32 + ic;
+                    w0 = __hip_atomic_load(rp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    w1 = __hip_atomic_load(rp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 } else {
-                    first = gm ? (uint32_t)__builtin_ctz(gm) : (uint32_t)G;
+                    const uint32_t base = lds_slot + (r < (uint32_t)RB ? r : 0u) * 32u + ic;
+                    w0 = lds[base];
+                    w1 = lds[base + 1];
                 }
-                uint32_t evf = (uint32_t)__shfl((int)ev, gbase + (int)(first < (uint32_t)G ? first : 0u));
-                if (first == (uint32_t)G) evf = 0;
+                // pattern char j sits at bit 31-j of a stored dword: TB_BIT(j+1) = 30-j, TB_BIT(j) = 31-j
+                const uint32_t sh = 30u - (jl < 30u ? jl : 30u);
+                const bool last = (jl + 1u == m);                // last pattern character, :336-343
+                const bool tl = il < n;                          // !i_limit, :312
+                const bool ins = room && (last || ((w0 >> sh) & 1u) == 0u);
+                const bool del = room && tl && !last && ((w1 >> (sh + 1u)) & 1u) == 0u;
+                const bool sub = room && tl && (last || ((w1 >> sh) & 1u) == 0u);
+                uint32_t ev = ins ? 1u : (del ? 2u : (sub ? 3u : 0u));     // priority I, D, X, = (:346-370)
+                ev = pos_ok ? ev : 4u;                           // 4 = the window's walk ends here
+                if (a.debug & 1) ev = pos_ok ? 0u : 4u;
+                const uint32_t key = (act && ev) ? (((uint32_t)t << 3) | ev) : 0xffffu;
+                const uint32_t kmin = slot_min<G>(key);
+                const bool none = kmin == 0xffffu;
+                const uint32_t n_eq = none ? (uint32_t)G : (kmin >> 3);
+                const uint32_t evf = none ? 0u : (kmin & 7u);
+
+                emit(act && n_eq != 0u, '=', n_eq);
+                emit(act && evf >= 1u && evf <= 3u, evf == 1u ? 'I' : (evf == 2u ? 'D' : 'X'), 1u);
                 if (act) {
-                    if (first) emit('=', first);
-                    i += first;
-                    j += first;
-                    if (evf == 1) { emit('I', 1); j++; dd--; }
-                    else if (evf == 2) { emit('D', 1); i++; dd--; }
-                    else if (evf == 3) { emit('X', 1); i++; j++; dd--; }
-                    else if (evf == 4) { act = false; }
+                    i += n_eq + ((evf == 2u || evf == 3u) ? 1u : 0u);
+                    j += n_eq + ((evf == 1u || evf == 3u) ? 1u : 0u);
+                    dd -= (evf >= 1u && evf <= 3u) ? 1u : 0u;
+                    act = evf != 4u;
                 }
             }
+            emit(has_pair, 0u, 0u);                              // per-window flush (:400-403)
             if (has_pair) {
-                if (cur_cnt) push_run(cur_op, cur_cnt);      // per-window flush (:400-403)
                 edits += dw - dd;
                 ref_idx += i;
                 read_idx += j;
             }
+        };
+        if (spilled) traceback(std::true_type{});
+        else traceback(std::false_type{});
+        if (timing) {
+            const uint64_t tm4 = __builtin_readcyclecounter();
+            cy_fetch += tm1 - tm0;
+            cy_setup += tm2 - tm1;
+            cy_dc += tm3 - tm2;
+            cy_tb += tm4 - tm3;
         }
+    }
+    if (a.stats && lane == 0) {
+        atomicAdd((unsigned long long*)&a.stats[0], (unsigned long long)st_rounds);
+        atomicAdd((unsigned long long*)&a.stats[1], (unsigned long long)st_steps);
+        atomicAdd((unsigned long long*)&a.stats[2], (unsigned long long)st_macro);
+        atomicAdd((unsigned long long*)&a.stats[3], (unsigned long long)cy_fetch);
+        atomicAdd((unsigned long long*)&a.stats[4], (unsigned long long)cy_setup);
+        atomicAdd((unsigned long long*)&a.stats[5], (unsigned long long)cy_dc);
+        atomicAdd((unsigned long long*)&a.stats[6], (unsigned long long)cy_tb);
     }
 }
 

@@ -117,6 +117,7 @@ struct scrg_ctx {
 
     DevBuf counter;     // work queue head
     DevBuf spill;       // HBM overflow rows of R
+    DevBuf stats;       // profiling counters (params.reserved[1] != 0)
     // staging used by the host-pointer entry points
     HostPinned h_ascii;
     DevBuf d_ascii, d_seq, d_pairs, d_runs, d_ed, d_nruns, d_status, d_bad, d_dense_off, d_dense;
@@ -150,8 +151,8 @@ void scrg_params_default(scrg_params* p)
     p->W = 64;                // src/genasm_cpu.cpp:7
     p->O = 33;                // src/genasm_cpu.cpp:9
     p->lanes_per_pair = 8;
-    p->lds_rows = 16;
-    p->waves_per_cu = 8;
+    p->lds_rows = 13;
+    p->waves_per_cu = 11;
     p->sort_by_length = 1;
 }
 
@@ -217,6 +218,7 @@ void scrg_ctx_destroy(scrg_ctx* c)
     (void)hipDeviceSynchronize();
     c->counter.release();
     c->spill.release();
+    c->stats.release();
     c->h_ascii.release();
     for (DevBuf* b : {&c->d_ascii, &c->d_seq, &c->d_pairs, &c->d_runs, &c->d_ed, &c->d_nruns, &c->d_status,
                       &c->d_bad, &c->d_dense_off, &c->d_dense})
@@ -341,6 +343,13 @@ scrg_status scrg_align_device(scrg_ctx* c, const scrg_params* params, uint64_t n
     a.W = p.W;
     a.tb_limit = p.W - p.O;
     a.lds_rows = p.lds_rows;
+    a.debug = params ? params->reserved[0] : 0;
+    a.stats = nullptr;
+    if (params && params->reserved[1]) {
+        HIP_TRY(c, c->stats.ensure(8 * sizeof(uint64_t)));
+        HIP_TRY(c, hipMemsetAsync(c->stats.p, 0, 8 * sizeof(uint64_t), c->stream));
+        a.stats = c->stats.as<uint64_t>();
+    }
 
     HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));
     HIP_TRY(c, scrg::launch_align(p.lanes_per_pair, a, n_waves, (size_t)lds, c->stream));
@@ -356,6 +365,17 @@ scrg_status scrg_last_kernel_ms(scrg_ctx* c, float* ms)
     if (!c->have_timing) return SCRG_OK;
     HIP_TRY(c, hipEventSynchronize(c->ev_stop));
     HIP_TRY(c, hipEventElapsedTime(ms, c->ev_start, c->ev_stop));
+    return SCRG_OK;
+}
+
+scrg_status scrg_debug_stats(scrg_ctx* c, uint64_t out[8])
+{
+    if (!c || !out) return SCRG_ERR_INVALID_ARG;
+    memset(out, 0, 8 * sizeof(uint64_t));
+    if (!c->stats.p) return SCRG_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(out, c->stats.p, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return SCRG_OK;
 }
 
