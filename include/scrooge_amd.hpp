@@ -1,0 +1,192 @@
+// scrooge_amd.hpp — header-only C++ shim that rebuilds the reference's library
+// surface (src/genasm_gpu.hpp:5-10, data types src/util.hpp:11-46) on top of the
+// C ABI in scrooge_amd.h, so code written against Scrooge's GPU interface
+// compiles against this library by swapping the include and the namespace:
+//
+//     #include "genasm_gpu.hpp"                 ->  #include "scrooge_amd.hpp"
+//     genasm_gpu::align_all(genome, reads)      ->  scrooge_amd::align_all(genome, reads)
+//     genasm_gpu::align_all(texts, queries)     ->  scrooge_amd::align_all(texts, queries)
+//     genasm_gpu::enabled_algorithm_log = false ->  scrooge_amd::enabled_algorithm_log(false)
+//
+// (or define SCROOGE_AMD_AS_GENASM_GPU before including to get a
+// `namespace genasm_gpu` alias and keep the call sites untouched).
+//
+// Semantics kept from the reference: result k belongs to the k-th (read,
+// location) in nested order / the k-th string pair; texts[i] is the target,
+// queries[i] is consumed completely; only Genome_t::content, Read_t::content and
+// CandidateLocation_t::start_in_reference are read (src/genasm_cpu.cpp:508-517);
+// *core_algorithm_ns is the align kernel's device time.  Differences: errors
+// throw std::runtime_error instead of exit()/assert, and the pairwise overload
+// returns all N results (the CPU overload drops odd ones, genasm_cpu.cpp:600-605).
+#pragma once
+
+#include <cstdint>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "scrooge_amd.h"
+
+// The reference declares these types at global scope in src/util.hpp.  They are
+// re-declared here (same member names and order) only when util.hpp has not been
+// included, so a translation unit may include both headers.
+#ifndef SCROOGE_AMD_NO_REFERENCE_TYPES
+#if !defined(SEED_FILE_MAF)   // util.hpp's first macro: its types are already visible if set
+typedef struct Genome {
+    std::map<std::string, long long> chromosome_starts;
+    std::string content;
+} Genome_t;
+
+typedef struct CandidateLocation {
+    std::string read_description;
+    std::string chromosome;
+    long long start_in_chromosome;
+    long long start_in_reference;
+    long long start_of_aligned_region;
+    long long size_of_aligned_region;
+    bool strand;
+} CandidateLocation_t;
+
+typedef struct Read {
+    std::string description;
+    std::string content;
+    std::vector<CandidateLocation_t> locations;
+} Read_t;
+
+typedef struct Alignment {
+    std::string cigar;
+    long long edit_distance;
+} Alignment_t;
+
+typedef struct CigarEntry {
+    uint8_t edit_count;
+    char edit_type;
+} CigarEntry_t;
+#endif
+#endif
+
+namespace scrooge_amd {
+
+// One lazily created handle per (thread, device); released at thread exit.
+class Handle {
+public:
+    explicit Handle(int device = 0)
+    {
+        scrg_status s = scrg_ctx_create(device, &ctx_);
+        if (s != SCRG_OK) throw std::runtime_error(std::string("scrooge_amd: ") + scrg_status_string(s));
+        scrg_params_default(&params_);
+    }
+    ~Handle() { scrg_ctx_destroy(ctx_); }
+    Handle(const Handle&) = delete;
+    Handle& operator=(const Handle&) = delete;
+
+    scrg_ctx* ctx() const { return ctx_; }
+    scrg_params& params() { return params_; }
+
+    std::vector<Alignment_t> align_all(std::vector<std::string>& texts, std::vector<std::string>& queries,
+                                       long long* core_algorithm_ns = nullptr)
+    {
+        if (texts.size() != queries.size())   // reference: assert, genasm_cpu.cpp:559
+            throw std::invalid_argument("scrooge_amd::align_all: texts and queries differ in size");
+        const size_t n = texts.size();
+        std::vector<const char*> tp(n), qp(n);
+        std::vector<uint64_t> tl(n), ql(n);
+        for (size_t i = 0; i < n; i++) {
+            tp[i] = texts[i].data();
+            tl[i] = texts[i].size();
+            qp[i] = queries[i].data();
+            ql[i] = queries[i].size();
+        }
+        scrg_result* r = nullptr;
+        scrg_status s = scrg_align_pairs(ctx_, &params_, n, tp.data(), tl.data(), qp.data(), ql.data(), &r);
+        return collect(s, r, core_algorithm_ns);
+    }
+
+    std::vector<Alignment_t> align_all(Genome_t& reference, std::vector<Read_t>& reads,
+                                       long long* core_algorithm_ns = nullptr)
+    {
+        const size_t nr = reads.size();
+        std::vector<const char*> rp(nr);
+        std::vector<uint64_t> rl(nr), off(nr + 1, 0), starts;
+        for (size_t r = 0; r < nr; r++) {
+            rp[r] = reads[r].content.data();
+            rl[r] = reads[r].content.size();
+            for (const CandidateLocation_t& loc : reads[r].locations) {
+                if (loc.start_in_reference < 0)
+                    throw std::invalid_argument("scrooge_amd::align_all: negative start_in_reference");
+                starts.push_back((uint64_t)loc.start_in_reference);
+            }
+            off[r + 1] = starts.size();
+        }
+        scrg_result* res = nullptr;
+        scrg_status s = scrg_align_mapping(ctx_, &params_, reference.content.data(), reference.content.size(), nr,
+                                           rp.data(), rl.data(), off.data(), starts.data(), &res);
+        return collect(s, res, core_algorithm_ns);
+    }
+
+private:
+    std::vector<Alignment_t> collect(scrg_status s, scrg_result* r, long long* ns)
+    {
+        if (s != SCRG_OK && s != SCRG_ERR_CIGAR_OVERFLOW) {
+            std::string msg = std::string("scrooge_amd: ") + scrg_status_string(s) + " (" + scrg_last_error(ctx_) + ")";
+            scrg_result_free(r);
+            throw std::runtime_error(msg);
+        }
+        std::vector<Alignment_t> out;
+        out.reserve(r->n_pairs);
+        for (uint64_t i = 0; i < r->n_pairs; i++) {
+            const char* b = r->cigar_text + r->cigar_offset[i];
+            out.push_back(Alignment_t{std::string(b, r->cigar_offset[i + 1] - r->cigar_offset[i] - 1),
+                                      (long long)r->edit_distance[i]});
+        }
+        if (ns) *ns = (long long)r->kernel_ns;
+        const bool overflowed = (s == SCRG_ERR_CIGAR_OVERFLOW);
+        scrg_result_free(r);
+        if (overflowed) throw std::runtime_error("scrooge_amd: a pair overflowed its CIGAR slice");
+        return out;
+    }
+
+    scrg_ctx* ctx_ = nullptr;
+    scrg_params params_;
+};
+
+inline Handle& default_handle()
+{
+    thread_local Handle h(0);
+    return h;
+}
+
+inline void enabled_algorithm_log(bool on) { scrg_set_log(on ? 1 : 0); }
+
+// src/genasm_gpu.hpp:7
+inline std::vector<Alignment_t> align_all(Genome_t& reference, std::vector<Read_t>& reads,
+                                          long long* core_algorithm_ns = nullptr)
+{
+    return default_handle().align_all(reference, reads, core_algorithm_ns);
+}
+
+// src/genasm_gpu.hpp:8
+inline std::vector<Alignment_t> align_all(std::vector<std::string>& texts, std::vector<std::string>& queries,
+                                          long long* core_algorithm_ns = nullptr)
+{
+    return default_handle().align_all(texts, queries, core_algorithm_ns);
+}
+
+// Same argument list as the CPU overloads (src/genasm_cpu.hpp:6-7); `threads` is accepted and ignored.
+inline std::vector<Alignment_t> align_all(Genome_t& reference, std::vector<Read_t>& reads, int /*threads*/,
+                                          long long* core_algorithm_ns)
+{
+    return default_handle().align_all(reference, reads, core_algorithm_ns);
+}
+inline std::vector<Alignment_t> align_all(std::vector<std::string>& texts, std::vector<std::string>& queries,
+                                          int /*threads*/, long long* core_algorithm_ns = nullptr)
+{
+    return default_handle().align_all(texts, queries, core_algorithm_ns);
+}
+
+}  // namespace scrooge_amd
+
+#ifdef SCROOGE_AMD_AS_GENASM_GPU
+namespace genasm_gpu = scrooge_amd;
+#endif

@@ -1,0 +1,85 @@
+"""Multi-GPU sharding of a batch of independent pairs.
+
+The path shards embarrassingly: pairs share nothing (src/genasm_cpu.cpp:451-455),
+so there is no data-path collective.  One process per GPU aligns its shard; the
+only exchange is the result gather to rank 0 (edit distances + CIGARs), done
+with torch.distributed — backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in
+the CPU tests.  The reference itself is single-GPU (GPU_ID 0,
+src/genasm_gpu.cu:67); this file is new functionality, not a port.
+
+Partitioning follows what the reference's callers do for load balance
+(src/tests.cu:375-377): order pairs by read length, longest first, then deal
+them round-robin so every rank sees the same length mix.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_plan(read_lens, world):
+    """-> list (per rank) of int64 index arrays into the input batch."""
+    order = np.argsort(-np.asarray(read_lens, dtype=np.int64), kind="stable")
+    return [order[r::world] for r in range(world)]
+
+
+def _device_for_backend(device=None):
+    if device is not None:
+        return device
+    if dist.is_initialized() and dist.get_backend() == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def gather_varlen(payload, dst=0, group=None):
+    """Gather 1-D tensors of different lengths to `dst`.
+
+    RCCL has no gatherv: lengths are all-gathered first, every rank pads to the
+    maximum and one fixed-size gather moves the data.  Returns the list of
+    trimmed tensors on dst, None elsewhere."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    n = torch.tensor([payload.numel()], dtype=torch.int64, device=payload.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n, group=group)
+    sizes = [int(s.item()) for s in sizes]
+    cap = max(max(sizes), 1)
+    send = torch.zeros(cap, dtype=payload.dtype, device=payload.device)
+    send[: payload.numel()] = payload
+    recv = [torch.empty(cap, dtype=payload.dtype, device=payload.device) for _ in range(world)] \
+        if rank == dst else None
+    dist.gather(send, recv, dst=dst, group=group)
+    if rank != dst:
+        return None
+    return [recv[r][: sizes[r]] for r in range(world)]
+
+
+def align_pairs_sharded(aligner, texts, queries, dst=0, group=None, device=None, **params):
+    """Every rank passes the full batch; rank r aligns plan[r] with `aligner`
+    (anything with the Aligner.align_pairs signature) and the results are
+    gathered to `dst`, which returns the alignments in input order
+    (list of (cigar, edit_distance)); other ranks return None."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    device = _device_for_backend(device)
+    plan = shard_plan([len(q) for q in queries], world)
+    mine = plan[rank]
+    local = aligner.align_pairs([texts[i] for i in mine], [queries[i] for i in mine], **params)
+
+    ed = torch.tensor([a[1] for a in local], dtype=torch.int64, device=device)
+    blob = b"\n".join(a[0].encode() for a in local)
+    cig = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(device) if blob else \
+        torch.zeros(0, dtype=torch.uint8, device=device)
+
+    eds = gather_varlen(ed, dst=dst, group=group)
+    cigs = gather_varlen(cig, dst=dst, group=group)
+    if rank != dst:
+        return None
+    out = [None] * len(texts)
+    for r in range(world):
+        e = eds[r].cpu().tolist()
+        c = bytes(cigs[r].cpu().numpy().tobytes()).decode().split("\n") if len(plan[r]) else []
+        if len(plan[r]) and len(c) != len(plan[r]):
+            raise RuntimeError("rank %d returned %d CIGARs for %d pairs" % (r, len(c), len(plan[r])))
+        for k, i in enumerate(plan[r]):
+            out[int(i)] = (c[k], e[k])
+    return out

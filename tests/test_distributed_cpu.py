@@ -1,0 +1,88 @@
+"""world_size-2 gloo test of the N>1 path: shard plan, per-rank alignment,
+variable-length gather to rank 0, restoration of input order.  The per-rank
+aligner here is a stand-in backed by the CPU oracle (tests only): what is under
+test is the sharding/gather logic, which is the same code the GPU ranks run
+with backend nccl (RCCL)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from scrooge_amd import distributed as sd
+from scrooge_amd import synth
+
+
+class OracleAligner:
+    def __init__(self):
+        from oracle.pyoracle import Oracle
+        self.o = Oracle()
+
+    def align_pairs(self, texts, queries, **kw):
+        if not texts:
+            return []
+        eds, cigars, _, _ = self.o.align(texts, queries, W=kw.get("W", 64), O=kw.get("O", 33))
+        return list(zip(cigars, eds))
+
+
+def _batch():
+    rng = np.random.Generator(np.random.PCG64(5))
+    T, Q = [], []
+    for L in [300, 40, 0, 1200, 77, 5, 640, 0, 90, 333, 1000]:
+        t, q = synth.make_pairs(1, max(L, 1), "ont", seed=L + 3)
+        T.append(t[0])
+        Q.append(q[0][:L])
+    return T, Q
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        T, Q = _batch()
+        res = sd.align_pairs_sharded(OracleAligner(), T, Q, dst=0)
+        if rank == 0:
+            q.put(res)
+        else:
+            assert res is None
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_shard_plan_is_a_balanced_partition():
+    lens = [5, 100, 7, 100, 3, 50, 50, 1]
+    plan = sd.shard_plan(lens, 3)
+    allidx = sorted(int(i) for p in plan for i in p)
+    assert allidx == list(range(len(lens)))
+    sums = [sum(lens[int(i)] for i in p) for p in plan]
+    assert max(sums) - min(sums) <= max(lens)
+    assert lens[int(plan[0][0])] == 100      # longest first
+
+
+@pytest.mark.timeout(180)
+def test_two_rank_gather_restores_input_order():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=150)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    T, Q = _batch()
+    want = OracleAligner().align_pairs(T, Q)
+    assert res == want
