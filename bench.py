@@ -162,7 +162,7 @@ def main():
     al.pack_planar(ascii_rows.view(-1), seq, bad)
     torch.cuda.synchronize()
     assert int(bad.item()) == 0
-    cap = 2 * L + 8                                   # runs per pair slice (genasm_gpu.cu:906-911)
+    cap = (2 * L + 8 + 15) // 16 * 16                 # runs per pair slice (genasm_gpu.cu:906-911), 32-byte pieces
     idx = torch.arange(n, dtype=torch.int64, device=device)
     desc = torch.stack([idx * row_words * 32, torch.full_like(idx, text_len),
                         (idx * row_words + tw) * 32, torch.full_like(idx, L),
@@ -184,16 +184,10 @@ def main():
     assert args.ablate or int(status.max().item()) == 0, "CIGAR slice overflow"
     total_runs = int(n_runs.sum().item())
     dense = torch.empty(total_runs * 2, dtype=torch.uint8, device=device)
-    max_total = total_runs
+    gather = None
     if world > 1:
-        tt = torch.tensor([total_runs], dtype=torch.int64, device=device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        max_total = int(tt.item())
-        send_runs = torch.zeros(max_total * 2, dtype=torch.uint8, device=device)
-        if rank == 0:
-            recv_runs = [torch.empty(max_total * 2, dtype=torch.uint8, device=device) for _ in range(world)]
-            recv_ed = [torch.empty(n, dtype=torch.int64, device=device) for _ in range(world)]
-            recv_cnt = [torch.empty(n, dtype=torch.int32, device=device) for _ in range(world)]
+        from scrooge_amd.distributed import ResultGather
+        gather = ResultGather(n, total_runs, device, dst=0)
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(args.steps)]
@@ -207,11 +201,8 @@ def main():
         cnt64 = n_runs.to(torch.int64)
         dense_off = torch.cumsum(cnt64, 0) - cnt64
         if world > 1:
-            al.compact_runs(n, desc, runs, n_runs, dense_off, send_runs)
-            # RCCL gather of scores + CIGAR runs to rank 0 over xGMI
-            dist.gather(ed, recv_ed if rank == 0 else None, dst=0)
-            dist.gather(n_runs, recv_cnt if rank == 0 else None, dst=0)
-            dist.gather(send_runs, recv_runs if rank == 0 else None, dst=0)
+            al.compact_runs(n, desc, runs, n_runs, dense_off, gather.send_runs)
+            gather(ed, n_runs)         # RCCL gather of scores + CIGAR runs to rank 0 over xGMI
         else:
             al.compact_runs(n, desc, runs, n_runs, dense_off, dense)
 

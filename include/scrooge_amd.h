@@ -151,8 +151,9 @@ typedef struct scrg_pair_desc {
     uint64_t text_len;
     uint64_t read_off;
     uint64_t read_len;
-    uint64_t cigar_off;   /* first run of this pair's slice, in scrg_run units */
-    uint64_t cigar_cap;   /* slice capacity in runs */
+    uint64_t cigar_off;   /* first run of this pair's slice, in scrg_run units; multiple of 16 */
+    uint64_t cigar_cap;   /* slice capacity in runs; multiple of 16 (runs leave the GPU in
+                             aligned 32-byte pieces), d_runs itself 32-byte aligned */
 } scrg_pair_desc;
 
 /* Aligns n_pairs problems.  Outputs: d_edit_distance[n], d_n_runs[n],

@@ -13,7 +13,7 @@ row_words = tw + rw
 seq = torch.zeros(n * row_words + 4, dtype=torch.int64, device=dev)
 bad = torch.zeros(1, dtype=torch.int32, device=dev)
 al.pack_planar(rows.view(-1), seq, bad); torch.cuda.synchronize()
-cap = 2 * L + 8
+cap = (2 * L + 8 + 15) // 16 * 16
 idx = torch.arange(n, dtype=torch.int64, device=dev)
 desc = torch.stack([idx * row_words * 32, torch.full_like(idx, text_len), (idx * row_words + tw) * 32,
                     torch.full_like(idx, L), idx * cap, torch.full_like(idx, cap)], dim=1).contiguous()

@@ -107,10 +107,11 @@ __device__ __forceinline__ uint64_t brev64(uint64_t v)
 // ----------------------------------------------------------------------------
 
 template <int G>
-__global__ __launch_bounds__(64) void genasm_align_kernel(AlignArgs a)
+__global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(AlignArgs a)
 {
     constexpr int CPL = 64 / G;          // text columns per lane
     constexpr int SLOTS = 64 / G;        // pairs per wavefront
+    constexpr uint32_t OBUF_DWORDS = 8;  // CIGAR runs leave the CU in aligned 32-byte pieces
     constexpr uint32_t GMASK = (G == 32) ? 0xffffffffu : ((G == 64) ? 0xffffffffu : ((1u << (G & 31)) - 1u));
 
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -124,8 +125,11 @@ __global__ __launch_bounds__(64) void genasm_align_kernel(AlignArgs a)
     const int W = a.W;
     const int TBL = a.tb_limit;          // W - O
     const int RB = a.lds_rows;
+    // LDS: [SLOTS x 8 dwords of CIGAR staging][SLOTS x (RB rows x 32 dwords + 1)]
+    const uint32_t obuf = (uint32_t)slot * OBUF_DWORDS;            // 16 runs (32 B) staged per slot
     const uint32_t slot_stride = (uint32_t)RB * 32u + 1u;          // +1 word: conflict-free slot banks
-    const uint32_t lds_slot = slot * slot_stride;                   // R[d][i] at lds[lds_slot + d*32 + i], d < RB
+    const uint32_t lds_slot = SLOTS * OBUF_DWORDS + slot * slot_stride;   // R[d][i] at lds[lds_slot + d*32 + i], d < RB
+    uint16_t* const lds16 = reinterpret_cast<uint16_t*>(lds);
     uint32_t* const Rs = a.spill + ((size_t)blockIdx.x * SLOTS + slot) * (size_t)(SPILL_ROWS * 32);
 
     // mask with bit (first lane of slot s) set for every slot
@@ -150,10 +154,18 @@ __global__ __launch_bounds__(64) void genasm_align_kernel(AlignArgs a)
         // ---------------- retire finished pairs, fetch new ones ----------------
         for (;;) {
             const bool fin = has_pair && read_idx >= read_len;
-            if (fin && leader) {
-                a.ed[pair] = (int64_t)edits;
-                a.n_runs[pair] = n_runs;
-                a.status[pair] = overflow ? 1u : 0u;
+            if (fin) {
+                // write out the runs still staged in LDS (the slice is a multiple of 16 runs long, so
+                // rounding the tail up to whole dwords stays inside it)
+                const uint32_t done = n_runs < cigar_cap ? n_runs : cigar_cap;
+                const uint32_t rem = done & 15u;
+                uint32_t* const dst = reinterpret_cast<uint32_t*>(a.runs + cigar_off + (done - rem));
+                for (uint32_t k = (uint32_t)t; 2u * k < rem; k += (uint32_t)G) dst[k] = lds[obuf + k];
+                if (leader) {
+                    a.ed[pair] = (int64_t)edits;
+                    a.n_runs[pair] = n_runs;
+                    a.status[pair] = overflow ? 1u : 0u;
+                }
             }
             has_pair = has_pair && !fin;
             const bool want = !has_pair && !queue_empty;
@@ -291,11 +303,18 @@ __global__ __launch_bounds__(64) void genasm_align_kernel(AlignArgs a)
             // rows >= RB of a live slot go to the HBM spill area (rare; L1-bypassing agent-scope stores)
             if (step >= RB + (G - ST)) {
                 if (d >= RB && st_limit > 0) {
+                    // plain (L2-resident) stores; the traceback reads them back with L1-bypassing loads
+                    // after an s_waitcnt vmcnt(0)
                     uint32_t* const rowp = Rs + (size_t)(d < SPILL_ROWS ? d : SPILL_ROWS - 1) * 32 + col0;
+                    if (CPL % 4 == 0) {
 #pragma unroll
-                    for (int k = 0; k < CPL; k++)
-                        __hip_atomic_store(rowp + k, (uint32_t)(po[k] >> 32), __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
+                        for (int k = 0; k < CPL; k += 4)
+                            *reinterpret_cast<uint4*>(rowp + k) = make_uint4((uint32_t)(po[k] >> 32), (uint32_t)(po[k + 1] >> 32),
+                                                                             (uint32_t)(po[(k + 2) % CPL] >> 32), (uint32_t)(po[(k + 3) % CPL] >> 32));
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < CPL; k++) rowp[k] = (uint32_t)(po[k] >> 32);
+                    }
                 }
             }
 
@@ -349,9 +368,13 @@ __global__ __launch_bounds__(64) void genasm_align_kernel(AlignArgs a)
 
             auto emit = [&](bool en, uint32_t op, uint32_t cnt) {
                 const bool same = (op == cur_op);
-                if (en && !same && cur_cnt != 0) {             // run ended: write {count, op}
+                if (en && !same && cur_cnt != 0) {             // run ended: stage {count, op}
                     if (n_runs < cigar_cap) {
-                        if (leader) a.runs[cigar_off + n_runs] = (uint16_t)(cur_cnt | (cur_op << 8));
+                        if (leader) lds16[2u * obuf + (n_runs & 15u)] = (uint16_t)(cur_cnt | (cur_op << 8));
+                        if ((n_runs & 15u) == 15u && !(a.debug & 4)) {   // 16 runs complete: one 32-byte store per slot
+                            uint32_t* const dst = reinterpret_cast<uint32_t*>(a.runs + cigar_off + (n_runs - 15u));
+                            for (uint32_t k = (uint32_t)t; k < OBUF_DWORDS; k += (uint32_t)G) dst[k] = lds[obuf + k];
+                        }
                     } else {
                         overflow = true;
                     }

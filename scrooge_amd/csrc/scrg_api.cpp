@@ -273,7 +273,8 @@ static bool resolve_params(const scrg_params* in, scrg_params* p)
 static size_t lds_bytes_for(const scrg_params& p)
 {
     const size_t slots = 64 / p.lanes_per_pair;
-    return slots * ((size_t)p.lds_rows * 32 + 1) * sizeof(uint32_t);
+    // CIGAR staging (8 dwords per slot) + R rows (+1 dword per slot against bank conflicts)
+    return slots * (8 + (size_t)p.lds_rows * 32 + 1) * sizeof(uint32_t);
 }
 
 scrg_status scrg_query_launch(scrg_ctx* c, const scrg_params* params, int32_t* n_waves, int32_t* pairs_per_wave,
@@ -510,7 +511,7 @@ scrg_status run_batch(scrg_ctx* c, const scrg_params& p, std::vector<SeqRef>& se
         d.read_len = q.read_len;
         d.cigar_off = arena;
         // same bound as the reference's GPU list sizing (2*read_len, genasm_gpu.cu:906-911)
-        d.cigar_cap = 2 * q.read_len + 8;
+        d.cigar_cap = (2 * q.read_len + 8 + 15) & ~(uint64_t)15;   // slices are whole 32-byte pieces
         arena += d.cigar_cap;
     }
     if (n == 0) {

