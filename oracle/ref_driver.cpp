@@ -94,3 +94,29 @@ int ref_align_mapping(const char *genome, uint64_t genome_len,
 }
 
 }
+
+/* ---- the reference's read-mapping front door (src/util.cpp), for tests of scrg_job_load ---- */
+#include <algorithm>
+#include <fstream>
+
+extern "C" int ref_dump_job(const char *genome_fa, const char *fastq, const char *seeds, const char *out_path)
+{
+    /* same preparation as the reference's perf tests, src/tests.cu:339-355: load, attach seeds,
+     * drop reverse-strand candidates; one line per read: name, sequence, forward start_in_reference list */
+    try {
+        Genome_t genome = read_genome(genome_fa);
+        std::vector<Read_t> reads;
+        read_fastq_and_seed_locations(genome, fastq, seeds, reads);
+        std::ofstream o(out_path);
+        o << "genome\t" << genome.content << "\n";
+        for (Read_t &r : reads) {
+            o << r.description << "\t" << r.content << "\t";
+            for (CandidateLocation_t &l : r.locations)
+                if (l.strand) o << l.start_in_reference << ",";
+            o << "\n";
+        }
+    } catch (const std::exception &e) {
+        return 1;
+    }
+    return 0;
+}

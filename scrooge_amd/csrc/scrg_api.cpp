@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "genasm_kernels.h"
+#include "../../include/scrooge_amd_io.h"
 
 namespace {
 
@@ -428,7 +429,17 @@ struct SeqRef {
     const char* p;
     uint64_t len;
     uint64_t word_off;   // first planar word of this sequence
+    bool revcomp = false;   // stage the reverse complement (reverse-strand candidates)
 };
+
+inline char complement_base(char c)
+{
+    switch (c) {
+    case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A';
+    case 'a': return 't'; case 'c': return 'g'; case 'g': return 'c'; case 't': return 'a';
+    default: return c;   // left as is: the pack kernel reports it as a bad base
+    }
+}
 
 struct Problem {         // one (text, read) problem in caller order
     uint64_t text_off, text_len, read_off, read_len;   // base offsets into the planar array
@@ -468,7 +479,9 @@ scrg_status run_batch(scrg_ctx* c, const scrg_params& p, std::vector<SeqRef>& se
             const SeqRef& q = seqs[s];
             char* dst = h + q.word_off * 32;
             const uint64_t span = ((q.len + 31) / 32) * 32;
-            if (q.len) memcpy(dst, q.p, q.len);
+            if (q.len && !q.revcomp) memcpy(dst, q.p, q.len);
+            if (q.len && q.revcomp)
+                for (uint64_t k = 0; k < q.len; k++) dst[k] = complement_base(q.p[q.len - 1 - k]);
             if (span > q.len) memset(dst + q.len, 0, span - q.len);
         });
     }
@@ -646,11 +659,11 @@ scrg_status scrg_align_pairs(scrg_ctx* c, const scrg_params* params, uint64_t n_
         if ((text_lens[i] && !texts[i]) || (query_lens[i] && !queries[i]))
             return c->fail(SCRG_ERR_INVALID_ARG, "null sequence pointer");
         if (query_lens[i] > 0x7fffffffull) return c->fail(SCRG_ERR_INVALID_ARG, "read longer than 2^31-1");
-        seqs[2 * i] = {texts[i], text_lens[i], w};
+        seqs[2 * i] = {texts[i], text_lens[i], w, false};
         probs[i].text_off = w * 32;
         probs[i].text_len = text_lens[i];
         w += (text_lens[i] + 31) / 32;
-        seqs[2 * i + 1] = {queries[i], query_lens[i], w};
+        seqs[2 * i + 1] = {queries[i], query_lens[i], w, false};
         probs[i].read_off = w * 32;
         probs[i].read_len = query_lens[i];
         w += (query_lens[i] + 31) / 32;
@@ -658,9 +671,10 @@ scrg_status scrg_align_pairs(scrg_ctx* c, const scrg_params* params, uint64_t n_
     return run_batch(c, p, seqs, w, probs, out);
 }
 
-scrg_status scrg_align_mapping(scrg_ctx* c, const scrg_params* params, const char* genome, uint64_t genome_len,
-                               uint64_t n_reads, const char* const* reads, const uint64_t* read_lens,
-                               const uint64_t* cand_offsets, const uint64_t* cand_start, scrg_result** out)
+scrg_status scrg_align_mapping_stranded(scrg_ctx* c, const scrg_params* params, const char* genome,
+                                        uint64_t genome_len, uint64_t n_reads, const char* const* reads,
+                                        const uint64_t* read_lens, const uint64_t* cand_offsets,
+                                        const uint64_t* cand_start, const uint8_t* cand_reverse, scrg_result** out)
 {
     if (!c || !out) return SCRG_ERR_INVALID_ARG;
     *out = nullptr;
@@ -672,28 +686,53 @@ scrg_status scrg_align_mapping(scrg_ctx* c, const scrg_params* params, const cha
     if (n_pairs > 0xfffffff0ull) return c->fail(SCRG_ERR_INVALID_ARG, "too many pairs");
     if (n_pairs && !cand_start) return c->fail(SCRG_ERR_INVALID_ARG, "null candidate array");
 
-    // genome and every read are packed exactly once (README.md:83 of the reference asks for this)
-    std::vector<SeqRef> seqs(1 + n_reads);
+    // genome and every read are packed exactly once (README.md:83 of the reference asks for this);
+    // a read with reverse-strand candidates is additionally staged reverse-complemented, once
+    std::vector<SeqRef> seqs;
+    seqs.reserve(1 + n_reads);
     std::vector<Problem> probs(n_pairs);
     uint64_t w = 0;
-    seqs[0] = {genome, genome_len, 0};
+    seqs.push_back({genome, genome_len, 0, false});
     w += (genome_len + 31) / 32;
     for (uint64_t r = 0; r < n_reads; r++) {
         if (read_lens[r] && !reads[r]) return c->fail(SCRG_ERR_INVALID_ARG, "null read pointer");
         if (read_lens[r] > 0x7fffffffull) return c->fail(SCRG_ERR_INVALID_ARG, "read longer than 2^31-1");
         if (cand_offsets[r + 1] < cand_offsets[r]) return c->fail(SCRG_ERR_INVALID_ARG, "cand_offsets not monotone");
-        seqs[1 + r] = {reads[r], read_lens[r], w};
+        bool any_fwd = false, any_rev = false;
+        for (uint64_t k = cand_offsets[r]; k < cand_offsets[r + 1]; k++) {
+            if (cand_reverse && cand_reverse[k]) any_rev = true;
+            else any_fwd = true;
+        }
+        const uint64_t words = (read_lens[r] + 31) / 32;
+        uint64_t fwd_off = 0, rev_off = 0;
+        if (any_fwd || !any_rev) {
+            seqs.push_back({reads[r], read_lens[r], w, false});
+            fwd_off = w * 32;
+            w += words;
+        }
+        if (any_rev) {
+            seqs.push_back({reads[r], read_lens[r], w, true});
+            rev_off = w * 32;
+            w += words;
+        }
         for (uint64_t k = cand_offsets[r]; k < cand_offsets[r + 1]; k++) {
             if (cand_start[k] > genome_len) return c->fail(SCRG_ERR_INVALID_ARG, "candidate past end of genome");
             // text = genome suffix from start_in_reference (genasm_cpu.cpp:512-514)
             probs[k].text_off = cand_start[k];
             probs[k].text_len = genome_len - cand_start[k];
-            probs[k].read_off = w * 32;
+            probs[k].read_off = (cand_reverse && cand_reverse[k]) ? rev_off : fwd_off;
             probs[k].read_len = read_lens[r];
         }
-        w += (read_lens[r] + 31) / 32;
     }
     return run_batch(c, p, seqs, w, probs, out);
+}
+
+scrg_status scrg_align_mapping(scrg_ctx* c, const scrg_params* params, const char* genome, uint64_t genome_len,
+                               uint64_t n_reads, const char* const* reads, const uint64_t* read_lens,
+                               const uint64_t* cand_offsets, const uint64_t* cand_start, scrg_result** out)
+{
+    return scrg_align_mapping_stranded(c, params, genome, genome_len, n_reads, reads, read_lens, cand_offsets,
+                                       cand_start, nullptr, out);
 }
 
 }  // extern "C"

@@ -17,8 +17,8 @@ def lib():
     return scrooge_amd.load_library()
 
 
-def declared_symbols():
-    src = open(os.path.join(ROOT, "include", "scrooge_amd.h")).read()
+def declared_symbols(header="scrooge_amd.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(scrg_[a-z_0-9]+)\s*\(", src)))
 
@@ -29,6 +29,14 @@ def test_header_symbols_exported(lib):
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(api.EXPORTED_SYMBOLS) == names
+
+
+def test_io_header_symbols_exported(lib):
+    from scrooge_amd import io as sio
+    names = declared_symbols("scrooge_amd_io.h")
+    for n in names:
+        assert hasattr(lib, n), n
+    assert sorted(sio.IO_SYMBOLS) == names
 
 
 def test_defaults_match_reference_knobs(lib):
