@@ -33,6 +33,15 @@ __global__ void __launch_bounds__(64) NAME(uint32_t* out, uint64_t* cyc) {      
 #define I_CNDMASK(n) "v_cndmask_b32 %" #n ", %" #n ", %8, vcc\n"
 #define I_CNDMASK64(n) "v_cndmask_b32_e64 %" #n ", %" #n ", %8, s[20:21]\n"
 #define I_ANDS(n) "v_and_b32 %" #n ", s20, %" #n "\n"
+#define I_MIN(n) "v_min_u32 %" #n ", %" #n ", %8\n"
+#define I_FFBH(n) "v_ffbh_u32 %" #n ", %" #n "\n"
+#define I_NOT(n) "v_not_b32 %" #n ", %" #n "\n"
+#define I_BFEU(n) "v_bfe_u32 %" #n ", %" #n ", 3, 2\n"
+#define I_ASHR(n) "v_ashrrev_i32 %" #n ", 31, %" #n "\n"
+#define I_LSHR(n) "v_lshrrev_b32 %" #n ", %8, %" #n "\n"
+#define I_MINDPP(n) "v_min_u32_dpp %" #n ", %8, %" #n " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+#define I_SUBREV(n) "v_subrev_u32 %" #n ", %8, %" #n "\n"
+#define I_MAXI(n) "v_max_i32 %" #n ", %" #n ", %8\n"
 #define I_SUB(n) "v_sub_u32 %" #n ", %" #n ", %8\n"
 #define I_LSHLADD(n) "v_lshl_add_u32 %" #n ", %" #n ", 1, %8\n"
 #define I_MBCNT(n) "v_mbcnt_lo_u32_b32 %" #n ", %8, %" #n "\n"
@@ -59,6 +68,14 @@ KERNEL(k_add, A8(I_ADD))
 KERNEL(k_cnd64, asm volatile("s_mov_b64 s[20:21], 0x5555" ::: "s20","s21"); A8(I_CNDMASK64))
 KERNEL(k_ands, asm volatile("s_mov_b64 s[20:21], 0x5555" ::: "s20","s21"); A8(I_ANDS))
 KERNEL(k_sub, A8(I_SUB))
+KERNEL(k_min, A8(I_MIN))
+KERNEL(k_ffbh, A8(I_FFBH))
+KERNEL(k_not, A8(I_NOT))
+KERNEL(k_bfeu, A8(I_BFEU))
+KERNEL(k_ashr, A8(I_ASHR))
+KERNEL(k_lshr, A8(I_LSHR))
+KERNEL(k_mindpp, A8(I_MINDPP))
+KERNEL(k_maxi, A8(I_MAXI))
 KERNEL(k_lshladd, A8(I_LSHLADD))
 KERNEL(k_mbcnt, A8(I_MBCNT))
 KERNEL(k_perm, A8(I_PERM))
@@ -106,11 +123,11 @@ int main() {
     int cus = p.multiProcessorCount;
     printf("device %s, %d CUs, clock %d kHz\n", p.name, cus, p.clockRate);
     std::vector<Entry> es = {{"v_and_b32", k_and}, {"v_xor_b32", k_xor}, {"v_or3_b32", k_or3}, {"v_lshl_or_b32", k_lshlor}, {"v_alignbit_b32", k_align},
-        {"v_and_or_b32", k_andor}, {"v_bitop3_b32", k_bitop3}, {"v_cndmask_b32", k_cndmask}, {"v_add_u32", k_add}, {"v_cndmask_e64 sgpr", k_cnd64}, {"v_and_b32 sgpr", k_ands}, {"v_sub_u32", k_sub}, {"v_lshl_add_u32", k_lshladd}, {"v_mbcnt_lo", k_mbcnt}, {"v_perm_b32", k_perm}, {"v_fma_f32", k_fma},
+        {"v_and_or_b32", k_andor}, {"v_bitop3_b32", k_bitop3}, {"v_cndmask_b32", k_cndmask}, {"v_add_u32", k_add}, {"v_cndmask_e64 sgpr", k_cnd64}, {"v_and_b32 sgpr", k_ands}, {"v_sub_u32", k_sub}, {"v_min_u32", k_min}, {"v_ffbh_u32", k_ffbh}, {"v_not_b32", k_not}, {"v_bfe_u32", k_bfeu}, {"v_ashrrev_i32", k_ashr}, {"v_lshrrev_b32 vgpr", k_lshr}, {"v_min_u32_dpp", k_mindpp}, {"v_max_i32", k_maxi}, {"v_lshl_add_u32", k_lshladd}, {"v_mbcnt_lo", k_mbcnt}, {"v_perm_b32", k_perm}, {"v_fma_f32", k_fma},
         {"v_mov_dpp wave_shl", k_dpp}, {"v_mov_dpp row_shl", k_dpprow}, {"v_lshlrev_b32", k_lshl}, {"v_bfe_i32", k_bfe}, {"v_bfrev_b32", k_bfrev},
         {"v_mov_b32", k_mov}, {"v_cmp_lt_i32", k_cmp}, {"v_lshlrev_b64", k_lshl64}, {"v_xor_b32 dependent", k_and_dep}};
     uint32_t* out; uint64_t* cyc;
-    for (int wps : {2, 3}) {            // waves per SIMD
+    for (int wps : {2}) {            // waves per SIMD
         int blocks = cus * 4 * wps;
         hipMalloc(&out, (size_t)blocks * 64 * 4); hipMalloc(&cyc, (size_t)blocks * 8);
         hipMemset(out, 0, (size_t)blocks * 64 * 4);

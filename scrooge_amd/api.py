@@ -53,12 +53,15 @@ class Result(C.Structure):
 
 
 def library_path():
-    return os.path.join(HERE, "libscrooge_amd.so")
+    # SCRG_LIB selects another build of the same library (kernel A/B experiments)
+    return os.environ.get("SCRG_LIB") or os.path.join(HERE, "libscrooge_amd.so")
 
 
 def build_library(force=False):
     """Compile the HIP kernels + host code for gfx950 (hipcc cross-compiles without a GPU)."""
     so = library_path()
+    if os.environ.get("SCRG_LIB"):
+        return so
     src_dir = os.path.join(HERE, "csrc")
     srcs = [os.path.join(src_dir, f) for f in os.listdir(src_dir)] + \
         [os.path.join(HERE, "..", "include", "scrooge_amd.h")]

@@ -106,3 +106,49 @@ def test_ascii_to_twobit_reference_layout(aligner):
     assert got[: len(b"".join(want))] == b"".join(want)
     assert got[len(b"".join(want)):] == b"\xee" * 8      # nothing written past the end
     assert int(bad.item()) == 0
+
+
+def test_cigar_slice_overflow_is_reported_not_overrun(aligner, oracle):
+    """Device-pointer API with deliberately tiny CIGAR slices: the pair's status flags the overflow,
+    n_runs still counts every run, nothing is written outside the slice, edit distance stays exact."""
+    import torch
+    import scrooge_amd
+    dev = torch.device("cuda", 0)
+    t, q = synth.make_pairs(6, 800, "ont", seed=31)
+    eds, cigars, _, _ = oracle.align(t, q)
+    tw, rw = (len(t[0]) + 31) // 32, (800 + 31) // 32
+    rows = np.zeros((6, (tw + rw) * 32), dtype=np.uint8)
+    for k in range(6):
+        rows[k, :len(t[k])] = np.frombuffer(t[k], dtype=np.uint8)
+        rows[k, tw * 32: tw * 32 + 800] = np.frombuffer(q[k], dtype=np.uint8)
+    ascii_t = torch.from_numpy(rows).to(dev)
+    seq = torch.zeros(6 * (tw + rw) + scrooge_amd.api.SEQ_PAD_WORDS, dtype=torch.int64, device=dev)
+    bad = torch.zeros(1, dtype=torch.int32, device=dev)
+    aligner.set_stream(0)
+    try:
+        aligner.pack_planar(ascii_t.view(-1), seq, bad)
+        caps = [16, 32, 4096, 16, 48, 4096]                      # multiples of 16; 3 of them far too small
+        offs = np.cumsum([0] + [c + 16 for c in caps])[:-1]       # 16-run guard band after every slice
+        desc = torch.tensor([[k * (tw + rw) * 32, len(t[k]), (k * (tw + rw) + tw) * 32, 800, int(offs[k]), caps[k]]
+                             for k in range(6)], dtype=torch.int64, device=dev)
+        total = int(offs[-1] + caps[-1] + 16)
+        runs = torch.full((total * 2,), 0xAB, dtype=torch.uint8, device=dev)
+        ed = torch.zeros(6, dtype=torch.int64, device=dev)
+        nr = torch.zeros(6, dtype=torch.int32, device=dev)
+        st = torch.zeros(6, dtype=torch.int32, device=dev)
+        aligner.align_device(6, seq, desc, runs, ed, nr, st)
+        torch.cuda.synchronize()
+    finally:
+        aligner.use_own_stream()
+    n_true = [len([c for c in cg if not c.isdigit()]) for cg in cigars]
+    assert ed.cpu().tolist() == eds
+    assert nr.cpu().tolist() == n_true
+    assert st.cpu().tolist() == [1 if n_true[k] > caps[k] else 0 for k in range(6)]
+    assert sum(st.cpu().tolist()) == 4
+    h = runs.cpu().numpy()
+    for k in range(6):
+        guard = h[2 * (offs[k] + caps[k]): 2 * (offs[k] + caps[k] + 16)]
+        assert (guard == 0xAB).all(), "pair %d wrote past its slice" % k
+        if n_true[k] <= caps[k]:
+            seg = h[2 * offs[k]: 2 * (offs[k] + n_true[k])]
+            assert "".join("%d%s" % (seg[2 * j], chr(seg[2 * j + 1])) for j in range(n_true[k])) == cigars[k]
