@@ -2,6 +2,7 @@
 import ctypes as C
 import os
 import subprocess
+import sys
 from collections import namedtuple
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -77,6 +78,14 @@ def load_library():
     if _LIB is not None:
         return _LIB
     so = library_path()
+    # PyTorch-ROCm ships its own libamdhip64.so; whichever HIP runtime is loaded first serves the whole
+    # process.  If this library pulled in /opt/rocm's copy first, a later `import torch` finds no GPU.
+    # So when torch is installed, let it load its runtime before us (SCRG_NO_TORCH_PRELOAD=1 skips this).
+    if "torch" not in sys.modules and not os.environ.get("SCRG_NO_TORCH_PRELOAD"):
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     if not os.path.exists(so):
         raise ScroogeError(SCRG_ERR_NO_DEVICE,
                            "%s not built; run scrooge_amd.build_library() (needs hipcc)" % so)
