@@ -229,7 +229,7 @@ def main():
         st = al.debug_stats()
         st["steps_per_round"] = st["dc_steps"] / max(1, st["rounds"])
         st["macro_per_round"] = st["tb_macro_steps"] / max(1, st["rounds"])
-        for k in ("fetch", "setup", "dc", "tb"):
+        for k in ("fetch", "setup", "dc", "tb", "tb_loop"):
             st["cyc_per_round_" + k] = st["cycles_" + k] / max(1, st["rounds"])
         print("stats(last launch):", st, file=sys.stderr)
     if rank != 0:

@@ -288,7 +288,7 @@ class Aligner:
         self._check(self.lib.scrg_debug_stats(self.h, out))
         return {"rounds": int(out[0]), "dc_steps": int(out[1]), "tb_macro_steps": int(out[2]),
                 "cycles_fetch": int(out[3]), "cycles_setup": int(out[4]), "cycles_dc": int(out[5]),
-                "cycles_tb": int(out[6])}
+                "cycles_tb": int(out[6]), "cycles_tb_loop": int(out[7])}
 
     def query_launch(self, **kw):
         a, b, c, d = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()

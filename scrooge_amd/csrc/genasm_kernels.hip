@@ -70,6 +70,23 @@ __device__ __forceinline__ Planes load_window(const uint64_t* __restrict__ seq, 
     return r;
 }
 
+// Conditions as 0 / ~0 masks.  Written as asm / intrinsics so that the optimiser cannot turn them
+// back into v_cmp + v_cndmask (both half rate on gfx950; v_ashrrev, v_sub and v_bitop3 are full rate).
+__device__ __forceinline__ uint32_t neg_mask(uint32_t x)      // ~0 iff (int32)x < 0
+{
+    uint32_t r;
+    asm("v_ashrrev_i32 %0, 31, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+__device__ __forceinline__ uint32_t nz_mask(uint32_t x)       // ~0 iff x != 0, for x < 2^31
+{
+    return neg_mask(0u - x);
+}
+template <int TT> __device__ __forceinline__ uint32_t bitop3(uint32_t a, uint32_t b, uint32_t c)
+{
+    return __builtin_amdgcn_bitop3_b32(a, b, c, TT);
+}
+
 // minimum of v over the G lanes of a slot, returned in every lane.  G <= 16: butterfly of
 // DPP-modified v_min_u32 (no LDS traffic, no SALU); wider slots finish with xor-shuffles.
 template <int CTRL> __device__ __forceinline__ uint32_t dpp_min(uint32_t v)
@@ -111,7 +128,7 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
 {
     constexpr int CPL = 64 / G;          // text columns per lane
     constexpr int SLOTS = 64 / G;        // pairs per wavefront
-    constexpr uint32_t OBUF_DWORDS = 8;  // CIGAR runs leave the CU in aligned 32-byte pieces
+    constexpr uint32_t OBUF_DWORDS = 16; // CIGAR runs leave the CU in aligned 32-byte pieces (16 runs) out of a 32-run ring
     constexpr uint32_t GMASK = (G == 32) ? 0xffffffffu : ((G == 64) ? 0xffffffffu : ((1u << (G & 31)) - 1u));
 
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -125,12 +142,15 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
     const int W = a.W;
     const int TBL = a.tb_limit;          // W - O
     const int RB = a.lds_rows;
-    // LDS: [SLOTS x 8 dwords of CIGAR staging][SLOTS x (RB rows x 32 dwords + 1)]
-    const uint32_t obuf = (uint32_t)slot * OBUF_DWORDS;            // 16 runs (32 B) staged per slot
+    // LDS: [SLOTS x 16 dwords of CIGAR staging: two 32-byte pieces][SLOTS x 1 scratch dword]
+    //      [SLOTS x (RB rows x 32 dwords + 1)][8 dwords pad]
+    const uint32_t obuf = (uint32_t)slot * OBUF_DWORDS;            // 32 runs staged per slot, written out 16 at a time
+    const uint32_t scratch_dw = SLOTS * OBUF_DWORDS + (uint32_t)slot;   // target of masked-off staging writes
     const uint32_t slot_stride = (uint32_t)RB * 32u + 1u;          // +1 word: conflict-free slot banks
-    const uint32_t lds_slot = SLOTS * OBUF_DWORDS + slot * slot_stride;   // R[d][i] at lds[lds_slot + d*32 + i], d < RB
+    const uint32_t lds_slot = SLOTS * (OBUF_DWORDS + 1u) + slot * slot_stride;   // R[d][i] at lds[lds_slot + d*32 + i], d < RB
     uint16_t* const lds16 = reinterpret_cast<uint16_t*>(lds);
     uint32_t* const Rs = a.spill + ((size_t)blockIdx.x * SLOTS + slot) * (size_t)(SPILL_ROWS * 32);
+    const uint32_t spill_slot_b = (blockIdx.x * SLOTS + slot) * (uint32_t)(SPILL_ROWS * 32 * 4);   // byte offset of my slot's spill rows
 
     // mask with bit (first lane of slot s) set for every slot
     uint64_t leaders = 0;
@@ -146,7 +166,7 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
     bool overflow = false;
     bool queue_empty = false;            // wave-uniform
     uint32_t st_rounds = 0, st_steps = 0, st_macro = 0;   // profiling counters (a.stats != nullptr)
-    uint64_t cy_fetch = 0, cy_setup = 0, cy_dc = 0, cy_tb = 0;
+    uint64_t cy_fetch = 0, cy_setup = 0, cy_dc = 0, cy_tb = 0, cy_tbloop = 0;
     const bool timing = a.stats != nullptr;
 
     for (;;) {
@@ -159,8 +179,9 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
                 // rounding the tail up to whole dwords stays inside it)
                 const uint32_t done = n_runs < cigar_cap ? n_runs : cigar_cap;
                 const uint32_t rem = done & 15u;
+                const uint32_t piece = ((done >> 4) & 1u) * 8u;          // which half of the ring holds the tail
                 uint32_t* const dst = reinterpret_cast<uint32_t*>(a.runs + cigar_off + (done - rem));
-                for (uint32_t k = (uint32_t)t; 2u * k < rem; k += (uint32_t)G) dst[k] = lds[obuf + k];
+                for (uint32_t k = (uint32_t)t; 2u * k < rem; k += (uint32_t)G) dst[k] = lds[obuf + piece + k];
                 if (leader) {
                     a.ed[pair] = (int64_t)edits;
                     a.n_runs[pair] = n_runs;
@@ -302,19 +323,16 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
             }
             // rows >= RB of a live slot go to the HBM spill area (rare; L1-bypassing agent-scope stores)
             if (step >= RB + (G - ST)) {
-                if (d >= RB && st_limit > 0) {
+                int d_here = d;
+                asm volatile("" : "+v"(d_here));      // keeps the per-lane tests inside this rarely taken scalar branch
+                if (d_here >= RB && st_limit > 0) {
                     // plain (L2-resident) stores; the traceback reads them back with L1-bypassing loads
                     // after an s_waitcnt vmcnt(0)
-                    uint32_t* const rowp = Rs + (size_t)(d < SPILL_ROWS ? d : SPILL_ROWS - 1) * 32 + col0;
-                    if (CPL % 4 == 0) {
+                    // uniform base + 32-bit per-lane byte offset: no 64-bit address or packing registers
+                    const uint32_t off = spill_slot_b + ((uint32_t)(d_here < SPILL_ROWS ? d_here : SPILL_ROWS - 1) * 32u + col0) * 4u;
+                    char* const sb = reinterpret_cast<char*>(a.spill);
 #pragma unroll
-                        for (int k = 0; k < CPL; k += 4)
-                            *reinterpret_cast<uint4*>(rowp + k) = make_uint4((uint32_t)(po[k] >> 32), (uint32_t)(po[k + 1] >> 32),
-                                                                             (uint32_t)(po[(k + 2) % CPL] >> 32), (uint32_t)(po[(k + 3) % CPL] >> 32));
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < CPL; k++) rowp[k] = (uint32_t)(po[k] >> 32);
-                    }
+                    for (int k = 0; k < CPL; k++) *reinterpret_cast<uint32_t*>(sb + off + 4 * k) = (uint32_t)(po[k] >> 32);
                 }
             }
 
@@ -346,7 +364,9 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
         st_rounds++;
         st_steps += (uint32_t)step;
         // some row of a live slot was spilled if the sweep ran past row RB on a storer lane
-        const bool spilled = step > RB + (G - ST);
+        // the traceback reads rows 0..dw-1: it needs the HBM spill rows only if some live slot's window
+        // distance exceeds the LDS rows (the sweep itself overshoots RB far more often than that)
+        const bool spilled = __any(has_pair && dw > (uint32_t)RB);
 
         // spilled rows were written by other lanes of this wave: make sure they reached L2
         // before the traceback reads them back (it reads them with L1-bypassing loads)
@@ -370,10 +390,11 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
                 const bool same = (op == cur_op);
                 if (en && !same && cur_cnt != 0) {             // run ended: stage {count, op}
                     if (n_runs < cigar_cap) {
-                        if (leader) lds16[2u * obuf + (n_runs & 15u)] = (uint16_t)(cur_cnt | (cur_op << 8));
+                        if (leader) lds16[2u * obuf + (n_runs & 31u)] = (uint16_t)(cur_cnt | (cur_op << 8));
                         if ((n_runs & 15u) == 15u && !(a.debug & 4)) {   // 16 runs complete: one 32-byte store per slot
+                            const uint32_t piece = ((n_runs >> 4) & 1u) * 8u;
                             uint32_t* const dst = reinterpret_cast<uint32_t*>(a.runs + cigar_off + (n_runs - 15u));
-                            for (uint32_t k = (uint32_t)t; k < OBUF_DWORDS; k += (uint32_t)G) dst[k] = lds[obuf + k];
+                            for (uint32_t k = (uint32_t)t; k < 8u; k += (uint32_t)G) dst[k] = lds[obuf + piece + k];
                         }
                     } else {
                         overflow = true;
@@ -433,7 +454,121 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
                 read_idx += j;
             }
         };
-        if (spilled) traceback(std::true_type{});
+        // ---- fast traceback: the same macro-step, branch-free, in integer/mask arithmetic ----------
+        // Valid when no row was spilled and, in every live slot, the window keeps more than W-O
+        // pattern characters and at least W-O text characters (so neither the last-character rule
+        // :336-343 nor the text limit :312 can trigger inside the W-O cells a window may consume) —
+        // i.e. everywhere except the last window or two of a pair.  A wave is bound by the length of
+        // its own instruction stream here, so the step has two branches (loop, rare 32-byte flush)
+        // instead of one per decision, and conditions are 0/~0 masks: on gfx950 compares, selects,
+        // min/max and left shifts issue at half the rate of and/or/xor/add/sub/right-shift/bitop3.
+        auto traceback_fast = [&]() {
+            constexpr uint32_t LOG2G = (G == 4) ? 2 : (G == 8) ? 3 : (G == 16) ? 4 : (G == 32) ? 5 : 6;
+            const uint32_t K0 = ~0x40000000u, K1 = ~0x30000000u;
+            uint32_t actmask = has_pair ? ~0u : 0u;
+            uint32_t dd = dw;
+            uint32_t irem = (uint32_t)TBL, jrem = (uint32_t)TBL;       // cells left before i or j reaches W-O
+            uint32_t it4 = (uint32_t)t * 4u;                            // (i + t) * 4
+            uint32_t rj = 0u - (uint32_t)t;                             // -(j + t): rotate amount, mod 32
+            uint32_t rowaddr = (lds_slot + (dd - 1u) * 32u) * 4u;       // byte address of row d-1 (garbage if d == 0)
+            uint32_t cur_op8 = 0, cur_cnt = 0, ovf = 0;                 // run in progress: op << 8, length
+            uint32_t nr2 = 2u * n_runs;                                 // 2 * n_runs: byte position of the next staged run
+            const uint32_t l8 = (uint32_t)t << 3;
+            const uint32_t leadmask = leader ? ~0u : 0u;
+            const uint32_t obuf_b = 4u * obuf, dummy_b = 4u * scratch_dw;
+            const uint32_t cap2 = 2u * cigar_cap;
+            char* const lds_b = reinterpret_cast<char*>(lds);
+
+            // stage the run in progress if `op8` differs from it; only the slot leader's write lands in
+            // the ring, every other lane (and every masked-off case) writes its slot's scratch cell
+            auto emit = [&](uint32_t enmask, uint32_t op8, uint32_t cnt) {
+                const uint32_t same = ~nz_mask(op8 ^ cur_op8);
+                const uint32_t flush = bitop3<0x40>(enmask, nz_mask(cur_cnt), same);   // en & havecur & ~same
+                const uint32_t room_ok = neg_mask(nr2 - cap2);                         // ~0 iff n_runs < cap
+                const uint32_t wr = flush & room_ok & leadmask;
+                const uint32_t addr = bitop3<0xCA>(wr, obuf_b + (nr2 & 62u), dummy_b);
+                *reinterpret_cast<uint16_t*>(lds_b + addr) = (uint16_t)(cur_cnt | cur_op8);
+                ovf |= flush & ~room_ok;
+                nr2 += flush & 2u;
+                cur_cnt = bitop3<0xD0>(cur_cnt, same, enmask) + (cnt & enmask);        // cur_cnt & (same | ~en)
+                cur_op8 = bitop3<0xCA>(enmask, op8, cur_op8);
+            };
+            // write out a 16-run piece of the ring once the staged count has moved past it
+            auto flush_pieces = [&](uint32_t before2) {
+                const uint32_t crossed = (before2 ^ nr2) & 32u;                        // bit 5 of 2*n flips every 16 runs
+                if (__any(crossed != 0u)) {
+                    if (crossed && !(a.debug & 4)) {
+                        const uint32_t first = (nr2 >> 5) * 16u - 16u;                 // first run of the completed piece
+                        if (first + 16u <= cigar_cap) {
+                            const uint32_t piece = ((first >> 4) & 1u) * 8u;
+                            uint32_t* const dst = reinterpret_cast<uint32_t*>(a.runs + cigar_off + first);
+                            for (uint32_t k = (uint32_t)t; k < 8u; k += (uint32_t)G) dst[k] = lds[obuf + piece + k];
+                        }
+                    }
+                }
+            };
+
+            const uint64_t tl0 = timing ? __builtin_readcyclecounter() : 0;
+            while (__any(actmask != 0u)) {
+                st_macro++;
+                const uint32_t before2 = nr2;
+                // R[i+l][d-1], R[i+l+1][d-1]
+                const uint32_t* const rp = reinterpret_cast<const uint32_t*>(lds_b + rowaddr + it4);
+                const uint32_t w0 = rp[0], w1 = rp[1];
+                // TB_BIT(j+1) = bit 30-j of the stored dword; rotate it to bit 30 (ins, from w0) and
+                // bits 28 (sub) / 29 (del) (from w1); a clear bit means the edit is available
+                const uint32_t r0 = __builtin_amdgcn_alignbit(w0, w0, rj);
+                const uint32_t r1 = __builtin_amdgcn_alignbit(w1, w1, rj + 2u);
+                const uint32_t avail = bitop3<0x1F>(r0 | K0, r1, K1);             // ~(a & (b | c)): bit30 ins, bit29 del, bit28 sub
+                const uint32_t code = (uint32_t)__builtin_clz(avail | 0x08000000u);   // 1 I, 2 D, 3 X, 4 none (priority :346-370)
+                // no edit possible without budget (d == 0) or in a finished slot
+                const uint32_t blocked = neg_mask(dd - 1u) | ~actmask;
+                const uint32_t key = l8 | code | (0u - (code >> 2)) | blocked;   // all ones when nothing ends the run here
+                uint32_t kmin = slot_min<G>(key);
+                // the walk stops at the first cell past the W-O limits (:307-310); with more than G cells
+                // left the macro-step simply ends after G matches (code 4)
+                const uint32_t lim = irem < jrem ? irem : jrem;
+                const uint32_t limc = lim < (uint32_t)G ? lim : (uint32_t)G;
+                const uint32_t stopkey = ((limc << 3) | ((limc >> (LOG2G - 2u)) & 4u)) & actmask;
+                kmin = kmin < stopkey ? kmin : stopkey;
+                const uint32_t n_eq = kmin >> 3;
+                const uint32_t c = kmin & 7u;                                 // 0 stop, 1 I, 2 D, 3 X, 4 continue
+                const uint32_t is_edit = ((c & 3u) + 3u) >> 2;                // 1 for I/D/X
+                const uint32_t inc_i = (c >> 1) & 1u, inc_j = c & 1u;
+
+                if (!(a.debug & 16)) {
+                emit(nz_mask(n_eq), (uint32_t)'=' << 8, n_eq);
+                // 'I' 0x49, 'D' 0x44, 'X' 0x58 in a table word indexed by the code
+                emit(0u - is_edit, ((0x58444900u >> ((c & 3u) * 8u)) & 0xffu) << 8, 1u);
+                flush_pieces(before2);
+                }
+
+                const uint32_t ai = n_eq + inc_i, aj = n_eq + inc_j;
+                irem -= ai;
+                jrem -= aj;
+                it4 += ((kmin >> 1) & ~3u) + (c & 2u) + (c & 2u);             // 4 * ai
+                rj -= aj;
+                dd -= is_edit;
+                rowaddr -= (0u - is_edit) & 128u;
+                actmask &= 0u - ((c + 7u) >> 3);                              // code 0: this slot's walk is over
+            }
+            if (timing) cy_tbloop += __builtin_readcyclecounter() - tl0;
+            {
+                const uint32_t before2 = nr2;
+                emit(has_pair ? ~0u : 0u, 0u, 0u);                            // per-window flush (:400-403)
+                flush_pieces(before2);
+            }
+            overflow = overflow || (ovf != 0u);
+            n_runs = nr2 >> 1;
+            if (has_pair) {
+                edits += dw - dd;
+                ref_idx += (uint32_t)TBL - irem;
+                read_idx += (uint32_t)TBL - jrem;
+            }
+        };
+        const bool fast_ok = !spilled && !__any(has_pair && (m <= (uint32_t)TBL || n < (uint32_t)TBL)) && !(a.debug & 8);
+        if (fast_ok) traceback_fast();
+        else if (spilled) traceback(std::true_type{});
         else traceback(std::false_type{});
         if (timing) {
             const uint64_t tm4 = __builtin_readcyclecounter();
@@ -451,6 +586,7 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
         atomicAdd((unsigned long long*)&a.stats[4], (unsigned long long)cy_setup);
         atomicAdd((unsigned long long*)&a.stats[5], (unsigned long long)cy_dc);
         atomicAdd((unsigned long long*)&a.stats[6], (unsigned long long)cy_tb);
+        atomicAdd((unsigned long long*)&a.stats[7], (unsigned long long)cy_tbloop);
     }
 }
 

@@ -274,8 +274,9 @@ static bool resolve_params(const scrg_params* in, scrg_params* p)
 static size_t lds_bytes_for(const scrg_params& p)
 {
     const size_t slots = 64 / p.lanes_per_pair;
-    // CIGAR staging (8 dwords per slot) + R rows (+1 dword per slot against bank conflicts)
-    return slots * (8 + (size_t)p.lds_rows * 32 + 1) * sizeof(uint32_t);
+    // per slot: CIGAR staging ring (16 dwords) + 1 scratch dword + R rows (+1 dword against bank
+    // conflicts); 8 dwords of padding at the end (the traceback's speculative lanes read a little past a row)
+    return (slots * (17 + (size_t)p.lds_rows * 32 + 1) + 8) * sizeof(uint32_t);
 }
 
 scrg_status scrg_query_launch(scrg_ctx* c, const scrg_params* params, int32_t* n_waves, int32_t* pairs_per_wave,
