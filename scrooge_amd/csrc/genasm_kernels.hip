@@ -38,7 +38,9 @@ namespace scrg {
 // lane i <- lane i+1 across the whole wave (DPP wave_shl:1, full rate, no LDS)
 __device__ __forceinline__ uint32_t dpp_from_next(uint32_t v)
 {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+    uint32_t r;   // lane 63 has no source and keeps an undefined value; it is a slot's last lane, which never uses it
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 wave_shl:1 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v));
+    return r;
 }
 __device__ __forceinline__ uint64_t dpp_from_next64(uint64_t v)
 {
@@ -91,8 +93,12 @@ template <int TT> __device__ __forceinline__ uint32_t bitop3(uint32_t a, uint32_
 // DPP-modified v_min_u32 (no LDS traffic, no SALU); wider slots finish with xor-shuffles.
 template <int CTRL> __device__ __forceinline__ uint32_t dpp_min(uint32_t v)
 {
-    const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
-    return o < v ? o : v;
+    uint32_t r;
+    if (CTRL == 0xB1) asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v));
+    else if (CTRL == 0x4E) asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v));
+    else if (CTRL == 0x141) asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v));
+    else asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %1, %1 row_mirror row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v));
+    return r;
 }
 template <int G> __device__ __forceinline__ uint32_t slot_min(uint32_t v)
 {
@@ -122,6 +128,13 @@ __device__ __forceinline__ uint64_t brev64(uint64_t v)
 // ----------------------------------------------------------------------------
 // the aligner
 // ----------------------------------------------------------------------------
+
+constexpr uint64_t leader_mask(int g)
+{
+    uint64_t m = 0;
+    for (int s = 0; s < 64 / g; s++) m |= 1ull << (s * g);
+    return m;
+}
 
 template <int G>
 __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(AlignArgs a)
@@ -153,9 +166,7 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
     const uint32_t spill_slot_b = (blockIdx.x * SLOTS + slot) * (uint32_t)(SPILL_ROWS * 32 * 4);   // byte offset of my slot's spill rows
 
     // mask with bit (first lane of slot s) set for every slot
-    uint64_t leaders = 0;
-#pragma unroll
-    for (int s = 0; s < SLOTS; s++) leaders |= 1ull << (s * G);
+    constexpr uint64_t leaders = leader_mask(G);
 
     // ---- per-slot state (replicated in the slot's G lanes) ----
     bool has_pair = false;
@@ -277,6 +288,8 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
         int32_t hit_thr = (has_pair && leader) ? -1 : INT32_MAX;
         uint32_t saddr = lds_slot + col0;          // LDS word index of my columns in row d (once d >= 0)
         int step = 0;
+        uint32_t lastmask = (t == G - 1) ? ~0u : 0u;
+        asm volatile("" : "+v"(lastmask));          // keep it a VGPR mask (v_bitop3 select, full rate) rather than v_cndmask
         const uint64_t tm2 = timing ? __builtin_readcyclecounter() : 0;
 
         // one skewed step: reads the row in (pi, psi, rni, rnsi), writes the next one to (po, pso, rno, rnso)
@@ -286,7 +299,11 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
             // right neighbour's first column at my row: it finished that row one step ago
             uint64_t rn = dpp_from_next64(pi[0]);
             const uint64_t bnds = shl1(bnd);
-            if (t == G - 1) rn = bnd;              // last lane: column 64 (always >= n)
+            {   // last lane of the slot: column 64 (always >= n) instead of the neighbour slot's data
+                const uint32_t lo = bitop3<0xCA>(lastmask, (uint32_t)bnd, (uint32_t)rn);
+                const uint32_t hi = bitop3<0xCA>(lastmask, (uint32_t)(bnd >> 32), (uint32_t)(rn >> 32));
+                rn = ((uint64_t)hi << 32) | lo;
+            }
             const uint64_t rns = shl1(rn);
             bnd = bnds;
 
