@@ -1,0 +1,57 @@
+"""BASELINE.json configs[2]: read-mapping interface — one synthetic chromosome, N x 150 bp reads x 4
+candidates each (true locus, two shifted loci, one random locus), through the host-pointer API
+(scrg_align_mapping).  Prints kernel-only and end-to-end pairs/s and spot-checks parity."""
+import json, sys, time
+sys.path.insert(0, ".")
+import numpy as np
+import scrooge_amd
+from scrooge_amd import synth
+from oracle.pyoracle import Oracle
+
+n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
+G = int(sys.argv[2]) if len(sys.argv) > 2 else 100_000_000
+rng = np.random.Generator(np.random.PCG64(42))
+t0 = time.time()
+gcodes = rng.integers(0, 4, G, dtype=np.uint8)
+genome = synth.BASES[gcodes].tobytes()
+starts = rng.integers(0, G - 400, n_reads)
+L = 150
+# vectorised 1 % substitution-dominated errors (90:5:5): build reads in bulk, indels via per-read fix-up
+idx = starts[:, None] + np.arange(L + 8)[None, :]
+seg = gcodes[idx]
+u = rng.random((n_reads, L + 8))
+sub = u < 0.009
+seg = np.where(sub, (seg + rng.integers(1, 4, seg.shape, dtype=np.uint8)) & 3, seg)
+reads_codes = seg[:, :L].copy()
+dele = np.nonzero(rng.random(n_reads) < 0.075)[0]          # ~0.05 % per base deletions
+for r in dele:
+    p = int(rng.integers(1, L - 1)); reads_codes[r, p:] = seg[r, p + 1:L + 1]
+ins = np.nonzero(rng.random(n_reads) < 0.075)[0]
+for r in ins:
+    p = int(rng.integers(1, L - 1)); reads_codes[r, p + 1:] = reads_codes[r, p:L - 1].copy(); reads_codes[r, p] = rng.integers(0, 4)
+ascii_reads = synth.BASES[reads_codes]
+reads = [ascii_reads[r].tobytes() for r in range(n_reads)]
+sh1 = np.maximum(0, starts - rng.integers(1, 4, n_reads)); sh2 = starts + rng.integers(1, 4, n_reads)
+rnd = rng.integers(0, G - 10, n_reads)
+cands = np.stack([starts, sh1, sh2, rnd], axis=1).tolist()
+gen_s = time.time() - t0
+a = scrooge_amd.Aligner(0)
+a.align_mapping(genome, reads[:1000], cands[:1000])     # warm-up / allocations
+t1 = time.time()
+alns = a.align_mapping(genome, reads, cands)
+wall = time.time() - t1
+tm = a.last_timing
+n_pairs = 4 * n_reads
+# parity on a sample
+k = 2000
+texts, qs = [], []
+for r in range(k):
+    for s in cands[r]:
+        texts.append(genome[s:s + 400]); qs.append(reads[r])
+eds, cigars, _, _ = Oracle().align(texts, qs, threads=16)
+ok = all(alns[i].edit_distance == eds[i] and alns[i].cigar == cigars[i] for i in range(4 * k))
+print(json.dumps({"workload": "read mapping: %d Mbp chromosome, %d x 150 bp reads x 4 candidates" % (G // 1000000, n_reads),
+                  "pairs": n_pairs, "kernel_pairs_per_s": n_pairs / (tm["kernel_ns"] * 1e-9), "kernel_ms": tm["kernel_ns"] / 1e6,
+                  "library_total_s": tm["total_ns"] / 1e9, "end_to_end_pairs_per_s": n_pairs / (tm["total_ns"] * 1e-9),
+                  "python_wall_s": wall, "parity_sample_pairs": 4 * k, "bit_exact": ok,
+                  "mean_ed_true_locus": float(np.mean([alns[4 * r].edit_distance for r in range(k)])), "gen_s": gen_s}))
