@@ -66,9 +66,16 @@ def build_library(force=False):
     src_dir = os.path.join(HERE, "csrc")
     srcs = [os.path.join(src_dir, f) for f in os.listdir(src_dir)] + \
         [os.path.join(HERE, "..", "include", "scrooge_amd.h")]
-    stale = (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
-    if force or stale:
-        subprocess.check_call(["make", "-C", src_dir, "--no-print-directory"] + (["-B"] if force else []))
+    def is_stale():
+        return (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
+
+    if force or is_stale():
+        # several ranks of one job may get here at once: serialise, and re-check under the lock
+        import fcntl
+        with open(os.path.join(HERE, ".build.lock"), "w") as lk:
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            if force or is_stale():
+                subprocess.check_call(["make", "-C", src_dir, "--no-print-directory"] + (["-B"] if force else []))
     return so
 
 

@@ -129,3 +129,21 @@ def test_two_rank_gather_restores_input_order():
     T, Q = _batch()
     want = OracleAligner().align_pairs(T, Q)
     assert res == want
+
+
+def test_bench_generator_shapes_on_cpu():
+    """bench.py's on-device generator (run here on CPU tensors): fixed read length, zero-padded
+    32-byte slots, and an error profile the oracle confirms (ONT 10 % -> ~0.1 edits per base)."""
+    import bench
+    from oracle.pyoracle import Oracle
+    n, L = 24, 600
+    err, ratio = synth.PROFILES["ont"]
+    rows, tw, rw, text_len = bench.device_pairs(torch, n, L, err, ratio, 7, torch.device("cpu"), chunk=16)
+    assert rows.shape == (n, (tw + rw) * 32) and text_len == 690
+    h = rows.numpy()
+    texts = [h[i, :text_len].tobytes() for i in range(n)]
+    reads = [h[i, tw * 32: tw * 32 + L].tobytes() for i in range(n)]
+    assert all(set(t) <= set(b"ACGT") for t in texts + reads)
+    assert (h[:, text_len:tw * 32] == 0).all() and (h[:, tw * 32 + L:] == 0).all()
+    eds, _, _, _ = Oracle().align(texts, reads)
+    assert 0.06 * L < np.mean(eds) < 0.14 * L
