@@ -201,19 +201,29 @@ def main():
         cnt64 = n_runs.to(torch.int64)
         dense_off = torch.cumsum(cnt64, 0) - cnt64
         if world > 1:
-            al.compact_runs(n, desc, runs, n_runs, dense_off, gather.send_runs)
-            gather(ed, n_runs)         # RCCL gather of scores + CIGAR runs to rank 0 over xGMI
+            # RCCL gather of scores + CIGAR runs to rank 0 over xGMI, double buffered: the gather of
+            # this step overlaps the next step's align kernel
+            j = step.count
+            step.count += 1
+            gather.finish(j)                       # buffers of step j-2 are free again
+            al.compact_runs(n, desc, runs, n_runs, dense_off, gather.send_runs[j % gather.DEPTH])
+            gather.start(j, ed, n_runs)
         else:
             al.compact_runs(n, desc, runs, n_runs, dense_off, dense)
 
+    step.count = 0
     for _ in range(args.warmup):
         step()
+    if gather is not None:
+        gather.finish_all()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(k)
+    if gather is not None:
+        gather.finish_all()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -305,7 +315,7 @@ def main():
                                % (n, L, args.profile, p.W, p.O),
                    "pairs_per_gpu": n, "read_len": L, "text_len": text_len, "error_profile": args.profile,
                    "W": p.W, "O": p.O, "lanes_per_pair": p.lanes_per_pair, "lds_rows": p.lds_rows,
-                   "launch": geom, "step": "align kernel + run compaction" + (" + RCCL gather to rank 0" if world > 1 else "")},
+                   "launch": geom, "step": "align kernel + run compaction" + (" + RCCL gather of scores and CIGAR runs to rank 0 (double buffered, overlaps the next kernel)" if world > 1 else "")},
         "gcups": value * L * L / 1e9,
         "kernel_ms": kernel_ms,
         "kernel_pairs_per_s_per_gpu": n / (kernel_ms * 1e-3),

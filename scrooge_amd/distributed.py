@@ -86,12 +86,17 @@ def align_pairs_sharded(aligner, texts, queries, dst=0, group=None, device=None,
 
 
 class ResultGather:
-    """Fixed-size gather of one batch's device results to rank `dst`, reusable across steps
-    (bench.py: the data, hence every size, is the same each step, so the receive buffers are
-    allocated once and no size exchange happens inside the timed region).
+    """Fixed-size, double-buffered gather of a batch's device results to rank `dst`
+    (bench.py: the data, hence every size, is the same each step, so buffers are allocated once
+    and no size exchange happens inside the timed region).
 
     Payload per rank: int64 edit distances [n], int32 run counts [n] and the dense scrg_run array
-    as bytes, padded to the largest total over ranks."""
+    as bytes, padded to the largest total over ranks.  `start(k, ...)` enqueues the collectives
+    asynchronously (RCCL runs them on its own stream, after the work already enqueued on the current
+    stream), so the gather of step k overlaps the align kernel of step k+1; `finish(k)` makes the
+    current stream wait for step k's gather before its buffers are reused."""
+
+    DEPTH = 2
 
     def __init__(self, n_pairs, total_runs, device, dst=0, group=None):
         self.group, self.dst = group, dst
@@ -102,19 +107,41 @@ class ResultGather:
         dist.all_gather(sizes, t, group=group)
         self.totals = [int(x.item()) for x in sizes]
         self.cap = max(max(self.totals), 1)
-        self.send_runs = torch.zeros(self.cap * 2, dtype=torch.uint8, device=device)
-        self.recv_runs = self.recv_ed = self.recv_cnt = None
+        d = self.DEPTH
+        self.send_runs = [torch.zeros(self.cap * 2, dtype=torch.uint8, device=device) for _ in range(d)]
+        self.send_ed = [torch.zeros(n_pairs, dtype=torch.int64, device=device) for _ in range(d)]
+        self.send_cnt = [torch.zeros(n_pairs, dtype=torch.int32, device=device) for _ in range(d)]
+        self.recv_runs = self.recv_ed = self.recv_cnt = [None] * d
         if self.rank == dst:
-            self.recv_runs = [torch.empty(self.cap * 2, dtype=torch.uint8, device=device) for _ in range(self.world)]
-            self.recv_ed = [torch.empty(n_pairs, dtype=torch.int64, device=device) for _ in range(self.world)]
-            self.recv_cnt = [torch.empty(n_pairs, dtype=torch.int32, device=device) for _ in range(self.world)]
+            mk = lambda shape, dt: [[torch.empty(shape, dtype=dt, device=device) for _ in range(self.world)]
+                                    for _ in range(d)]
+            self.recv_runs = mk(self.cap * 2, torch.uint8)
+            self.recv_ed = mk(n_pairs, torch.int64)
+            self.recv_cnt = mk(n_pairs, torch.int32)
+        self.pending = [None] * d
 
-    def __call__(self, ed, n_runs):
-        """`self.send_runs` must already hold this rank's dense runs."""
-        dist.gather(ed, self.recv_ed, dst=self.dst, group=self.group)
-        dist.gather(n_runs, self.recv_cnt, dst=self.dst, group=self.group)
-        dist.gather(self.send_runs, self.recv_runs, dst=self.dst, group=self.group)
+    def start(self, k, ed, n_runs):
+        """`self.send_runs[k % DEPTH]` must already hold this rank's dense runs of step k."""
+        b = k % self.DEPTH
+        self.send_ed[b].copy_(ed)
+        self.send_cnt[b].copy_(n_runs)
+        self.pending[b] = [
+            dist.gather(self.send_ed[b], self.recv_ed[b], dst=self.dst, group=self.group, async_op=True),
+            dist.gather(self.send_cnt[b], self.recv_cnt[b], dst=self.dst, group=self.group, async_op=True),
+            dist.gather(self.send_runs[b], self.recv_runs[b], dst=self.dst, group=self.group, async_op=True)]
 
-    def results(self, r):
-        """(ed, counts, run bytes) of rank r, on dst."""
-        return self.recv_ed[r], self.recv_cnt[r], self.recv_runs[r][: 2 * self.totals[r]]
+    def finish(self, k):
+        b = k % self.DEPTH
+        if self.pending[b]:
+            for w in self.pending[b]:
+                w.wait()
+            self.pending[b] = None
+
+    def finish_all(self):
+        for b in range(self.DEPTH):
+            self.finish(b)
+
+    def results(self, k, r):
+        """(ed, counts, run bytes) of rank r for step k, on dst (after finish(k))."""
+        b = k % self.DEPTH
+        return self.recv_ed[b][r], self.recv_cnt[b][r], self.recv_runs[b][r][: 2 * self.totals[r]]

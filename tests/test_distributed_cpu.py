@@ -62,15 +62,18 @@ def _worker_fixed(rank, world, port, q):
         counts = torch.tensor([rank + 1, 0, 3, 2 * rank, 1], dtype=torch.int32)
         total = int(counts.sum())
         g = sd.ResultGather(n, total, torch.device("cpu"), dst=0)
-        g.send_runs[: 2 * total] = torch.arange(2 * total, dtype=torch.uint8) + 10 * rank
         ed = torch.arange(n, dtype=torch.int64) * (rank + 1)
-        for _ in range(2):        # reusable across steps
-            g(ed, counts)
+        for k in range(5):        # double buffered, reusable across steps
+            g.finish(k)
+            g.send_runs[k % g.DEPTH][: 2 * total] = torch.arange(2 * total, dtype=torch.uint8) + 10 * rank + k
+            g.start(k, ed + k, counts)
+        g.finish_all()
         if rank == 0:
             out = []
             for r in range(world):
-                e, c, b = g.results(r)
-                out.append((e.tolist(), c.tolist(), b.tolist()))
+                e, c, b = g.results(4, r)
+                e3, _, b3 = g.results(3, r)
+                out.append((e.tolist(), c.tolist(), b.tolist(), e3.tolist(), b3.tolist()))
             q.put(out)
     finally:
         dist.destroy_process_group()
@@ -91,9 +94,11 @@ def test_fixed_size_result_gather():
     for r in range(2):
         counts = [r + 1, 0, 3, 2 * r, 1]
         total = sum(counts)
-        assert out[r][0] == [k * (r + 1) for k in range(5)]
+        assert out[r][0] == [k * (r + 1) + 4 for k in range(5)]
         assert out[r][1] == counts
-        assert out[r][2] == [(x + 10 * r) % 256 for x in range(2 * total)]
+        assert out[r][2] == [(x + 10 * r + 4) % 256 for x in range(2 * total)]
+        assert out[r][3] == [k * (r + 1) + 3 for k in range(5)]            # the other buffer still holds step 3
+        assert out[r][4] == [(x + 10 * r + 3) % 256 for x in range(2 * total)]
 
 
 def _free_port():
