@@ -152,3 +152,17 @@ def test_cigar_slice_overflow_is_reported_not_overrun(aligner, oracle):
         if n_true[k] <= caps[k]:
             seg = h[2 * offs[k]: 2 * (offs[k] + n_true[k])]
             assert "".join("%d%s" % (seg[2 * j], chr(seg[2 * j + 1])) for j in range(n_true[k])) == cigars[k]
+
+
+def test_extreme_inputs(aligner, oracle):
+    """Window distances pinned at their maximum (no text left: m insertions per window, every row
+    of R up to K=64 in use), all-mismatch pairs, homopolymers, and a 300 kb read."""
+    rng = np.random.Generator(np.random.PCG64(77))
+    big_t, big_q = synth.make_pairs(1, 300000, "ont", seed=123)
+    T = [b"", b"ACGT", b"T" * 6000, b"A" * 3000, b"A" * 3000, b"AC" * 2000, big_t[0], b"G" * 10]
+    Q = [synth.random_seq(5000, rng), synth.random_seq(3000, rng), b"A" * 5000, b"A" * 2500, b"A" * 3500,
+         b"CA" * 1500, big_q[0], b"g" * 700]
+    eds, cigars, st, _ = oracle.align(T, Q, threads=8)
+    assert eds[0] == 5000 and eds[2] == 5000 and eds[3] == 0
+    for g, rows in [(8, 13), (8, 2), (64, 13), (16, 5)]:
+        _same(aligner.align_pairs(T, Q, lanes_per_pair=g, lds_rows=rows), eds, cigars)
