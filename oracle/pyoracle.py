@@ -77,11 +77,19 @@ class Reference:
     PATH = os.path.join(HERE, "_ref", "libgenasm_ref.so")
 
     @classmethod
-    def available(cls):
-        return os.path.exists(cls.PATH)
+    def path_for(cls, W=64, O=33):
+        if (W, O) == (64, 33):
+            return cls.PATH
+        return os.path.join(HERE, "_ref", "libgenasm_ref_w%d_o%d.so" % (W, O))
 
-    def __init__(self):
-        self.lib = C.CDLL(self.PATH)
+    @classmethod
+    def available(cls, W=64, O=33):
+        return os.path.exists(cls.path_for(W, O))
+
+    def __init__(self, W=64, O=33):
+        """W/O other than the defaults load a build of the same reference sources with
+        -DCLI_KNOBS -DCLI_W -DCLI_K=W -DCLI_O (oracle/Makefile)."""
+        self.lib = C.CDLL(self.path_for(W, O))
         self.lib.ref_align_pairs.restype = C.c_int
         self.lib.ref_align_pairs.argtypes = [
             C.c_size_t, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64),

@@ -130,6 +130,23 @@ def main():
         "ed": eds, "cigar": cigs})
     print("pairs cases:", len(cases), " mapping pairs:", len(eds))
 
+    # --- other knob settings: the same reference sources built with -DCLI_KNOBS -DCLI_W/-DCLI_K/-DCLI_O
+    #     (src/genasm_cpu.cpp:22-35); W=32,O=17 is the paper's short-read setting, O=2 the README's sweep row
+    for W, O in [(32, 17), (64, 2), (48, 24), (64, 40)]:
+        r2 = Reference(W, O)
+        rng2 = np.random.Generator(np.random.PCG64(1000 * W + O))
+        T, Q = synth.make_pairs(25, 300, "ont", seed=W * 7 + O)
+        t2, q2 = synth.make_pairs(10, 150, "illumina", seed=W + O)
+        T, Q = T + t2, Q + q2
+        for _ in range(45):
+            T.append(synth.random_seq(int(rng2.integers(0, 180)), rng2))
+            Q.append(synth.random_seq(int(rng2.integers(0, 180)), rng2))
+        eds2, cigs2, _ = r2.align(T, Q)
+        dump("pairs_w%d_o%d.json" % (W, O), {"W": W, "O": O, "cases": [
+            {"group": "knobs", "text": t.decode(), "read": q.decode(), "ed": e, "cigar": c}
+            for t, q, e, c in zip(T, Q, eds2, cigs2)]})
+        print("W=%d O=%d cases:" % (W, O), len(T))
+
 
 if __name__ == "__main__":
     main()

@@ -35,6 +35,18 @@ def test_golden_mapping(aligner, golden_mapping, g):
     _check(alns, gm["ed"], gm["cigar"], "mapping g=%d" % g)
 
 
+@pytest.mark.parametrize("name", ["pairs_w32_o17.json", "pairs_w48_o24.json", "pairs_w64_o40.json"])
+def test_golden_other_knobs(aligner, name):
+    """Reference fixtures at other W/O (the reference recompiles for these; here they are runtime values)."""
+    from tests.conftest import load_golden
+    g = load_golden(name)
+    cases = g["cases"]
+    for lanes in (8, 64):
+        alns = aligner.align_pairs([c["text"] for c in cases], [c["read"] for c in cases], W=g["W"], O=g["O"],
+                                   lanes_per_pair=lanes)
+        _check(alns, [c["ed"] for c in cases], [c["cigar"] for c in cases], "%s g=%d" % (name, lanes))
+
+
 def test_known_edit_distances(aligner):
     """src/tests.cu:224-271 (cpu/gpu_algorithm_correctness_test)"""
     ref = "AAAACCCCGGGGTTTT"

@@ -33,6 +33,17 @@ def test_oracle_matches_golden_pairs(oracle, golden_pairs):
         assert g == c["cigar"], c["group"]
 
 
+@pytest.mark.parametrize("name", ["pairs_w32_o17.json", "pairs_w64_o2.json", "pairs_w48_o24.json", "pairs_w64_o40.json"])
+def test_oracle_matches_golden_other_knobs(oracle, name):
+    """Fixtures from the reference built with its own -DCLI_W/-DCLI_K/-DCLI_O switches."""
+    from tests.conftest import load_golden
+    g = load_golden(name)
+    cases = g["cases"]
+    eds, cigars, _, _ = oracle.align([c["text"] for c in cases], [c["read"] for c in cases], W=g["W"], O=g["O"])
+    assert eds == [c["ed"] for c in cases]
+    assert cigars == [c["cigar"] for c in cases]
+
+
 def test_oracle_matches_golden_mapping(oracle, golden_mapping):
     g = golden_mapping
     texts, reads = [], []
