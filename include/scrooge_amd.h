@@ -48,8 +48,9 @@ enum {
 /* Tunables.  Zero-initialise and call scrg_params_default(). */
 typedef struct scrg_params {
     int32_t W;               /* window length, 2..64; reference default 64 (genasm_cpu.cpp:7)   */
-    int32_t O;               /* window overlap; reference default 33 (genasm_cpu.cpp:9);
-                                the kernel stores W-O+1 <= 32 traceback columns, so 1 <= W-O <= 31 */
+    int32_t O;               /* window overlap, 1 <= O < W; reference default 33 (genasm_cpu.cpp:9).
+                                W-O <= 31 (e.g. the defaults) uses the compact DENT storage; larger
+                                W-O switches to whole 64-bit entries of all columns (4x the LDS per row) */
     int32_t lanes_per_pair;  /* 64 = one pair per wavefront (lane = text column);
                                 4/8/16/32 pack 64/lanes pairs into one wavefront.  0 = default   */
     int32_t lds_rows;        /* rows of the R table kept in LDS per pair (rest spills to HBM);

@@ -4,7 +4,7 @@ configuration with the reference's column names where a knob has an equivalent h
     python scripts/sweep.py out.csv [pairs] [read_len]
 
 W and O are runtime parameters here (the reference recompiles per configuration, profile.py:131-142);
-supported range W <= 64, 1 <= W-O <= 31.  "threadblocks/sm" = persistent wavefronts per CU,
+supported range W <= 64, 1 <= O < W (W-O > 31 uses the 4x larger WIDE table).  "threadblocks/sm" = persistent wavefronts per CU,
 "used smem per threadblock (B)" = LDS bytes per wavefront; SENE/DENT/ET are always on (they do not
 change results)."""
 import csv, sys
@@ -37,6 +37,7 @@ name = torch.cuda.get_device_name(0)
 configs = [(64, 33, 8, 13, 11)]
 configs += [(W, min(W // 2 + 1, W - 1), 8, 13, 11) for W in (16, 24, 32, 40, 48, 56)]      # W sweep, O = W/2+1 (profile.py:78)
 configs += [(64, O, 8, 13, 11) for O in (36, 40, 48, 56, 60)]                                  # O sweep at W=64 (profile.py:88-100)
+configs += [(64, O, 8, 13, 3) for O in (2, 16, 32)]                                             # small overlaps: WIDE storage
 configs += [(64, 33, g, 13, w) for g, w in ((64, 16), (32, 16), (16, 16), (4, 6))]             # lane mappings
 configs += [(64, 33, 8, r, w) for r, w in ((16, 9), (12, 12), (10, 14))]                        # LDS rows vs occupancy
 with open(out, "w", newline="") as f:

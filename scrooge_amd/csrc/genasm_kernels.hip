@@ -136,11 +136,15 @@ constexpr uint64_t leader_mask(int g)
     return m;
 }
 
-template <int G>
+// WIDE stores every column's whole 64-bit entry instead of the DENT dword of columns 0..31: needed
+// when the traceback may consume more than 31 characters per window (W-O > 31, e.g. the reference's
+// O sweeps, scripts/profile.py:88-100).  It costs 4x the LDS per row and uses the generic traceback.
+template <int G, bool WIDE>
 __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(AlignArgs a)
 {
     constexpr int CPL = 64 / G;          // text columns per lane
     constexpr int SLOTS = 64 / G;        // pairs per wavefront
+    constexpr uint32_t ROWDW = WIDE ? 128u : 32u;   // dwords per stored row of R
     constexpr uint32_t OBUF_DWORDS = 16; // CIGAR runs leave the CU in aligned 32-byte pieces (16 runs) out of a 32-run ring
     constexpr uint32_t GMASK = (G == 32) ? 0xffffffffu : ((G == 64) ? 0xffffffffu : ((1u << (G & 31)) - 1u));
 
@@ -159,11 +163,11 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
     //      [SLOTS x (RB rows x 32 dwords + 1)][8 dwords pad]
     const uint32_t obuf = (uint32_t)slot * OBUF_DWORDS;            // 32 runs staged per slot, written out 16 at a time
     const uint32_t scratch_dw = SLOTS * OBUF_DWORDS + (uint32_t)slot;   // target of masked-off staging writes
-    const uint32_t slot_stride = (uint32_t)RB * 32u + 1u;          // +1 word: conflict-free slot banks
+    const uint32_t slot_stride = (uint32_t)RB * ROWDW + 1u;        // +1 word: conflict-free slot banks
     const uint32_t lds_slot = SLOTS * (OBUF_DWORDS + 1u) + slot * slot_stride;   // R[d][i] at lds[lds_slot + d*32 + i], d < RB
     uint16_t* const lds16 = reinterpret_cast<uint16_t*>(lds);
-    uint32_t* const Rs = a.spill + ((size_t)blockIdx.x * SLOTS + slot) * (size_t)(SPILL_ROWS * 32);
-    const uint32_t spill_slot_b = (blockIdx.x * SLOTS + slot) * (uint32_t)(SPILL_ROWS * 32 * 4);   // byte offset of my slot's spill rows
+    uint32_t* const Rs = a.spill + ((size_t)blockIdx.x * SLOTS + slot) * (size_t)(SPILL_ROWS * ROWDW);
+    const uint32_t spill_slot_b = (blockIdx.x * SLOTS + slot) * (uint32_t)(SPILL_ROWS * ROWDW * 4);   // byte offset of my slot's spill rows
 
     // mask with bit (first lane of slot s) set for every slot
     constexpr uint64_t leaders = leader_mask(G);
@@ -280,13 +284,13 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
         uint64_t done_mask = __ballot(!has_pair);  // wave-uniform: lanes of finished slots
         bool all_done = (done_mask & leaders) == leaders;
         const uint32_t col0 = (uint32_t)(t * CPL);
-        constexpr int ST = (32 + CPL - 1) / CPL;   // lanes 0..ST-1 of a slot own the DENT columns 0..31 (:258-259)
+        constexpr int ST = WIDE ? G : (32 + CPL - 1) / CPL;   // lanes 0..ST-1 of a slot own the stored columns (DENT: 0..31, :258-259)
         // Per-lane thresholds keep the per-step control flow to one compare each:
         //   rows d < st_limit of a live slot's storer lanes go to LDS,
         //   a live slot's leader reports a hit when the high dword of column 0 is > hit_thr (= bit 63 clear).
         int32_t st_limit = (has_pair && t < ST) ? RB : INT32_MIN;
         int32_t hit_thr = (has_pair && leader) ? -1 : INT32_MAX;
-        uint32_t saddr = lds_slot + col0;          // LDS word index of my columns in row d (once d >= 0)
+        uint32_t saddr = lds_slot + col0 * (WIDE ? 2u : 1u);   // LDS word index of my columns in row d (once d >= 0)
         int step = 0;
         uint32_t lastmask = (t == G - 1) ? ~0u : 0u;
         asm volatile("" : "+v"(lastmask));          // keep it a VGPR mask (v_bitop3 select, full rate) rather than v_cndmask
@@ -333,10 +337,18 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
                 // SENE + DENT store of the row just computed (genasm_cpu.cpp:258-267): plain
                 // ds_write of the high dwords (never a flat access)
                 if (d < st_limit) {
+                    if (WIDE) {
 #pragma unroll
-                    for (int k = 0; k < CPL; k++) lds[saddr + k] = (uint32_t)(po[k] >> 32);
+                        for (int k = 0; k < CPL; k++) {
+                            lds[saddr + 2 * k] = (uint32_t)po[k];
+                            lds[saddr + 2 * k + 1] = (uint32_t)(po[k] >> 32);
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < CPL; k++) lds[saddr + k] = (uint32_t)(po[k] >> 32);
+                    }
                 }
-                saddr += 32u;
+                saddr += ROWDW;
             }
             // rows >= RB of a live slot go to the HBM spill area (rare; L1-bypassing agent-scope stores)
             if (step >= RB + (G - ST)) {
@@ -346,10 +358,15 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
                     // plain (L2-resident) stores; the traceback reads them back with L1-bypassing loads
                     // after an s_waitcnt vmcnt(0)
                     // uniform base + 32-bit per-lane byte offset: no 64-bit address or packing registers
-                    const uint32_t off = spill_slot_b + ((uint32_t)(d_here < SPILL_ROWS ? d_here : SPILL_ROWS - 1) * 32u + col0) * 4u;
+                    const uint32_t off = spill_slot_b + ((uint32_t)(d_here < SPILL_ROWS ? d_here : SPILL_ROWS - 1) * ROWDW + col0 * (WIDE ? 2u : 1u)) * 4u;
                     char* const sb = reinterpret_cast<char*>(a.spill);
+                    if (WIDE) {
 #pragma unroll
-                    for (int k = 0; k < CPL; k++) *reinterpret_cast<uint32_t*>(sb + off + 4 * k) = (uint32_t)(po[k] >> 32);
+                        for (int k = 0; k < CPL; k++) *reinterpret_cast<uint64_t*>(sb + off + 8 * k) = po[k];
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < CPL; k++) *reinterpret_cast<uint32_t*>(sb + off + 4 * k) = (uint32_t)(po[k] >> 32);
+                    }
                 }
             }
 
@@ -428,24 +445,40 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
                 const bool pos_ok = (jl < jlim) && (il < (uint32_t)TBL);
                 const bool room = dd > 0;                       // d_limit, :313
                 const uint32_t r = room ? dd - 1 : 0u;
-                const uint32_t ic = il < 30u ? il : 30u;
-                uint32_t w0, w1;                                // R[i][d-1], R[i+1][d-1] (DENT dwords)
+                // entries as 64-bit values with pattern char j at bit 63-j (a DENT dword is the high half)
+                constexpr uint32_t ICMAX = WIDE ? 62u : 30u;
+                const uint32_t ic = il < ICMAX ? il : ICMAX;
+                uint64_t e0, e1;                                // R[i][d-1], R[i+1][d-1]
                 if (SPILL && r >= (uint32_t)RB) {
-                    uint32_t* rp = Rs + (size_t)r * 32 + ic;
-                    w0 = __hip_atomic_load(rp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    w1 = __hip_atomic_load(rp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    uint32_t* rp = Rs + (size_t)r * ROWDW + ic * (WIDE ? 2u : 1u);
+                    if (WIDE) {
+                        const uint32_t a0 = __hip_atomic_load(rp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const uint32_t a1 = __hip_atomic_load(rp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const uint32_t a2 = __hip_atomic_load(rp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const uint32_t a3 = __hip_atomic_load(rp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        e0 = ((uint64_t)a1 << 32) | a0;
+                        e1 = ((uint64_t)a3 << 32) | a2;
+                    } else {
+                        e0 = (uint64_t)__hip_atomic_load(rp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 32;
+                        e1 = (uint64_t)__hip_atomic_load(rp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 32;
+                    }
                 } else {
-                    const uint32_t base = lds_slot + (r < (uint32_t)RB ? r : 0u) * 32u + ic;
-                    w0 = lds[base];
-                    w1 = lds[base + 1];
+                    const uint32_t base = lds_slot + (r < (uint32_t)RB ? r : 0u) * ROWDW + ic * (WIDE ? 2u : 1u);
+                    if (WIDE) {
+                        e0 = ((uint64_t)lds[base + 1] << 32) | lds[base];
+                        e1 = ((uint64_t)lds[base + 3] << 32) | lds[base + 2];
+                    } else {
+                        e0 = (uint64_t)lds[base] << 32;
+                        e1 = (uint64_t)lds[base + 1] << 32;
+                    }
                 }
-                // pattern char j sits at bit 31-j of a stored dword: TB_BIT(j+1) = 30-j, TB_BIT(j) = 31-j
-                const uint32_t sh = 30u - (jl < 30u ? jl : 30u);
+                // TB_BIT(j+1) = bit 62-j, TB_BIT(j) = bit 63-j (genasm_cpu.cpp:57-60 in the left-aligned layout)
+                const uint32_t sh = 62u - (jl < 62u ? jl : 62u);
                 const bool last = (jl + 1u == m);                // last pattern character, :336-343
                 const bool tl = il < n;                          // !i_limit, :312
-                const bool ins = room && (last || ((w0 >> sh) & 1u) == 0u);
-                const bool del = room && tl && !last && ((w1 >> (sh + 1u)) & 1u) == 0u;
-                const bool sub = room && tl && (last || ((w1 >> sh) & 1u) == 0u);
+                const bool ins = room && (last || ((e0 >> sh) & 1ull) == 0ull);
+                const bool del = room && tl && !last && ((e1 >> (sh + 1u)) & 1ull) == 0ull;
+                const bool sub = room && tl && (last || ((e1 >> sh) & 1ull) == 0ull);
                 uint32_t ev = ins ? 1u : (del ? 2u : (sub ? 3u : 0u));     // priority I, D, X, = (:346-370)
                 ev = pos_ok ? ev : 4u;                           // 4 = the window's walk ends here
                 if (a.debug & 1) ev = pos_ok ? 0u : 4u;
@@ -583,7 +616,7 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
                 read_idx += (uint32_t)TBL - jrem;
             }
         };
-        const bool fast_ok = !spilled && !__any(has_pair && (m <= (uint32_t)TBL || n < (uint32_t)TBL)) && !(a.debug & 8);
+        const bool fast_ok = !WIDE && !spilled && !__any(has_pair && (m <= (uint32_t)TBL || n < (uint32_t)TBL)) && !(a.debug & 8);
         if (fast_ok) traceback_fast();
         else if (spilled) traceback(std::true_type{});
         else traceback(std::false_type{});
@@ -721,14 +754,20 @@ __global__ __launch_bounds__(256) void compact_runs_kernel(uint64_t n_pairs, con
 // ----------------------------------------------------------------------------
 // host-side launchers
 // ----------------------------------------------------------------------------
+template <int G, bool WIDE>
+static hipError_t launch_align_tw(const AlignArgs& a, int grid, size_t lds_bytes, hipStream_t s)
+{
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&genasm_align_kernel<G, WIDE>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((genasm_align_kernel<G, WIDE>), dim3(grid), dim3(64), lds_bytes, s, a);
+    return hipGetLastError();
+}
 template <int G>
 static hipError_t launch_align_t(const AlignArgs& a, int grid, size_t lds_bytes, hipStream_t s)
 {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&genasm_align_kernel<G>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(genasm_align_kernel<G>, dim3(grid), dim3(64), lds_bytes, s, a);
-    return hipGetLastError();
+    // the traceback consumes up to W-O characters per window: more than 31 needs whole entries of all columns
+    return a.tb_limit > 31 ? launch_align_tw<G, true>(a, grid, lds_bytes, s) : launch_align_tw<G, false>(a, grid, lds_bytes, s);
 }
 
 hipError_t launch_align(int lanes_per_pair, const AlignArgs& a, int grid, size_t lds_bytes, hipStream_t s)

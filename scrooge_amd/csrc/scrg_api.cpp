@@ -264,7 +264,7 @@ static bool resolve_params(const scrg_params* in, scrg_params* p)
     if (!(g == 4 || g == 8 || g == 16 || g == 32 || g == 64)) return false;
     if (p->W < 2 || p->W > 64) return false;
     const int tbl = p->W - p->O;
-    if (tbl < 1 || tbl > 31) return false;
+    if (tbl < 1 || p->O < 1) return false;   // O = 0 (no overlap) would let the traceback read the boundary column
     if (p->lds_rows < 1) return false;
     if (p->lds_rows > 65) p->lds_rows = 65;
     if (p->waves_per_cu < 1 || p->waves_per_cu > 32) return false;
@@ -275,8 +275,10 @@ static size_t lds_bytes_for(const scrg_params& p)
 {
     const size_t slots = 64 / p.lanes_per_pair;
     // per slot: CIGAR staging ring (16 dwords) + 1 scratch dword + R rows (+1 dword against bank
-    // conflicts); 8 dwords of padding at the end (the traceback's speculative lanes read a little past a row)
-    return (slots * (17 + (size_t)p.lds_rows * 32 + 1) + 8) * sizeof(uint32_t);
+    // conflicts); 8 dwords of padding at the end (the traceback's speculative lanes read a little past a
+    // row).  A row is 32 DENT dwords, or 64 whole entries when W-O > 31 (the kernel's WIDE variant).
+    const size_t row_dw = (p.W - p.O > 31) ? 128 : 32;
+    return (slots * (17 + (size_t)p.lds_rows * row_dw + 1) + 8) * sizeof(uint32_t);
 }
 
 scrg_status scrg_query_launch(scrg_ctx* c, const scrg_params* params, int32_t* n_waves, int32_t* pairs_per_wave,
@@ -330,7 +332,7 @@ scrg_status scrg_align_device(scrg_ctx* c, const scrg_params* params, uint64_t n
     if ((uint64_t)n_waves > need_waves) n_waves = (int32_t)need_waves;
 
     HIP_TRY(c, c->counter.ensure(sizeof(uint32_t)));
-    HIP_TRY(c, c->spill.ensure((size_t)n_waves * ppw * scrg::SPILL_ROWS * 32 * sizeof(uint32_t)));
+    HIP_TRY(c, c->spill.ensure((size_t)n_waves * ppw * scrg::SPILL_ROWS * ((p.W - p.O > 31) ? 128 : 32) * sizeof(uint32_t)));
     HIP_TRY(c, hipMemsetAsync(c->counter.p, 0, sizeof(uint32_t), c->stream));
 
     scrg::AlignArgs a;

@@ -35,7 +35,7 @@ def test_golden_mapping(aligner, golden_mapping, g):
     _check(alns, gm["ed"], gm["cigar"], "mapping g=%d" % g)
 
 
-@pytest.mark.parametrize("name", ["pairs_w32_o17.json", "pairs_w48_o24.json", "pairs_w64_o40.json"])
+@pytest.mark.parametrize("name", ["pairs_w32_o17.json", "pairs_w48_o24.json", "pairs_w64_o40.json", "pairs_w64_o2.json"])
 def test_golden_other_knobs(aligner, name):
     """Reference fixtures at other W/O (the reference recompiles for these; here they are runtime values)."""
     from tests.conftest import load_golden
@@ -119,6 +119,22 @@ def test_other_window_settings(aligner, oracle, w, o):
     eds, cigars, _, _ = oracle.align(t, q, W=w, O=o)
     _check(aligner.align_pairs(t, q, W=w, O=o), eds, cigars, "W=%d O=%d" % (w, o))
     _check(aligner.align_pairs(t, q, W=w, O=o, lanes_per_pair=64), eds, cigars, "W=%d O=%d g64" % (w, o))
+
+
+@pytest.mark.parametrize("w,o", [(64, 2), (64, 20), (64, 32), (40, 5), (33, 1), (64, 1)])
+@pytest.mark.parametrize("g", [8, 64, 16])
+def test_small_overlap_uses_wide_storage(aligner, oracle, w, o, g):
+    """W-O > 31 (e.g. the reference's O sweep down to small overlaps, scripts/profile.py:88-100; README's
+    W=64,O=2 row): the traceback may consume up to W-O characters per window, so whole 64-bit entries of
+    all columns are stored (kernel variant WIDE)."""
+    t, q = synth.make_pairs(50, 400, "ont", seed=w * 31 + o)
+    rng = np.random.Generator(np.random.PCG64(w + o))
+    for _ in range(80):
+        t.append(synth.random_seq(int(rng.integers(0, 200)), rng))
+        q.append(synth.random_seq(int(rng.integers(0, 200)), rng))
+    eds, cigars, _, _ = oracle.align(t, q, W=w, O=o)
+    _check(aligner.align_pairs(t, q, W=w, O=o, lanes_per_pair=g), eds, cigars, "W=%d O=%d g=%d" % (w, o, g))
+    _check(aligner.align_pairs(t, q, W=w, O=o, lanes_per_pair=g, lds_rows=3), eds, cigars, "W=%d O=%d g=%d spill" % (w, o, g))
 
 
 def test_long_reads_10kb(aligner, oracle):
