@@ -203,3 +203,17 @@ def test_job_end_to_end_with_reverse_strand(tmp_path, aligner, oracle):
     job.align(aligner, out_path=sam_out, fmt="sam")
     body = [l for l in open(sam_out) if not l.startswith("@")]
     assert len(body) == len(alns) and body[0].split("\t")[5] == alns[0].cigar
+
+
+@pytest.mark.gpu
+def test_cli_end_to_end(tmp_path, capsys):
+    """`python -m scrooge_amd.cli` = the reference's `tests --reference= --reads= --seeds=` harness."""
+    from scrooge_amd import cli
+    fa, fq, seeds, chroms, truth = make_dataset(str(tmp_path), n_reads=120, seed=33)
+    out = os.path.join(str(tmp_path), "cli.paf")
+    rc = cli.main(["--reference=" + fa, "--reads=" + fq, "--seeds=" + seeds, "--out=" + out, "--reverse_strand",
+                   "--validate", "--dataset_inflation=2"])
+    text = capsys.readouterr().out
+    assert rc == 0
+    assert "GPU kernel ran at" in text and "validated 240 alignments, 0 failed" in text
+    assert len(open(out).read().splitlines()) == 240
