@@ -3,7 +3,8 @@
  *
  * Plain-C restatement of the windowed GenASM aligner in the reference's
  * src/genasm_cpu.cpp.  It is written from the algorithm's definition, one
- * uint64_t per bitvector (W <= 64, src/bitvector.hpp:42-44), and keeps the
+ * unsigned integer per bitvector (uint64_t for W <= 64, src/bitvector.hpp:42-44; unsigned __int128 up to
+ * W = 128; the core lives in genasm_oracle_core.inc), and keeps the
  * full (W+1) x (W+1) table of centre entries ("SENE" storage,
  * genasm_cpu.cpp:63-78); the reference's three storage/termination toggles do
  * not change results, so one variant is enough for a checker.
@@ -23,70 +24,7 @@
 #include <omp.h>
 #endif
 
-#define GO_MAXW 64
-
-typedef struct go_scratch {
-    uint64_t R[GO_MAXW + 1][GO_MAXW + 1]; /* R[d][i] */
-} go_scratch;
-
-static inline uint64_t shl64(uint64_t v, unsigned s)
-{
-    /* bitvector::operator<< yields zero once the shift reaches the width
-     * (src/bitvector.hpp:116-122). */
-    return s >= 64 ? 0 : v << s;
-}
-
-static inline int bit_is_zero(uint64_t v, unsigned b)
-{
-    return ((v >> b) & 1u) == 0; /* has_zero_at, src/bitvector.hpp:163-175 */
-}
-
-/* Pattern masks, genasm_cpu.cpp:178-198. */
-static void pattern_masks(const uint8_t *pattern, size_t m, uint64_t pm[4])
-{
-    pm[0] = pm[1] = pm[2] = pm[3] = ~(uint64_t)0;
-    for (size_t b = 0; b < m; b++)
-        pm[pattern[m - 1 - b]] &= ~((uint64_t)1 << b);
-}
-
-/*
- * Distance calculation, genasm_cpu.cpp:210-288: rows d = 0..K, columns
- * i = n..0, stops at the first row whose column 0 has bit m-1 clear
- * (EARLY_TERMINATION, :278-283).  Returns that row, or -1 if none exists
- * (cannot happen while K >= m, since m insertions always work).
- */
-static int distance_sweep(const uint8_t *text, size_t n,
-                          const uint8_t *pattern, size_t m, int K,
-                          go_scratch *s, go_stats *st)
-{
-    uint64_t pm[4];
-    pattern_masks(pattern, m, pm);
-
-    for (int d = 0; d <= K; d++) {
-        uint64_t *row = s->R[d];
-        const uint64_t *up = d ? s->R[d - 1] : NULL;
-
-        /* column n: nothing of the text left, only insertions (:239-245) */
-        row[n] = d ? shl64(~(uint64_t)0, (unsigned)d) : ~(uint64_t)0;
-
-        for (size_t i = n; i-- > 0;) {
-            uint64_t match = (row[i + 1] << 1) | pm[text[i]];
-            if (d == 0) {
-                row[i] = match; /* :232-238 */
-            } else {
-                uint64_t sub = up[i + 1] << 1;
-                uint64_t ins = up[i] << 1;
-                uint64_t del = up[i + 1];
-                row[i] = match & sub & ins & del; /* :246-252 */
-            }
-        }
-        if (st)
-            st->dc_cells += n + 1;
-        if (bit_is_zero(row[0], (unsigned)(m - 1)))
-            return d;
-    }
-    return -1;
-}
+#define GO_MAXW 128
 
 typedef struct run_sink {
     go_run *runs;
@@ -106,64 +44,26 @@ static void sink_push(run_sink *o, char op, unsigned count)
     o->n++;
 }
 
-/*
- * Traceback of one window, genasm_cpu.cpp:290-409.  Walks from (i,j,d) =
- * (0,0,window distance); stops when the pattern is used up or either index
- * reaches W-O (:307-310).  Edit preference: insertion, deletion,
- * substitution, match (:346-370); the last pattern character has its own
- * rule (:336-343).  Runs are flushed per window and never merged with the
- * next window's (:304-305, 400-403).
- */
-static int traceback(const go_scratch *s, size_t n, size_t m, int dist,
-                     size_t limit, size_t *text_used, size_t *pattern_used,
-                     run_sink *out, go_stats *st)
-{
-    size_t i = 0, j = 0;
-    int d = dist;
-    char cur = 0;
-    unsigned cur_len = 0;
 
-    while (j < m && i < limit && j < limit) {
-        int room = d > 0;
-        int text_left = i < n;
-        int ins, del, sub;
+#define GO_BV uint64_t
+#define GO_BV_BITS 64u
+#define GO_BV_MAXW 64
+#define GO_NAME(x) x##_64
+#include "genasm_oracle_core.inc"
+#undef GO_BV
+#undef GO_BV_BITS
+#undef GO_BV_MAXW
+#undef GO_NAME
 
-        if (j + 1 < m) {
-            unsigned bj = (unsigned)(m - 1 - j);      /* TB_BIT(j), :59 */
-            unsigned bj1 = bj - 1;                    /* TB_BIT(j+1) */
-            ins = room && bit_is_zero(s->R[d - 1][i], bj1);
-            del = room && text_left && bit_is_zero(s->R[d - 1][i + 1], bj);
-            sub = room && text_left && bit_is_zero(s->R[d - 1][i + 1], bj1);
-        } else {
-            ins = room;
-            del = 0;
-            sub = room && text_left;
-        }
-
-        char op;
-        if (ins)      { op = 'I'; j++; d--; }
-        else if (del) { op = 'D'; i++; d--; }
-        else if (sub) { op = 'X'; i++; j++; d--; }
-        else          { op = '='; i++; j++; }
-
-        if (op == cur) {
-            cur_len++;
-        } else {
-            if (cur_len)
-                sink_push(out, cur, cur_len);
-            cur = op;
-            cur_len = 1;
-        }
-        if (st)
-            st->tb_steps++;
-    }
-    if (cur_len)
-        sink_push(out, cur, cur_len);
-
-    *text_used = i;
-    *pattern_used = j;
-    return dist - d;
-}
+#define GO_BV unsigned __int128
+#define GO_BV_BITS 128u
+#define GO_BV_MAXW 128
+#define GO_NAME(x) x##_128
+#include "genasm_oracle_core.inc"
+#undef GO_BV
+#undef GO_BV_BITS
+#undef GO_BV_MAXW
+#undef GO_NAME
 
 int go_align_codes(const uint8_t *text, size_t text_len,
                    const uint8_t *read, size_t read_len,
@@ -171,44 +71,10 @@ int go_align_codes(const uint8_t *text, size_t text_len,
                    go_run *runs, size_t cap, size_t *n_runs,
                    long long *edit_distance, go_stats *stats)
 {
-    if (W < 2 || W > GO_MAXW || O < 0 || O >= W)
-        return GO_ERR_PARAMS;
-
-    /* per-thread table, like the per-thread R of genasm_cpu.cpp:444 */
-    static _Thread_local go_scratch scratch;
-    go_scratch *s = &scratch;
-
-    run_sink out = { runs, cap, 0, 0 };
-    size_t ti = 0, ri = 0;
-    long long total = 0;
-    const size_t limit = (size_t)(W - O);
-
-    /* window loop, genasm_cpu.cpp:411-438 */
-    while (ri < read_len) {
-        size_t n = text_len - ti < (size_t)W ? text_len - ti : (size_t)W;
-        size_t m = read_len - ri < (size_t)W ? read_len - ri : (size_t)W;
-
-        int dist = distance_sweep(text + ti, n, read + ri, m, W, s, stats);
-        if (dist < 0) /* unreachable with K == W */
-            return GO_ERR_PARAMS;
-        if (stats)
-            stats->windows++;
-
-        size_t tu, pu;
-        total += traceback(s, n, m, dist, limit, &tu, &pu, &out, stats);
-        ti += tu;
-        ri += pu;
-    }
-
-    if (n_runs)
-        *n_runs = out.n;
-    if (edit_distance)
-        *edit_distance = total;
-    if (stats) {
-        stats->runs += out.n;
-        stats->text_used += ti;
-    }
-    return out.overflow ? GO_ERR_CAPACITY : GO_OK;
+    /* one 64-bit word per bitvector up to W = 64 (src/bitvector.hpp:42-44), 128-bit beyond */
+    if (W <= 64)
+        return go_align_codes_64(text, text_len, read, read_len, W, O, runs, cap, n_runs, edit_distance, stats);
+    return go_align_codes_128(text, text_len, read, read_len, W, O, runs, cap, n_runs, edit_distance, stats);
 }
 
 /* ASCII -> 0..3, genasm_cpu.cpp:462-493 (upper and lower case ACGT only). */

@@ -132,7 +132,7 @@ def main():
 
     # --- other knob settings: the same reference sources built with -DCLI_KNOBS -DCLI_W/-DCLI_K/-DCLI_O
     #     (src/genasm_cpu.cpp:22-35); W=32,O=17 is the paper's short-read setting, O=2 the README's sweep row
-    for W, O in [(32, 17), (64, 2), (48, 24), (64, 40)]:
+    for W, O in [(32, 17), (64, 2), (48, 24), (64, 40), (128, 65), (96, 49)]:
         r2 = Reference(W, O)
         rng2 = np.random.Generator(np.random.PCG64(1000 * W + O))
         T, Q = synth.make_pairs(25, 300, "ont", seed=W * 7 + O)
