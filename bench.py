@@ -141,7 +141,7 @@ def main():
         kw["lds_rows"] = args.lds_rows
     if args.waves_per_cu:
         kw["waves_per_cu"] = args.waves_per_cu
-    p = al._params(kw)
+    p = al.resolved_params(**kw)
     geom = al.query_launch(**kw)
     if args.stats:
         al.params.reserved[1] = 1

@@ -47,12 +47,14 @@ enum {
 
 /* Tunables.  Zero-initialise and call scrg_params_default(). */
 typedef struct scrg_params {
-    int32_t W;               /* window length, 2..64; reference default 64 (genasm_cpu.cpp:7)   */
+    int32_t W;               /* window length, 2..256; reference default 64 (genasm_cpu.cpp:7).
+                                W > 64 uses multi-word entries (src/bitvector.hpp:45-48)           */
     int32_t O;               /* window overlap, 1 <= O < W; reference default 33 (genasm_cpu.cpp:9).
                                 W-O <= 31 (e.g. the defaults) uses the compact DENT storage; larger
                                 W-O switches to whole 64-bit entries of all columns (4x the LDS per row) */
     int32_t lanes_per_pair;  /* 64 = one pair per wavefront (lane = text column);
-                                4/8/16/32 pack 64/lanes pairs into one wavefront.  0 = default   */
+                                4/8/16/32 pack 64/lanes pairs into one wavefront.  0 = default
+                                (8; for W > 64 only 32 and 64 exist: 32 up to W = 128, then 64)                      */
     int32_t lds_rows;        /* rows of the R table kept in LDS per pair (rest spills to HBM);
                                 0 = default                                                        */
     int32_t waves_per_cu;    /* persistent wavefronts launched per CU; 0 = default                */
@@ -63,6 +65,8 @@ typedef struct scrg_params {
 } scrg_params;
 
 void scrg_params_default(scrg_params *p);
+/* Fills in every 0 ("default") field for the given W/O and validates; the values a launch will use. */
+scrg_status scrg_params_resolve(const scrg_params *in, scrg_params *out);
 
 /* One CIGAR run, layout-compatible with the reference's CigarEntry_t
  * (src/util.hpp:43-46). */

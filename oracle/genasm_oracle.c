@@ -4,7 +4,7 @@
  * Plain-C restatement of the windowed GenASM aligner in the reference's
  * src/genasm_cpu.cpp.  It is written from the algorithm's definition, one
  * unsigned integer per bitvector (uint64_t for W <= 64, src/bitvector.hpp:42-44; unsigned __int128 up to
- * W = 128; the core lives in genasm_oracle_core.inc), and keeps the
+ * W = 128, four 64-bit words up to W = 256; the core lives in genasm_oracle_core.inc), and keeps the
  * full (W+1) x (W+1) table of centre entries ("SENE" storage,
  * genasm_cpu.cpp:63-78); the reference's three storage/termination toggles do
  * not change results, so one variant is enough for a checker.
@@ -24,7 +24,7 @@
 #include <omp.h>
 #endif
 
-#define GO_MAXW 128
+#define GO_MAXW 256
 
 typedef struct run_sink {
     go_run *runs;
@@ -45,6 +45,14 @@ static void sink_push(run_sink *o, char op, unsigned count)
 }
 
 
+#define GO_ONES() (~(GO_BV)0)
+#define GO_ZERO() ((GO_BV)0)
+#define GO_SHL(v, s) ((v) << (s))
+#define GO_OR(a, b) ((a) | (b))
+#define GO_AND(a, b) ((a) & (b))
+#define GO_CLRBIT(v, b) ((v) & ~((GO_BV)1 << (b)))
+#define GO_BIT0(v, b) ((((v) >> (b)) & 1u) == 0)
+
 #define GO_BV uint64_t
 #define GO_BV_BITS 64u
 #define GO_BV_MAXW 64
@@ -64,6 +72,71 @@ static void sink_push(run_sink *o, char op, unsigned count)
 #undef GO_BV_BITS
 #undef GO_BV_MAXW
 #undef GO_NAME
+#undef GO_ONES
+#undef GO_ZERO
+#undef GO_SHL
+#undef GO_OR
+#undef GO_AND
+#undef GO_CLRBIT
+#undef GO_BIT0
+
+/* 256 bits as four 64-bit words, w[0] least significant (the reference: N/32 elements of 32 bits,
+ * src/bitvector.hpp:45-48, shifts carried across elements, :124-139). */
+typedef struct go_bv256 {
+    uint64_t w[4];
+} go_bv256;
+
+static inline go_bv256 bv256_fill(uint64_t x)
+{
+    go_bv256 r = { { x, x, x, x } };
+    return r;
+}
+static inline go_bv256 bv256_shl(go_bv256 v, unsigned s) /* s < 256 */
+{
+    go_bv256 r;
+    const unsigned ws = s / 64u, bs = s % 64u;
+    for (int k = 3; k >= 0; k--) {
+        uint64_t x = 0;
+        if (k >= (int)ws) {
+            x = v.w[k - (int)ws] << bs;
+            if (bs && k - (int)ws - 1 >= 0)
+                x |= v.w[k - (int)ws - 1] >> (64u - bs);
+        }
+        r.w[k] = x;
+    }
+    return r;
+}
+static inline go_bv256 bv256_or(go_bv256 a, go_bv256 b)
+{
+    for (int k = 0; k < 4; k++) a.w[k] |= b.w[k];
+    return a;
+}
+static inline go_bv256 bv256_and(go_bv256 a, go_bv256 b)
+{
+    for (int k = 0; k < 4; k++) a.w[k] &= b.w[k];
+    return a;
+}
+static inline go_bv256 bv256_clrbit(go_bv256 v, unsigned b)
+{
+    v.w[b / 64u] &= ~(1ull << (b % 64u));
+    return v;
+}
+#define GO_ONES() bv256_fill(~0ull)
+#define GO_ZERO() bv256_fill(0ull)
+#define GO_SHL(v, s) bv256_shl((v), (s))
+#define GO_OR(a, b) bv256_or((a), (b))
+#define GO_AND(a, b) bv256_and((a), (b))
+#define GO_CLRBIT(v, b) bv256_clrbit((v), (b))
+#define GO_BIT0(v, b) ((((v).w[(b) / 64u] >> ((b) % 64u)) & 1u) == 0)
+#define GO_BV go_bv256
+#define GO_BV_BITS 256u
+#define GO_BV_MAXW 256
+#define GO_NAME(x) x##_256
+#include "genasm_oracle_core.inc"
+#undef GO_BV
+#undef GO_BV_BITS
+#undef GO_BV_MAXW
+#undef GO_NAME
 
 int go_align_codes(const uint8_t *text, size_t text_len,
                    const uint8_t *read, size_t read_len,
@@ -71,10 +144,12 @@ int go_align_codes(const uint8_t *text, size_t text_len,
                    go_run *runs, size_t cap, size_t *n_runs,
                    long long *edit_distance, go_stats *stats)
 {
-    /* one 64-bit word per bitvector up to W = 64 (src/bitvector.hpp:42-44), 128-bit beyond */
+    /* one 64-bit word per bitvector up to W = 64 (src/bitvector.hpp:42-44), wider types beyond */
     if (W <= 64)
         return go_align_codes_64(text, text_len, read, read_len, W, O, runs, cap, n_runs, edit_distance, stats);
-    return go_align_codes_128(text, text_len, read, read_len, W, O, runs, cap, n_runs, edit_distance, stats);
+    if (W <= 128)
+        return go_align_codes_128(text, text_len, read, read_len, W, O, runs, cap, n_runs, edit_distance, stats);
+    return go_align_codes_256(text, text_len, read, read_len, W, O, runs, cap, n_runs, edit_distance, stats);
 }
 
 /* ASCII -> 0..3, genasm_cpu.cpp:462-493 (upper and lower case ACGT only). */

@@ -46,7 +46,7 @@ enum {
     GO_ERR_CAPACITY = 3    /* caller-provided run/char buffer too small */
 };
 
-/* Align one pair given 0..3 base codes.  W in [2,128], 0 <= O < W.  K == W as in
+/* Align one pair given 0..3 base codes.  W in [2,256], 0 <= O < W.  K == W as in
  * the reference defaults (genasm_cpu.cpp:7-9).  Writes up to cap runs. */
 int go_align_codes(const uint8_t *text, size_t text_len,
                    const uint8_t *read, size_t read_len,

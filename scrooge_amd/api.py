@@ -100,6 +100,7 @@ def load_library():
     vp, u64, i32p = C.c_void_p, C.c_uint64, C.POINTER(C.c_int32)
     sigs = {
         "scrg_params_default": (None, [C.POINTER(Params)]),
+        "scrg_params_resolve": (C.c_int32, [C.POINTER(Params), C.POINTER(Params)]),
         "scrg_ctx_create": (C.c_int32, [C.c_int, C.POINTER(vp)]),
         "scrg_ctx_destroy": (None, [vp]),
         "scrg_ctx_set_stream": (C.c_int32, [vp, vp]),
@@ -132,7 +133,7 @@ def load_library():
 
 
 EXPORTED_SYMBOLS = [
-    "scrg_params_default", "scrg_ctx_create", "scrg_ctx_destroy", "scrg_ctx_set_stream",
+    "scrg_params_default", "scrg_params_resolve", "scrg_ctx_create", "scrg_ctx_destroy", "scrg_ctx_set_stream",
     "scrg_ctx_use_own_stream",
     "scrg_last_error", "scrg_status_string", "scrg_set_log", "scrg_device_count",
     "scrg_result_free", "scrg_align_pairs", "scrg_align_mapping", "scrg_pack_planar",
@@ -296,6 +297,14 @@ class Aligner:
         return {"rounds": int(out[0]), "dc_steps": int(out[1]), "tb_macro_steps": int(out[2]),
                 "cycles_fetch": int(out[3]), "cycles_setup": int(out[4]), "cycles_dc": int(out[5]),
                 "cycles_tb": int(out[6]), "cycles_tb_loop": int(out[7])}
+
+    def resolved_params(self, **kw):
+        """The parameters a launch with these overrides will really use (defaults filled in)."""
+        out = Params()
+        st = self.lib.scrg_params_resolve(C.byref(self._params(kw)), C.byref(out))
+        if st != SCRG_OK:
+            raise ScroogeError(st, "invalid parameters")
+        return out
 
     def query_launch(self, **kw):
         a, b, c, d = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()

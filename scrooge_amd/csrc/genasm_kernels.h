@@ -12,6 +12,7 @@ namespace scrg {
 // rows of the HBM spill area per pair slot: K+1 = 65 rows of R can exist, plus
 // the rows lanes ahead of the slot leader run past the final row
 constexpr int SPILL_ROWS = 72;
+// (genasm_kernel_multiword.hip, 64 < W <= 256, sizes its spill area as W+1 rows of stored_row_dwords())
 
 struct AlignArgs {
     const uint64_t* seq;          // planar 2-bit words
@@ -31,6 +32,17 @@ struct AlignArgs {
 };
 
 hipError_t launch_align(int lanes_per_pair, const AlignArgs& a, int grid, size_t lds_bytes, hipStream_t s);
+hipError_t launch_align_multiword(int lanes_per_pair, const AlignArgs& a, int grid, size_t lds_bytes, hipStream_t s);
+
+// dwords of one stored row of R (the part the traceback can reach):
+//   W <= 64: the high dword of columns 0..31, or whole entries of all 64 columns when W-O > 31;
+//   W  > 64: words 0..SW-1 of columns 0..64*SW-1 with SW = (W-O)/64 + 1.
+inline unsigned stored_row_dwords(int W, int tb_limit)
+{
+    if (W <= 64) return tb_limit > 31 ? 128u : 32u;
+    const unsigned sw = (unsigned)tb_limit / 64u + 1u;
+    return 64u * sw * sw * 2u;
+}
 hipError_t launch_pack_planar(const char* d_ascii, uint64_t n_words, uint64_t* d_planar, uint32_t* d_bad,
                               int n_cus, hipStream_t s);
 hipError_t launch_ascii_to_twobit(uint64_t count, const uint64_t* d_lens, const uint64_t* d_ascii_off,

@@ -28,113 +28,13 @@
 #include <type_traits>
 
 #include "genasm_kernels.h"
+#include "genasm_device.h"
 
 namespace scrg {
 
 // ----------------------------------------------------------------------------
-// small device helpers
+// the aligner (device helpers: genasm_device.h)
 // ----------------------------------------------------------------------------
-
-// lane i <- lane i+1 across the whole wave (DPP wave_shl:1, full rate, no LDS)
-__device__ __forceinline__ uint32_t dpp_from_next(uint32_t v)
-{
-    uint32_t r;   // lane 63 has no source and keeps an undefined value; it is a slot's last lane, which never uses it
-    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 wave_shl:1 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v));
-    return r;
-}
-__device__ __forceinline__ uint64_t dpp_from_next64(uint64_t v)
-{
-    uint32_t lo = dpp_from_next((uint32_t)v);
-    uint32_t hi = dpp_from_next((uint32_t)(v >> 32));
-    return ((uint64_t)hi << 32) | lo;
-}
-
-__device__ __forceinline__ uint64_t ones_shl(int d)
-{
-    // bitvector::ones() << d with the reference's ">= width gives zero" rule
-    // (src/bitvector.hpp:116-122)
-    return d >= 64 ? 0ull : (~0ull << d);
-}
-
-// 64 bases starting at base offset p of a planar array: returns the low-bit
-// plane in .x and the high-bit plane in .y (bit k <-> base p+k)
-struct Planes { uint64_t lo, hi; };
-__device__ __forceinline__ Planes load_window(const uint64_t* __restrict__ seq, uint64_t p)
-{
-    const uint64_t w = p >> 5;
-    const uint32_t s = (uint32_t)p & 31u;
-    const uint64_t a = seq[w], b = seq[w + 1], c = seq[w + 2];
-    const uint32_t l0 = (uint32_t)a, l1 = (uint32_t)b, l2 = (uint32_t)c;
-    const uint32_t h0 = (uint32_t)(a >> 32), h1 = (uint32_t)(b >> 32), h2 = (uint32_t)(c >> 32);
-    Planes r;
-    r.lo = (uint64_t)__builtin_amdgcn_alignbit(l1, l0, s) | ((uint64_t)__builtin_amdgcn_alignbit(l2, l1, s) << 32);
-    r.hi = (uint64_t)__builtin_amdgcn_alignbit(h1, h0, s) | ((uint64_t)__builtin_amdgcn_alignbit(h2, h1, s) << 32);
-    return r;
-}
-
-// Conditions as 0 / ~0 masks.  Written as asm / intrinsics so that the optimiser cannot turn them
-// back into v_cmp + v_cndmask (both half rate on gfx950; v_ashrrev, v_sub and v_bitop3 are full rate).
-__device__ __forceinline__ uint32_t neg_mask(uint32_t x)      // ~0 iff (int32)x < 0
-{
-    uint32_t r;
-    asm("v_ashrrev_i32 %0, 31, %1" : "=v"(r) : "v"(x));
-    return r;
-}
-__device__ __forceinline__ uint32_t nz_mask(uint32_t x)       // ~0 iff x != 0, for x < 2^31
-{
-    return neg_mask(0u - x);
-}
-template <int TT> __device__ __forceinline__ uint32_t bitop3(uint32_t a, uint32_t b, uint32_t c)
-{
-    return __builtin_amdgcn_bitop3_b32(a, b, c, TT);
-}
-
-// minimum of v over the G lanes of a slot, returned in every lane.  G <= 16: butterfly of
-// DPP-modified v_min_u32 (no LDS traffic, no SALU); wider slots finish with xor-shuffles.
-template <int CTRL> __device__ __forceinline__ uint32_t dpp_min(uint32_t v)
-{
-    uint32_t r;
-    if (CTRL == 0xB1) asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v));
-    else if (CTRL == 0x4E) asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v));
-    else if (CTRL == 0x141) asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v));
-    else asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %1, %1 row_mirror row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v));
-    return r;
-}
-template <int G> __device__ __forceinline__ uint32_t slot_min(uint32_t v)
-{
-    v = dpp_min<0xB1>(v);                    // quad_perm:[1,0,3,2]
-    v = dpp_min<0x4E>(v);                    // quad_perm:[2,3,0,1]
-    if (G >= 8) v = dpp_min<0x141>(v);       // row_half_mirror
-    if (G >= 16) v = dpp_min<0x140>(v);      // row_mirror
-    if (G >= 32) { const uint32_t o = (uint32_t)__shfl_xor((int)v, 16); v = o < v ? o : v; }
-    if (G >= 64) { const uint32_t o = (uint32_t)__shfl_xor((int)v, 32); v = o < v ? o : v; }
-    return v;
-}
-
-// 64-bit shift left by one as ONE v_lshlrev_b64 (quarter-rate class, like any 32-bit shift on
-// gfx950); written as asm so the compiler does not split it into lshl + alignbit (two of them)
-__device__ __forceinline__ uint64_t shl1(uint64_t v)
-{
-    uint64_t r;
-    asm("v_lshlrev_b64 %0, 1, %1" : "=v"(r) : "v"(v));
-    return r;
-}
-
-__device__ __forceinline__ uint64_t brev64(uint64_t v)
-{
-    return ((uint64_t)__builtin_bitreverse32((uint32_t)v) << 32) | __builtin_bitreverse32((uint32_t)(v >> 32));
-}
-
-// ----------------------------------------------------------------------------
-// the aligner
-// ----------------------------------------------------------------------------
-
-constexpr uint64_t leader_mask(int g)
-{
-    uint64_t m = 0;
-    for (int s = 0; s < 64 / g; s++) m |= 1ull << (s * g);
-    return m;
-}
 
 // WIDE stores every column's whole 64-bit entry instead of the DENT dword of columns 0..31: needed
 // when the traceback may consume more than 31 characters per window (W-O > 31, e.g. the reference's

@@ -151,9 +151,9 @@ void scrg_params_default(scrg_params* p)
     memset(p, 0, sizeof(*p));
     p->W = 64;                // src/genasm_cpu.cpp:7
     p->O = 33;                // src/genasm_cpu.cpp:9
-    p->lanes_per_pair = 8;
-    p->lds_rows = 13;
-    p->waves_per_cu = 11;
+    p->lanes_per_pair = 0;    // 0 = chosen for W: see scrg_params_resolve()
+    p->lds_rows = 0;
+    p->waves_per_cu = 0;
     p->sort_by_length = 1;
 }
 
@@ -255,18 +255,37 @@ static bool resolve_params(const scrg_params* in, scrg_params* p)
     if (in) {
         if (in->W) p->W = in->W;
         if (in->O || in->W) p->O = in->O;
-        if (in->lanes_per_pair) p->lanes_per_pair = in->lanes_per_pair;
-        if (in->lds_rows) p->lds_rows = in->lds_rows;
-        if (in->waves_per_cu) p->waves_per_cu = in->waves_per_cu;
+        p->lanes_per_pair = in->lanes_per_pair;
+        p->lds_rows = in->lds_rows;
+        p->waves_per_cu = in->waves_per_cu;
         p->sort_by_length = in->sort_by_length;
     }
-    const int g = p->lanes_per_pair;
-    if (!(g == 4 || g == 8 || g == 16 || g == 32 || g == 64)) return false;
-    if (p->W < 2 || p->W > 64) return false;
+    if (p->W < 2 || p->W > 256) return false;
     const int tbl = p->W - p->O;
     if (tbl < 1 || p->O < 1) return false;   // O = 0 (no overlap) would let the traceback read the boundary column
+    const size_t row_bytes = (size_t)scrg::stored_row_dwords(p->W, tbl) * 4;
+    if (p->W > 64) {
+        // multi-word entries (genasm_kernel_multiword.hip): slots of 32 or 64 lanes; as many rows of R
+        // in LDS as fit in about 40 KB per wavefront, the rest of a window's rows go to HBM
+        if (p->lanes_per_pair == 0) p->lanes_per_pair = p->W > 128 ? 64 : 32;
+        if (p->lanes_per_pair != 32 && p->lanes_per_pair != 64) return false;
+        if (p->lds_rows == 0) {
+            const size_t fit = (40u << 10) / (row_bytes * (64 / p->lanes_per_pair));
+            p->lds_rows = (int32_t)std::min<size_t>(32, std::max<size_t>(4, fit));
+        }
+    } else {
+        // measured optimum on MI355X for 10 kb reads at 10 % error
+        if (p->lanes_per_pair == 0) p->lanes_per_pair = 8;
+        if (p->lds_rows == 0) p->lds_rows = 13;
+    }
+    if (p->waves_per_cu == 0) p->waves_per_cu = 11;    // the LDS footprint caps it (scrg_query_launch)
+    const int g = p->lanes_per_pair;
+    if (!(g == 4 || g == 8 || g == 16 || g == 32 || g == 64)) return false;
     if (p->lds_rows < 1) return false;
-    if (p->lds_rows > 65) p->lds_rows = 65;
+    if (p->lds_rows > p->W + 1) p->lds_rows = p->W + 1;
+    // one wavefront's table has to fit the 160 KB of a CU
+    const size_t per_row = row_bytes * (64 / g);
+    if ((size_t)p->lds_rows * per_row > (150u << 10)) p->lds_rows = (int32_t)std::max<size_t>(1, (150u << 10) / per_row);
     if (p->waves_per_cu < 1 || p->waves_per_cu > 32) return false;
     return true;
 }
@@ -276,9 +295,16 @@ static size_t lds_bytes_for(const scrg_params& p)
     const size_t slots = 64 / p.lanes_per_pair;
     // per slot: CIGAR staging ring (16 dwords) + 1 scratch dword + R rows (+1 dword against bank
     // conflicts); 8 dwords of padding at the end (the traceback's speculative lanes read a little past a
-    // row).  A row is 32 DENT dwords, or 64 whole entries when W-O > 31 (the kernel's WIDE variant).
-    const size_t row_dw = (p.W - p.O > 31) ? 128 : 32;
+    // row).  A row is 32 DENT dwords, or 64 whole entries when W-O > 31 (the kernel's WIDE variant);
+    // see stored_row_dwords() for W > 64.
+    const size_t row_dw = scrg::stored_row_dwords(p.W, p.W - p.O);
     return (slots * (17 + (size_t)p.lds_rows * row_dw + 1) + 8) * sizeof(uint32_t);
+}
+
+scrg_status scrg_params_resolve(const scrg_params* in, scrg_params* out)
+{
+    if (!out) return SCRG_ERR_INVALID_ARG;
+    return resolve_params(in, out) ? SCRG_OK : SCRG_ERR_INVALID_ARG;
 }
 
 scrg_status scrg_query_launch(scrg_ctx* c, const scrg_params* params, int32_t* n_waves, int32_t* pairs_per_wave,
@@ -332,7 +358,9 @@ scrg_status scrg_align_device(scrg_ctx* c, const scrg_params* params, uint64_t n
     if ((uint64_t)n_waves > need_waves) n_waves = (int32_t)need_waves;
 
     HIP_TRY(c, c->counter.ensure(sizeof(uint32_t)));
-    HIP_TRY(c, c->spill.ensure((size_t)n_waves * ppw * scrg::SPILL_ROWS * ((p.W - p.O > 31) ? 128 : 32) * sizeof(uint32_t)));
+    const size_t spill_rows = p.W > 64 ? (size_t)p.W + 1 : scrg::SPILL_ROWS;
+    const size_t spill_row_dw = scrg::stored_row_dwords(p.W, p.W - p.O);
+    HIP_TRY(c, c->spill.ensure((size_t)n_waves * ppw * spill_rows * spill_row_dw * sizeof(uint32_t)));
     HIP_TRY(c, hipMemsetAsync(c->counter.p, 0, sizeof(uint32_t), c->stream));
 
     scrg::AlignArgs a;
@@ -357,7 +385,10 @@ scrg_status scrg_align_device(scrg_ctx* c, const scrg_params* params, uint64_t n
     }
 
     HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));
-    HIP_TRY(c, scrg::launch_align(p.lanes_per_pair, a, n_waves, (size_t)lds, c->stream));
+    if (p.W > 64)
+        HIP_TRY(c, scrg::launch_align_multiword(p.lanes_per_pair, a, n_waves, (size_t)lds, c->stream));
+    else
+        HIP_TRY(c, scrg::launch_align(p.lanes_per_pair, a, n_waves, (size_t)lds, c->stream));
     HIP_TRY(c, hipEventRecord(c->ev_stop, c->stream));
     c->have_timing = true;
     return SCRG_OK;

@@ -147,6 +147,23 @@ def main():
             for t, q, e, c in zip(T, Q, eds2, cigs2)]})
         print("W=%d O=%d cases:" % (W, O), len(T))
 
+    # --- windows of more than 128 characters (four-word bitvectors) and W=128 with a small overlap
+    #     (the traceback then reads past character 63): longer inputs so that several windows chain
+    for W, O in [(256, 129), (192, 97), (128, 20), (200, 50)]:
+        r2 = Reference(W, O)
+        rng2 = np.random.Generator(np.random.PCG64(1000 * W + O))
+        T, Q = synth.make_pairs(20, 1200, "ont", seed=W * 7 + O)
+        t2, q2 = synth.make_pairs(8, 600, "pacbio15", seed=W + O)
+        T, Q = T + t2, Q + q2
+        for _ in range(40):
+            T.append(synth.random_seq(int(rng2.integers(0, 500)), rng2))
+            Q.append(synth.random_seq(int(rng2.integers(0, 500)), rng2))
+        eds2, cigs2, _ = r2.align(T, Q)
+        dump("pairs_w%d_o%d.json" % (W, O), {"W": W, "O": O, "cases": [
+            {"group": "knobs", "text": t.decode(), "read": q.decode(), "ed": e, "cigar": c}
+            for t, q, e, c in zip(T, Q, eds2, cigs2)]})
+        print("W=%d O=%d cases:" % (W, O), len(T))
+
 
 if __name__ == "__main__":
     main()

@@ -142,3 +142,46 @@ def test_long_reads_10kb(aligner, oracle):
     eds, cigars, st, _ = oracle.align(t, q, threads=8)
     _check(aligner.align_pairs(t, q), eds, cigars, "10kb")
     _check(aligner.align_pairs(t, q, lanes_per_pair=64), eds, cigars, "10kb g64")
+
+
+@pytest.mark.parametrize("name", ["pairs_w128_o65.json", "pairs_w96_o49.json", "pairs_w256_o129.json",
+                                  "pairs_w192_o97.json", "pairs_w128_o20.json", "pairs_w200_o50.json"])
+@pytest.mark.parametrize("g", [32, 64])
+def test_golden_windows_over_64(aligner, name, g):
+    """Reference fixtures built with -DCLI_W=96 ... 256 (the reference's bitvector<N> path,
+    src/bitvector.hpp:45-48): multi-word entries here (genasm_kernel_multiword.hip)."""
+    from tests.conftest import load_golden
+    gd = load_golden(name)
+    cases = gd["cases"]
+    alns = aligner.align_pairs([c["text"] for c in cases], [c["read"] for c in cases], W=gd["W"], O=gd["O"],
+                               lanes_per_pair=g)
+    _check(alns, [c["ed"] for c in cases], [c["cigar"] for c in cases], "%s g=%d" % (name, g))
+    alns = aligner.align_pairs([c["text"] for c in cases], [c["read"] for c in cases], W=gd["W"], O=gd["O"],
+                               lanes_per_pair=g, lds_rows=5)
+    _check(alns, [c["ed"] for c in cases], [c["cigar"] for c in cases], "%s g=%d spill" % (name, g))
+
+
+@pytest.mark.parametrize("w,o", [(128, 65), (96, 49), (100, 40), (65, 2), (128, 127), (127, 64), (80, 41),
+                                 (256, 129), (256, 1), (129, 65), (192, 64), (255, 200), (160, 81)])
+@pytest.mark.parametrize("g", [32, 64])
+def test_windows_over_64_vs_oracle(aligner, oracle, w, o, g):
+    t, q = synth.make_pairs(40, 900, "ont", seed=w * 7 + o)
+    a, b = synth.make_pairs(10, 2500, "pacbio15", seed=w + o)
+    t, q = t + a, q + b
+    rng = np.random.Generator(np.random.PCG64(w * 3 + o))
+    for _ in range(100):
+        t.append(synth.random_seq(int(rng.integers(0, 600)), rng))
+        q.append(synth.random_seq(int(rng.integers(0, 600)), rng))
+    eds, cigars, _, _ = oracle.align(t, q, W=w, O=o, threads=8)
+    _check(aligner.align_pairs(t, q, W=w, O=o, lanes_per_pair=g), eds, cigars, "W=%d O=%d g=%d" % (w, o, g))
+    _check(aligner.align_pairs(t, q, W=w, O=o, lanes_per_pair=g, lds_rows=4), eds, cigars,
+           "W=%d O=%d g=%d spill" % (w, o, g))
+
+
+def test_windows_over_64_limits(aligner):
+    import scrooge_amd
+    with pytest.raises(scrooge_amd.ScroogeError):
+        aligner.align_pairs(["ACGT"], ["ACGT"], W=128, O=65, lanes_per_pair=8)   # slots of 32 or 64 lanes only
+    with pytest.raises(scrooge_amd.ScroogeError):
+        aligner.align_pairs(["ACGT"], ["ACGT"], W=257, O=129)
+    assert aligner.align_pairs(["ACGT"], ["ACGT"], W=256, O=129) == [("4=", 0)]
