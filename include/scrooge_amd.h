@@ -54,7 +54,7 @@ typedef struct scrg_params {
                                 W-O switches to whole 64-bit entries of all columns (4x the LDS per row) */
     int32_t lanes_per_pair;  /* 64 = one pair per wavefront (lane = text column);
                                 4/8/16/32 pack 64/lanes pairs into one wavefront.  0 = default
-                                (8; for W > 64 only 32 and 64 exist: 32 up to W = 128, then 64)                      */
+                                (8; for W > 64 only 32 and 64 exist, default 32)                      */
     int32_t lds_rows;        /* rows of the R table kept in LDS per pair (rest spills to HBM);
                                 0 = default                                                        */
     int32_t waves_per_cu;    /* persistent wavefronts launched per CU; 0 = default                */

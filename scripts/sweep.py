@@ -4,7 +4,7 @@ configuration with the reference's column names where a knob has an equivalent h
     python scripts/sweep.py out.csv [pairs] [read_len]
 
 W and O are runtime parameters here (the reference recompiles per configuration, profile.py:131-142);
-supported range W <= 64, 1 <= O < W (W-O > 31 uses the 4x larger WIDE table).  "threadblocks/sm" = persistent wavefronts per CU,
+supported range 2 <= W <= 256, 1 <= O < W (W-O > 31 uses the 4x larger WIDE table, W > 64 the multi-word kernel).  "threadblocks/sm" = persistent wavefronts per CU,
 "used smem per threadblock (B)" = LDS bytes per wavefront; SENE/DENT/ET are always on (they do not
 change results)."""
 import csv, sys
@@ -21,7 +21,7 @@ al = scrooge_amd.Aligner(0)
 al.set_stream(0)
 err, ratio = synth.PROFILES["ont"]
 rows_a, tw, rw, text_len = bench.device_pairs(torch, n, L, err, ratio, 42, dev)
-seq = torch.zeros(n * (tw + rw) + 4, dtype=torch.int64, device=dev)
+seq = torch.zeros(n * (tw + rw) + scrooge_amd.api.SEQ_PAD_WORDS, dtype=torch.int64, device=dev)
 bad = torch.zeros(1, dtype=torch.int32, device=dev)
 al.pack_planar(rows_a.view(-1), seq, bad)
 del rows_a
@@ -38,6 +38,8 @@ configs = [(64, 33, 8, 13, 11)]
 configs += [(W, min(W // 2 + 1, W - 1), 8, 13, 11) for W in (16, 24, 32, 40, 48, 56)]      # W sweep, O = W/2+1 (profile.py:78)
 configs += [(64, O, 8, 13, 11) for O in (36, 40, 48, 56, 60)]                                  # O sweep at W=64 (profile.py:88-100)
 configs += [(64, O, 8, 13, 3) for O in (2, 16, 32)]                                             # small overlaps: WIDE storage
+configs += [(W, W // 2 + 1, 0, 0, 0) for W in (80, 96, 112, 128, 160, 192, 224, 256)]         # W sweep past one word (profile.py:180-185)
+configs += [(128, 65, 64, 0, 0), (256, 129, 64, 0, 0), (256, 129, 32, 20, 0), (128, 20, 0, 0, 0)]
 configs += [(64, 33, g, 13, w) for g, w in ((64, 16), (32, 16), (16, 16), (4, 6))]             # lane mappings
 configs += [(64, 33, 8, r, w) for r, w in ((16, 9), (12, 12), (10, 14))]                        # LDS rows vs occupancy
 with open(out, "w", newline="") as f:
@@ -48,6 +50,8 @@ with open(out, "w", newline="") as f:
     for W, O, g, r, w in configs:
         kw = dict(W=W, O=O, lanes_per_pair=g, lds_rows=r, waves_per_cu=w)
         geo = al.query_launch(**kw)
+        rp = al.resolved_params(**kw)
+        g, r = rp.lanes_per_pair, rp.lds_rows
         for rep in range(2):
             al.align_device(n, seq, desc, runs, ed, nr, st, **kw)
             ms = al.last_kernel_ms()

@@ -267,7 +267,7 @@ static bool resolve_params(const scrg_params* in, scrg_params* p)
     if (p->W > 64) {
         // multi-word entries (genasm_kernel_multiword.hip): slots of 32 or 64 lanes; as many rows of R
         // in LDS as fit in about 40 KB per wavefront, the rest of a window's rows go to HBM
-        if (p->lanes_per_pair == 0) p->lanes_per_pair = p->W > 128 ? 64 : 32;
+        if (p->lanes_per_pair == 0) p->lanes_per_pair = 32;    // measured faster than 64 also at W = 256
         if (p->lanes_per_pair != 32 && p->lanes_per_pair != 64) return false;
         if (p->lds_rows == 0) {
             const size_t fit = (40u << 10) / (row_bytes * (64 / p->lanes_per_pair));

@@ -49,7 +49,7 @@ def test_defaults_match_reference_knobs(lib):
     p.W, p.O = 128, 65
     assert lib.scrg_params_resolve(p, r) == 0 and r.lanes_per_pair == 32
     p.W, p.O = 256, 129
-    assert lib.scrg_params_resolve(p, r) == 0 and r.lanes_per_pair == 64
+    assert lib.scrg_params_resolve(p, r) == 0 and r.lanes_per_pair == 32
     p.W, p.O = 257, 129
     assert lib.scrg_params_resolve(p, r) != 0
     p.W, p.O = 64, 0
