@@ -241,6 +241,10 @@ def main():
         st["macro_per_round"] = st["tb_macro_steps"] / max(1, st["rounds"])
         for k in ("fetch", "setup", "dc", "tb", "tb_loop"):
             st["cyc_per_round_" + k] = st["cycles_" + k] / max(1, st["rounds"])
+        old_rounds = max(1, st["rounds"] - st["diag_rounds"])
+        for k in ("dc", "tb"):
+            st["cyc_per_old_round_" + k] = st["cycles_" + k] / old_rounds
+            st["cyc_per_diag_round_" + k] = st["cycles_diag_" + k] / max(1, st["diag_rounds"])
         print("stats(last launch):", st, file=sys.stderr)
     if rank != 0:
         if world > 1:

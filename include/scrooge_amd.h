@@ -195,10 +195,13 @@ scrg_status scrg_last_kernel_ms(scrg_ctx *ctx, float *ms);
 
 /* Profiling aid: when params.reserved[1] != 0 the align kernel accumulates
  * {window rounds, DC sweep steps, TB macro-steps, and shader cycles summed over
- * wavefronts for fetch / window setup / DC / TB, 0} per launch; this reads them
- * back (blocks on the stream).  params.reserved[0] holds ablation switches and
- * must be 0 for correct results. */
-scrg_status scrg_debug_stats(scrg_ctx *ctx, uint64_t out[8]);
+ * wavefronts for fetch / window setup / DC / TB / TB loop, rounds on the
+ * diagonal-major path, rounds that fell back from it, and the DC / TB cycles of
+ * the diagonal-major rounds (not included in the former)} per launch; this
+ * reads them back (blocks on the stream).  params.reserved[0] holds ablation
+ * switches and must be 0 for correct results (32 only turns the diagonal-major
+ * path off and keeps results intact). */
+scrg_status scrg_debug_stats(scrg_ctx *ctx, uint64_t out[12]);
 
 #ifdef __cplusplus
 }

@@ -292,11 +292,12 @@ class Aligner:
         return float(ms.value)
 
     def debug_stats(self):
-        out = (C.c_uint64 * 8)()
+        out = (C.c_uint64 * 12)()
         self._check(self.lib.scrg_debug_stats(self.h, out))
         return {"rounds": int(out[0]), "dc_steps": int(out[1]), "tb_macro_steps": int(out[2]),
                 "cycles_fetch": int(out[3]), "cycles_setup": int(out[4]), "cycles_dc": int(out[5]),
-                "cycles_tb": int(out[6]), "cycles_tb_loop": int(out[7])}
+                "cycles_tb": int(out[6]), "cycles_tb_loop": int(out[7]), "diag_rounds": int(out[8]),
+                "diag_fallbacks": int(out[9]), "cycles_diag_dc": int(out[10]), "cycles_diag_tb": int(out[11])}
 
     def resolved_params(self, **kw):
         """The parameters a launch with these overrides will really use (defaults filled in)."""

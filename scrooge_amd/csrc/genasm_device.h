@@ -25,6 +25,39 @@ __device__ __forceinline__ uint64_t dpp_from_next64(uint64_t v)
     return ((uint64_t)hi << 32) | lo;
 }
 
+// lane i <- lane i-1 (DPP wave_shr:1); lane 0 keeps an undefined value
+__device__ __forceinline__ uint32_t dpp_from_prev(uint32_t v)
+{
+    uint32_t r;
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v));
+    return r;
+}
+__device__ __forceinline__ uint64_t dpp_from_prev64(uint64_t v)
+{
+    uint32_t lo = dpp_from_prev((uint32_t)v);
+    uint32_t hi = dpp_from_prev((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// a + b + carry-in, where the carry-in of lane l is bit l of the SGPR mask cin (v_addc_co_u32 x2)
+__device__ __forceinline__ uint64_t add64_cin(uint64_t a, uint64_t b, uint64_t cin)
+{
+    uint32_t lo, hi;
+    uint64_t c1, c2;
+    asm("v_addc_co_u32 %0, %1, %2, %3, %4" : "=v"(lo), "=s"(c1) : "v"((uint32_t)a), "v"((uint32_t)b), "s"(cin));
+    asm("v_addc_co_u32 %0, %1, %2, %3, %4" : "=v"(hi), "=s"(c2) : "v"((uint32_t)(a >> 32)), "v"((uint32_t)(b >> 32)), "s"(c1));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// truth table of a 3-input function for v_bitop3_b32 (bit index = a*4 + b*2 + c)
+template <typename F> constexpr int bitop3_table(F f)
+{
+    int tt = 0;
+    for (int k = 0; k < 8; k++)
+        if (f((k >> 2) & 1, (k >> 1) & 1, k & 1) & 1) tt |= 1 << k;
+    return tt;
+}
+
 __device__ __forceinline__ uint64_t ones_shl(int d)
 {
     // bitvector::ones() << d with the reference's ">= width gives zero" rule

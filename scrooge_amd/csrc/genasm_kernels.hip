@@ -81,6 +81,9 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
     bool overflow = false;
     bool queue_empty = false;            // wave-uniform
     uint32_t st_rounds = 0, st_steps = 0, st_macro = 0;   // profiling counters (a.stats != nullptr)
+    uint32_t st_diag = 0, st_diag_fail = 0;
+    uint64_t cy_ddc = 0, cy_dtb = 0;
+    uint32_t diag_skip = 0, diag_backoff = 0;   // rounds to stay off the diagonal-major path after it failed
     uint64_t cy_fetch = 0, cy_setup = 0, cy_dc = 0, cy_tb = 0, cy_tbloop = 0;
     const bool timing = a.stats != nullptr;
 
@@ -132,6 +135,239 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
         // ---------------- window setup (genasm_cpu.cpp:417-420) ----------------
         const uint32_t n = (has_pair && ref_idx < text_len) ? min((uint32_t)W, text_len - ref_idx) : 0u;
         const uint32_t m = has_pair ? min((uint32_t)W, read_len - read_idx) : 1u;   // >= 1 for live pairs
+
+        // ---------------- diagonal-major window (full windows with a small distance) ----------------
+        // The common case — W = 64, a full window (n = m = 64) and a window distance <= 15 — is computed
+        // in a different layout: one 64-bit word per DIAGONAL delta = j - i (pattern index minus text
+        // index), bit p = 63 - i, in positive logic (a = ~R: 1 = "alignable").  Then
+        //   a(i,j,d) = y(i,j,d) | (match(i,j) & a(i+1,j+1,d)),   y = a(i+1,j+1,d-1) | a(i,j+1,d-1) | a(i+1,j,d-1)
+        // (genasm_cpu.cpp:246-252 restated): the in-row dependency runs along the word, from bit p-1
+        // to bit p, i.e. it is a carry chain with generate y and propagate match, solved for all 64
+        // positions by ONE 64-bit addition: C = ((y|mt) + y + cin) ^ (y|mt) ^ y, a = y | (mt & C).  Rows
+        // therefore need no skew across lanes (the column layout below needs G-1 extra steps per window)
+        // and y only needs the previous row of the two neighbouring diagonals: y_x = S_x | A_{x+1} | S_{x-1}
+        // with S = A << 1.  Only the band |delta| <= d can influence the goal cell (0,0,d) and the cells
+        // the traceback visits, so 32 diagonals delta = -16..15 (4 per lane) are exact for d <= 15; the
+        // text/pattern ends enter as carry-ins (boundary column i = 64: a = [64-j <= d], genasm_cpu.cpp:239-245)
+        // and as forced cells below each diagonal's first valid bit (pattern end j = 64: a = 1).
+        // The traceback walks a diagonal with one count-leading-zeros per edit.  Windows this path does
+        // not cover (ragged ends, larger distances) take the column-major path below; results are
+        // identical (tests/proto/diag_proto.c restates this arithmetic on the CPU for tests/test_diag_proto.py).
+        if constexpr (G == 8 && !WIDE) {
+            // LDS rows of this layout: high dwords (positions i <= 31) of the 32 diagonals; from row 8 on the
+            // traceback can only be within |delta| <= 7, so those rows keep the 16 diagonals of lanes 2..5
+            // and 16 rows fit the 13 x 32 dwords the column layout uses
+            const int cmp_row = RB >= 13 ? 8 : 64;
+            const int rows_cap = RB >= 13 ? 16 : RB;
+            const int max_rows = rows_cap < 15 ? rows_cap : 15;
+            bool try_diag = W == 64 && !(a.debug & 32) && !__any(has_pair && (n != 64u || m != 64u));
+            if (try_diag && diag_skip) {
+                diag_skip--;
+                try_diag = false;
+            }
+            if (try_diag) {
+                // ---- setup: match words of my four diagonals x = 4t+k (delta = x-16) ----
+                uint64_t mt[4];
+                int32_t thr[4];            // carry-in of diagonal delta <= 0 at row d: d >= -delta
+                {
+                    Planes tw = {0, 0}, pw = {0, 0};
+                    if (has_pair) {
+                        tw = load_window(a.seq, text_off + ref_idx);
+                        pw = load_window(a.seq, read_off + read_idx);
+                    }
+                    const uint64_t trl = brev64(tw.lo), trh = brev64(tw.hi);     // bit p = text char 63-p
+                    const uint64_t prl = brev64(pw.lo), prh = brev64(pw.hi);     // bit p = pattern char 63-p
+                    // pattern planes moved onto diagonal delta: P << delta (>> for delta < 0) = (P << 15) >> (15 - delta)
+                    const uint32_t l0 = (uint32_t)prl << 15, l1 = __builtin_amdgcn_alignbit((uint32_t)(prl >> 32), (uint32_t)prl, 17),
+                                   l2 = (uint32_t)(prl >> 32) >> 17;
+                    const uint32_t h0 = (uint32_t)prh << 15, h1 = __builtin_amdgcn_alignbit((uint32_t)(prh >> 32), (uint32_t)prh, 17),
+                                   h2 = (uint32_t)(prh >> 32) >> 17;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const uint32_t x = (uint32_t)(4 * t + k);
+                        const uint32_t sh = 31u - x;
+                        const uint32_t pl_lo = __builtin_amdgcn_alignbit(l1, l0, sh), pl_hi = __builtin_amdgcn_alignbit(l2, l1, sh);
+                        const uint32_t ph_lo = __builtin_amdgcn_alignbit(h1, h0, sh), ph_hi = __builtin_amdgcn_alignbit(h2, h1, sh);
+                        // valid positions: 0 <= i, j < 64
+                        const uint32_t v_lo = __builtin_amdgcn_alignbit(0xffffffffu, 0xffff8000u, sh);
+                        const uint32_t v_hi = __builtin_amdgcn_alignbit(0x00007fffu, 0xffffffffu, sh);
+                        const uint32_t m_lo = v_lo & ~(((uint32_t)trl ^ pl_lo) | ((uint32_t)trh ^ ph_lo));
+                        const uint32_t m_hi = v_hi & ~(((uint32_t)(trl >> 32) ^ pl_hi) | ((uint32_t)(trh >> 32) ^ ph_hi));
+                        mt[k] = ((uint64_t)m_hi << 32) | m_lo;
+                        thr[k] = x <= 16u ? (int32_t)(16u - x) : 0x40000000;
+                    }
+                }
+                const uint64_t tmd0 = timing ? __builtin_readcyclecounter() : 0;
+                // ---- rows ----
+                uint64_t A0[4], S0[4], A1[4], S1[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t x = (uint32_t)(4 * t + k);
+                    A0[k] = 0;
+                    S0[k] = x >= 17u ? (1ull << (x - 17u)) : 0ull;     // "row -1": only the forced pattern-end cells
+                }
+                uint32_t not_first = (t != 0) ? ~0u : 0u, not_last = (t != G - 1) ? ~0u : 0u;
+                asm volatile("" : "+v"(not_first), "+v"(not_last));
+                uint32_t ddw = 0;
+                int32_t hit_cmp = (has_pair && t == 4) ? 0 : INT32_MIN;     // lane 4, k = 0 holds delta = 0: goal = bit 63
+                uint64_t done_mask = __ballot(!has_pair);
+                bool all_done = (done_mask & leaders) == leaders;
+                uint32_t waddr = lds_slot + 4u * (uint32_t)t, wstride = 32u;
+                int d = 0;
+                constexpr int TT_A = bitop3_table([](int sum, int y, int mm) { return y | (mm & (sum ^ (y | mm) ^ y)); });
+                auto row = [&](const uint64_t (&Ap)[4], const uint64_t (&Sp)[4], uint64_t (&Ac)[4], uint64_t (&Sc)[4]) {
+                    uint64_t up_n = dpp_from_next64(Ap[0]);          // A of diagonal x+1 for my k = 3
+                    uint64_t dn_p = dpp_from_prev64(Sp[3]);          // S of diagonal x-1 for my k = 0
+                    up_n = ((uint64_t)((uint32_t)(up_n >> 32) & not_last) << 32) | ((uint32_t)up_n & not_last);
+                    dn_p = ((uint64_t)((uint32_t)(dn_p >> 32) & not_first) << 32) | ((uint32_t)dn_p & not_first);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const uint64_t up = k < 3 ? Ap[k < 3 ? k + 1 : 3] : up_n;
+                        const uint64_t dn = k > 0 ? Sp[k > 0 ? k - 1 : 0] : dn_p;
+                        const uint32_t y_lo = bitop3<0xFE>((uint32_t)Sp[k], (uint32_t)up, (uint32_t)dn);
+                        const uint32_t y_hi = bitop3<0xFE>((uint32_t)(Sp[k] >> 32), (uint32_t)(up >> 32), (uint32_t)(dn >> 32));
+                        const uint64_t y = ((uint64_t)y_hi << 32) | y_lo;
+                        const uint64_t cin = __ballot(d >= thr[k]);
+                        const uint64_t sum = add64_cin(y | mt[k], y, cin);
+                        const uint32_t a_lo = bitop3<TT_A>((uint32_t)sum, y_lo, (uint32_t)mt[k]);
+                        const uint32_t a_hi = bitop3<TT_A>((uint32_t)(sum >> 32), y_hi, (uint32_t)(mt[k] >> 32));
+                        Ac[k] = ((uint64_t)a_hi << 32) | a_lo;
+                        Sc[k] = add64_cin(Ac[k], Ac[k], cin);        // (a << 1) | boundary cell of the next row
+                    }
+                    if (d < rows_cap) {                               // the traceback reads positions i <= 31: the high dwords
+                        if (d == cmp_row) {                           // compact rows: lanes 2..5 keep storing, the rest park
+                            const bool mid = (t >= 2 && t <= 5);
+                            waddr = lds_slot + (mid ? 256u + 4u * (uint32_t)(t - 2) : 384u + 4u * (uint32_t)(t & 3));
+                            wstride = mid ? 16u : 0u;
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; k++) lds[waddr + k] = (uint32_t)(Ac[k] >> 32);
+                        waddr += wstride;
+                    }
+                    const uint64_t hits = __ballot((int32_t)(Ac[0] >> 32) < hit_cmp);
+                    if (hits) {
+                        const uint64_t lead = (hits >> 4) & leaders;
+                        const uint64_t newly = ((uint64_t)((uint32_t)lead * 0xffu)) | ((uint64_t)((uint32_t)(lead >> 32) * 0xffu) << 32);
+                        if ((newly >> lane) & 1ull) {
+                            hit_cmp = INT32_MIN;
+                            ddw = (uint32_t)d;
+                        }
+                        done_mask |= newly;
+                        all_done = (done_mask & leaders) == leaders;
+                    }
+                    d++;
+                };
+                while (!all_done && d <= max_rows) {
+                    row(A0, S0, A1, S1);
+                    if (all_done || d > max_rows) break;
+                    row(A1, S1, A0, S0);
+                }
+                const uint64_t tmd1 = timing ? __builtin_readcyclecounter() : 0;
+                st_steps += (uint32_t)d;
+                if (all_done) {
+                    // ---- traceback along diagonals (genasm_cpu.cpp:290-409; neither the last-character rule
+                    // :336-343 nor the text limit :312 can trigger: 64 > W-O characters remain on both sides).
+                    // Runs go to the staging ring as soon as they start; a repeated edit rewrites the last run
+                    // (the only one that can still grow), so a 16-run piece leaves for HBM one run late. ----
+                    uint32_t actmask = has_pair ? ~0u : 0u;
+                    uint32_t ti = 0, tj = 0, dd = ddw;
+                    uint32_t cur_op8 = 0, cur_cnt = 0, ovf = 0;       // last run written, if it is an edit run of this window
+                    uint32_t nr = n_runs;
+                    const uint32_t leadmask = leader ? ~0u : 0u;
+                    const uint32_t obuf_b = 4u * obuf, dummy_b = 4u * scratch_dw;
+                    char* const lds_b = reinterpret_cast<char*>(lds);
+                    // stage run number pos (value v) when en; only the leader's write lands in the ring
+                    auto put = [&](uint32_t en, uint32_t pos, uint32_t v) {
+                        const uint32_t room_ok = neg_mask(pos - cigar_cap);                   // ~0 iff pos < cap
+                        const uint32_t wr = en & room_ok & leadmask;
+                        const uint32_t addr = bitop3<0xCA>(wr, obuf_b + ((2u * pos) & 62u), dummy_b);
+                        *reinterpret_cast<uint16_t*>(lds_b + addr) = (uint16_t)v;
+                        ovf |= en & ~room_ok;
+                    };
+                    // the piece below run `upto` is complete once a later run exists
+                    auto flush_piece = [&](uint32_t first) {
+                        if (first + 16u <= cigar_cap && !(a.debug & 4)) {
+                            const uint32_t piece = ((first >> 4) & 1u) * 8u;
+                            uint32_t* const dst = reinterpret_cast<uint32_t*>(a.runs + cigar_off + first);
+                            for (uint32_t k = (uint32_t)t; k < 8u; k += (uint32_t)G) dst[k] = lds[obuf + piece + k];
+                        }
+                    };
+                    while (__any(actmask != 0u)) {
+                        st_macro++;
+                        const uint32_t nr_before = nr;
+                        // row d-1 of diagonals x-1, x, x+1 (x = j-i+16); garbage when d == 0 (masked below)
+                        const uint32_t r = dd ? dd - 1u : 0u;
+                        const uint32_t rmin = r < (uint32_t)cmp_row ? r : (uint32_t)cmp_row;
+                        const uint32_t roff = 16u * (r + rmin) - (r >= (uint32_t)cmp_row ? 8u : 0u);
+                        const uint32_t base = lds_slot + roff + (tj - ti + 15u);
+                        const uint32_t h_del = lds[base] << 1;         // a(i+1, j)   on diagonal x-1
+                        const uint32_t h_sub = lds[base + 1] << 1;     // a(i+1, j+1) on diagonal x
+                        const uint32_t h_ins = lds[base + 2];          // a(i, j+1)   on diagonal x+1
+                        const uint32_t roomm = nz_mask(dd) & actmask;
+                        const uint32_t E = (h_ins | h_del | h_sub) & (0xffffffffu >> ti) & roomm;
+                        const uint32_t i2 = (uint32_t)__clz((int)E);               // 32 when no edit is available
+                        const uint32_t run = i2 - ti;
+                        const uint32_t mx = ti > tj ? ti : tj;
+                        const uint32_t lim = (uint32_t)TBL - mx;                   // :307-310
+                        const uint32_t n_eq = (run < lim ? run : lim) & actmask;
+                        const uint32_t edit = run < lim ? actmask : 0u;
+                        // the '=' run
+                        const uint32_t eqm = nz_mask(n_eq);
+                        put(eqm, nr, n_eq | ((uint32_t)'=' << 8));
+                        nr += eqm & 1u;
+                        cur_cnt &= ~eqm;
+                        ti += n_eq;
+                        tj += n_eq;
+                        // the edit that ends it: priority I, D, X (:346-370)
+                        const uint32_t bit = 0x80000000u >> (ti & 31u);
+                        const uint32_t is_i = (h_ins & bit) ? ~0u : 0u;
+                        const uint32_t is_d = ((h_del & bit) ? ~0u : 0u) & ~is_i;
+                        const uint32_t op8 = (is_i ? (uint32_t)'I' : (is_d ? (uint32_t)'D' : (uint32_t)'X')) << 8;
+                        const uint32_t merge = edit & nz_mask(cur_cnt) & ~nz_mask(op8 ^ cur_op8);
+                        cur_cnt = (cur_cnt & merge) + 1u;
+                        cur_op8 = op8;
+                        put(edit, nr - (merge & 1u), cur_cnt | op8);
+                        nr += edit & ~merge & 1u;
+                        cur_cnt &= edit;
+                        const uint32_t crossed = ((nr + 15u) ^ (nr_before + 15u)) & 16u;
+                        if (__any(crossed != 0u && nr_before != 0u)) {
+                            if (crossed != 0u && nr_before != 0u) flush_piece(((nr_before + 15u) >> 4) * 16u - 16u);
+                        }
+                        ti += edit & ~is_i & 1u;
+                        tj += edit & ~is_d & 1u;
+                        dd -= edit & 1u;
+                        const uint32_t mx2 = ti > tj ? ti : tj;
+                        actmask &= edit & ((mx2 < (uint32_t)TBL) ? ~0u : 0u);
+                    }
+                    // runs never merge across windows (:400-403): everything staged is final now; hand over
+                    // with the column path's invariant (every piece below floor16(n_runs) is in HBM)
+                    if (has_pair && nr != n_runs && (nr & 15u) == 0u) flush_piece(nr - 16u);
+                    overflow = overflow || (ovf != 0u);
+                    n_runs = nr;
+                    if (has_pair) {
+                        edits += ddw - dd;
+                        ref_idx += ti;
+                        read_idx += tj;
+                    }
+                    st_rounds++;
+                    st_diag++;
+                    diag_backoff >>= 1;
+                    if (timing) {
+                        const uint64_t tmd2 = __builtin_readcyclecounter();
+                        cy_fetch += tm1 - tm0;
+                        cy_setup += tmd0 - tm1;
+                        cy_ddc += tmd1 - tmd0;
+                        cy_dtb += tmd2 - tmd1;
+                    }
+                    continue;
+                }
+                // some window needs more rows than this path holds: redo the round column-major and stay off
+                // the diagonal path for a while (exponential back-off: high-error reads fail most rounds)
+                st_diag_fail++;
+                diag_backoff = diag_backoff ? (diag_backoff < 64u ? 2u * diag_backoff : 64u) : 1u;
+                diag_skip = diag_backoff;
+            }
+        }
 
         // Bit layout inside a window ("left-aligned"): pattern character j lives at bit 63-j,
         // i.e. every bitvector is the reference's (genasm_cpu.cpp:178-198, bit b <-> pattern[m-1-b])
@@ -537,6 +773,10 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
         atomicAdd((unsigned long long*)&a.stats[5], (unsigned long long)cy_dc);
         atomicAdd((unsigned long long*)&a.stats[6], (unsigned long long)cy_tb);
         atomicAdd((unsigned long long*)&a.stats[7], (unsigned long long)cy_tbloop);
+        atomicAdd((unsigned long long*)&a.stats[8], (unsigned long long)st_diag);
+        atomicAdd((unsigned long long*)&a.stats[9], (unsigned long long)st_diag_fail);
+        atomicAdd((unsigned long long*)&a.stats[10], (unsigned long long)cy_ddc);
+        atomicAdd((unsigned long long*)&a.stats[11], (unsigned long long)cy_dtb);
     }
 }
 

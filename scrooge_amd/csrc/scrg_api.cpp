@@ -379,8 +379,8 @@ scrg_status scrg_align_device(scrg_ctx* c, const scrg_params* params, uint64_t n
     a.debug = params ? params->reserved[0] : 0;
     a.stats = nullptr;
     if (params && params->reserved[1]) {
-        HIP_TRY(c, c->stats.ensure(8 * sizeof(uint64_t)));
-        HIP_TRY(c, hipMemsetAsync(c->stats.p, 0, 8 * sizeof(uint64_t), c->stream));
+        HIP_TRY(c, c->stats.ensure(12 * sizeof(uint64_t)));
+        HIP_TRY(c, hipMemsetAsync(c->stats.p, 0, 12 * sizeof(uint64_t), c->stream));
         a.stats = c->stats.as<uint64_t>();
     }
 
@@ -404,14 +404,14 @@ scrg_status scrg_last_kernel_ms(scrg_ctx* c, float* ms)
     return SCRG_OK;
 }
 
-scrg_status scrg_debug_stats(scrg_ctx* c, uint64_t out[8])
+scrg_status scrg_debug_stats(scrg_ctx* c, uint64_t out[12])
 {
     if (!c || !out) return SCRG_ERR_INVALID_ARG;
-    memset(out, 0, 8 * sizeof(uint64_t));
+    memset(out, 0, 12 * sizeof(uint64_t));
     if (!c->stats.p) return SCRG_OK;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipMemcpy(out, c->stats.p, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(out, c->stats.p, 12 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return SCRG_OK;
 }
 
