@@ -102,6 +102,45 @@ __global__ void __launch_bounds__(64) k_lshl64(uint32_t* out, uint64_t* cyc) {
     out[blockIdx.x * 64 + threadIdx.x] = (uint32_t)(a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7);
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
+// carry ops: v_addc_co_u32 (VOP3, carry in/out in SGPR pairs), 8 independent accumulators, carry-in from one fixed pair
+#define I_ADDC(n) "v_addc_co_u32 %" #n ", s[22:23], %" #n ", %8, s[20:21]\n"
+KERNEL(k_addc, asm volatile("s_mov_b64 s[20:21], 0x5555" ::: "s20","s21","s22","s23"); A8(I_ADDC))
+// 64-bit add as a carry pair: lo writes s[22:23], hi consumes it (4 independent 64-bit accumulators = 8 instructions)
+__global__ void __launch_bounds__(64) k_addc_pair(uint32_t* out, uint64_t* cyc) {
+    uint32_t a0=threadIdx.x+1,a1=a0*3,a2=a0*5,a3=a0*7,a4=a0*11,a5=a0*13,a6=a0*17,a7=a0*19;
+    uint32_t b = out[threadIdx.x & 3] | 1;
+    uint64_t t0 = __builtin_readcyclecounter();
+    for (int i = 0; i < ITER; i++) {
+#define P2(l, h, s) "v_addc_co_u32 %" #l ", " s ", %" #l ", %8, s[20:21]\n" "v_addc_co_u32 %" #h ", " s ", %" #h ", %8, " s "\n"
+#define PAIRS P2(0,1,"s[22:23]") P2(2,3,"s[24:25]") P2(4,5,"s[26:27]") P2(6,7,"s[28:29]")
+        asm volatile("s_mov_b64 s[20:21], 0x5555\n" PAIRS PAIRS
+            : "+v"(a0),"+v"(a1),"+v"(a2),"+v"(a3),"+v"(a4),"+v"(a5),"+v"(a6),"+v"(a7) : "v"(b) : "s20","s21","s22","s23","s24","s25","s26","s27","s28","s29");
+    }
+    uint64_t t1 = __builtin_readcyclecounter();
+    out[blockIdx.x * 64 + threadIdx.x] = a0^a1^a2^a3^a4^a5^a6^a7;
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+// v_lshl_add_u64: 64-bit add in one instruction, 8 independent 64-bit accumulators
+__global__ void __launch_bounds__(64) k_lshladd64(uint32_t* out, uint64_t* cyc) {
+    uint64_t a0 = threadIdx.x + 1, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, a6 = a0 * 17, a7 = a0 * 19;
+    uint64_t b = out[threadIdx.x & 3] | 1;
+    uint64_t t0 = __builtin_readcyclecounter();
+    for (int i = 0; i < ITER; i++) {
+#define LA64(n) "v_lshl_add_u64 %" #n ", %" #n ", 0, %8\n"
+        asm volatile(LA64(0) LA64(1) LA64(2) LA64(3) LA64(4) LA64(5) LA64(6) LA64(7) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+        asm volatile(LA64(0) LA64(1) LA64(2) LA64(3) LA64(4) LA64(5) LA64(6) LA64(7) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+    }
+    uint64_t t1 = __builtin_readcyclecounter();
+    out[blockIdx.x * 64 + threadIdx.x] = (uint32_t)(a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7);
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+// v_cmp writing an SGPR pair (VOP3)
+#define I_CMP64(n) "v_cmp_lt_i32 s[22:23], %" #n ", %8\n"
+KERNEL(k_cmp64, A8(I_CMP64))
+// v_add_co_u32 (VOP2, carry-out to vcc)
+#define I_ADDCO(n) "v_add_co_u32 %" #n ", vcc, %" #n ", %8\n"
+KERNEL(k_addco, A8(I_ADDCO))
+// ds_write_b32 / ds_read_b32 issue cost (address from accumulator, small range)
 // dependent chain of v_and_b32 (one accumulator)
 __global__ void __launch_bounds__(64) k_and_dep(uint32_t* out, uint64_t* cyc) {
     uint32_t a0 = threadIdx.x + 1, b = out[threadIdx.x & 3] | 1;
@@ -125,7 +164,8 @@ int main() {
     std::vector<Entry> es = {{"v_and_b32", k_and}, {"v_xor_b32", k_xor}, {"v_or3_b32", k_or3}, {"v_lshl_or_b32", k_lshlor}, {"v_alignbit_b32", k_align},
         {"v_and_or_b32", k_andor}, {"v_bitop3_b32", k_bitop3}, {"v_cndmask_b32", k_cndmask}, {"v_add_u32", k_add}, {"v_cndmask_e64 sgpr", k_cnd64}, {"v_and_b32 sgpr", k_ands}, {"v_sub_u32", k_sub}, {"v_min_u32", k_min}, {"v_ffbh_u32", k_ffbh}, {"v_not_b32", k_not}, {"v_bfe_u32", k_bfeu}, {"v_ashrrev_i32", k_ashr}, {"v_lshrrev_b32 vgpr", k_lshr}, {"v_min_u32_dpp", k_mindpp}, {"v_max_i32", k_maxi}, {"v_lshl_add_u32", k_lshladd}, {"v_mbcnt_lo", k_mbcnt}, {"v_perm_b32", k_perm}, {"v_fma_f32", k_fma},
         {"v_mov_dpp wave_shl", k_dpp}, {"v_mov_dpp row_shl", k_dpprow}, {"v_lshlrev_b32", k_lshl}, {"v_bfe_i32", k_bfe}, {"v_bfrev_b32", k_bfrev},
-        {"v_mov_b32", k_mov}, {"v_cmp_lt_i32", k_cmp}, {"v_lshlrev_b64", k_lshl64}, {"v_xor_b32 dependent", k_and_dep}};
+        {"v_mov_b32", k_mov}, {"v_cmp_lt_i32", k_cmp}, {"v_lshlrev_b64", k_lshl64}, {"v_addc_co_u32 vop3", k_addc}, {"v_addc pair (64b add)", k_addc_pair},
+        {"v_lshl_add_u64", k_lshladd64}, {"v_cmp -> sgpr pair", k_cmp64}, {"v_add_co_u32 vcc", k_addco}, {"v_xor_b32 dependent", k_and_dep}};
     uint32_t* out; uint64_t* cyc;
     for (int wps : {2}) {            // waves per SIMD
         int blocks = cus * 4 * wps;

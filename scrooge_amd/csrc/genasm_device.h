@@ -49,6 +49,21 @@ __device__ __forceinline__ uint64_t add64_cin(uint64_t a, uint64_t b, uint64_t c
     return ((uint64_t)hi << 32) | lo;
 }
 
+// 64-bit add / shift-by-one-and-add in ONE instruction (v_lshl_add_u64, gfx940+): half the issue cost of a
+// v_addc pair and no carry through SGPRs
+__device__ __forceinline__ uint64_t add64(uint64_t a, uint64_t b)
+{
+    uint64_t r;
+    asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint64_t shl1_add64(uint64_t a, uint64_t b)
+{
+    uint64_t r;
+    asm("v_lshl_add_u64 %0, %1, 1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // truth table of a 3-input function for v_bitop3_b32 (bit index = a*4 + b*2 + c)
 template <typename F> constexpr int bitop3_table(F f)
 {

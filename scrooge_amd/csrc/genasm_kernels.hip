@@ -83,7 +83,8 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
     uint32_t st_rounds = 0, st_steps = 0, st_macro = 0;   // profiling counters (a.stats != nullptr)
     uint32_t st_diag = 0, st_diag_fail = 0;
     uint64_t cy_ddc = 0, cy_dtb = 0;
-    uint32_t diag_skip = 0, diag_backoff = 0;   // rounds to stay off the diagonal-major path after it failed
+    uint32_t diag_skip = 0, diag_fails = 0;     // rounds to stay off the diagonal-major path after repeated failures
+    bool force_column = false;                  // the next round must be column-major (some slot sat the last one out)
     uint64_t cy_fetch = 0, cy_setup = 0, cy_dc = 0, cy_tb = 0, cy_tbloop = 0;
     const bool timing = a.stats != nullptr;
 
@@ -160,7 +161,15 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
             const int cmp_row = RB >= 13 ? 8 : 64;
             const int rows_cap = RB >= 13 ? 16 : RB;
             const int max_rows = rows_cap < 15 ? rows_cap : 15;
-            bool try_diag = W == 64 && !(a.debug & 32) && !__any(has_pair && (n != 64u || m != 64u));
+            // slots with a ragged window (text or pattern end) sit a diagonal round out; so do slots whose
+            // window turns out to need more than max_rows rows.  Either kind makes the NEXT round a
+            // column-major one (which serves every slot), so a diagonal round pays off when more than half
+            // of the live slots can use it.
+            const bool capable = has_pair && n == 64u && m == 64u && n_runs + 64u <= cigar_cap;   // (a window adds < 64 runs)
+            const uint32_t n_live = (uint32_t)__popcll(__ballot(has_pair));
+            const uint32_t n_cap = (uint32_t)__popcll(__ballot(capable));
+            bool try_diag = W == 64 && !(a.debug & 32) && !force_column && (n_cap == n_live || n_cap >= 5u * G);
+            force_column = false;
             if (try_diag && diag_skip) {
                 diag_skip--;
                 try_diag = false;
@@ -168,7 +177,7 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
             if (try_diag) {
                 // ---- setup: match words of my four diagonals x = 4t+k (delta = x-16) ----
                 uint64_t mt[4];
-                int32_t thr[4];            // carry-in of diagonal delta <= 0 at row d: d >= -delta
+                int32_t cnt[4];            // carry-in of diagonal delta <= 0 at row d is [d >= -delta]: sign of -delta-1-d
                 {
                     Planes tw = {0, 0}, pw = {0, 0};
                     if (has_pair) {
@@ -194,7 +203,7 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
                         const uint32_t m_lo = v_lo & ~(((uint32_t)trl ^ pl_lo) | ((uint32_t)trh ^ ph_lo));
                         const uint32_t m_hi = v_hi & ~(((uint32_t)(trl >> 32) ^ pl_hi) | ((uint32_t)(trh >> 32) ^ ph_hi));
                         mt[k] = ((uint64_t)m_hi << 32) | m_lo;
-                        thr[k] = x <= 16u ? (int32_t)(16u - x) : 0x40000000;
+                        cnt[k] = x <= 16u ? (int32_t)(15u - x) : 0x40000000;
                     }
                 }
                 const uint64_t tmd0 = timing ? __builtin_readcyclecounter() : 0;
@@ -209,8 +218,9 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
                 uint32_t not_first = (t != 0) ? ~0u : 0u, not_last = (t != G - 1) ? ~0u : 0u;
                 asm volatile("" : "+v"(not_first), "+v"(not_last));
                 uint32_t ddw = 0;
-                int32_t hit_cmp = (has_pair && t == 4) ? 0 : INT32_MIN;     // lane 4, k = 0 holds delta = 0: goal = bit 63
-                uint64_t done_mask = __ballot(!has_pair);
+                int32_t hit_cmp = (capable && t == 4) ? 0 : INT32_MIN;      // lane 4, k = 0 holds delta = 0: goal = bit 63
+                bool found = false;
+                uint64_t done_mask = __ballot(!capable);
                 bool all_done = (done_mask & leaders) == leaders;
                 uint32_t waddr = lds_slot + 4u * (uint32_t)t, wstride = 32u;
                 int d = 0;
@@ -224,20 +234,23 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
                     for (int k = 0; k < 4; k++) {
                         const uint64_t up = k < 3 ? Ap[k < 3 ? k + 1 : 3] : up_n;
                         const uint64_t dn = k > 0 ? Sp[k > 0 ? k - 1 : 0] : dn_p;
+                        const uint32_t u = (uint32_t)cnt[k] >> 31;   // boundary cell a(64, j+1, d) of this diagonal: the chain's carry-in
+                        cnt[k]--;
+                        // generate: y, plus the carry-in where the first cell matches
                         const uint32_t y_lo = bitop3<0xFE>((uint32_t)Sp[k], (uint32_t)up, (uint32_t)dn);
                         const uint32_t y_hi = bitop3<0xFE>((uint32_t)(Sp[k] >> 32), (uint32_t)(up >> 32), (uint32_t)(dn >> 32));
-                        const uint64_t y = ((uint64_t)y_hi << 32) | y_lo;
-                        const uint64_t cin = __ballot(d >= thr[k]);
-                        const uint64_t sum = add64_cin(y | mt[k], y, cin);
-                        const uint32_t a_lo = bitop3<TT_A>((uint32_t)sum, y_lo, (uint32_t)mt[k]);
+                        const uint32_t g_lo = bitop3<0xF8>(y_lo, (uint32_t)mt[k], u);                  // y | (mt & u)
+                        const uint64_t g = ((uint64_t)y_hi << 32) | g_lo;
+                        const uint64_t sum = add64(g | mt[k], g);
+                        const uint32_t a_lo = bitop3<TT_A>((uint32_t)sum, g_lo, (uint32_t)mt[k]);
                         const uint32_t a_hi = bitop3<TT_A>((uint32_t)(sum >> 32), y_hi, (uint32_t)(mt[k] >> 32));
                         Ac[k] = ((uint64_t)a_hi << 32) | a_lo;
-                        Sc[k] = add64_cin(Ac[k], Ac[k], cin);        // (a << 1) | boundary cell of the next row
+                        Sc[k] = shl1_add64(Ac[k], (uint64_t)u);     // (a << 1) | boundary cell: the next row's sub/del source
                     }
                     if (d < rows_cap) {                               // the traceback reads positions i <= 31: the high dwords
                         if (d == cmp_row) {                           // compact rows: lanes 2..5 keep storing, the rest park
                             const bool mid = (t >= 2 && t <= 5);
-                            waddr = lds_slot + (mid ? 256u + 4u * (uint32_t)(t - 2) : 384u + 4u * (uint32_t)(t & 3));
+                            waddr = lds_slot + (mid ? 256u + 4u * (uint32_t)t : 392u + 4u * (uint32_t)(t & 3));
                             wstride = mid ? 16u : 0u;
                         }
 #pragma unroll
@@ -251,6 +264,7 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
                         if ((newly >> lane) & 1ull) {
                             hit_cmp = INT32_MIN;
                             ddw = (uint32_t)d;
+                            found = true;
                         }
                         done_mask |= newly;
                         all_done = (done_mask & leaders) == leaders;
@@ -264,94 +278,103 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
                 }
                 const uint64_t tmd1 = timing ? __builtin_readcyclecounter() : 0;
                 st_steps += (uint32_t)d;
-                if (all_done) {
+                {
                     // ---- traceback along diagonals (genasm_cpu.cpp:290-409; neither the last-character rule
                     // :336-343 nor the text limit :312 can trigger: 64 > W-O characters remain on both sides).
-                    // Runs go to the staging ring as soon as they start; a repeated edit rewrites the last run
-                    // (the only one that can still grow), so a 16-run piece leaves for HBM one run late. ----
-                    uint32_t actmask = has_pair ? ~0u : 0u;
+                    // One iteration = the '=' run up to the next edit (count-leading-zeros over the three
+                    // neighbouring diagonals of row d-1) plus that edit.  Runs go to the staging ring as soon
+                    // as they start — every lane of the slot writes the same halfword — and a repeated edit
+                    // rewrites the last run, the only one that can still grow.  Room for a whole window's runs
+                    // was checked up front (capable), so nothing here tests the capacity. ----
+                    uint32_t actmask = found ? ~0u : 0u;
                     uint32_t ti = 0, tj = 0, dd = ddw;
-                    uint32_t cur_op8 = 0, cur_cnt = 0, ovf = 0;       // last run written, if it is an edit run of this window
-                    uint32_t nr = n_runs;
-                    const uint32_t leadmask = leader ? ~0u : 0u;
+                    uint32_t xoff = lds_slot + 15u;                  // lds_slot + (x - 1), x = j - i + 16
+                    uint32_t cur_op8 = 0, cur_cnt = 0;               // last run written, if it is an edit run of this window
+                    uint32_t nr2 = 2u * n_runs;                       // byte position of the next run
+                    uint32_t flushed = n_runs & ~15u;                 // runs below this are in HBM (the column path's invariant)
                     const uint32_t obuf_b = 4u * obuf, dummy_b = 4u * scratch_dw;
                     char* const lds_b = reinterpret_cast<char*>(lds);
-                    // stage run number pos (value v) when en; only the leader's write lands in the ring
-                    auto put = [&](uint32_t en, uint32_t pos, uint32_t v) {
-                        const uint32_t room_ok = neg_mask(pos - cigar_cap);                   // ~0 iff pos < cap
-                        const uint32_t wr = en & room_ok & leadmask;
-                        const uint32_t addr = bitop3<0xCA>(wr, obuf_b + ((2u * pos) & 62u), dummy_b);
-                        *reinterpret_cast<uint16_t*>(lds_b + addr) = (uint16_t)v;
-                        ovf |= en & ~room_ok;
-                    };
-                    // the piece below run `upto` is complete once a later run exists
-                    auto flush_piece = [&](uint32_t first) {
-                        if (first + 16u <= cigar_cap && !(a.debug & 4)) {
-                            const uint32_t piece = ((first >> 4) & 1u) * 8u;
-                            uint32_t* const dst = reinterpret_cast<uint32_t*>(a.runs + cigar_off + first);
-                            for (uint32_t k = (uint32_t)t; k < 8u; k += (uint32_t)G) dst[k] = lds[obuf + piece + k];
+                    // 16-run pieces leave for HBM once a later run exists (or the window is over)
+                    auto flush_check = [&](bool final) {
+                        for (;;) {
+                            const uint32_t nr = nr2 >> 1;
+                            const uint32_t upto = final ? nr : (nr ? nr - 1u : 0u);
+                            const bool need = found && (upto & ~15u) > flushed;
+                            if (!__any(need)) break;
+                            if (need) {
+                                if (!(a.debug & 4)) {
+                                    const uint32_t piece = ((flushed >> 4) & 1u) * 8u;
+                                    uint32_t* const dst = reinterpret_cast<uint32_t*>(a.runs + cigar_off + flushed);
+                                    for (uint32_t k = (uint32_t)t; k < 8u; k += (uint32_t)G) dst[k] = lds[obuf + piece + k];
+                                }
+                                flushed += 16u;
+                            }
                         }
                     };
-                    while (__any(actmask != 0u)) {
+                    int iter = 0;
+                    do {
                         st_macro++;
-                        const uint32_t nr_before = nr;
-                        // row d-1 of diagonals x-1, x, x+1 (x = j-i+16); garbage when d == 0 (masked below)
+                        // row d-1 of diagonals x-1, x, x+1; garbage when d == 0 (masked below)
                         const uint32_t r = dd ? dd - 1u : 0u;
                         const uint32_t rmin = r < (uint32_t)cmp_row ? r : (uint32_t)cmp_row;
-                        const uint32_t roff = 16u * (r + rmin) - (r >= (uint32_t)cmp_row ? 8u : 0u);
-                        const uint32_t base = lds_slot + roff + (tj - ti + 15u);
-                        const uint32_t h_del = lds[base] << 1;         // a(i+1, j)   on diagonal x-1
-                        const uint32_t h_sub = lds[base + 1] << 1;     // a(i+1, j+1) on diagonal x
-                        const uint32_t h_ins = lds[base + 2];          // a(i, j+1)   on diagonal x+1
-                        const uint32_t roomm = nz_mask(dd) & actmask;
-                        const uint32_t E = (h_ins | h_del | h_sub) & (0xffffffffu >> ti) & roomm;
+                        const uint32_t base = xoff + 16u * (r + rmin);
+                        const uint32_t w_del = lds[base];              // a(i+1, j)   on diagonal x-1, one position down
+                        const uint32_t w_sub = lds[base + 1];          // a(i+1, j+1) on diagonal x,   one position down
+                        const uint32_t w_ins = lds[base + 2];          // a(i, j+1)   on diagonal x+1
+                        const uint32_t roomm = neg_mask(0u - dd) & actmask;          // d > 0 (:313)
+                        const uint32_t E = (((w_del | w_sub) << 1) | w_ins) & (0xffffffffu >> ti) & roomm;
                         const uint32_t i2 = (uint32_t)__clz((int)E);               // 32 when no edit is available
                         const uint32_t run = i2 - ti;
-                        const uint32_t mx = ti > tj ? ti : tj;
-                        const uint32_t lim = (uint32_t)TBL - mx;                   // :307-310
+                        const uint32_t lim = (uint32_t)TBL - (ti > tj ? ti : tj);  // :307-310
+                        const uint32_t edit = neg_mask(run - lim) & actmask;       // an edit ends the run inside the window
                         const uint32_t n_eq = (run < lim ? run : lim) & actmask;
-                        const uint32_t edit = run < lim ? actmask : 0u;
                         // the '=' run
                         const uint32_t eqm = nz_mask(n_eq);
-                        put(eqm, nr, n_eq | ((uint32_t)'=' << 8));
-                        nr += eqm & 1u;
+                        *reinterpret_cast<uint16_t*>(lds_b + bitop3<0xCA>(eqm, obuf_b + (nr2 & 62u), dummy_b)) =
+                            (uint16_t)(n_eq | ((uint32_t)'=' << 8));
+                        nr2 += eqm & 2u;
                         cur_cnt &= ~eqm;
                         ti += n_eq;
                         tj += n_eq;
                         // the edit that ends it: priority I, D, X (:346-370)
-                        const uint32_t bit = 0x80000000u >> (ti & 31u);
-                        const uint32_t is_i = (h_ins & bit) ? ~0u : 0u;
-                        const uint32_t is_d = ((h_del & bit) ? ~0u : 0u) & ~is_i;
-                        const uint32_t op8 = (is_i ? (uint32_t)'I' : (is_d ? (uint32_t)'D' : (uint32_t)'X')) << 8;
+                        const uint32_t sh = 31u - (ti & 31u);
+                        const uint32_t is_i = 0u - ((w_ins >> sh) & 1u);
+                        const uint32_t is_d = (0u - (((w_del << 1) >> sh) & 1u)) & ~is_i;
+                        const uint32_t op8 = bitop3<0xCA>(is_i, (uint32_t)'I' << 8, bitop3<0xCA>(is_d, (uint32_t)'D' << 8, (uint32_t)'X' << 8));
                         const uint32_t merge = edit & nz_mask(cur_cnt) & ~nz_mask(op8 ^ cur_op8);
                         cur_cnt = (cur_cnt & merge) + 1u;
                         cur_op8 = op8;
-                        put(edit, nr - (merge & 1u), cur_cnt | op8);
-                        nr += edit & ~merge & 1u;
+                        *reinterpret_cast<uint16_t*>(lds_b + bitop3<0xCA>(edit, obuf_b + ((nr2 - (merge & 2u)) & 62u), dummy_b)) =
+                            (uint16_t)(cur_cnt | op8);
+                        nr2 += edit & ~merge & 2u;
                         cur_cnt &= edit;
-                        const uint32_t crossed = ((nr + 15u) ^ (nr_before + 15u)) & 16u;
-                        if (__any(crossed != 0u && nr_before != 0u)) {
-                            if (crossed != 0u && nr_before != 0u) flush_piece(((nr_before + 15u) >> 4) * 16u - 16u);
-                        }
-                        ti += edit & ~is_i & 1u;
-                        tj += edit & ~is_d & 1u;
-                        dd -= edit & 1u;
-                        const uint32_t mx2 = ti > tj ? ti : tj;
-                        actmask &= edit & ((mx2 < (uint32_t)TBL) ? ~0u : 0u);
-                    }
-                    // runs never merge across windows (:400-403): everything staged is final now; hand over
-                    // with the column path's invariant (every piece below floor16(n_runs) is in HBM)
-                    if (has_pair && nr != n_runs && (nr & 15u) == 0u) flush_piece(nr - 16u);
-                    overflow = overflow || (ovf != 0u);
-                    n_runs = nr;
-                    if (has_pair) {
+                        const uint32_t e1 = edit & 1u;
+                        ti += e1 & ~is_i;
+                        tj += e1 & ~is_d;
+                        xoff += (e1 & is_i) - (e1 & is_d);
+                        dd -= e1;
+                        actmask = edit & neg_mask((ti > tj ? ti : tj) - (uint32_t)TBL);
+                        if ((++iter & 7) == 0) flush_check(false);    // at most 16 runs between checks: the 32-run ring cannot wrap
+                    } while (__any(actmask != 0u));
+                    flush_check(true);          // runs never merge across windows (:400-403): everything staged is final
+                    n_runs = nr2 >> 1;
+                    if (found) {
                         edits += ddw - dd;
                         ref_idx += ti;
                         read_idx += tj;
                     }
                     st_rounds++;
                     st_diag++;
-                    diag_backoff >>= 1;
+                    // slots that sat out or ran out of rows: serve them column-major next; after repeated
+                    // row failures stay off this path for a while (high-error reads fail most rounds)
+                    if (__any(has_pair && !found)) force_column = true;
+                    if (all_done) {
+                        diag_fails = diag_fails ? diag_fails - 1u : 0u;
+                    } else {
+                        st_diag_fail++;
+                        diag_fails = diag_fails < 8u ? diag_fails + 1u : 8u;
+                        if (diag_fails >= 3u) diag_skip = 1u << (diag_fails - 2u);
+                    }
                     if (timing) {
                         const uint64_t tmd2 = __builtin_readcyclecounter();
                         cy_fetch += tm1 - tm0;
@@ -361,11 +384,6 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
                     }
                     continue;
                 }
-                // some window needs more rows than this path holds: redo the round column-major and stay off
-                // the diagonal path for a while (exponential back-off: high-error reads fail most rounds)
-                st_diag_fail++;
-                diag_backoff = diag_backoff ? (diag_backoff < 64u ? 2u * diag_backoff : 64u) : 1u;
-                diag_skip = diag_backoff;
             }
         }
 
