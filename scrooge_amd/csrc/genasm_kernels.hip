@@ -226,16 +226,23 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
                 int d = 0;
                 constexpr int TT_A = bitop3_table([](int sum, int y, int mm) { return y | (mm & (sum ^ (y | mm) ^ y)); });
                 auto row = [&](const uint64_t (&Ap)[4], const uint64_t (&Sp)[4], uint64_t (&Ac)[4], uint64_t (&Sc)[4]) {
-                    uint64_t up_n = dpp_from_next64(Ap[0]);          // A of diagonal x+1 for my k = 3
-                    uint64_t dn_p = dpp_from_prev64(Sp[3]);          // S of diagonal x-1 for my k = 0
-                    up_n = ((uint64_t)((uint32_t)(up_n >> 32) & not_last) << 32) | ((uint32_t)up_n & not_last);
-                    dn_p = ((uint64_t)((uint32_t)(dn_p >> 32) & not_first) << 32) | ((uint32_t)dn_p & not_first);
+                    // A of diagonal x+1 for my k = 3 (from the next lane), S of diagonal x-1 for my k = 0 (from the previous one)
+                    uint32_t un_lo, un_hi, dp_lo, dp_hi;
+                    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %4 wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+                                 "v_mov_b32_dpp %1, %5 wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+                                 "v_mov_b32_dpp %2, %6 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                                 "v_mov_b32_dpp %3, %7 wave_shr:1 row_mask:0xf bank_mask:0xf"
+                                 : "=&v"(un_lo), "=&v"(un_hi), "=&v"(dp_lo), "=&v"(dp_hi)
+                                 : "v"((uint32_t)Ap[0]), "v"((uint32_t)(Ap[0] >> 32)), "v"((uint32_t)Sp[3]), "v"((uint32_t)(Sp[3] >> 32)));
+                    const uint64_t up_n = ((uint64_t)(un_hi & not_last) << 32) | (un_lo & not_last);
+                    const uint64_t dn_p = ((uint64_t)(dp_hi & not_first) << 32) | (dp_lo & not_first);
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         const uint64_t up = k < 3 ? Ap[k < 3 ? k + 1 : 3] : up_n;
                         const uint64_t dn = k > 0 ? Sp[k > 0 ? k - 1 : 0] : dn_p;
                         const uint32_t u = (uint32_t)cnt[k] >> 31;   // boundary cell a(64, j+1, d) of this diagonal: the chain's carry-in
                         cnt[k]--;
+                        asm volatile("" : "+v"(cnt[k]));              // keep it a VGPR counter (an SGPR-operand add issues at half rate)
                         // generate: y, plus the carry-in where the first cell matches
                         const uint32_t y_lo = bitop3<0xFE>((uint32_t)Sp[k], (uint32_t)up, (uint32_t)dn);
                         const uint32_t y_hi = bitop3<0xFE>((uint32_t)(Sp[k] >> 32), (uint32_t)(up >> 32), (uint32_t)(dn >> 32));
@@ -249,6 +256,7 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
                     }
                     if (d < rows_cap) {                               // the traceback reads positions i <= 31: the high dwords
                         if (d == cmp_row) {                           // compact rows: lanes 2..5 keep storing, the rest park
+                            asm volatile("" ::: "memory");            // (a real branch, taken once per window)
                             const bool mid = (t >= 2 && t <= 5);
                             waddr = lds_slot + (mid ? 256u + 4u * (uint32_t)t : 392u + 4u * (uint32_t)(t & 3));
                             wstride = mid ? 16u : 0u;
@@ -271,10 +279,11 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
                     }
                     d++;
                 };
-                while (!all_done && d <= max_rows) {
+                for (;;) {
                     row(A0, S0, A1, S1);
                     if (all_done || d > max_rows) break;
                     row(A1, S1, A0, S0);
+                    if (all_done || d > max_rows) break;
                 }
                 const uint64_t tmd1 = timing ? __builtin_readcyclecounter() : 0;
                 st_steps += (uint32_t)d;

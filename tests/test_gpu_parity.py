@@ -185,3 +185,25 @@ def test_windows_over_64_limits(aligner):
     with pytest.raises(scrooge_amd.ScroogeError):
         aligner.align_pairs(["ACGT"], ["ACGT"], W=257, O=129)
     assert aligner.align_pairs(["ACGT"], ["ACGT"], W=256, O=129) == [("4=", 0)]
+
+
+@pytest.mark.parametrize("lds_rows", [13, 16, 12, 6])
+def test_diagonal_path_on_and_off(aligner, oracle, lds_rows):
+    """Full W=64 windows with a small distance take the diagonal-major path of the G=8 kernel (carry-chain
+    rows, clz traceback), everything else the column-major path; rounds of both kinds interleave inside a
+    pair and share the CIGAR staging ring.  Same results with the path on, off (reserved[0] = 32) and with
+    row budgets that change how many rows it may use (lds_rows >= 13: 16 compacted rows, else lds_rows)."""
+    T, Q = synth.make_pairs(300, 3000, "ont", seed=5)
+    a, b = synth.make_pairs(100, 3000, "pacbio15", seed=6)       # many windows beyond 15 edits: fall back mid-pair
+    c, d = synth.make_pairs(400, 500, "illumina", seed=7)
+    T, Q = T + a + c, Q + b + d
+    eds, cigars, _, _ = oracle.align(T, Q, threads=8)
+    _check(aligner.align_pairs(T, Q, lds_rows=lds_rows), eds, cigars, "diag on rows=%d" % lds_rows)
+    p = aligner.make_params(lds_rows=lds_rows)
+    p.reserved[0] = 32
+    keep = aligner.params
+    aligner.params = p
+    try:
+        _check(aligner.align_pairs(T, Q), eds, cigars, "diag off rows=%d" % lds_rows)
+    finally:
+        aligner.params = keep
