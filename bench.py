@@ -325,7 +325,7 @@ def main():
         "kernel_pairs_per_s_per_gpu": n / (kernel_ms * 1e-3),
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "genasm_align_kernel<%d>" % p.lanes_per_pair,
+                     "kernel": "genasm_align_kernel<%d, false>" % p.lanes_per_pair,
                      "algorithmic_bytes_per_pair": bytes_per_pair,
                      "note": "path is VALU/LDS-bound, not HBM-bound (SURVEY.md §8d); see 'valu'"},
         "cpu_baseline": cpu,
