@@ -108,8 +108,17 @@ __global__ __launch_bounds__(64, 1) void genasm_align_multiword_kernel(AlignArgs
             has_pair = has_pair && !fin;
             const bool want = !has_pair && !queue_empty;
             if (!__any(want)) break;
+            // one atomic per wavefront for all the slots that want a pair (a queue of millions of short
+            // reads is otherwise bound by same-address atomics at L2)
             uint32_t idx = 0xffffffffu;
-            if (want && leader) idx = atomicAdd(a.counter, 1u);
+            {
+                const uint64_t askers = __ballot(want && leader);
+                const int first = __ffsll((unsigned long long)askers) - 1;
+                uint32_t base = 0;
+                if (lane == first) base = atomicAdd(a.counter, (uint32_t)__popcll(askers));
+                base = (uint32_t)__shfl((int)base, first);
+                if (want && leader) idx = base + (uint32_t)__popcll(askers & ((1ull << lane) - 1ull));
+            }
             idx = (uint32_t)__shfl((int)idx, gbase);
             const bool got = want && idx < a.n_pairs;
             if (__any(want && idx >= a.n_pairs)) queue_empty = true;

@@ -111,8 +111,17 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
             const bool want = !has_pair && !queue_empty;
             if (!__any(want)) break;
 
+            // one atomic per wavefront for all the slots that want a pair (a queue of millions of short
+            // reads is otherwise bound by same-address atomics at L2)
             uint32_t idx = 0xffffffffu;
-            if (want && leader) idx = atomicAdd(a.counter, 1u);
+            {
+                const uint64_t askers = __ballot(want && leader);
+                const int first = __ffsll((unsigned long long)askers) - 1;
+                uint32_t base = 0;
+                if (lane == first) base = atomicAdd(a.counter, (uint32_t)__popcll(askers));
+                base = (uint32_t)__shfl((int)base, first);
+                if (want && leader) idx = base + (uint32_t)__popcll(askers & ((1ull << lane) - 1ull));
+            }
             idx = (uint32_t)__shfl((int)idx, gbase);
             const bool got = want && idx < a.n_pairs;
             if (__any(want && idx >= a.n_pairs)) queue_empty = true;
@@ -165,7 +174,7 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
             // window turns out to need more than max_rows rows.  Either kind makes the NEXT round a
             // column-major one (which serves every slot), so a diagonal round pays off when more than half
             // of the live slots can use it.
-            const bool capable = has_pair && n == 64u && m == 64u && n_runs + 64u <= cigar_cap;   // (a window adds < 64 runs)
+            const bool capable = has_pair && n == 64u && n_runs + 64u <= cigar_cap;   // (a window adds < 64 runs)
             const uint32_t n_live = (uint32_t)__popcll(__ballot(has_pair));
             const uint32_t n_cap = (uint32_t)__popcll(__ballot(capable));
             bool try_diag = W == 64 && !(a.debug & 32) && !force_column && (n_cap == n_live || n_cap >= 5u * G);
@@ -178,6 +187,7 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
                 // ---- setup: match words of my four diagonals x = 4t+k (delta = x-16) ----
                 uint64_t mt[4];
                 int32_t cnt[4];            // carry-in of diagonal delta <= 0 at row d is [d >= -delta]: sign of -delta-1-d
+                uint64_t A0[4], S0[4], A1[4], S1[4];
                 {
                     Planes tw = {0, 0}, pw = {0, 0};
                     if (has_pair) {
@@ -191,30 +201,47 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
                                    l2 = (uint32_t)(prl >> 32) >> 17;
                     const uint32_t h0 = (uint32_t)prh << 15, h1 = __builtin_amdgcn_alignbit((uint32_t)(prh >> 32), (uint32_t)prh, 17),
                                    h2 = (uint32_t)(prh >> 32) >> 17;
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const uint32_t x = (uint32_t)(4 * t + k);
-                        const uint32_t sh = 31u - x;
+                    // A pattern window of m < 64 characters (the last windows of a read) moves the pattern end, and
+                    // with it every boundary role, by 64-m diagonals: with e = delta + 64 - m, diagonals e >= 1 start
+                    // at the pattern end (forced cell at bit e-1, valid bits from e), e = 0 has carry-in 1, e < 0
+                    // carry-in [d >= -e].  m = 64 is the e = delta special case with the masks from one funnel shift.
+                    const bool short_pattern = __any(capable && m != 64u);
+                    auto match_word = [&](int k, uint32_t v_lo, uint32_t v_hi) {
+                        const uint32_t sh = 31u - (uint32_t)(4 * t + k);
                         const uint32_t pl_lo = __builtin_amdgcn_alignbit(l1, l0, sh), pl_hi = __builtin_amdgcn_alignbit(l2, l1, sh);
                         const uint32_t ph_lo = __builtin_amdgcn_alignbit(h1, h0, sh), ph_hi = __builtin_amdgcn_alignbit(h2, h1, sh);
-                        // valid positions: 0 <= i, j < 64
-                        const uint32_t v_lo = __builtin_amdgcn_alignbit(0xffffffffu, 0xffff8000u, sh);
-                        const uint32_t v_hi = __builtin_amdgcn_alignbit(0x00007fffu, 0xffffffffu, sh);
                         const uint32_t m_lo = v_lo & ~(((uint32_t)trl ^ pl_lo) | ((uint32_t)trh ^ ph_lo));
                         const uint32_t m_hi = v_hi & ~(((uint32_t)(trl >> 32) ^ pl_hi) | ((uint32_t)(trh >> 32) ^ ph_hi));
                         mt[k] = ((uint64_t)m_hi << 32) | m_lo;
-                        cnt[k] = x <= 16u ? (int32_t)(15u - x) : 0x40000000;
+                        A0[k] = 0;
+                    };
+                    if (!short_pattern) {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const uint32_t x = (uint32_t)(4 * t + k);
+                            const uint32_t sh = 31u - x;
+                            // valid positions 0 <= j < 64: both ends from one funnel shift of 64 ones
+                            match_word(k, __builtin_amdgcn_alignbit(0xffffffffu, 0xffff8000u, sh),
+                                       __builtin_amdgcn_alignbit(0x00007fffu, 0xffffffffu, sh));
+                            cnt[k] = x <= 16u ? (int32_t)(15u - x) : 0x40000000;
+                            S0[k] = x >= 17u ? (1ull << (x - 17u)) : 0ull;     // "row -1": only the forced pattern-end cells
+                        }
+                    } else {
+                        asm volatile("" ::: "memory");       // (a real branch: only the last windows of a read come here)
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const uint32_t x = (uint32_t)(4 * t + k);
+                            const int32_t e = (int32_t)x - 16 + (int32_t)(64u - m);
+                            const uint64_t lowm = e <= 0 ? ~0ull : (e >= 64 ? 0ull : (~0ull << (e & 63)));     // j < m
+                            match_word(k, (uint32_t)lowm,
+                                       (uint32_t)(lowm >> 32) & __builtin_amdgcn_alignbit(0x00007fffu, 0xffffffffu, 31u - x));   // j >= 0
+                            cnt[k] = e <= 0 ? -e - 1 : 0x40000000;
+                            S0[k] = (e >= 1 && e <= 64) ? (1ull << ((e - 1) & 63)) : 0ull;
+                        }
                     }
                 }
                 const uint64_t tmd0 = timing ? __builtin_readcyclecounter() : 0;
                 // ---- rows ----
-                uint64_t A0[4], S0[4], A1[4], S1[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const uint32_t x = (uint32_t)(4 * t + k);
-                    A0[k] = 0;
-                    S0[k] = x >= 17u ? (1ull << (x - 17u)) : 0ull;     // "row -1": only the forced pattern-end cells
-                }
                 uint32_t not_first = (t != 0) ? ~0u : 0u, not_last = (t != G - 1) ? ~0u : 0u;
                 asm volatile("" : "+v"(not_first), "+v"(not_last));
                 uint32_t ddw = 0;
@@ -288,8 +315,10 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
                 const uint64_t tmd1 = timing ? __builtin_readcyclecounter() : 0;
                 st_steps += (uint32_t)d;
                 {
-                    // ---- traceback along diagonals (genasm_cpu.cpp:290-409; neither the last-character rule
-                    // :336-343 nor the text limit :312 can trigger: 64 > W-O characters remain on both sides).
+                    // ---- traceback along diagonals (genasm_cpu.cpp:290-409).  The text limit :312 cannot trigger
+                    // (n = 64 > W-O), and the last-character rule :336-343 (insertion whenever there is budget)
+                    // is what the forced pattern-end cell produces by itself: it sits on diagonal x+1 at the
+                    // position of the last character, and insertions have the highest priority.
                     // One iteration = the '=' run up to the next edit (count-leading-zeros over the three
                     // neighbouring diagonals of row d-1) plus that edit.  Runs go to the staging ring as soon
                     // as they start — every lane of the slot writes the same halfword — and a repeated edit
@@ -297,6 +326,7 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
                     // was checked up front (capable), so nothing here tests the capacity. ----
                     uint32_t actmask = found ? ~0u : 0u;
                     uint32_t ti = 0, tj = 0, dd = ddw;
+                    const uint32_t jlim = m < (uint32_t)TBL ? m : (uint32_t)TBL;     // j < m && j < W-O (:307-310)
                     uint32_t xoff = lds_slot + 15u;                  // lds_slot + (x - 1), x = j - i + 16
                     uint32_t cur_op8 = 0, cur_cnt = 0;               // last run written, if it is an edit run of this window
                     uint32_t nr2 = 2u * n_runs;                       // byte position of the next run
@@ -334,7 +364,8 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
                         const uint32_t E = (((w_del | w_sub) << 1) | w_ins) & (0xffffffffu >> ti) & roomm;
                         const uint32_t i2 = (uint32_t)__clz((int)E);               // 32 when no edit is available
                         const uint32_t run = i2 - ti;
-                        const uint32_t lim = (uint32_t)TBL - (ti > tj ? ti : tj);  // :307-310
+                        const uint32_t li = (uint32_t)TBL - ti, lj = jlim - tj;
+                        const uint32_t lim = li < lj ? li : lj;                    // :307-310
                         const uint32_t edit = neg_mask(run - lim) & actmask;       // an edit ends the run inside the window
                         const uint32_t n_eq = (run < lim ? run : lim) & actmask;
                         // the '=' run
@@ -362,7 +393,7 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
                         tj += e1 & ~is_d;
                         xoff += (e1 & is_i) - (e1 & is_d);
                         dd -= e1;
-                        actmask = edit & neg_mask((ti > tj ? ti : tj) - (uint32_t)TBL);
+                        actmask = edit & neg_mask(ti - (uint32_t)TBL) & neg_mask(tj - jlim);
                         if ((++iter & 7) == 0) flush_check(false);    // at most 16 runs between checks: the 32-run ring cannot wrap
                     } while (__any(actmask != 0u));
                     flush_check(true);          // runs never merge across windows (:400-403): everything staged is final

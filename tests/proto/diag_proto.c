@@ -21,24 +21,28 @@ static uint64_t brev64(uint64_t v)
 }
 
 /* returns window distance or -1 (not covered); fills H[d][x] (high dwords) for d < dist */
-static int diag_dc(const uint8_t *t, const uint8_t *q, int max_rows, uint32_t H[][NDIAG], proto_stats *ps)
+static int diag_dc(const uint8_t *t, const uint8_t *q, int m, int max_rows, uint32_t H[][NDIAG], proto_stats *ps)
 {
     uint64_t Tlo = 0, Thi = 0, Plo = 0, Phi = 0;
     for (int k = 0; k < 64; k++) {
         Tlo |= (uint64_t)(t[k] & 1) << k; Thi |= (uint64_t)(t[k] >> 1) << k;
-        Plo |= (uint64_t)(q[k] & 1) << k; Phi |= (uint64_t)(q[k] >> 1) << k;
+        /* beyond the pattern's end the planes hold whatever follows in memory: use a fixed non-zero filler here */
+        uint8_t qc = k < m ? q[k] : (uint8_t)((k * 7 + 3) & 3);
+        Plo |= (uint64_t)(qc & 1) << k; Phi |= (uint64_t)(qc >> 1) << k;
     }
     Tlo = brev64(Tlo); Thi = brev64(Thi); Plo = brev64(Plo); Phi = brev64(Phi);   /* bit p = char 63-p */
     uint64_t mt[NDIAG], A[NDIAG], S[NDIAG], An[NDIAG], Sn[NDIAG];
     int thr[NDIAG];
     for (int x = 0; x < NDIAG; x++) {
         int dl = x - DOFF;
+        int e = dl + (64 - m);                      /* a pattern of m < 64 characters shifts every boundary role by 64-m diagonals */
         uint64_t slo = dl >= 0 ? Plo << dl : Plo >> -dl, shi = dl >= 0 ? Phi << dl : Phi >> -dl;
-        uint64_t valid = dl >= 0 ? ~0ull << dl : ~0ull >> -dl;
-        mt[x] = ~((Tlo ^ slo) | (Thi ^ shi)) & valid;
-        thr[x] = dl <= 0 ? -dl : 1 << 20;
+        uint64_t lowm = e <= 0 ? ~0ull : (e >= 64 ? 0ull : ~0ull << e);     /* j < m  */
+        uint64_t highm = dl >= 0 ? ~0ull : ~0ull >> -dl;                      /* j >= 0 */
+        mt[x] = ~((Tlo ^ slo) | (Thi ^ shi)) & lowm & highm;
+        thr[x] = e <= 0 ? -e : 1 << 20;
         A[x] = 0;
-        S[x] = dl >= 1 ? 1ull << (dl - 1) : 0;      /* row "-1": only the forced boundary-row cells */
+        S[x] = (e >= 1 && e <= 64) ? 1ull << (e - 1) : 0;      /* row "-1": only the forced pattern-end cells */
     }
     for (int d = 0; d <= max_rows; d++) {
         for (int x = 0; x < NDIAG; x++) {
@@ -61,12 +65,13 @@ static int diag_dc(const uint8_t *t, const uint8_t *q, int max_rows, uint32_t H[
 static int clz32(uint32_t v) { return v ? __builtin_clz(v) : 32; }
 
 /* traceback over the diagonal rows; TBL = W - O <= 31 */
-static int diag_tb(uint32_t H[][NDIAG], int dist, int TBL, size_t *tu, size_t *pu, run_sink *out)
+static int diag_tb(uint32_t H[][NDIAG], int dist, int TBL, int m, size_t *tu, size_t *pu, run_sink *out)
 {
     int i = 0, j = 0, d = dist;
     char cur = 0; unsigned cur_len = 0;
 #define EMIT(op_, n_) do { if ((n_)) { if (cur == (op_)) cur_len += (n_); else { if (cur_len) sink_push(out, cur, cur_len); cur = (op_); cur_len = (n_); } } } while (0)
-    while (i < TBL && j < TBL) {
+    const int jlim = m < TBL ? m : TBL;            /* j < m && j < W-O, genasm_cpu.cpp:307-310 */
+    while (i < TBL && j < jlim) {
         int x = j - i + DOFF;
         uint32_t E = 0, hi = 0, hd = 0, hs = 0;
         if (d > 0) {
@@ -77,7 +82,7 @@ static int diag_tb(uint32_t H[][NDIAG], int dist, int TBL, size_t *tu, size_t *p
         }
         int i2 = clz32(E);
         int run = i2 - i;
-        int lim = TBL - (i > j ? i : j);
+        int lim = (TBL - i) < (jlim - j) ? (TBL - i) : (jlim - j);
         if (run >= lim) { EMIT('=', (unsigned)lim); i += lim; j += lim; break; }
         EMIT('=', (unsigned)run); i += run; j += run;
         uint32_t bit = 0x80000000u >> i;
@@ -104,10 +109,10 @@ int proto_align_codes(const uint8_t *text, size_t text_len, const uint8_t *read,
         size_t n = text_len - ti < (size_t)W ? text_len - ti : (size_t)W;
         size_t m = read_len - ri < (size_t)W ? read_len - ri : (size_t)W;
         size_t tu, pu; int dist = -1;
-        if (n == 64 && m == 64 && limit <= 31) dist = diag_dc(text + ti, read + ri, max_rows, H, ps);
+        if (n == 64 && limit <= 31) dist = diag_dc(text + ti, read + ri, (int)m, max_rows, H, ps);
         if (dist >= 0) {
             ps->diag_windows++;
-            total += diag_tb(H, dist, (int)limit, &tu, &pu, &out);
+            total += diag_tb(H, dist, (int)limit, (int)m, &tu, &pu, &out);
         } else {
             ps->fallback_windows++;
             dist = distance_sweep_64(text + ti, n, read + ri, m, W, &scratch, NULL);
