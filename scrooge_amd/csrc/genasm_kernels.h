@@ -37,11 +37,28 @@ hipError_t launch_align_multiword(int lanes_per_pair, const AlignArgs& a, int gr
 // dwords of one stored row of R (the part the traceback can reach):
 //   W <= 64: the high dword of columns 0..31, or whole entries of all 64 columns when W-O > 31;
 //   W  > 64: words 0..SW-1 of columns 0..64*SW-1 with SW = (W-O)/64 + 1.
-inline unsigned stored_row_dwords(int W, int tb_limit)
+#ifdef __HIPCC__
+#define SCRG_HD __host__ __device__
+#else
+#define SCRG_HD
+#endif
+SCRG_HD inline unsigned stored_row_dwords(int W, int tb_limit)
 {
     if (W <= 64) return tb_limit > 31 ? 128u : 32u;
     const unsigned sw = (unsigned)tb_limit / 64u + 1u;
     return 64u * sw * sw * 2u;
+}
+
+// dwords of LDS per pair slot for the table R: lds_rows stored rows + 1 (slots land on distinct banks).
+// The G = 8 kernel's diagonal-major path (W = 64, W-O <= 31) keeps 16 rows in its own compacted
+// layout — 8 rows x 32 diagonals, 8 rows x 16, 4 dwords where idle lanes park their stores — and needs
+// 397 dwords whatever lds_rows says.
+constexpr unsigned DIAG_SLOT_DWORDS = 397;
+SCRG_HD inline unsigned slot_stride_dwords(int W, int tb_limit, int lanes_per_pair, int lds_rows)
+{
+    unsigned s = (unsigned)lds_rows * stored_row_dwords(W, tb_limit) + 1u;
+    if (W == 64 && lanes_per_pair == 8 && tb_limit <= 31 && s < DIAG_SLOT_DWORDS) s = DIAG_SLOT_DWORDS;
+    return s;
 }
 hipError_t launch_pack_planar(const char* d_ascii, uint64_t n_words, uint64_t* d_planar, uint32_t* d_bad,
                               int n_cus, hipStream_t s);

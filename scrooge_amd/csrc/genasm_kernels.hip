@@ -63,7 +63,7 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
     //      [SLOTS x (RB rows x 32 dwords + 1)][8 dwords pad]
     const uint32_t obuf = (uint32_t)slot * OBUF_DWORDS;            // 32 runs staged per slot, written out 16 at a time
     const uint32_t scratch_dw = SLOTS * OBUF_DWORDS + (uint32_t)slot;   // target of masked-off staging writes
-    const uint32_t slot_stride = (uint32_t)RB * ROWDW + 1u;        // +1 word: conflict-free slot banks
+    const uint32_t slot_stride = slot_stride_dwords(W, TBL, G, RB);  // RB rows + 1 word: conflict-free slot banks (>= 397 for the diagonal path)
     const uint32_t lds_slot = SLOTS * (OBUF_DWORDS + 1u) + slot * slot_stride;   // R[d][i] at lds[lds_slot + d*32 + i], d < RB
     uint16_t* const lds16 = reinterpret_cast<uint16_t*>(lds);
     uint32_t* const Rs = a.spill + ((size_t)blockIdx.x * SLOTS + slot) * (size_t)(SPILL_ROWS * ROWDW);
@@ -166,10 +166,8 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
         if constexpr (G == 8 && !WIDE) {
             // LDS rows of this layout: high dwords (positions i <= 31) of the 32 diagonals; from row 8 on the
             // traceback can only be within |delta| <= 7, so those rows keep the 16 diagonals of lanes 2..5
-            // and 16 rows fit the 13 x 32 dwords the column layout uses
-            const int cmp_row = RB >= 13 ? 8 : 64;
-            const int rows_cap = RB >= 13 ? 16 : RB;
-            const int max_rows = rows_cap < 15 ? rows_cap : 15;
+            // and 16 rows take 8*32 + 8*16 + 4 (parking) = 396 dwords
+            constexpr int cmp_row = 8, rows_cap = 16, max_rows = 15;      // (slot_stride_dwords() reserves the 397 dwords)
             // slots with a ragged window (text or pattern end) sit a diagonal round out; so do slots whose
             // window turns out to need more than max_rows rows.  Either kind makes the NEXT round a
             // column-major one (which serves every slot), so a diagonal round pays off when more than half
@@ -285,7 +283,7 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
                         if (d == cmp_row) {                           // compact rows: lanes 2..5 keep storing, the rest park
                             asm volatile("" ::: "memory");            // (a real branch, taken once per window)
                             const bool mid = (t >= 2 && t <= 5);
-                            waddr = lds_slot + (mid ? 256u + 4u * (uint32_t)t : 392u + 4u * (uint32_t)(t & 3));
+                            waddr = lds_slot + (mid ? 256u + 4u * (uint32_t)t : 392u);
                             wstride = mid ? 16u : 0u;
                         }
 #pragma unroll

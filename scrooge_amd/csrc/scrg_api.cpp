@@ -276,9 +276,9 @@ static bool resolve_params(const scrg_params* in, scrg_params* p)
     } else {
         // measured optimum on MI355X for 10 kb reads at 10 % error
         if (p->lanes_per_pair == 0) p->lanes_per_pair = 8;
-        if (p->lds_rows == 0) p->lds_rows = 13;
+        if (p->lds_rows == 0) p->lds_rows = 12;
     }
-    if (p->waves_per_cu == 0) p->waves_per_cu = 11;    // the LDS footprint caps it (scrg_query_launch)
+    if (p->waves_per_cu == 0) p->waves_per_cu = 12;    // the LDS footprint caps it (scrg_query_launch)
     const int g = p->lanes_per_pair;
     if (!(g == 4 || g == 8 || g == 16 || g == 32 || g == 64)) return false;
     if (p->lds_rows < 1) return false;
@@ -297,8 +297,7 @@ static size_t lds_bytes_for(const scrg_params& p)
     // conflicts); 8 dwords of padding at the end (the traceback's speculative lanes read a little past a
     // row).  A row is 32 DENT dwords, or 64 whole entries when W-O > 31 (the kernel's WIDE variant);
     // see stored_row_dwords() for W > 64.
-    const size_t row_dw = scrg::stored_row_dwords(p.W, p.W - p.O);
-    return (slots * (17 + (size_t)p.lds_rows * row_dw + 1) + 8) * sizeof(uint32_t);
+    return (slots * (17 + (size_t)scrg::slot_stride_dwords(p.W, p.W - p.O, p.lanes_per_pair, p.lds_rows)) + 8) * sizeof(uint32_t);
 }
 
 scrg_status scrg_params_resolve(const scrg_params* in, scrg_params* out)
