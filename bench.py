@@ -16,6 +16,7 @@ Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
+import numpy as np
 import os
 import sys
 import time
@@ -291,8 +292,13 @@ def main():
             if cig != c_cpu[i] or ed_h[i] != e_cpu[i]:
                 ok = False
                 break
-        parity = {"checked_pairs": k, "bit_exact": ok}
-        assert ok, "GPU result differs from the CPU checker on the bench sample"
+        # edit distance and run count of every pair the CPU leg aligned (CIGAR text of the first k)
+        ed_all = ed[:m].cpu().numpy()
+        nr_all = n_runs[:m].cpu().numpy()
+        n_ops_cpu = np.array([sum(1 for ch in c if not ch.isdigit()) for c in c_cpu[:m]])
+        ok_all = bool((ed_all == np.array(e_cpu[:m])).all() and (nr_all == n_ops_cpu).all())
+        parity = {"checked_pairs": k, "bit_exact": ok, "checked_edit_distances_and_run_counts": m, "all_equal": ok_all}
+        assert ok and ok_all, "GPU result differs from the CPU checker on the bench sample"
 
     pairs_total = world * n * args.steps
     value = pairs_total / dt

@@ -244,9 +244,9 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
                 asm volatile("" : "+v"(not_first), "+v"(not_last));
                 uint32_t ddw = 0;
                 int32_t hit_cmp = (capable && t == 4) ? 0 : INT32_MIN;      // lane 4, k = 0 holds delta = 0: goal = bit 63
+                asm volatile("" : "+v"(hit_cmp));                            // (a register, not a select recomputed per row)
                 bool found = false;
-                uint64_t done_mask = __ballot(!capable);
-                bool all_done = (done_mask & leaders) == leaders;
+                int waiting = __popcll(__ballot(capable) & leaders);        // slots that have not reached the goal yet
                 uint32_t waddr = lds_slot + 4u * (uint32_t)t, wstride = 32u;
                 int d = 0;
                 constexpr int TT_A = bitop3_table([](int sum, int y, int mm) { return y | (mm & (sum ^ (y | mm) ^ y)); });
@@ -299,17 +299,18 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
                             ddw = (uint32_t)d;
                             found = true;
                         }
-                        done_mask |= newly;
-                        all_done = (done_mask & leaders) == leaders;
+                        asm volatile("" : "+v"(hit_cmp));
+                        waiting -= __popcll(lead);
                     }
                     d++;
                 };
                 for (;;) {
                     row(A0, S0, A1, S1);
-                    if (all_done || d > max_rows) break;
+                    if (waiting == 0 || d > max_rows) break;
                     row(A1, S1, A0, S0);
-                    if (all_done || d > max_rows) break;
+                    if (waiting == 0 || d > max_rows) break;
                 }
+                const bool all_done = waiting == 0;
                 const uint64_t tmd1 = timing ? __builtin_readcyclecounter() : 0;
                 st_steps += (uint32_t)d;
                 {
