@@ -22,6 +22,12 @@
 // needed by the traceback go to LDS (rows >= lds_rows spill to an HBM scratch).
 // The traceback itself is lane-parallel: lane l of a slot tests the cell l steps
 // down the current diagonal, a ballot finds the first non-match.
+//
+// The G = 8 instantiation has a second, faster layout for the common window (W = 64,
+// full text window, distance <= 15): the same table indexed by DIAGONAL, where a row
+// is a carry chain solved by one 64-bit addition per diagonal, no skew is needed and
+// the traceback finds each edit with one count-leading-zeros ("diagonal-major window"
+// below).  Rounds of the two kinds interleave freely inside a pair.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
