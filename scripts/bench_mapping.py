@@ -35,12 +35,20 @@ sh1 = np.maximum(0, starts - rng.integers(1, 4, n_reads)); sh2 = starts + rng.in
 rnd = rng.integers(0, G - 10, n_reads)
 cands = np.stack([starts, sh1, sh2, rnd], axis=1).tolist()
 gen_s = time.time() - t0
+import os
 a = scrooge_amd.Aligner(0)
+# optional knobs for experiments: SCRG_KNOBS="reserved0,lds_rows,waves_per_cu"
+kn = [int(v) for v in os.environ.get("SCRG_KNOBS", "0,0,0").split(",")]
+a.params.reserved[0], a.params.lds_rows, a.params.waves_per_cu = kn[0], kn[1], kn[2]
 a.align_mapping(genome, reads[:1000], cands[:1000])     # warm-up / allocations
 t1 = time.time()
 alns = a.align_mapping(genome, reads, cands)
 wall = time.time() - t1
 tm = a.last_timing
+if os.environ.get("SCRG_STATS"):
+    a.params.reserved[1] = 1
+    a.align_mapping(genome, reads, cands)
+    print("stats", a.debug_stats(), file=sys.stderr)
 n_pairs = 4 * n_reads
 # parity on a sample
 k = 2000

@@ -188,6 +188,10 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
                 try_diag = false;
             }
             if (try_diag) {
+                // (an opaque copy of the lane index: per-lane constants of this path are recomputed each round
+                // instead of living in — and being spilled from — registers across the column-major path)
+                int tq = t;
+                asm volatile("" : "+v"(tq));
                 // ---- setup: match words of my four diagonals x = 4t+k (delta = x-16) ----
                 uint64_t mt[4];
                 int32_t cnt[4];            // carry-in of diagonal delta <= 0 at row d is [d >= -delta]: sign of -delta-1-d
@@ -211,7 +215,7 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
                     // carry-in [d >= -e].  m = 64 is the e = delta special case with the masks from one funnel shift.
                     const bool short_pattern = __any(capable && m != 64u);
                     auto match_word = [&](int k, uint32_t v_lo, uint32_t v_hi) {
-                        const uint32_t sh = 31u - (uint32_t)(4 * t + k);
+                        const uint32_t sh = 31u - (uint32_t)(4 * tq + k);
                         const uint32_t pl_lo = __builtin_amdgcn_alignbit(l1, l0, sh), pl_hi = __builtin_amdgcn_alignbit(l2, l1, sh);
                         const uint32_t ph_lo = __builtin_amdgcn_alignbit(h1, h0, sh), ph_hi = __builtin_amdgcn_alignbit(h2, h1, sh);
                         const uint32_t m_lo = v_lo & ~(((uint32_t)trl ^ pl_lo) | ((uint32_t)trh ^ ph_lo));
@@ -222,7 +226,7 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
                     if (!short_pattern) {
 #pragma unroll
                         for (int k = 0; k < 4; k++) {
-                            const uint32_t x = (uint32_t)(4 * t + k);
+                            const uint32_t x = (uint32_t)(4 * tq + k);
                             const uint32_t sh = 31u - x;
                             // valid positions 0 <= j < 64: both ends from one funnel shift of 64 ones
                             match_word(k, __builtin_amdgcn_alignbit(0xffffffffu, 0xffff8000u, sh),
@@ -234,7 +238,7 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
                         asm volatile("" ::: "memory");       // (a real branch: only the last windows of a read come here)
 #pragma unroll
                         for (int k = 0; k < 4; k++) {
-                            const uint32_t x = (uint32_t)(4 * t + k);
+                            const uint32_t x = (uint32_t)(4 * tq + k);
                             const int32_t e = (int32_t)x - 16 + (int32_t)(64u - m);
                             const uint64_t lowm = e <= 0 ? ~0ull : (e >= 64 ? 0ull : (~0ull << (e & 63)));     // j < m
                             match_word(k, (uint32_t)lowm,
@@ -246,14 +250,14 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
                 }
                 const uint64_t tmd0 = timing ? __builtin_readcyclecounter() : 0;
                 // ---- rows ----
-                uint32_t not_first = (t != 0) ? ~0u : 0u, not_last = (t != G - 1) ? ~0u : 0u;
+                uint32_t not_first = (tq != 0) ? ~0u : 0u, not_last = (tq != G - 1) ? ~0u : 0u;
                 asm volatile("" : "+v"(not_first), "+v"(not_last));
                 uint32_t ddw = 0;
-                int32_t hit_cmp = (capable && t == 4) ? 0 : INT32_MIN;      // lane 4, k = 0 holds delta = 0: goal = bit 63
+                int32_t hit_cmp = (capable && tq == 4) ? 0 : INT32_MIN;      // lane 4, k = 0 holds delta = 0: goal = bit 63
                 asm volatile("" : "+v"(hit_cmp));                            // (a register, not a select recomputed per row)
                 bool found = false;
                 int waiting = __popcll(__ballot(capable) & leaders);        // slots that have not reached the goal yet
-                uint32_t waddr = lds_slot + 4u * (uint32_t)t, wstride = 32u;
+                uint32_t waddr = lds_slot + 4u * (uint32_t)tq, wstride = 32u;
                 int d = 0;
                 constexpr int TT_A = bitop3_table([](int sum, int y, int mm) { return y | (mm & (sum ^ (y | mm) ^ y)); });
                 auto row = [&](const uint64_t (&Ap)[4], const uint64_t (&Sp)[4], uint64_t (&Ac)[4], uint64_t (&Sc)[4]) {
@@ -417,8 +421,8 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
                         diag_fails = diag_fails ? diag_fails - 1u : 0u;
                     } else {
                         st_diag_fail++;
-                        diag_fails = diag_fails < 8u ? diag_fails + 1u : 8u;
-                        if (diag_fails >= 3u) diag_skip = 1u << (diag_fails - 2u);
+                        diag_fails = diag_fails < 12u ? diag_fails + 1u : 12u;
+                        if (diag_fails >= 3u) diag_skip = 1u << (diag_fails - 2u);      // 2, 4, ... 1024 rounds
                     }
                     if (timing) {
                         const uint64_t tmd2 = __builtin_readcyclecounter();

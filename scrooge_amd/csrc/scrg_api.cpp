@@ -259,6 +259,8 @@ static bool resolve_params(const scrg_params* in, scrg_params* p)
         p->lds_rows = in->lds_rows;
         p->waves_per_cu = in->waves_per_cu;
         p->sort_by_length = in->sort_by_length;
+        p->reserved[0] = in->reserved[0];      // ablation switches and profiling counters travel with the parameters
+        p->reserved[1] = in->reserved[1];
     }
     if (p->W < 2 || p->W > 256) return false;
     const int tbl = p->W - p->O;
