@@ -1,0 +1,40 @@
+"""Randomised soak of the default path against the oracle: many pairs of mixed lengths and error
+rates (0-30 %), unrelated pairs, homopolymers and ragged text ends, every CIGAR compared.
+usage: python scripts/soak.py [n_pairs] [seed]"""
+import sys, time
+sys.path.insert(0, ".")
+import numpy as np
+import scrooge_amd
+from scrooge_amd import synth
+from oracle.pyoracle import Oracle
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 60000
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.Generator(np.random.PCG64(seed))
+T, Q = [], []
+t0 = time.time()
+while len(T) < n:
+    L = int(rng.choice([30, 150, 400, 1000, 3000])) + int(rng.integers(0, 64))
+    err = float(rng.choice([0.0, 0.01, 0.05, 0.1, 0.15, 0.2, 0.3]))
+    ratio = [(1, 1, 1), (23, 31, 46), (6, 50, 54), (90, 5, 5)][int(rng.integers(0, 4))]
+    k = int(rng.integers(0, 10))
+    if k == 0:                                   # unrelated
+        T.append(synth.random_seq(L + int(rng.integers(0, 100)), rng)); Q.append(synth.random_seq(L, rng))
+    elif k == 1:                                 # homopolymer / low complexity
+        a = b"ACGT"[int(rng.integers(0, 4))]; T.append(bytes([a]) * (L + 20)); Q.append(bytes([a]) * int(L * rng.uniform(0.7, 1.3)))
+    else:
+        slack = float(rng.choice([0.0, 0.02, 0.15, 0.5]))   # 0: the text ends with (or before) the read
+        t, q = synth.make_pair(L, err, ratio, rng, slack)
+        T.append(synth.BASES[t].tobytes()); Q.append(synth.BASES[q].tobytes())
+print("generated %d pairs in %.1fs" % (len(T), time.time() - t0))
+t0 = time.time()
+eds, cigars, _, _ = Oracle().align(T, Q, threads=16)
+print("oracle %.1fs" % (time.time() - t0))
+a = scrooge_amd.Aligner(0)
+for kw in ({}, {"lds_rows": 7}, {"sort_by_length": 0}):
+    t0 = time.time()
+    got = a.align_pairs(T, Q, **kw)
+    bad = [i for i in range(len(T)) if got[i].edit_distance != eds[i] or got[i].cigar != cigars[i]]
+    print(kw, "gpu %.1fs" % (time.time() - t0), "mismatches:", len(bad), bad[:5])
+    assert not bad
+print("soak ok")
