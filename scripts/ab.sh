@@ -7,7 +7,7 @@ if [ "$1" = build ]; then
   src=${3:-$root/scrooge_amd/csrc/genasm_kernels.hip}
   cp $src /tmp/ab_$2.hip
   cd $root/scrooge_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -I$root/scrooge_amd/csrc \
-     -o $root/ab_libs/lib_$2.so -x hip /tmp/ab_$2.hip genasm_kernel_multiword.hip -x hip scrg_api.cpp scrg_io.cpp -lpthread 2>&1 | grep -E "error" -A3
+     -o $root/ab_libs/lib_$2.so -x hip /tmp/ab_$2.hip genasm_kernel_multiword.hip seq_kernels.hip -x hip scrg_api.cpp scrg_io.cpp -lpthread 2>&1 | grep -E "error" -A3
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -I$root/scrooge_amd/csrc -c -x hip /tmp/ab_$2.hip -o /tmp/ab.o -Rpass-analysis=kernel-resource-usage 2>&1 | grep -E "Function Name|VGPRs:|ScratchSize" | grep -A2 "kernelILi8E" | grep -E "VGPRs|Scratch" | sed 's/.*remark: *//;s/\[-Rpass.*//' | tr '\n' ' '; echo " <- $2"
 else
   shift

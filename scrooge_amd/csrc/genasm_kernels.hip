@@ -847,116 +847,6 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
     }
 }
 
-// ----------------------------------------------------------------------------
-// ASCII -> planar 2-bit.  One thread per 32 bases: two 16-byte loads, one
-// 8-byte store; a wave reads 2 KiB contiguous and writes 512 B contiguous.
-// ----------------------------------------------------------------------------
-__device__ __forceinline__ void pack4(uint32_t v, uint32_t& lo, uint32_t& hi, uint32_t& bad)
-{
-    // per byte: x = (c>>1)&3 gives A0 C1 T2 G3; code = x ^ (x>>1) gives A0 C1 G2 T3
-    const uint32_t b1 = (v >> 1) & 0x01010101u;
-    const uint32_t b2 = (v >> 2) & 0x01010101u;
-    const uint32_t l = b1 ^ b2;
-    const uint32_t h = b2;
-    // gather the four byte-lsbs into a nibble
-    lo = ((l * 0x01020408u) >> 24) & 0xfu;
-    hi = ((h * 0x01020408u) >> 24) & 0xfu;
-    // validity: upper-cased byte must be one of A C G T, or the byte is 0 (padding)
-    const uint32_t u = v & 0xdfdfdfdfu;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const uint32_t c = (u >> (8 * k)) & 0xffu;
-        const uint32_t raw = (v >> (8 * k)) & 0xffu;
-        const bool ok = (c == 'A') || (c == 'C') || (c == 'G') || (c == 'T') || (raw == 0u);
-        bad += ok ? 0u : 1u;
-    }
-}
-
-__global__ __launch_bounds__(256) void pack_planar_kernel(const uint4* __restrict__ ascii, uint64_t n_words,
-                                                          uint64_t* __restrict__ planar, uint32_t* __restrict__ bad_count)
-{
-    uint32_t bad = 0;
-    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words;
-         w += (uint64_t)gridDim.x * blockDim.x) {
-        const uint4 q0 = ascii[2 * w], q1 = ascii[2 * w + 1];
-        const uint32_t v[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
-        uint32_t lo = 0, hi = 0;
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            uint32_t l, h;
-            pack4(v[k], l, h, bad);
-            lo |= l << (4 * k);
-            hi |= h << (4 * k);
-        }
-        planar[w] = ((uint64_t)hi << 32) | lo;
-    }
-    if (bad) atomicAdd(bad_count, bad);
-}
-
-// ----------------------------------------------------------------------------
-// Reference-layout packer (src/genasm_gpu.cu:631-685): 4 bases per byte, the
-// first base of each quad in bits 7..6; one thread per output byte, strings
-// concatenated.  (The reference launches every block over the whole buffer;
-// here each output byte is produced exactly once.)
-// ----------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ascii_to_twobit_kernel(uint64_t count, const uint64_t* __restrict__ lens,
-                                                              const uint64_t* __restrict__ ascii_off,
-                                                              const char* __restrict__ ascii,
-                                                              const uint64_t* __restrict__ twobit_off,
-                                                              uint8_t* __restrict__ twobit,
-                                                              uint32_t* __restrict__ bad_count)
-{
-    // grid.y strides over strings, grid.x*block over bytes of a string
-    uint32_t bad = 0;
-    for (uint64_t s = blockIdx.y; s < count; s += gridDim.y) {
-        const uint64_t len = lens[s];
-        const uint64_t nbytes = (len + 3) / 4;
-        const char* src = ascii + ascii_off[s];
-        uint8_t* dst = twobit + twobit_off[s];
-        for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < nbytes;
-             b += (uint64_t)gridDim.x * blockDim.x) {
-            uint32_t out = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint64_t p = 4 * b + k;
-                uint32_t code = 0;
-                if (p < len) {
-                    const uint32_t c = (uint8_t)src[p];
-                    const uint32_t u = c & 0xdfu;
-                    if (!(u == 'A' || u == 'C' || u == 'G' || u == 'T')) bad++;
-                    const uint32_t x = (c >> 1) & 3u;
-                    code = x ^ (x >> 1);
-                }
-                out |= code << (6 - 2 * k);
-            }
-            dst[b] = (uint8_t)out;
-        }
-    }
-    if (bad) atomicAdd(bad_count, bad);
-}
-
-// ----------------------------------------------------------------------------
-// Run compaction: one wavefront per pair copies its runs from the pair's
-// arena slice into the dense output.
-// ----------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void compact_runs_kernel(uint64_t n_pairs, const scrg_pair_desc* __restrict__ pairs,
-                                                           const uint16_t* __restrict__ runs,
-                                                           const uint32_t* __restrict__ n_runs,
-                                                           const uint64_t* __restrict__ dense_off,
-                                                           uint16_t* __restrict__ dense)
-{
-    const int lane = threadIdx.x & 63;
-    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    for (uint64_t p = wave; p < n_pairs; p += n_waves) {
-        const uint64_t src = pairs[p].cigar_off;
-        const uint64_t cap = pairs[p].cigar_cap;
-        uint64_t cnt = n_runs[p];
-        if (cnt > cap) cnt = cap;
-        const uint64_t dst = dense_off[p];
-        for (uint64_t k = lane; k < cnt; k += 64) dense[dst + k] = runs[src + k];
-    }
-}
 
 // ----------------------------------------------------------------------------
 // host-side launchers
@@ -987,45 +877,6 @@ hipError_t launch_align(int lanes_per_pair, const AlignArgs& a, int grid, size_t
     case 64: return launch_align_t<64>(a, grid, lds_bytes, s);
     default: return hipErrorInvalidValue;
     }
-}
-
-hipError_t launch_pack_planar(const char* d_ascii, uint64_t n_words, uint64_t* d_planar, uint32_t* d_bad,
-                              int n_cus, hipStream_t s)
-{
-    if (n_words == 0) return hipSuccess;
-    uint64_t blocks = (n_words + 255) / 256;
-    const uint64_t cap = (uint64_t)n_cus * 8;
-    if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(pack_planar_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
-                       reinterpret_cast<const uint4*>(d_ascii), n_words, d_planar, d_bad);
-    return hipGetLastError();
-}
-
-hipError_t launch_ascii_to_twobit(uint64_t count, const uint64_t* d_lens, const uint64_t* d_ascii_off,
-                                  const char* d_ascii, const uint64_t* d_twobit_off, uint8_t* d_twobit,
-                                  uint32_t* d_bad, uint64_t max_len, hipStream_t s)
-{
-    if (count == 0) return hipSuccess;
-    uint64_t bx = ((max_len + 3) / 4 + 255) / 256;
-    if (bx < 1) bx = 1;
-    if (bx > 64) bx = 64;
-    uint64_t by = count < 4096 ? count : 4096;
-    hipLaunchKernelGGL(ascii_to_twobit_kernel, dim3((unsigned)bx, (unsigned)by), dim3(256), 0, s,
-                       count, d_lens, d_ascii_off, d_ascii, d_twobit_off, d_twobit, d_bad);
-    return hipGetLastError();
-}
-
-hipError_t launch_compact_runs(uint64_t n_pairs, const scrg_pair_desc* d_pairs, const uint16_t* d_runs,
-                               const uint32_t* d_n_runs, const uint64_t* d_dense_off, uint16_t* d_dense,
-                               int n_cus, hipStream_t s)
-{
-    if (n_pairs == 0) return hipSuccess;
-    uint64_t blocks = (n_pairs + 3) / 4;
-    const uint64_t cap = (uint64_t)n_cus * 8;
-    if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(compact_runs_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
-                       n_pairs, d_pairs, d_runs, d_n_runs, d_dense_off, d_dense);
-    return hipGetLastError();
 }
 
 }  // namespace scrg
