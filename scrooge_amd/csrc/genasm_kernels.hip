@@ -337,7 +337,6 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
                     uint32_t ti = 0, tj = 0, dd = ddw;
                     const uint32_t jlim = m < (uint32_t)TBL ? m : (uint32_t)TBL;     // j < m && j < W-O (:307-310)
                     uint32_t xoff = lds_slot + 15u;                  // lds_slot + (x - 1), x = j - i + 16
-                    uint32_t cur_op8 = 0, cur_cnt = 0;               // last run written, if it is an edit run of this window
                     uint32_t nr2 = 2u * n_runs;                       // byte position of the next run
                     uint32_t flushed = n_runs & ~15u;                 // runs below this are in HBM (the column path's invariant)
                     const uint32_t obuf_b = 4u * obuf, dummy_b = 4u * scratch_dw;
@@ -360,6 +359,8 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
                         }
                     };
                     int iter = 0;
+                    uint32_t cur = 0;                                 // last run written if it is an edit run of this window: count | op << 8
+                    uint32_t lim = (uint32_t)TBL < jlim ? (uint32_t)TBL : jlim;     // cells left before i or j reaches its limit (:307-310)
                     do {
                         st_macro++;
                         // row d-1 of diagonals x-1, x, x+1; garbage when d == 0 (masked below)
@@ -371,10 +372,7 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
                         const uint32_t w_ins = lds[base + 2];          // a(i, j+1)   on diagonal x+1
                         const uint32_t roomm = neg_mask(0u - dd) & actmask;          // d > 0 (:313)
                         const uint32_t E = (((w_del | w_sub) << 1) | w_ins) & (0xffffffffu >> ti) & roomm;
-                        const uint32_t i2 = (uint32_t)__clz((int)E);               // 32 when no edit is available
-                        const uint32_t run = i2 - ti;
-                        const uint32_t li = (uint32_t)TBL - ti, lj = jlim - tj;
-                        const uint32_t lim = li < lj ? li : lj;                    // :307-310
+                        const uint32_t run = (uint32_t)__clz((int)E) - ti;         // clz = 32 when no edit is available
                         const uint32_t edit = neg_mask(run - lim) & actmask;       // an edit ends the run inside the window
                         const uint32_t n_eq = (run < lim ? run : lim) & actmask;
                         // the '=' run
@@ -382,27 +380,26 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
                         *reinterpret_cast<uint16_t*>(lds_b + bitop3<0xCA>(eqm, obuf_b + (nr2 & 62u), dummy_b)) =
                             (uint16_t)(n_eq | ((uint32_t)'=' << 8));
                         nr2 += eqm & 2u;
-                        cur_cnt &= ~eqm;
-                        ti += n_eq;
-                        tj += n_eq;
-                        // the edit that ends it: priority I, D, X (:346-370)
-                        const uint32_t sh = 31u - (ti & 31u);
-                        const uint32_t is_i = 0u - ((w_ins >> sh) & 1u);
-                        const uint32_t is_d = (0u - (((w_del << 1) >> sh) & 1u)) & ~is_i;
+                        cur &= ~eqm;
+                        // the edit that ends it, at position i + n_eq: priority I, D, X (:346-370)
+                        const uint32_t ie = ti + n_eq;
+                        const uint32_t sh = 31u - ie;
+                        const uint32_t is_i = (uint32_t)__builtin_amdgcn_sbfe((int)w_ins, sh, 1u);
+                        const uint32_t is_d = (uint32_t)__builtin_amdgcn_sbfe((int)(w_del << 1), sh, 1u) & ~is_i;
                         const uint32_t op8 = bitop3<0xCA>(is_i, (uint32_t)'I' << 8, bitop3<0xCA>(is_d, (uint32_t)'D' << 8, (uint32_t)'X' << 8));
-                        const uint32_t merge = edit & nz_mask(cur_cnt) & ~nz_mask(op8 ^ cur_op8);
-                        cur_cnt = (cur_cnt & merge) + 1u;
-                        cur_op8 = op8;
-                        *reinterpret_cast<uint16_t*>(lds_b + bitop3<0xCA>(edit, obuf_b + ((nr2 - (merge & 2u)) & 62u), dummy_b)) =
-                            (uint16_t)(cur_cnt | op8);
+                        const uint32_t merge = edit & neg_mask((cur ^ op8) - 256u);   // same op as the last run (cur != 0)
+                        cur = bitop3<0xCA>(merge, cur, op8) + 1u;
+                        *reinterpret_cast<uint16_t*>(lds_b + bitop3<0xCA>(edit, obuf_b + ((nr2 - (merge & 2u)) & 62u), dummy_b)) = (uint16_t)cur;
                         nr2 += edit & ~merge & 2u;
-                        cur_cnt &= edit;
+                        cur &= edit;
                         const uint32_t e1 = edit & 1u;
-                        ti += e1 & ~is_i;
-                        tj += e1 & ~is_d;
+                        ti = ie + (e1 & ~is_i);
+                        tj += n_eq + (e1 & ~is_d);
                         xoff += (e1 & is_i) - (e1 & is_d);
                         dd -= e1;
-                        actmask = edit & neg_mask(ti - (uint32_t)TBL) & neg_mask(tj - jlim);
+                        const uint32_t li = (uint32_t)TBL - ti, lj = jlim - tj;
+                        lim = li < lj ? li : lj;
+                        actmask = edit & nz_mask(lim);
                         if ((++iter & 7) == 0) flush_check(false);    // at most 16 runs between checks: the 32-run ring cannot wrap
                     } while (__any(actmask != 0u));
                     flush_check(true);          // runs never merge across windows (:400-403): everything staged is final
