@@ -280,7 +280,9 @@ static bool resolve_params(const scrg_params* in, scrg_params* p)
         if (p->lanes_per_pair == 0) p->lanes_per_pair = 8;
         if (p->lds_rows == 0) p->lds_rows = 12;
     }
-    if (p->waves_per_cu == 0) p->waves_per_cu = 12;    // the LDS footprint caps it (scrg_query_launch)
+    // 11 and 12 wavefronts per CU align equally fast (the kernel is issue-bound); 11 leaves VGPRs and LDS on
+    // every CU for kernels of other streams (RCCL's gather in bench.py --gpus N).  The LDS footprint caps it.
+    if (p->waves_per_cu == 0) p->waves_per_cu = 11;
     const int g = p->lanes_per_pair;
     if (!(g == 4 || g == 8 || g == 16 || g == 32 || g == 64)) return false;
     if (p->lds_rows < 1) return false;
