@@ -173,7 +173,7 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
             // LDS rows of this layout: high dwords (positions i <= 31) of the 32 diagonals; from row 8 on the
             // traceback can only be within |delta| <= 7, so those rows keep the 16 diagonals of lanes 2..5
             // and 16 rows take 8*32 + 8*16 + 4 (parking) = 396 dwords
-            constexpr int cmp_row = 8, rows_cap = 16, max_rows = 15;      // (slot_stride_dwords() reserves the 397 dwords)
+            constexpr int cmp_row = 8, max_rows = 15;      // (slot_stride_dwords() reserves the 397 dwords: 16 rows)
             // slots with a ragged window (text or pattern end) sit a diagonal round out; so do slots whose
             // window turns out to need more than max_rows rows.  Either kind makes the NEXT round a
             // column-major one (which serves every slot), so a diagonal round pays off when more than half
@@ -289,17 +289,10 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
                         Ac[k] = ((uint64_t)a_hi << 32) | a_lo;
                         Sc[k] = shl1_add64(Ac[k], (uint64_t)u);     // (a << 1) | boundary cell: the next row's sub/del source
                     }
-                    if (d < rows_cap) {                               // the traceback reads positions i <= 31: the high dwords
-                        if (d == cmp_row) {                           // compact rows: lanes 2..5 keep storing, the rest park
-                            asm volatile("" ::: "memory");            // (a real branch, taken once per window)
-                            const bool mid = (t >= 2 && t <= 5);
-                            waddr = lds_slot + (mid ? 256u + 4u * (uint32_t)t : 392u);
-                            wstride = mid ? 16u : 0u;
-                        }
+                    // the traceback reads positions i <= 31: the high dwords (every row 0..15 has its place)
 #pragma unroll
-                        for (int k = 0; k < 4; k++) lds[waddr + k] = (uint32_t)(Ac[k] >> 32);
-                        waddr += wstride;
-                    }
+                    for (int k = 0; k < 4; k++) lds[waddr + k] = (uint32_t)(Ac[k] >> 32);
+                    waddr += wstride;
                     const uint64_t hits = __ballot((int32_t)(Ac[0] >> 32) < hit_cmp);
                     if (hits) {
                         const uint64_t lead = (hits >> 4) & leaders;
@@ -314,11 +307,20 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
                     }
                     d++;
                 };
-                for (;;) {
-                    row(A0, S0, A1, S1);
-                    if (waiting == 0 || d > max_rows) break;
-                    row(A1, S1, A0, S0);
-                    if (waiting == 0 || d > max_rows) break;
+                auto rows_until = [&](int end) {                      // an even number of rows unless every slot is done
+                    for (;;) {
+                        row(A0, S0, A1, S1);
+                        if (waiting == 0 || d == end) break;
+                        row(A1, S1, A0, S0);
+                        if (waiting == 0 || d == end) break;
+                    }
+                };
+                rows_until(cmp_row);
+                if (waiting != 0) {                                   // compact rows: lanes 2..5 keep storing, the rest park
+                    const bool mid = (tq >= 2 && tq <= 5);
+                    waddr = lds_slot + (mid ? 256u + 4u * (uint32_t)tq : 392u);
+                    wstride = mid ? 16u : 0u;
+                    rows_until(max_rows + 1);
                 }
                 const bool all_done = waiting == 0;
                 const uint64_t tmd1 = timing ? __builtin_readcyclecounter() : 0;
