@@ -53,7 +53,10 @@ SCRG_HD inline unsigned stored_row_dwords(int W, int tb_limit)
 // The G = 8 kernel's diagonal-major path (W = 64, W-O <= 31) keeps 16 rows in its own compacted
 // layout — 8 rows x 32 diagonals, 8 rows x 16, 4 dwords where idle lanes park their stores — and needs
 // 397 dwords whatever lds_rows says.
-constexpr unsigned DIAG_SLOT_DWORDS = 397;
+constexpr unsigned DIAG_WIDE_ROWS = 8;                    // rows 0..7: all 32 diagonals, 32 dwords each
+constexpr unsigned DIAG_LATE_BASE = 128;                  // rows r >= 8: diagonal x at 128 + 16 r + x (x = 8..23), i.e. from dword 264
+constexpr unsigned DIAG_PARK_DWORD = 392;                 // lanes without a late diagonal park their four stores here
+constexpr unsigned DIAG_SLOT_DWORDS = DIAG_PARK_DWORD + 4 + 1;     // 397
 SCRG_HD inline unsigned slot_stride_dwords(int W, int tb_limit, int lanes_per_pair, int lds_rows)
 {
     unsigned s = (unsigned)lds_rows * stored_row_dwords(W, tb_limit) + 1u;

@@ -173,7 +173,7 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
             // LDS rows of this layout: high dwords (positions i <= 31) of the 32 diagonals; from row 8 on the
             // traceback can only be within |delta| <= 7, so those rows keep the 16 diagonals of lanes 2..5
             // and 16 rows take 8*32 + 8*16 + 4 (parking) = 396 dwords
-            constexpr int cmp_row = 8, max_rows = 15;      // (slot_stride_dwords() reserves the 397 dwords: 16 rows)
+            constexpr int cmp_row = (int)DIAG_WIDE_ROWS, max_rows = 15;      // (slot_stride_dwords() reserves the 397 dwords: 16 rows)
             // slots with a ragged window (text or pattern end) sit a diagonal round out; so do slots whose
             // window turns out to need more than max_rows rows.  Either kind makes the NEXT round a
             // column-major one (which serves every slot), so a diagonal round pays off when more than half
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
                 rows_until(cmp_row);
                 if (waiting != 0) {                                   // compact rows: lanes 2..5 keep storing, the rest park
                     const bool mid = (tq >= 2 && tq <= 5);
-                    waddr = lds_slot + (mid ? 256u + 4u * (uint32_t)tq : 392u);
+                    waddr = lds_slot + (mid ? DIAG_LATE_BASE + 16u * DIAG_WIDE_ROWS + 4u * (uint32_t)tq : DIAG_PARK_DWORD);
                     wstride = mid ? 16u : 0u;
                     rows_until(max_rows + 1);
                 }
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
                         // row d-1 of diagonals x-1, x, x+1; garbage when d == 0 (masked below)
                         const uint32_t r = dd ? dd - 1u : 0u;
                         const uint32_t rmin = r < (uint32_t)cmp_row ? r : (uint32_t)cmp_row;
-                        const uint32_t base = xoff + 16u * (r + rmin);
+                        const uint32_t base = xoff + 16u * (r + rmin);              // 32 r for r < 8, DIAG_LATE_BASE + 16 r after
                         const uint32_t w_del = lds[base];              // a(i+1, j)   on diagonal x-1, one position down
                         const uint32_t w_sub = lds[base + 1];          // a(i+1, j+1) on diagonal x,   one position down
                         const uint32_t w_ins = lds[base + 2];          // a(i, j+1)   on diagonal x+1
