@@ -100,22 +100,61 @@ __global__ __launch_bounds__(256) void ascii_to_twobit_kernel(uint64_t count, co
 // Run compaction: one wavefront per pair copies its runs from the pair's
 // arena slice into the dense output.
 // ----------------------------------------------------------------------------
+struct __attribute__((aligned(4))) Dwords4 {
+    uint32_t x, y, z, w;      // 16 bytes that are only known to be dword aligned
+};
+
 __global__ __launch_bounds__(256) void compact_runs_kernel(uint64_t n_pairs, const scrg_pair_desc* __restrict__ pairs,
                                                            const uint16_t* __restrict__ runs,
                                                            const uint32_t* __restrict__ n_runs,
                                                            const uint64_t* __restrict__ dense_off,
                                                            uint16_t* __restrict__ dense)
 {
-    const int lane = threadIdx.x & 63;
+    // One wavefront per pair.  The slice starts 32-byte aligned, the destination at any run (2-byte)
+    // boundary: an odd destination run index means every output dword straddles two source dwords
+    // (v_alignbit by 16).  The bulk moves 16 bytes per lane with 16-byte aligned stores.
+    const uint32_t lane = threadIdx.x & 63;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     for (uint64_t p = wave; p < n_pairs; p += n_waves) {
-        const uint64_t src = pairs[p].cigar_off;
         const uint64_t cap = pairs[p].cigar_cap;
         uint64_t cnt = n_runs[p];
         if (cnt > cap) cnt = cap;
-        const uint64_t dst = dense_off[p];
-        for (uint64_t k = lane; k < cnt; k += 64) dense[dst + k] = runs[src + k];
+        if (cnt == 0) continue;
+        const uint16_t* const s16 = runs + pairs[p].cigar_off;
+        const uint32_t* const s32 = reinterpret_cast<const uint32_t*>(s16);
+        uint16_t* const d16 = dense + dense_off[p];
+        const uint32_t odd = (uint32_t)(dense_off[p] & 1u);          // the first run goes out alone, the rest is dword aligned
+        if (odd && lane == 0) d16[0] = s16[0];
+        const uint64_t rem = cnt - odd;
+        const uint64_t nd = rem >> 1;                                  // whole output dwords
+        uint32_t* const d32 = reinterpret_cast<uint32_t*>(d16 + odd);
+        // output dword q = source runs (odd + 2q, odd + 2q + 1)
+        auto out_dword = [&](uint64_t q) -> uint32_t {
+            return odd ? __builtin_amdgcn_alignbit(s32[q + 1], s32[q], 16) : s32[q];
+        };
+        uint64_t head = (uint64_t)((0u - (uint32_t)(reinterpret_cast<uintptr_t>(d32) >> 2)) & 3u);   // dwords up to 16-byte alignment
+        if (head > nd) head = nd;
+        if (lane < head) d32[lane] = out_dword(lane);
+        const uint64_t groups = (nd - head) >> 2;
+        for (uint64_t g = lane; g < groups; g += 64) {
+            const uint64_t q = head + 4 * g;
+            const Dwords4 a = *reinterpret_cast<const Dwords4*>(s32 + q);
+            uint4 o;
+            if (odd) {
+                const uint32_t e = s32[q + 4];
+                o.x = __builtin_amdgcn_alignbit(a.y, a.x, 16);
+                o.y = __builtin_amdgcn_alignbit(a.z, a.y, 16);
+                o.z = __builtin_amdgcn_alignbit(a.w, a.z, 16);
+                o.w = __builtin_amdgcn_alignbit(e, a.w, 16);
+            } else {
+                o.x = a.x; o.y = a.y; o.z = a.z; o.w = a.w;
+            }
+            *reinterpret_cast<uint4*>(d32 + q) = o;
+        }
+        const uint64_t done = head + 4 * groups;
+        if (done + lane < nd) d32[done + lane] = out_dword(done + lane);          // up to 3 dwords
+        if ((rem & 1u) && lane == 63) d16[cnt - 1] = s16[cnt - 1];
     }
 }
 hipError_t launch_pack_planar(const char* d_ascii, uint64_t n_words, uint64_t* d_planar, uint32_t* d_bad,
