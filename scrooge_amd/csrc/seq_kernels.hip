@@ -22,15 +22,14 @@ __device__ __forceinline__ void pack4(uint32_t v, uint32_t& lo, uint32_t& hi, ui
     // gather the four byte-lsbs into a nibble
     lo = ((l * 0x01020408u) >> 24) & 0xfu;
     hi = ((h * 0x01020408u) >> 24) & 0xfu;
-    // validity: upper-cased byte must be one of A C G T, or the byte is 0 (padding)
+    // validity, all four bytes at once: the upper-cased byte must be the letter its code stands for
+    // ('A' + {0, 2, 6, 19} for codes 0..3), or the byte is 0 (padding)
     const uint32_t u = v & 0xdfdfdfdfu;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const uint32_t c = (u >> (8 * k)) & 0xffu;
-        const uint32_t raw = (v >> (8 * k)) & 0xffu;
-        const bool ok = (c == 'A') || (c == 'C') || (c == 'G') || (c == 'T') || (raw == 0u);
-        bad += ok ? 0u : 1u;
-    }
+    const uint32_t expect = 0x41414141u + 2u * l + 6u * h + 11u * (l & h);
+    const uint32_t diff = u ^ expect;
+    const uint32_t nz_diff = (((diff & 0x7f7f7f7fu) + 0x7f7f7f7fu) | diff) & 0x80808080u;   // bit 7 of every non-zero byte
+    const uint32_t nz_raw = (((v & 0x7f7f7f7fu) + 0x7f7f7f7fu) | v) & 0x80808080u;
+    bad += (uint32_t)__popc(nz_diff & nz_raw);
 }
 
 __global__ __launch_bounds__(256) void pack_planar_kernel(const uint4* __restrict__ ascii, uint64_t n_words,
@@ -162,7 +161,7 @@ hipError_t launch_pack_planar(const char* d_ascii, uint64_t n_words, uint64_t* d
 {
     if (n_words == 0) return hipSuccess;
     uint64_t blocks = (n_words + 255) / 256;
-    const uint64_t cap = (uint64_t)n_cus * 8;
+    const uint64_t cap = (uint64_t)n_cus * 32;
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(pack_planar_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
                        reinterpret_cast<const uint4*>(d_ascii), n_words, d_planar, d_bad);
