@@ -44,6 +44,10 @@ def parse():
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--stats", action="store_true", help="profiling only: print kernel round/step counters")
     ap.add_argument("--ablate", type=int, default=0, help="profiling only: 1 = no TB table reads, 2 = no DC sweep")
+    ap.add_argument("--serial", action="store_true",
+                    help="one stream: every step waits for the previous one to finish (default: consecutive steps "
+                         "alternate between two streams and two handles, so the next step's wavefronts fill the "
+                         "GPU while the previous step's last pairs finish)")
     return ap.parse_args()
 
 
@@ -135,6 +139,7 @@ def main():
     scrooge_amd.build_library()
     al = scrooge_amd.Aligner(local_rank)
     al.set_stream(torch.cuda.current_stream().cuda_stream)
+    n_lanes = 1 if (args.serial or args.stats or args.ablate) else 2      # software pipeline depth over streams
     kw = {}
     if args.lanes:
         kw["lanes_per_pair"] = args.lanes
@@ -168,10 +173,12 @@ def main():
     desc = torch.stack([idx * row_words * 32, torch.full_like(idx, text_len),
                         (idx * row_words + tw) * 32, torch.full_like(idx, L),
                         idx * cap, torch.full_like(idx, cap)], dim=1).contiguous()
-    runs = torch.empty(n * cap * 2, dtype=torch.uint8, device=device)       # scrg_run = 2 bytes
-    ed = torch.empty(n, dtype=torch.int64, device=device)
-    n_runs = torch.empty(n, dtype=torch.int32, device=device)
-    status = torch.empty(n, dtype=torch.int32, device=device)
+    # result buffers, one set per pipeline lane (scrg_run = 2 bytes)
+    outs = [dict(runs=torch.empty(n * cap * 2, dtype=torch.uint8, device=device),
+                 ed=torch.empty(n, dtype=torch.int64, device=device),
+                 n_runs=torch.empty(n, dtype=torch.int32, device=device),
+                 status=torch.empty(n, dtype=torch.int32, device=device)) for _ in range(n_lanes)]
+    runs, ed, n_runs, status = (outs[0][k] for k in ("runs", "ed", "n_runs", "status"))
     # keep a host copy of a sample for the CPU leg before freeing the ASCII staging
     sample_cap = min(n, 20000)
     sample_rows = ascii_rows[:sample_cap].cpu() if (rank == 0 and world == 1 and args.cpu_seconds > 0) else None
@@ -184,7 +191,7 @@ def main():
     torch.cuda.synchronize()
     assert args.ablate or int(status.max().item()) == 0, "CIGAR slice overflow"
     total_runs = int(n_runs.sum().item())
-    dense = torch.empty(total_runs * 2, dtype=torch.uint8, device=device)
+    denses = [torch.empty(total_runs * 2, dtype=torch.uint8, device=device) for _ in range(n_lanes)]
     gather = None
     if world > 1:
         from scrooge_amd.distributed import ResultGather
@@ -192,25 +199,39 @@ def main():
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(args.steps)]
+    # Consecutive steps are independent batches.  With two lanes, step k runs on stream k % 2 with its own
+    # library handle (work queue, spill area) and output buffers: its persistent wavefronts start as soon as
+    # the previous step's wavefronts begin to retire, instead of after its last pair has finished.
+    aligners = [al] + [scrooge_amd.Aligner(local_rank) for _ in range(n_lanes - 1)]
+    for extra in aligners[1:]:
+        extra.params = al.params
+    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=device) for _ in range(n_lanes - 1)]
+    for st_ in streams[1:]:
+        st_.wait_stream(streams[0])
+    for a_, st_ in zip(aligners, streams):
+        a_.set_stream(st_.cuda_stream)
 
     def step(k=None):
-        if k is not None:
-            ev[k][0].record()
-        al.align_device(n, seq, desc, runs, ed, n_runs, status, **kw)
-        if k is not None:
-            ev[k][1].record()
-        cnt64 = n_runs.to(torch.int64)
-        dense_off = torch.cumsum(cnt64, 0) - cnt64
-        if world > 1:
-            # RCCL gather of scores + CIGAR runs to rank 0 over xGMI, double buffered: the gather of
-            # this step overlaps the next step's align kernel
-            j = step.count
-            step.count += 1
-            gather.finish(j)                       # buffers of step j-2 are free again
-            al.compact_runs(n, desc, runs, n_runs, dense_off, gather.send_runs[j % gather.DEPTH])
-            gather.start(j, ed, n_runs)
-        else:
-            al.compact_runs(n, desc, runs, n_runs, dense_off, dense)
+        j = step.count
+        step.count += 1
+        b = j % n_lanes
+        o = outs[b]
+        with torch.cuda.stream(streams[b]):
+            if k is not None:
+                ev[k][0].record()
+            aligners[b].align_device(n, seq, desc, o["runs"], o["ed"], o["n_runs"], o["status"], **kw)
+            if k is not None:
+                ev[k][1].record()
+            cnt64 = o["n_runs"].to(torch.int64)
+            dense_off = torch.cumsum(cnt64, 0) - cnt64
+            if world > 1:
+                # RCCL gather of scores + CIGAR runs to rank 0 over xGMI, double buffered: the gather of
+                # this step overlaps the next step's align kernel
+                gather.finish(j)                       # buffers of step j-2 are free again
+                aligners[b].compact_runs(n, desc, o["runs"], o["n_runs"], dense_off, gather.send_runs[j % gather.DEPTH])
+                gather.start(j, o["ed"], o["n_runs"])
+            else:
+                aligners[b].compact_runs(n, desc, o["runs"], o["n_runs"], dense_off, denses[b])
 
     step.count = 0
     for _ in range(args.warmup):
@@ -230,11 +251,36 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    last = (step.count - 1) % n_lanes
+    ed, n_runs, dense = outs[last]["ed"], outs[last]["n_runs"], denses[last]
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)
+    # reference point outside the timed region: the same step on ONE stream (no overlap between launches)
+    serial = None
+    if n_lanes > 1 and world == 1:
+        sev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(3)]
+        o = outs[0]
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        for a_, b_ in sev:
+            a_.record()
+            aligners[0].align_device(n, seq, desc, o["runs"], o["ed"], o["n_runs"], o["status"], **kw)
+            b_.record()
+            cnt64 = o["n_runs"].to(torch.int64)
+            aligners[0].compact_runs(n, desc, o["runs"], o["n_runs"], torch.cumsum(cnt64, 0) - cnt64, denses[0])
+        torch.cuda.synchronize()
+        serial = {"ms_per_step": (time.perf_counter() - ts) / 3 * 1e3,
+                  "kernel_ms": sum(a_.elapsed_time(b_) for a_, b_ in sev) / 3}
+        serial["value"] = n / (serial["ms_per_step"] * 1e-3)
+    # duration of one align launch for the roofline line: events around a launch that has the GPU to itself.
+    # (Events around a pipelined launch also contain the time its wavefronts wait for the previous launch's
+    # to retire; rocprofv3 timestamps start at the first dispatch and agree with the stand-alone figure.)
+    events_ms = kernel_ms
+    if serial is not None:
+        kernel_ms = serial["kernel_ms"]
 
     if args.stats:
         st = al.debug_stats()
@@ -325,15 +371,21 @@ def main():
                                % (n, L, args.profile, p.W, p.O),
                    "pairs_per_gpu": n, "read_len": L, "text_len": text_len, "error_profile": args.profile,
                    "W": p.W, "O": p.O, "lanes_per_pair": p.lanes_per_pair, "lds_rows": p.lds_rows,
-                   "launch": geom, "step": "align kernel + run compaction" + (" + RCCL gather of scores and CIGAR runs to rank 0 (double buffered, overlaps the next kernel)" if world > 1 else "")},
+                   "launch": geom, "step": "align kernel + run compaction" + (" + RCCL gather of scores and CIGAR runs to rank 0 (double buffered, overlaps the next kernel)" if world > 1 else ""),
+                   "pipeline": ("consecutive steps alternate between %d streams (own handle, work queue and output buffers each): "
+                                "a step's wavefronts start while the previous step's last pairs finish" % n_lanes) if n_lanes > 1
+                               else "one stream: a step starts after the previous one has finished"},
         "gcups": value * L * L / 1e9,
-        "kernel_ms": kernel_ms,
+        "kernel_ms": kernel_ms,        # HIP events around one align launch that has the GPU to itself
         "kernel_pairs_per_s_per_gpu": n / (kernel_ms * 1e-3),
+        "kernel_ms_events_in_timed_region": events_ms,   # pipelined launches: includes waiting for the previous launch's wavefronts to retire
+        "serial": serial,              # the same step without overlap between launches, measured after the timed region
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "genasm_align_kernel<%d, false>" % p.lanes_per_pair,
                      "algorithmic_bytes_per_pair": bytes_per_pair,
-                     "note": "path is VALU/LDS-bound, not HBM-bound (SURVEY.md §8d); see 'valu'"},
+                     "note": "path is VALU/LDS-bound, not HBM-bound (SURVEY.md §8d); see 'valu'.  'achieved' divides by "
+                             "kernel_ms, the duration of a launch that has the GPU to itself"},
         "cpu_baseline": cpu,
         "parity": parity,
         "gen_seconds": gen_s,
@@ -342,8 +394,9 @@ def main():
         lane_ops = 14 * dc_cells      # 7 64-bit logic ops per DC cell = 14 int32 lane-ops (genasm_cpu.cpp:247-251)
         out["valu"] = {"algorithmic_lane_ops_per_pair": lane_ops, "dc_cells_per_pair": dc_cells,
                        "tb_steps_per_pair": tb_steps,
-                       "achieved": lane_ops * n / (kernel_ms * 1e-3), "peak": VALU_PEAK_LANE_OPS,
-                       "frac": lane_ops * n / (kernel_ms * 1e-3) / VALU_PEAK_LANE_OPS, "unit": "int32 lane-ops/s"}
+                       "achieved": lane_ops * value / world, "peak": VALU_PEAK_LANE_OPS,
+                       "frac": lane_ops * value / world / VALU_PEAK_LANE_OPS, "unit": "int32 lane-ops/s",
+                       "note": "per GPU, from the whole-step rate"}
         out["bit_cell_gcups"] = value * dc_cells * 64 / 1e9
     print(json.dumps(out))
     if world > 1:
