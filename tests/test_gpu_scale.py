@@ -166,3 +166,55 @@ def test_extreme_inputs(aligner, oracle):
     assert eds[0] == 5000 and eds[2] == 5000 and eds[3] == 0
     for g, rows in [(8, 13), (8, 2), (64, 13), (16, 5)]:
         _same(aligner.align_pairs(T, Q, lanes_per_pair=g, lds_rows=rows), eds, cigars)
+
+
+def test_two_handles_on_two_streams_overlap(oracle):
+    """Batches pipelined the way bench.py and INTEGRATION.md §4b do it: two handles, two streams, launches in
+    flight at the same time (each handle owns its work queue and spill area).  Every launch's results are
+    checked, including a handle reused while the other one is still running."""
+    import torch
+    import scrooge_amd
+    dev = torch.device("cuda", 0)
+    batches = []
+    for b in range(4):
+        t, q = synth.make_pairs(3000, 2000, "ont" if b % 2 == 0 else "pacbio15", seed=100 + b)
+        eds, cigars, _, _ = oracle.align(t, q, threads=16)
+        tw, rw = (max(len(x) for x in t) + 31) // 32, (2000 + 31) // 32
+        rows = np.zeros((len(t), (tw + rw) * 32), dtype=np.uint8)
+        for k in range(len(t)):
+            rows[k, :len(t[k])] = np.frombuffer(t[k], dtype=np.uint8)
+            rows[k, tw * 32: tw * 32 + len(q[k])] = np.frombuffer(q[k], dtype=np.uint8)
+        batches.append((t, q, eds, cigars, tw, rw, torch.from_numpy(rows).to(dev)))
+    als = [scrooge_amd.Aligner(0), scrooge_amd.Aligner(0)]
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    outs = []
+    torch.cuda.synchronize()
+    for b, (t, q, eds, cigars, tw, rw, ascii_t) in enumerate(batches):
+        a, st = als[b % 2], streams[b % 2]
+        a.set_stream(st.cuda_stream)
+        n = len(t)
+        with torch.cuda.stream(st):
+            seq = torch.zeros(n * (tw + rw) + scrooge_amd.api.SEQ_PAD_WORDS, dtype=torch.int64, device=dev)
+            bad = torch.zeros(1, dtype=torch.int32, device=dev)
+            a.pack_planar(ascii_t.view(-1), seq, bad)
+            cap = (2 * 2000 + 8 + 15) // 16 * 16
+            idx = torch.arange(n, dtype=torch.int64, device=dev)
+            desc = torch.stack([idx * (tw + rw) * 32, torch.tensor([len(x) for x in t], device=dev),
+                                (idx * (tw + rw) + tw) * 32, torch.tensor([len(x) for x in q], device=dev),
+                                idx * cap, torch.full_like(idx, cap)], dim=1).contiguous()
+            runs = torch.empty(n * cap * 2, dtype=torch.uint8, device=dev)
+            ed = torch.empty(n, dtype=torch.int64, device=dev)
+            nr = torch.empty(n, dtype=torch.int32, device=dev)
+            status = torch.empty(n, dtype=torch.int32, device=dev)
+            a.align_device(n, seq, desc, runs, ed, nr, status)       # no synchronisation between the launches
+        outs.append((runs, ed, nr, status, cap, seq, desc, bad))
+    torch.cuda.synchronize()
+    for (t, q, eds, cigars, tw, rw, _), (runs, ed, nr, status, cap, _, _, bad) in zip(batches, outs):
+        assert int(bad.item()) == 0 and int(status.max().item()) == 0
+        assert ed.cpu().tolist() == eds
+        h, cnt = runs.cpu().numpy(), nr.cpu().tolist()
+        for k in range(0, len(t), 7):
+            seg = h[2 * k * cap: 2 * (k * cap + cnt[k])]
+            assert "".join("%d%s" % (seg[2 * j], chr(seg[2 * j + 1])) for j in range(cnt[k])) == cigars[k]
+    for a in als:
+        a.close()
