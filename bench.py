@@ -32,8 +32,8 @@ VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9   # 256 CUs x 4 SIMD-32 x 2.4 GHz = 78
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--pairs", type=int, default=100000, help="pairs per GPU")
     ap.add_argument("--read-len", type=int, default=10000)
     ap.add_argument("--profile", default="ont", help="error profile (scrooge_amd.synth.PROFILES)")
