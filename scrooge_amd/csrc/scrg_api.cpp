@@ -490,6 +490,14 @@ scrg_status run_batch(scrg_ctx* c, const scrg_params& p, std::vector<SeqRef>& se
     const int64_t t_begin = now_ns();
     const uint64_t n = probs.size();
     HIP_TRY(c, hipSetDevice(c->device));
+    const bool host_timing = getenv("SCRG_HOST_TIMING") != nullptr;
+    int64_t t_mark = t_begin;
+    auto mark = [&](const char* what) {
+        if (!host_timing) return;
+        const int64_t t = now_ns();
+        fprintf(stderr, "[scrooge_amd host] %-28s %8.3f ms\n", what, (double)(t - t_mark) / 1e6);
+        t_mark = t;
+    };
 
     scrg_result* r = static_cast<scrg_result*>(calloc(1, sizeof(scrg_result)));
     if (!r) return c->fail(SCRG_ERR_OOM, "result header");
@@ -526,6 +534,7 @@ scrg_status run_batch(scrg_ctx* c, const scrg_params& p, std::vector<SeqRef>& se
     if ((e = c->d_ascii.ensure(ascii_bytes + 32)) != hipSuccess || (e = c->d_seq.ensure(seq_words * 8)) != hipSuccess ||
         (e = c->d_bad.ensure(4)) != hipSuccess)
         return bail(c->fail(SCRG_ERR_OOM, "device sequence buffers", e));
+    mark("result arrays + staging copy");
     const int64_t t_pack0 = now_ns();
     if ((e = hipMemsetAsync(c->d_bad.p, 0, 4, c->stream)) != hipSuccess ||
         (e = hipMemsetAsync(c->d_seq.as<uint64_t>() + total_words, 0, SCRG_SEQ_PAD_WORDS * 8, c->stream)) != hipSuccess)
@@ -542,6 +551,7 @@ scrg_status run_batch(scrg_ctx* c, const scrg_params& p, std::vector<SeqRef>& se
         (e = hipStreamSynchronize(c->stream)) != hipSuccess)
         return bail(c->fail(SCRG_ERR_HIP, "pack", e));
     r->pack_ns = now_ns() - t_pack0;
+    mark("H2D + pack kernel");
     if (bad) return bail(c->fail(SCRG_ERR_BAD_BASE, "input contains characters other than ACGTacgt"));
 
     // ---- problem descriptors, longest read first (src/tests.cu:375-377) ----
@@ -580,6 +590,7 @@ scrg_status run_batch(scrg_ctx* c, const scrg_params& p, std::vector<SeqRef>& se
         hipSuccess)
         return bail(c->fail(SCRG_ERR_HIP, "H2D descriptors", e));
 
+    mark("descriptors (sort, build, H2D)");
     // ---- the timed region of the reference: kernel + sync (genasm_gpu.cu:939-944) ----
     scrg_status s = scrg_align_device(c, &p, n, c->d_seq.as<uint64_t>(), c->d_pairs.as<scrg_pair_desc>(),
                                       c->d_runs.as<scrg_run>(), c->d_ed.as<int64_t>(), c->d_nruns.as<uint32_t>(),
@@ -592,6 +603,7 @@ scrg_status run_batch(scrg_ctx* c, const scrg_params& p, std::vector<SeqRef>& se
     if (g_log.load() && ms > 0.f)   // the reference's log line, genasm_gpu.cu:949-951
         fprintf(stderr, "core algorithm ran at %lld aligns/second\n", (long long)((double)n * 1000.0 / ms));
 
+    mark("align kernel");
     // ---- read back: per-pair scalars, then the compacted runs ----
     std::vector<int64_t> ed(n);
     std::vector<uint32_t> nr(n), st(n);
@@ -635,6 +647,7 @@ scrg_status run_batch(scrg_ctx* c, const scrg_params& p, std::vector<SeqRef>& se
             return bail(c->fail(SCRG_ERR_HIP, "D2H runs", e));
     }
 
+    mark("D2H scalars, compaction, D2H runs");
     scrg_status worst = SCRG_OK;
     for (uint64_t k = 0; k < n; k++) {
         r->edit_distance[order[k]] = ed[k];
@@ -644,15 +657,20 @@ scrg_status run_batch(scrg_ctx* c, const scrg_params& p, std::vector<SeqRef>& se
 
     // ---- "%d%c" text, as genasm_cpu.cpp:387-403 ----
     {
-        uint64_t acc = 0;
-        for (uint64_t i = 0; i < n; i++) {
-            r->cigar_offset[i] = acc;
+        // length of every pair's text (in parallel: this pass touches every run), then the offsets
+        std::vector<uint64_t> chars_of(n);
+        parallel_for(n, [&](uint64_t i) {
             uint64_t chars = 0;
             for (uint64_t k = r->run_offset[i]; k < r->run_offset[i + 1]; k++) {
                 const unsigned cnt = r->runs[k].count;
                 chars += (cnt >= 100 ? 4 : (cnt >= 10 ? 3 : 2));
             }
-            acc += chars + 1;
+            chars_of[i] = chars;
+        });
+        uint64_t acc = 0;
+        for (uint64_t i = 0; i < n; i++) {
+            r->cigar_offset[i] = acc;
+            acc += chars_of[i] + 1;
         }
         r->cigar_offset[n] = acc;
         r->cigar_text = static_cast<char*>(malloc(acc + 1));
@@ -669,6 +687,7 @@ scrg_status run_batch(scrg_ctx* c, const scrg_params& p, std::vector<SeqRef>& se
             *w = '\0';
         });
     }
+    mark("CIGAR text");
     r->total_ns = now_ns() - t_begin;
     *out = r;
     if (worst != SCRG_OK) c->fail(worst, "at least one pair overflowed its CIGAR slice (see pair_status)");
