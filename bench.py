@@ -205,7 +205,9 @@ def main():
     aligners = [al] + [scrooge_amd.Aligner(local_rank) for _ in range(n_lanes - 1)]
     for extra in aligners[1:]:
         extra.params = al.params
-    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=device) for _ in range(n_lanes - 1)]
+    # The second lane's stream has a different priority: HIP then gives it a hardware queue of its own (two
+    # streams of one priority can share a queue, and kernels in one queue never overlap).
+    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=device, priority=-1) for _ in range(n_lanes - 1)]
     for st_ in streams[1:]:
         st_.wait_stream(streams[0])
     for a_, st_ in zip(aligners, streams):
