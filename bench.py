@@ -205,11 +205,17 @@ def main():
     aligners = [al] + [scrooge_amd.Aligner(local_rank) for _ in range(n_lanes - 1)]
     for extra in aligners[1:]:
         extra.params = al.params
-    # The second lane's stream has a different priority: HIP then gives it a hardware queue of its own (two
-    # streams of one priority can share a queue, and kernels in one queue never overlap).
-    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=device, priority=-1) for _ in range(n_lanes - 1)]
-    for st_ in streams[1:]:
-        st_.wait_stream(streams[0])
+    # Lane streams of different priorities (low, high; everything else, RCCL included, runs at normal priority):
+    # HIP gives each priority its own hardware queues, whereas two streams of one priority can share a queue,
+    # and kernels in one queue never overlap (scripts/side_stream_probe.py).
+    if n_lanes > 1:
+        streams = [torch.cuda.ExternalStream(scrooge_amd.api.create_stream(local_rank, pr), device=device) for pr in (1, -1)]
+    else:
+        streams = [torch.cuda.current_stream()]
+    setup_stream = torch.cuda.current_stream()
+    for st_ in streams:
+        if st_ != setup_stream:
+            st_.wait_stream(setup_stream)
     for a_, st_ in zip(aligners, streams):
         a_.set_stream(st_.cuda_stream)
 
@@ -267,12 +273,13 @@ def main():
         o = outs[0]
         torch.cuda.synchronize()
         ts = time.perf_counter()
-        for a_, b_ in sev:
-            a_.record()
-            aligners[0].align_device(n, seq, desc, o["runs"], o["ed"], o["n_runs"], o["status"], **kw)
-            b_.record()
-            cnt64 = o["n_runs"].to(torch.int64)
-            aligners[0].compact_runs(n, desc, o["runs"], o["n_runs"], torch.cumsum(cnt64, 0) - cnt64, denses[0])
+        with torch.cuda.stream(streams[0]):
+            for a_, b_ in sev:
+                a_.record()
+                aligners[0].align_device(n, seq, desc, o["runs"], o["ed"], o["n_runs"], o["status"], **kw)
+                b_.record()
+                cnt64 = o["n_runs"].to(torch.int64)
+                aligners[0].compact_runs(n, desc, o["runs"], o["n_runs"], torch.cumsum(cnt64, 0) - cnt64, denses[0])
         torch.cuda.synchronize()
         serial = {"ms_per_step": (time.perf_counter() - ts) / 3 * 1e3,
                   "kernel_ms": sum(a_.elapsed_time(b_) for a_, b_ in sev) / 3}

@@ -87,6 +87,12 @@ void        scrg_ctx_destroy(scrg_ctx *ctx);
  * scrg_ctx_use_own_stream() goes back to the handle's private stream. */
 scrg_status scrg_ctx_set_stream(scrg_ctx *ctx, void *hip_stream);
 scrg_status scrg_ctx_use_own_stream(scrg_ctx *ctx);
+
+/* A HIP stream (hipStream_t) of the given priority: -1 high, 0 normal, 1 low.  Streams of different
+ * priorities never share a hardware queue, which is what lets launches of two handles overlap
+ * (INTEGRATION.md §4b); streams of one priority may be multiplexed onto one queue. */
+scrg_status scrg_stream_create(int device, int priority, void **stream);
+scrg_status scrg_stream_destroy(void *stream);
 const char *scrg_last_error(const scrg_ctx *ctx);
 const char *scrg_status_string(scrg_status s);
 /* mirrors genasm_gpu::enabled_algorithm_log (src/genasm_gpu.hpp:6) */

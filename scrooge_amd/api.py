@@ -105,6 +105,8 @@ def load_library():
         "scrg_ctx_destroy": (None, [vp]),
         "scrg_ctx_set_stream": (C.c_int32, [vp, vp]),
         "scrg_ctx_use_own_stream": (C.c_int32, [vp]),
+        "scrg_stream_create": (C.c_int32, [C.c_int, C.c_int, C.POINTER(vp)]),
+        "scrg_stream_destroy": (C.c_int32, [vp]),
         "scrg_last_error": (C.c_char_p, [vp]),
         "scrg_status_string": (C.c_char_p, [C.c_int32]),
         "scrg_set_log": (None, [C.c_int]),
@@ -134,11 +136,22 @@ def load_library():
 
 EXPORTED_SYMBOLS = [
     "scrg_params_default", "scrg_params_resolve", "scrg_ctx_create", "scrg_ctx_destroy", "scrg_ctx_set_stream",
-    "scrg_ctx_use_own_stream",
+    "scrg_ctx_use_own_stream", "scrg_stream_create", "scrg_stream_destroy",
     "scrg_last_error", "scrg_status_string", "scrg_set_log", "scrg_device_count",
     "scrg_result_free", "scrg_align_pairs", "scrg_align_mapping", "scrg_pack_planar",
     "scrg_align_device", "scrg_compact_runs", "scrg_ascii_to_twobit", "scrg_query_launch",
     "scrg_last_kernel_ms", "scrg_debug_stats"]
+
+
+def create_stream(device=0, priority=0):
+    """A raw HIP stream handle of the given priority (-1 high, 0 normal, 1 low); wrap it with
+    torch.cuda.ExternalStream(handle) to use it from torch."""
+    lib = load_library()
+    h = C.c_void_p()
+    st = lib.scrg_stream_create(int(device), int(priority), C.byref(h))
+    if st != SCRG_OK:
+        raise ScroogeError(st, lib.scrg_status_string(st).decode())
+    return h.value
 
 
 def _bytes_list(seqs):

@@ -246,6 +246,22 @@ scrg_status scrg_ctx_use_own_stream(scrg_ctx* c)
     return SCRG_OK;
 }
 
+scrg_status scrg_stream_create(int device, int priority, void** stream)
+{
+    if (!stream || priority < -1 || priority > 1) return SCRG_ERR_INVALID_ARG;
+    hipStream_t s = nullptr;
+    if (hipSetDevice(device) != hipSuccess) return SCRG_ERR_NO_DEVICE;
+    if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, priority) != hipSuccess) return SCRG_ERR_HIP;
+    *stream = s;
+    return SCRG_OK;
+}
+
+scrg_status scrg_stream_destroy(void* stream)
+{
+    if (!stream) return SCRG_OK;
+    return hipStreamDestroy(static_cast<hipStream_t>(stream)) == hipSuccess ? SCRG_OK : SCRG_ERR_HIP;
+}
+
 const char* scrg_last_error(const scrg_ctx* c) { return c ? c->last_error.c_str() : "null context"; }
 
 // ---------------------------------------------------------------------------
