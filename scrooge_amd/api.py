@@ -234,8 +234,36 @@ class Aligner:
             self.lib.scrg_result_free(res_p)
         return out
 
+    def _collect_arrays(self, res_p, st):
+        """The result as numpy arrays (copies): no per-pair Python objects — for batches of millions of pairs."""
+        import numpy as np
+        try:
+            r = res_p.contents
+            n = int(r.n_pairs)
+
+            def arr(ptr, count, dtype):
+                if count == 0:
+                    return np.zeros(0, dtype=dtype)
+                return np.ctypeslib.as_array(ptr, shape=(count,)).view(dtype).copy()
+
+            run_offset = arr(r.run_offset, n + 1, np.uint64)
+            cigar_offset = arr(r.cigar_offset, n + 1, np.uint64)
+            total_runs = int(run_offset[n]) if n else 0
+            out = {"edit_distance": arr(r.edit_distance, n, np.int64),
+                   "status": arr(r.pair_status, n, np.uint32),
+                   "run_offset": run_offset,
+                   "runs": np.frombuffer(C.string_at(r.runs, 2 * total_runs), dtype=np.uint8).reshape(-1, 2).copy()
+                           if total_runs else np.zeros((0, 2), np.uint8),      # columns: count, op
+                   "cigar_offset": cigar_offset,
+                   "cigar_text": C.string_at(r.cigar_text, int(cigar_offset[n])) if n else b""}
+            self.last_timing = {"kernel_ns": int(r.kernel_ns), "pack_ns": int(r.pack_ns),
+                                "total_ns": int(r.total_ns)}
+        finally:
+            self.lib.scrg_result_free(res_p)
+        return out
+
     # -- genasm_gpu::align_all(texts, queries)  (src/genasm_gpu.cu:982-1065) --------
-    def align_pairs(self, texts, queries, **kw):
+    def align_pairs(self, texts, queries, arrays=False, **kw):
         texts, queries = _bytes_list(texts), _bytes_list(queries)
         if len(texts) != len(queries):
             raise ValueError("texts and queries differ in length")   # reference: assert, genasm_cpu.cpp:559
@@ -248,10 +276,10 @@ class Aligner:
         st = self.lib.scrg_align_pairs(self.h, C.byref(self._params(kw)), n, tp, tl, qp, ql,
                                        C.byref(res))
         self._check(st, allow=(SCRG_ERR_CIGAR_OVERFLOW,))
-        return self._collect(res, st)
+        return self._collect_arrays(res, st) if arrays else self._collect(res, st)
 
     # -- genasm_gpu::align_all(genome, reads)  (src/genasm_gpu.cu:890-980) ----------
-    def align_mapping(self, genome, reads, candidates, **kw):
+    def align_mapping(self, genome, reads, candidates, arrays=False, **kw):
         """candidates[r] = list of start_in_reference for read r (forward strand)."""
         genome = genome.encode() if isinstance(genome, str) else bytes(genome)
         reads = _bytes_list(reads)
@@ -270,7 +298,7 @@ class Aligner:
         st = self.lib.scrg_align_mapping(self.h, C.byref(self._params(kw)), genome, len(genome),
                                          nr, rp, rl, co, cs, C.byref(res))
         self._check(st, allow=(SCRG_ERR_CIGAR_OVERFLOW,))
-        return self._collect(res, st)
+        return self._collect_arrays(res, st) if arrays else self._collect(res, st)
 
     # -- device-pointer layer (torch tensors as plain device memory) -----------
     def set_stream(self, stream_handle):

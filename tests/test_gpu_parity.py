@@ -207,3 +207,21 @@ def test_diagonal_path_on_and_off(aligner, oracle, lds_rows):
         _check(aligner.align_pairs(T, Q), eds, cigars, "diag off rows=%d" % lds_rows)
     finally:
         aligner.params = keep
+
+
+def test_array_results_match_object_results(aligner):
+    """align_pairs(arrays=True) returns the same edit distances and CIGAR text as the per-pair objects."""
+    t, q = synth.make_pairs(200, 700, "ont", seed=12)
+    t += [b"ACGT", b""]
+    q += [b"", b"ACG"]
+    objs = aligner.align_pairs(t, q)
+    arr = aligner.align_pairs(t, q, arrays=True)
+    assert arr["edit_distance"].tolist() == [a.edit_distance for a in objs]
+    off = arr["cigar_offset"]
+    for i, a in enumerate(objs):
+        assert arr["cigar_text"][int(off[i]):int(off[i + 1]) - 1].decode() == a.cigar
+    ro = arr["run_offset"]
+    for i in (0, 7, 199):
+        seg = arr["runs"][int(ro[i]):int(ro[i + 1])]
+        assert "".join("%d%s" % (c, chr(o)) for c, o in seg) == objs[i].cigar
+    assert aligner.align_pairs([], [], arrays=True)["edit_distance"].shape == (0,)
