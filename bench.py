@@ -131,10 +131,16 @@ def main():
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    dryrun = os.environ.get("SCRG_BENCH_DRYRUN") == "1"    # test only: all ranks on GPU 0, gloo through the host
+    if dryrun:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)    # nccl == RCCL on ROCm
+        if dryrun:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)    # nccl == RCCL on ROCm
 
     scrooge_amd.build_library()
     al = scrooge_amd.Aligner(local_rank)
@@ -394,7 +400,7 @@ def main():
                      "kernel": "genasm_align_kernel<%d, false>" % p.lanes_per_pair,
                      "algorithmic_bytes_per_pair": bytes_per_pair,
                      "note": "path is VALU/LDS-bound, not HBM-bound (SURVEY.md §8d); see 'valu'.  'achieved' divides by "
-                             "kernel_ms, the duration of a launch that has the GPU to itself"},
+                             "kernel_ms" + (", the duration of a launch that has the GPU to itself" if serial is not None else "")},
         "cpu_baseline": cpu,
         "parity": parity,
         "gen_seconds": gen_s,

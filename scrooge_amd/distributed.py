@@ -119,12 +119,25 @@ class ResultGather:
             self.recv_ed = mk(n_pairs, torch.int64)
             self.recv_cnt = mk(n_pairs, torch.int32)
         self.pending = [None] * d
+        # gloo cannot gather device tensors: stage through the host (the multi-rank dry run of bench.py on a
+        # box with one GPU, SCRG_BENCH_DRYRUN=1; never the measured configuration)
+        self.host_stage = dist.get_backend(group) == "gloo" and torch.device(device).type == "cuda"
 
     def start(self, k, ed, n_runs):
         """`self.send_runs[k % DEPTH]` must already hold this rank's dense runs of step k."""
         b = k % self.DEPTH
         self.send_ed[b].copy_(ed)
         self.send_cnt[b].copy_(n_runs)
+        if self.host_stage:
+            torch.cuda.current_stream().synchronize()
+            for send, recv in ((self.send_ed[b], self.recv_ed[b]), (self.send_cnt[b], self.recv_cnt[b]),
+                               (self.send_runs[b], self.recv_runs[b])):
+                host = [torch.empty(send.shape, dtype=send.dtype) for _ in range(self.world)] if self.rank == self.dst else None
+                dist.gather(send.cpu(), host, dst=self.dst, group=self.group)
+                if host is not None:
+                    for r in range(self.world):
+                        recv[r].copy_(host[r])
+            return
         self.pending[b] = [
             dist.gather(self.send_ed[b], self.recv_ed[b], dst=self.dst, group=self.group, async_op=True),
             dist.gather(self.send_cnt[b], self.recv_cnt[b], dst=self.dst, group=self.group, async_op=True),

@@ -218,3 +218,21 @@ def test_two_handles_on_two_streams_overlap(oracle):
             assert "".join("%d%s" % (seg[2 * j], chr(seg[2 * j + 1])) for j in range(cnt[k])) == cigars[k]
     for a in als:
         a.close()
+
+
+def test_bench_two_ranks_dry_run():
+    """bench.py's multi-rank control flow (two pipeline lanes, double-buffered gather, barriers, rank 0
+    printing) with two processes on this one GPU: gloo through the host instead of RCCL (SCRG_BENCH_DRYRUN),
+    so only the logic is checked, not the speed."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SCRG_BENCH_DRYRUN="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
+                          "--gpus", "2", "--steps", "5", "--warmup", "1", "--pairs", "6000", "--read-len", "2000"],
+                         env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, out.stdout[-2000:]              # rank 0 only
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 5 and j["value"] > 0 and j["scaling"] == "weak"
