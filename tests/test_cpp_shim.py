@@ -51,3 +51,28 @@ def test_shim_matches_reference_answers():
     p = subprocess.run([EXE], capture_output=True, text=True)
     assert p.returncode == 0, p.stderr
     assert p.stdout.strip().splitlines() == EXPECTED
+
+
+PIPE_EXE = "/tmp/scrg_pipeline_example"
+
+
+def build_pipeline_example():
+    scrooge_amd.build_library()
+    libdir = os.path.join(ROOT, "scrooge_amd")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-std=c++17", "-Wall",
+                           "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "pipeline_example.cpp"),
+                           "-L" + libdir, "-lscrooge_amd", "-Wl,-rpath," + libdir, "-o", PIPE_EXE])
+
+
+def test_pipeline_example_builds():
+    """examples/pipeline_example.cpp: the device-pointer layer driven from C++ over two handles and two
+    streams."""
+    build_pipeline_example()
+
+
+@pytest.mark.gpu
+def test_pipeline_example_runs():
+    build_pipeline_example()
+    p = subprocess.run([PIPE_EXE], capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert p.stdout.strip().endswith("mismatches=0")
