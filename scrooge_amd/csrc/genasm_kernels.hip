@@ -159,7 +159,7 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
         //   a(i,j,d) = y(i,j,d) | (match(i,j) & a(i+1,j+1,d)),   y = a(i+1,j+1,d-1) | a(i,j+1,d-1) | a(i+1,j,d-1)
         // (genasm_cpu.cpp:246-252 restated): the in-row dependency runs along the word, from bit p-1
         // to bit p, i.e. it is a carry chain with generate y and propagate match, solved for all 64
-        // positions by ONE 64-bit addition: C = ((y|mt) + y + cin) ^ (y|mt) ^ y, a = y | (mt & C).  Rows
+        // positions by ONE 64-bit addition: C = ((y|mt) + y) ^ (y|mt) ^ y, a = y | (mt & C).  Rows
         // therefore need no skew across lanes (the column layout below needs G-1 extra steps per window)
         // and y only needs the previous row of the two neighbouring diagonals: y_x = S_x | A_{x+1} | S_{x-1}
         // with S = A << 1.  Only the band |delta| <= d can influence the goal cell (0,0,d) and the cells
@@ -167,14 +167,14 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
         // text/pattern ends enter as carry-ins (boundary column i = 64: a = [64-j <= d], genasm_cpu.cpp:239-245)
         // and as forced cells below each diagonal's first valid bit (pattern end j = 64: a = 1).
         // The traceback walks a diagonal with one count-leading-zeros per edit.  Windows this path does
-        // not cover (ragged ends, larger distances) take the column-major path below; results are
+        // not cover (a short text window, larger distances) take the column-major path below; results are
         // identical (tests/proto/diag_proto.c restates this arithmetic on the CPU for tests/test_diag_proto.py).
         if constexpr (G == 8 && !WIDE) {
             // LDS rows of this layout: high dwords (positions i <= 31) of the 32 diagonals; from row 8 on the
             // traceback can only be within |delta| <= 7, so those rows keep the 16 diagonals of lanes 2..5
             // and 16 rows take 8*32 + 8*16 + 4 (parking) = 396 dwords
             constexpr int cmp_row = (int)DIAG_WIDE_ROWS, max_rows = 15;      // (slot_stride_dwords() reserves the 397 dwords: 16 rows)
-            // slots with a ragged window (text or pattern end) sit a diagonal round out; so do slots whose
+            // slots with a short text window (the text ends inside it) sit a diagonal round out; so do slots whose
             // window turns out to need more than max_rows rows.  Either kind makes the NEXT round a
             // column-major one (which serves every slot), so a diagonal round pays off when more than half
             // of the live slots can use it.
