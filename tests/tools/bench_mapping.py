@@ -2,7 +2,7 @@
 candidates each (true locus, two shifted loci, one random locus), through the host-pointer API
 (scrg_align_mapping).  Prints kernel-only and end-to-end pairs/s and spot-checks parity."""
 import json, sys, time
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))))
 import numpy as np
 import scrooge_amd
 from scrooge_amd import synth

@@ -1,5 +1,5 @@
 import sys, os
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))))
 import torch, numpy as np
 import scrooge_amd, bench
 from scrooge_amd import synth

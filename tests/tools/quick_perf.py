@@ -1,6 +1,6 @@
 """Ad-hoc throughput probe through the host-pointer API (kernel_ns only)."""
 import sys, time
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))))
 import scrooge_amd
 from scrooge_amd import synth
 from oracle.pyoracle import Oracle

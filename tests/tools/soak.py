@@ -1,8 +1,8 @@
 """Randomised soak of the default path against the oracle: many pairs of mixed lengths and error
 rates (0-30 %), unrelated pairs, homopolymers and ragged text ends, every CIGAR compared.
-usage: python scripts/soak.py [n_pairs] [seed]"""
+usage: python tests/tools/soak.py [n_pairs] [seed]"""
 import sys, time
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))))
 import numpy as np
 import scrooge_amd
 from scrooge_amd import synth
