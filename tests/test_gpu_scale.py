@@ -236,3 +236,65 @@ def test_bench_two_ranks_dry_run():
     assert len(lines) == 1, out.stdout[-2000:]              # rank 0 only
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["steps"] == 5 and j["value"] > 0 and j["scaling"] == "weak"
+
+
+def test_full_bench_size_two_algorithms_agree(aligner):
+    """BASELINE configs[1] at full size (100k x 10 kb ONT-error pairs, generated on the GPU like bench.py):
+    the diagonal-major and the column-major window paths are two independent formulations of the same table;
+    every edit distance, run count and run must be identical between them, the edit distances must respect
+    the read length and error rate, and 500 sampled pairs must validate against their sequences."""
+    import torch
+    import bench
+    import scrooge_amd
+    from tests.cigar_check import validate
+    dev = torch.device("cuda", 0)
+    n, L = 100000, 10000
+    err, ratio = synth.PROFILES["ont"]
+    rows, tw, rw, text_len = bench.device_pairs(torch, n, L, err, ratio, 4242, dev)
+    sample = rows[:500].cpu().numpy()
+    seq = torch.zeros(n * (tw + rw) + scrooge_amd.api.SEQ_PAD_WORDS, dtype=torch.int64, device=dev)
+    bad = torch.zeros(1, dtype=torch.int32, device=dev)
+    aligner.set_stream(0)
+    try:
+        aligner.pack_planar(rows.view(-1), seq, bad)
+        del rows
+        cap = (2 * L + 8 + 15) // 16 * 16
+        idx = torch.arange(n, dtype=torch.int64, device=dev)
+        desc = torch.stack([idx * (tw + rw) * 32, torch.full_like(idx, text_len), (idx * (tw + rw) + tw) * 32,
+                            torch.full_like(idx, L), idx * cap, torch.full_like(idx, cap)], dim=1).contiguous()
+        res = []
+        for flags in (0, 32):                                   # 32: diagonal path off
+            p = aligner.make_params()
+            p.reserved[0] = flags
+            keep, aligner.params = aligner.params, p
+            try:
+                runs = torch.zeros(n * cap * 2, dtype=torch.uint8, device=dev)
+                ed = torch.empty(n, dtype=torch.int64, device=dev)
+                nr = torch.empty(n, dtype=torch.int32, device=dev)
+                st = torch.empty(n, dtype=torch.int32, device=dev)
+                aligner.align_device(n, seq, desc, runs, ed, nr, st)
+                cnt = nr.to(torch.int64)
+                off = torch.cumsum(cnt, 0) - cnt
+                dense = torch.empty(int(cnt.sum().item()) * 2, dtype=torch.uint8, device=dev)
+                aligner.compact_runs(n, desc, runs, nr, off, dense)
+                torch.cuda.synchronize()
+                del runs
+                res.append((ed, nr, st, dense, off))
+            finally:
+                aligner.params = keep
+        assert int(bad.item()) == 0
+    finally:
+        aligner.use_own_stream()
+    (ed0, nr0, st0, d0, off0), (ed1, nr1, st1, d1, _) = res
+    assert int(st0.max()) == 0 and int(st1.max()) == 0
+    assert torch.equal(ed0, ed1) and torch.equal(nr0, nr1) and torch.equal(d0, d1)
+    # ~10 % of 10 kb on average (the greedy windows lose the diagonal in a few pairs, here as in the reference,
+    # so there is no useful bound on the maximum)
+    assert 700 < float(ed0.double().mean()) < 1300 and float((ed0 > 2000).double().mean()) < 0.01
+    h, o, c = d0.cpu().numpy(), off0.cpu().tolist(), nr0.cpu().tolist()
+    for k in range(500):
+        seg = h[2 * o[k]: 2 * (o[k] + c[k])]
+        cigar = "".join("%d%s" % (seg[2 * j], chr(seg[2 * j + 1])) for j in range(c[k]))
+        text = bytes(sample[k, :text_len])
+        read = bytes(sample[k, tw * 32: tw * 32 + L])
+        assert validate(text, read, cigar, int(ed0[k])) is None
