@@ -186,7 +186,7 @@ def main():
                  status=torch.empty(n, dtype=torch.int32, device=device)) for _ in range(n_lanes)]
     runs, ed, n_runs, status = (outs[0][k] for k in ("runs", "ed", "n_runs", "status"))
     # keep a host copy of a sample for the CPU leg before freeing the ASCII staging
-    sample_cap = min(n, 20000)
+    sample_cap = min(n, 50000)
     sample_rows = ascii_rows[:sample_cap].cpu() if (rank == 0 and world == 1 and args.cpu_seconds > 0) else None
     del ascii_rows
     torch.cuda.empty_cache()
