@@ -33,6 +33,8 @@ struct AlignArgs {
 
 hipError_t launch_align(int lanes_per_pair, const AlignArgs& a, int grid, size_t lds_bytes, hipStream_t s);
 hipError_t launch_align_multiword(int lanes_per_pair, const AlignArgs& a, int grid, size_t lds_bytes, hipStream_t s);
+// lanes_per_pair = 1: one pair per lane, 64 pairs per wavefront (genasm_lane_kernel.hip; W <= 64, W-O <= 31)
+hipError_t launch_align_lane(const AlignArgs& a, int grid, size_t lds_bytes, hipStream_t s);
 
 // dwords of one stored row of R (the part the traceback can reach):
 //   W <= 64: the high dword of columns 0..31, or whole entries of all 64 columns when W-O > 31;

@@ -1,0 +1,289 @@
+// genasm_lane_kernel.hip — the lane-per-pair aligner for gfx950 (W <= 64, W-O <= 31): every lane of a
+// wavefront aligns its own read pair, 64 pairs per wavefront, the window's traceback table in VGPRs.
+//
+// What is computed is the reference's windowed GenASM (src/genasm_cpu.cpp:411-438: window loop, :210-288
+// distance calculation, :290-409 traceback); how the table is held is different.  Bit j of R[i][d] is clear
+// exactly when D[i][j] <= d, D[i][j] being the least number of edits that align pattern[j..m) to a prefix
+// of text[i..n): :225-252 is the Wu-Manber recurrence of that matrix, the boundary column R[n][d] = ones<<d
+// (:239-245) is D[n][j] = m-j, the zero shifted in by `<< 1` is D[i][m] = 0.  The traceback keeps
+// d == D[i][j] and asks, in the order insertion, deletion, substitution (:319-370),
+//     D[i][j+1] == d-1 ?    D[i+1][j] == d-1 ?    D[i+1][j+1] == d-1 ?
+// i.e. it only ever looks at the vertical, horizontal and diagonal DIFFERENCES of D.  Those differences
+// are what the Myers/Hyyro bit-vector recurrence carries (Pv/Mv vertical, Ph/Mh horizontal, Xh|Mv the
+// zero diagonal steps), so one text column — all 64 pattern rows and every distance d at once — costs 23
+// VALU instructions, there is no loop over d, and the cost of a window does not depend on its distance
+// (early termination, :278-283, has nothing left to skip).  Per text column i < W-O two dwords are kept
+// for the traceback (SENE + DENT, :63-78, :200-208, :258-267, in this form):
+//     V1 = Pv' | Ph            insertion or deletion
+//     V0 = Pv' | ~(Ph | Xh)    insertion or substitution         (both = insertion, neither = match)
+// left-aligned: bit 31-j belongs to pattern character j.  The traceback is column-synchronous — in column
+// i the run of insertions is one count-leading-zeros over V1 & V0, then one D / X / = step moves every
+// lane to column i+1 — so the table is indexed by compile-time constants and lives in 62 VGPRs.
+// tests/proto/lane_proto.c restates this arithmetic in C; tests/test_lane_proto.py checks it against the
+// oracle on the CPU.
+//
+// LDS holds only the CIGAR staging ring: 32 runs per lane, written out in aligned 32-byte pieces.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "genasm_kernels.h"
+#include "genasm_device.h"
+
+namespace scrg {
+
+constexpr int LANE_TB_COLS = 31;                 // W-O <= 31 columns can be consumed per window
+constexpr uint32_t LANE_RING_BYTES = 68;         // 32 runs + one dword: lanes land on distinct LDS banks
+
+// truth tables (inputs a, b, c in that order)
+constexpr int TT_NE  = bitop3_table([](int x, int rh, int sh) { return x | (rh ^ sh); });          // not-equal mask
+constexpr int TT_XV  = bitop3_table([](int ne, int mv, int) { return ~ne | mv; });
+constexpr int TT_T   = bitop3_table([](int ne, int pv, int) { return ~ne & pv; });
+constexpr int TT_XH  = bitop3_table([](int sum, int pv, int ne) { return (sum ^ pv) | ~ne; });
+constexpr int TT_PH  = bitop3_table([](int mv, int xh, int pv) { return mv | ~(xh | pv); });
+constexpr int TT_PVN = bitop3_table([](int mhs, int xv, int phs) { return mhs | ~(xv | phs); });
+constexpr int TT_V0  = bitop3_table([](int pvn, int ph, int xh) { return pvn | ~(ph | xh); });
+
+__device__ __forceinline__ uint32_t ffbh_u32(uint32_t v)      // count leading zeros; 0xffffffff for v == 0
+{
+    uint32_t r;
+    asm("v_ffbh_u32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+
+// GEN = false: every lane of the wave has a full window (n = m = 64).  GEN = true: any n, m <= 64 per lane
+// (window ends, W < 64): columns >= n are skipped per lane, the table is shifted left by 64-m.
+template <bool GEN>
+__device__ __forceinline__ void lane_window_table(const Planes tw, const Planes pw, const uint32_t n, const uint32_t m,
+                                                  uint32_t (&v1)[LANE_TB_COLS], uint32_t (&v0)[LANE_TB_COLS])
+{
+    // reversed pattern, right-aligned: bit b <-> pattern[m-1-b] (the reference's layout, genasm_cpu.cpp:178-198);
+    // whatever lies above bit m-1 never reaches the bits below it (carries and shifts only move up)
+    const uint32_t sft = 64u - m;
+    uint64_t rlo = brev64(pw.lo), rhi = brev64(pw.hi);
+    if (GEN) {
+        rlo >>= sft;
+        rhi >>= sft;
+    }
+    const uint32_t rl0 = (uint32_t)rlo, rl1 = (uint32_t)(rlo >> 32), rh0 = (uint32_t)rhi, rh1 = (uint32_t)(rhi >> 32);
+    const uint32_t tl0 = (uint32_t)tw.lo, tl1 = (uint32_t)(tw.lo >> 32), th0 = (uint32_t)tw.hi, th1 = (uint32_t)(tw.hi >> 32);
+    uint32_t pv0 = ~0u, pv1 = ~0u, mv0 = 0u, mv1 = 0u;           // D[n][j] = m-j: every vertical step is +1
+    if (GEN) {
+#pragma unroll
+        for (int i = 0; i < LANE_TB_COLS; i++) v1[i] = v0[i] = ~0u;   // columns >= n: only insertions (genasm_cpu.cpp:239-245)
+    }
+#pragma unroll
+    for (int i = 63; i >= 0; i--) {
+        if (!GEN || (uint32_t)i < n) {
+            const uint32_t sl = (uint32_t)__builtin_amdgcn_sbfe((int)(i < 32 ? tl0 : tl1), i & 31, 1);
+            const uint32_t sh = (uint32_t)__builtin_amdgcn_sbfe((int)(i < 32 ? th0 : th1), i & 31, 1);
+            const uint32_t ne0 = bitop3<TT_NE>(rl0 ^ sl, rh0, sh), ne1 = bitop3<TT_NE>(rl1 ^ sl, rh1, sh);
+            const uint32_t xv0 = bitop3<TT_XV>(ne0, mv0, mv0), xv1 = bitop3<TT_XV>(ne1, mv1, mv1);
+            const uint32_t t0 = bitop3<TT_T>(ne0, pv0, pv0), t1 = bitop3<TT_T>(ne1, pv1, pv1);
+            const uint64_t sum = add64(((uint64_t)t1 << 32) | t0, ((uint64_t)pv1 << 32) | pv0);
+            const uint32_t xh0 = bitop3<TT_XH>((uint32_t)sum, pv0, ne0), xh1 = bitop3<TT_XH>((uint32_t)(sum >> 32), pv1, ne1);
+            const uint32_t ph0 = bitop3<TT_PH>(mv0, xh0, pv0), ph1 = bitop3<TT_PH>(mv1, xh1, pv1);
+            const uint32_t mh0 = pv0 & xh0, mh1 = pv1 & xh1;
+            const uint64_t phs = shl1(((uint64_t)ph1 << 32) | ph0);       // row 0 of the matrix is all zeros: 0 comes in
+            const uint64_t mhs = shl1(((uint64_t)mh1 << 32) | mh0);
+            pv0 = bitop3<TT_PVN>((uint32_t)mhs, xv0, (uint32_t)phs);
+            pv1 = bitop3<TT_PVN>((uint32_t)(mhs >> 32), xv1, (uint32_t)(phs >> 32));
+            mv0 = (uint32_t)phs & xv0;
+            mv1 = (uint32_t)(phs >> 32) & xv1;
+            if (i < LANE_TB_COLS) {
+                if (GEN) {
+                    const uint64_t a = ((uint64_t)(pv1 | ph1) << 32) | (pv0 | ph0);
+                    const uint64_t b = ((uint64_t)bitop3<TT_V0>(pv1, ph1, xh1) << 32) | bitop3<TT_V0>(pv0, ph0, xh0);
+                    v1[i] = (uint32_t)((a << sft) >> 32);
+                    v0[i] = (uint32_t)((b << sft) >> 32);
+                } else {
+                    v1[i] = pv1 | ph1;
+                    v0[i] = bitop3<TT_V0>(pv1, ph1, xh1);
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void genasm_lane_kernel(AlignArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    char* const lds_b = reinterpret_cast<char*>(lds);
+
+    const uint32_t lane = threadIdx.x;
+    const uint32_t ring_b = lane * LANE_RING_BYTES;
+    const uint32_t W = (uint32_t)a.W;
+    const uint32_t TBL = (uint32_t)a.tb_limit;         // W - O, 1..31
+
+    // ---- per-lane pair state ----
+    bool has_pair = false;
+    uint32_t pair = 0;
+    uint64_t text_off = 0, read_off = 0, cigar_off = 0;
+    uint32_t text_len = 0, read_len = 0, cigar_cap = 0;
+    uint32_t ref_idx = 0, read_idx = 0, edits = 0;
+    int32_t nr = -1;                   // index of the run in progress (or of the last finished one); n_runs = nr + 1
+    uint32_t flushed = 0;              // runs below this index are in HBM (a multiple of 16)
+    bool queue_empty = false;          // wave-uniform
+    const bool timing = a.stats != nullptr;
+    uint64_t cy_fetch = 0, cy_setup = 0, cy_dc = 0, cy_tb = 0;
+    uint32_t st_rounds = 0, st_gen = 0;
+
+    // one 16-run piece of my ring -> my slice (two 16-byte stores); pieces past the slice's capacity are dropped
+    auto write_piece = [&]() {
+        const uint32_t rd = (ring_b >> 2) + ((flushed & 16u) >> 1);
+        uint32_t w[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) w[k] = lds[rd + k];
+        if (flushed + 16u <= cigar_cap) {
+            uint4* const dst = reinterpret_cast<uint4*>(a.runs + cigar_off + flushed);
+            dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
+            dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
+        }
+        flushed += 16u;
+    };
+    // write out every piece that consists of finished runs only (the run at index nr may still grow)
+    auto flush_pieces = [&]() {
+        for (;;) {
+            const bool need = has_pair && nr - (int32_t)flushed >= 16;
+            if (!__any(need)) break;
+            if (need) write_piece();
+        }
+    };
+
+    for (;;) {
+        const uint64_t tm0 = timing ? __builtin_readcyclecounter() : 0;
+        // ---------------- retire finished pairs, fetch new ones (genasm_cpu.cpp:440-460) ----------------
+        for (;;) {
+            const bool fin = has_pair && read_idx >= read_len;
+            if (__any(fin)) {
+                if (fin) {
+                    const uint32_t n_runs = (uint32_t)(nr + 1);
+                    while (n_runs - flushed >= 16u) write_piece();
+                    // the tail: whole dwords of the last, partial piece
+                    const uint32_t rem = n_runs - flushed;
+                    const uint32_t rd = (ring_b >> 2) + ((flushed & 16u) >> 1);
+                    uint32_t* const dst = reinterpret_cast<uint32_t*>(a.runs + cigar_off + flushed);
+                    for (uint32_t k = 0; 2u * k < rem; k++)
+                        if (flushed + 2u * k < cigar_cap) dst[k] = lds[rd + k];
+                    a.ed[pair] = (int64_t)edits;
+                    a.n_runs[pair] = n_runs;
+                    a.status[pair] = n_runs > cigar_cap ? 1u : 0u;
+                }
+                has_pair = has_pair && !fin;
+            }
+            const bool want = !has_pair && !queue_empty;
+            if (!__any(want)) break;
+            // one atomic per wavefront for all the lanes that want a pair
+            const uint64_t askers = __ballot(want);
+            const int first = __ffsll((unsigned long long)askers) - 1;
+            uint32_t base = 0;
+            if ((int)lane == first) base = atomicAdd(a.counter, (uint32_t)__popcll(askers));
+            base = (uint32_t)__shfl((int)base, first);
+            const uint32_t idx = base + (uint32_t)__popcll(askers & ((1ull << lane) - 1ull));
+            const bool got = want && idx < a.n_pairs;
+            if (__any(want && idx >= a.n_pairs)) queue_empty = true;
+            if (got) {
+                const scrg_pair_desc pd = a.pairs[idx];
+                pair = idx;
+                text_off = pd.text_off;
+                read_off = pd.read_off;
+                text_len = pd.text_len > 0xffffffffull ? 0xffffffffu : (uint32_t)pd.text_len;
+                read_len = (uint32_t)pd.read_len;
+                cigar_off = pd.cigar_off;
+                cigar_cap = pd.cigar_cap > 0xffffffffull ? 0xffffffffu : (uint32_t)pd.cigar_cap;
+                ref_idx = read_idx = edits = flushed = 0;
+                nr = -1;
+                has_pair = true;
+            }
+        }
+        if (!__any(has_pair)) break;
+
+        const uint64_t tm1 = timing ? __builtin_readcyclecounter() : 0;
+        // ---------------- window setup (genasm_cpu.cpp:417-420) ----------------
+        const uint32_t n = (has_pair && ref_idx < text_len) ? min(W, text_len - ref_idx) : 0u;
+        const uint32_t m = has_pair ? min(W, read_len - read_idx) : 1u;      // >= 1 for live pairs
+        Planes tw = {0, 0}, pw = {0, 0};
+        if (has_pair) {
+            tw = load_window(a.seq, text_off + ref_idx);
+            pw = load_window(a.seq, read_off + read_idx);
+        }
+        const uint64_t tm2 = timing ? __builtin_readcyclecounter() : 0;
+
+        // ---------------- the window's table: all distances at once (genasm_cpu.cpp:210-288) ----------------
+        uint32_t v1[LANE_TB_COLS], v0[LANE_TB_COLS];
+        const bool general = __any(has_pair && (n != 64u || m != 64u));
+        if (general) {
+            lane_window_table<true>(tw, pw, n, m, v1, v0);
+            st_gen++;
+        } else {
+            lane_window_table<false>(tw, pw, n, m, v1, v0);
+        }
+        const uint64_t tm3 = timing ? __builtin_readcyclecounter() : 0;
+
+        // ---------------- traceback, column-synchronous (genasm_cpu.cpp:290-409) ----------------
+        // Lanes stop by themselves when j reaches jlim = min(m, W-O) (:301, :310); i < W-O (:309) is the
+        // loop bound; i < n (:312) needs no test because columns >= n hold "insertion" in every row.  The
+        // last-character rule (:336-343, insertion whenever there is budget) is what the matrix says anyway:
+        // D[i][m] = 0, so an insertion is possible exactly when D[i][m-1] > 0.
+        {
+            const uint32_t jlim = has_pair ? min(m, TBL) : 0u;
+            uint32_t j = 0, ti = 0;
+            uint32_t cur = 0xff00u;                   // run in progress: count | op << 8 (a window starts a new run, :400-403)
+#pragma unroll
+            for (int i = 0; i < LANE_TB_COLS; i++) {
+                if ((uint32_t)i >= TBL) continue;      // (uniform)
+                // the insertions in a row from (i, j): leading ones of (V1 & V0) << j
+                const uint32_t iv = v1[i] & v0[i];
+                const uint32_t r = ffbh_u32(~(iv << j));
+                const uint32_t ni = min(r, jlim - j);
+                if (ni) {
+                    nr++;
+                    cur = ((uint32_t)'I' << 8) | ni;
+                    *reinterpret_cast<uint16_t*>(lds_b + ring_b + (((uint32_t)nr & 31u) << 1)) = (uint16_t)cur;
+                    j += ni;
+                    edits += ni;
+                }
+                if (j < jlim) {
+                    const uint32_t dm = (uint32_t)((int32_t)(v1[i] << j) >> 31);     // ~0: deletion
+                    const uint32_t xm = (uint32_t)((int32_t)(v0[i] << j) >> 31);     // ~0: substitution (if not a deletion)
+                    const uint32_t op8 = dm ? ((uint32_t)'D' << 8) : (xm ? ((uint32_t)'X' << 8) : ((uint32_t)'=' << 8));
+                    j += 1u + dm;
+                    ti++;
+                    edits -= dm | xm;
+                    const bool same = (cur & 0xff00u) == op8;
+                    nr += same ? 0 : 1;
+                    cur = same ? cur + 1u : (op8 | 1u);
+                    *reinterpret_cast<uint16_t*>(lds_b + ring_b + (((uint32_t)nr & 31u) << 1)) = (uint16_t)cur;
+                }
+                if ((i & 7) == 7) flush_pieces();      // at most 16 new runs between checks: the 32-run ring cannot wrap
+            }
+            flush_pieces();
+            ref_idx += ti;
+            read_idx += j;
+        }
+        st_rounds++;
+        if (timing) {
+            const uint64_t tm4 = __builtin_readcyclecounter();
+            cy_fetch += tm1 - tm0;
+            cy_setup += tm2 - tm1;
+            cy_dc += tm3 - tm2;
+            cy_tb += tm4 - tm3;
+        }
+    }
+    if (a.stats && lane == 0) {
+        atomicAdd((unsigned long long*)&a.stats[0], (unsigned long long)st_rounds);
+        atomicAdd((unsigned long long*)&a.stats[1], (unsigned long long)st_gen);
+        atomicAdd((unsigned long long*)&a.stats[3], (unsigned long long)cy_fetch);
+        atomicAdd((unsigned long long*)&a.stats[4], (unsigned long long)cy_setup);
+        atomicAdd((unsigned long long*)&a.stats[5], (unsigned long long)cy_dc);
+        atomicAdd((unsigned long long*)&a.stats[6], (unsigned long long)cy_tb);
+    }
+}
+
+hipError_t launch_align_lane(const AlignArgs& a, int grid, size_t lds_bytes, hipStream_t s)
+{
+    hipLaunchKernelGGL(genasm_lane_kernel, dim3(grid), dim3(64), lds_bytes, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace scrg

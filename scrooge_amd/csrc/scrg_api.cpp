@@ -294,14 +294,17 @@ static bool resolve_params(const scrg_params* in, scrg_params* p)
             p->lds_rows = (int32_t)std::min<size_t>(32, std::max<size_t>(4, fit));
         }
     } else {
-        // measured optimum on MI355X for 10 kb reads at 10 % error
-        if (p->lanes_per_pair == 0) p->lanes_per_pair = 8;
+        // one pair per lane (genasm_lane_kernel.hip) wherever it applies: a window's traceback consumes at most
+        // W-O <= 31 characters; wider traceback limits take the G = 8 kernel's whole-entry storage
+        if (p->lanes_per_pair == 0) p->lanes_per_pair = tbl <= 31 ? 1 : 8;
+        if (p->lanes_per_pair == 1 && tbl > 31) return false;
         if (p->lds_rows == 0) p->lds_rows = 12;
     }
     // 11 and 12 wavefronts per CU align equally fast (the kernel is issue-bound); 11 leaves VGPRs and LDS on
     // every CU for kernels of other streams (RCCL's gather in bench.py --gpus N).  The LDS footprint caps it.
-    if (p->waves_per_cu == 0) p->waves_per_cu = 11;
+    if (p->waves_per_cu == 0) p->waves_per_cu = p->lanes_per_pair == 1 ? 12 : 11;
     const int g = p->lanes_per_pair;
+    if (g == 1) return p->waves_per_cu >= 1 && p->waves_per_cu <= 32;      // no table in LDS: lds_rows is not used
     if (!(g == 4 || g == 8 || g == 16 || g == 32 || g == 64)) return false;
     if (p->lds_rows < 1) return false;
     if (p->lds_rows > p->W + 1) p->lds_rows = p->W + 1;
@@ -314,6 +317,7 @@ static bool resolve_params(const scrg_params* in, scrg_params* p)
 
 static size_t lds_bytes_for(const scrg_params& p)
 {
+    if (p.lanes_per_pair == 1) return 64 * 68;       // the CIGAR staging rings: 32 runs + 1 dword per lane
     const size_t slots = 64 / p.lanes_per_pair;
     // per slot: CIGAR staging ring (16 dwords) + 1 scratch dword + R rows (+1 dword against bank
     // conflicts); 8 dwords of padding at the end (the traceback's speculative lanes read a little past a
@@ -408,6 +412,8 @@ scrg_status scrg_align_device(scrg_ctx* c, const scrg_params* params, uint64_t n
     HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));
     if (p.W > 64)
         HIP_TRY(c, scrg::launch_align_multiword(p.lanes_per_pair, a, n_waves, (size_t)lds, c->stream));
+    else if (p.lanes_per_pair == 1)
+        HIP_TRY(c, scrg::launch_align_lane(a, n_waves, (size_t)lds, c->stream));
     else
         HIP_TRY(c, scrg::launch_align(p.lanes_per_pair, a, n_waves, (size_t)lds, c->stream));
     HIP_TRY(c, hipEventRecord(c->ev_stop, c->stream));

@@ -1,0 +1,115 @@
+/*
+ * lane_proto.c — CPU prototype (not shipped, not part of the oracle) of the lane-per-pair window of the
+ * HIP kernel (genasm_lane_kernel.hip).  Used to validate its arithmetic against the oracle before and
+ * after porting it.
+ *
+ * The GenASM table is a thresholded edit-distance matrix: bit j of R[i][d] is clear exactly when
+ * D[i][j] <= d, where D[i][j] is the least number of edits that align pattern[j..m) to a prefix of
+ * text[i..n) (genasm_cpu.cpp:225-252 is the Wu-Manber recurrence of that matrix; D[n][j] = m-j is the
+ * boundary column :239-245, D[i][m] = 0 the bit shifted in by `<< 1`).  The traceback (:290-409) keeps
+ * d == D[i][j] and asks three questions per cell, in the order I, D, X:
+ *     D[i][j+1] == d-1 ?   D[i+1][j] == d-1 ?   D[i+1][j+1] == d-1 ?
+ * i.e. it looks at the vertical, horizontal and diagonal DIFFERENCES of D.  Those differences are what
+ * the Myers/Hyyro bit-vector recurrence carries (Pv/Mv vertical, Ph/Mh horizontal, D0 diagonal), so a
+ * whole window column — all 64 pattern rows, every distance at once — is ~20 word operations, with no
+ * loop over d and nothing that depends on the window distance.  Per text column i (processed n-1..0)
+ * the prototype keeps two words for the traceback, in the order the kernel uses them:
+ *     V1 = Pv' | Ph          "insertion or deletion"
+ *     V0 = Pv' | ~(Ph | Xh)  "insertion or substitution"        (both set = insertion)
+ * left-aligned so that bit 31-j belongs to pattern character j (the DENT word, :200-208).
+ * The traceback is column-synchronous: in column i the run of insertions is one count-leading-zeros
+ * over V1 & V0, then one D / X / = step moves to column i+1.
+ */
+#include "../../oracle/genasm_oracle.c"
+
+static uint64_t lp_brev64(uint64_t v)
+{
+    uint64_t r = 0;
+    for (int k = 0; k < 64; k++) if ((v >> k) & 1) r |= 1ull << (63 - k);
+    return r;
+}
+
+typedef struct lane_stats { uint64_t windows, columns, tb_columns; } lane_stats;
+
+/* window table: V1[i], V0[i] for i < TBL (<= 63): 64-bit left-aligned (bit 63-j <-> pattern char j) */
+static void lane_dc(const uint8_t *t, int n, const uint8_t *q, int m, int TBL, uint64_t *V1, uint64_t *V0, lane_stats *ls)
+{
+    /* planes as load_window() delivers them: bit k <-> character k; characters past the end are whatever
+     * follows in memory (a fixed filler here) */
+    uint64_t Tlo = 0, Thi = 0, Plo = 0, Phi = 0;
+    for (int k = 0; k < 64; k++) {
+        uint8_t tc = k < n ? t[k] : (uint8_t)((k * 5 + 1) & 3);
+        uint8_t qc = k < m ? q[k] : (uint8_t)((k * 7 + 3) & 3);
+        Tlo |= (uint64_t)(tc & 1) << k; Thi |= (uint64_t)(tc >> 1) << k;
+        Plo |= (uint64_t)(qc & 1) << k; Phi |= (uint64_t)(qc >> 1) << k;
+    }
+    /* right-aligned reversed pattern: bit b <-> pattern[m-1-b] (the reference's own layout, genasm_cpu.cpp:178-198) */
+    const uint64_t Rlo = lp_brev64(Plo) >> (64 - m), Rhi = lp_brev64(Phi) >> (64 - m);
+    uint64_t Pv = ~0ull, Mv = 0;
+    for (int i = 0; i < TBL; i++) V1[i] = V0[i] = ~0ull;          /* columns >= n: only insertions */
+    for (int i = n - 1; i >= 0; i--) {
+        const uint64_t sl = 0ull - ((Tlo >> i) & 1), sh = 0ull - ((Thi >> i) & 1);
+        const uint64_t Eq = ~((Rlo ^ sl) | (Rhi ^ sh));           /* garbage above bit m-1 never reaches the bits below */
+        const uint64_t Xv = Eq | Mv;
+        const uint64_t Xh = ((((Eq & Pv) + Pv) ^ Pv) | Eq);
+        const uint64_t Ph = Mv | ~(Xh | Pv);
+        const uint64_t Mh = Pv & Xh;
+        const uint64_t Ph1 = Ph << 1, Mh1 = Mh << 1;              /* row 0 of the matrix is all zeros: shift in 0 */
+        const uint64_t Pvn = Mh1 | ~(Xv | Ph1);
+        const uint64_t Mvn = Ph1 & Xv;
+        if (i < TBL) {
+            V1[i] = (Pvn | Ph) << (64 - m);
+            V0[i] = (Pvn | ~(Ph | Xh)) << (64 - m);
+        }
+        Pv = Pvn; Mv = Mvn;
+        ls->columns++;
+    }
+}
+
+static int lp_clz64(uint64_t v) { return v ? __builtin_clzll(v) : 64; }
+
+static int lane_tb(const uint64_t *V1, const uint64_t *V0, int m, int TBL, size_t *tu, size_t *pu, run_sink *out, lane_stats *ls)
+{
+    const int jlim = m < TBL ? m : TBL;            /* j < m && j < W-O, genasm_cpu.cpp:307-310 */
+    int i = 0, j = 0, edits = 0;
+    /* the run in progress is (cur_op, cur_len); a window never merges with its neighbours (:400-403) */
+    char cur = 0; unsigned cur_len = 0;
+#define LP_EVENT(op_, n_) do { if (cur == (op_)) cur_len += (n_); else { if (cur_len) sink_push(out, cur, cur_len); cur = (op_); cur_len = (n_); } } while (0)
+    for (i = 0; i < TBL && j < jlim; i++) {
+        ls->tb_columns++;
+        const uint64_t Iv = V1[i] & V0[i];
+        int r = lp_clz64(~(Iv << j));               /* insertions in a row from (i, j) */
+        int ni = r < jlim - j ? r : jlim - j;
+        if (ni) { LP_EVENT('I', (unsigned)ni); j += ni; edits += ni; }
+        if (j >= jlim) break;
+        const int c1 = (int)((V1[i] << j) >> 63), c0 = (int)((V0[i] << j) >> 63);
+        if (c1) { LP_EVENT('D', 1u); edits++; }
+        else if (c0) { LP_EVENT('X', 1u); j++; edits++; }
+        else { LP_EVENT('=', 1u); j++; }
+    }
+    /* (the loop's i++ after a D/X/= step is the text character that step consumed) */
+    if (cur_len) sink_push(out, cur, cur_len);
+    *tu = (size_t)i; *pu = (size_t)j;
+    return edits;
+}
+
+int lane_align_codes(const uint8_t *text, size_t text_len, const uint8_t *read, size_t read_len, int W, int O,
+                     go_run *runs, size_t cap, size_t *n_runs, long long *edit_distance, lane_stats *ls)
+{
+    if (W < 2 || W > 64 || O < 1 || O >= W) return GO_ERR_PARAMS;
+    run_sink out = { runs, cap, 0, 0 };
+    size_t ti = 0, ri = 0; long long total = 0;
+    const int TBL = W - O;
+    uint64_t V1[64], V0[64];
+    while (ri < read_len) {
+        size_t n = text_len - ti < (size_t)W ? text_len - ti : (size_t)W;
+        size_t m = read_len - ri < (size_t)W ? read_len - ri : (size_t)W;
+        size_t tu, pu;
+        lane_dc(text + ti, (int)n, read + ri, (int)m, TBL, V1, V0, ls);
+        total += lane_tb(V1, V0, (int)m, TBL, &tu, &pu, &out, ls);
+        ls->windows++;
+        ti += tu; ri += pu;
+    }
+    *n_runs = out.n; *edit_distance = total;
+    return out.overflow ? GO_ERR_CAPACITY : GO_OK;
+}

@@ -45,7 +45,7 @@ def test_defaults_match_reference_knobs(lib):
     assert (p.W, p.O) == (64, 33)        # src/genasm_cpu.cpp:7-9
     r = api.Params()
     assert lib.scrg_params_resolve(p, r) == 0
-    assert (r.W, r.O, r.lanes_per_pair) == (64, 33, 8) and r.lds_rows > 0 and r.waves_per_cu > 0
+    assert (r.W, r.O, r.lanes_per_pair) == (64, 33, 1) and r.lds_rows > 0 and r.waves_per_cu > 0
     p.W, p.O = 128, 65
     assert lib.scrg_params_resolve(p, r) == 0 and r.lanes_per_pair == 32
     p.W, p.O = 256, 129

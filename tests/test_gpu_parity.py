@@ -8,7 +8,7 @@ from scrooge_amd import synth
 
 pytestmark = pytest.mark.gpu
 
-MAPPINGS = [8, 64, 16, 4, 32]     # lanes per pair; 64 = one pair per wavefront
+MAPPINGS = [1, 8, 64, 16, 4, 32]     # lanes per pair; 1 = one pair per lane (the default), 64 = one pair per wavefront
 
 
 def _check(alns, eds, cigars, tag=""):
@@ -28,7 +28,7 @@ def test_golden_pairs(aligner, golden_pairs, g):
     _check(alns, [c["ed"] for c in cases], [c["cigar"] for c in cases], "golden g=%d" % g)
 
 
-@pytest.mark.parametrize("g", [8, 64])
+@pytest.mark.parametrize("g", [1, 8, 64])
 def test_golden_mapping(aligner, golden_mapping, g):
     gm = golden_mapping
     alns = aligner.align_mapping(gm["genome"], gm["reads"], gm["candidates"], lanes_per_pair=g)
@@ -41,7 +41,7 @@ def test_golden_other_knobs(aligner, name):
     from tests.conftest import load_golden
     g = load_golden(name)
     cases = g["cases"]
-    for lanes in (8, 64):
+    for lanes in ((1, 8, 64) if g["W"] - g["O"] <= 31 else (8, 64)):
         alns = aligner.align_pairs([c["text"] for c in cases], [c["read"] for c in cases], W=g["W"], O=g["O"],
                                    lanes_per_pair=lanes)
         _check(alns, [c["ed"] for c in cases], [c["cigar"] for c in cases], "%s g=%d" % (name, lanes))
@@ -107,7 +107,7 @@ def test_result_order_is_input_order(aligner, oracle, sort):
     _check(aligner.align_pairs(t, q, sort_by_length=sort), eds, cigars, "order sort=%d" % sort)
 
 
-@pytest.mark.parametrize("w,o", [(32, 17), (64, 40), (48, 24), (17, 3)])
+@pytest.mark.parametrize("w,o", [(32, 17), (64, 40), (48, 24), (17, 3), (64, 63), (2, 1), (33, 2), (31, 1)])
 def test_other_window_settings(aligner, oracle, w, o):
     """W/O are runtime parameters here (compile-time macros in the reference,
     src/genasm_cpu.cpp:22-35); the short-read setting of the paper is W=32, O=17."""
@@ -118,6 +118,7 @@ def test_other_window_settings(aligner, oracle, w, o):
         q.append(synth.random_seq(int(rng.integers(0, 120)), rng))
     eds, cigars, _, _ = oracle.align(t, q, W=w, O=o)
     _check(aligner.align_pairs(t, q, W=w, O=o), eds, cigars, "W=%d O=%d" % (w, o))
+    _check(aligner.align_pairs(t, q, W=w, O=o, lanes_per_pair=8), eds, cigars, "W=%d O=%d g8" % (w, o))
     _check(aligner.align_pairs(t, q, W=w, O=o, lanes_per_pair=64), eds, cigars, "W=%d O=%d g64" % (w, o))
 
 
@@ -141,6 +142,7 @@ def test_long_reads_10kb(aligner, oracle):
     t, q = synth.make_pairs(64, 10000, "ont", seed=42)
     eds, cigars, st, _ = oracle.align(t, q, threads=8)
     _check(aligner.align_pairs(t, q), eds, cigars, "10kb")
+    _check(aligner.align_pairs(t, q, lanes_per_pair=8), eds, cigars, "10kb g8")
     _check(aligner.align_pairs(t, q, lanes_per_pair=64), eds, cigars, "10kb g64")
 
 
@@ -198,8 +200,8 @@ def test_diagonal_path_on_and_off(aligner, oracle, lds_rows):
     c, d = synth.make_pairs(400, 500, "illumina", seed=7)
     T, Q = T + a + c, Q + b + d
     eds, cigars, _, _ = oracle.align(T, Q, threads=8)
-    _check(aligner.align_pairs(T, Q, lds_rows=lds_rows), eds, cigars, "diag on rows=%d" % lds_rows)
-    p = aligner.make_params(lds_rows=lds_rows)
+    _check(aligner.align_pairs(T, Q, lanes_per_pair=8, lds_rows=lds_rows), eds, cigars, "diag on rows=%d" % lds_rows)
+    p = aligner.make_params(lanes_per_pair=8, lds_rows=lds_rows)
     p.reserved[0] = 32
     keep = aligner.params
     aligner.params = p

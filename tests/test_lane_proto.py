@@ -1,0 +1,70 @@
+"""The lane-per-pair window arithmetic of the HIP kernel (genasm_lane_kernel.hip: Myers/Hyyro difference
+vectors per text column, two traceback words per column, column-synchronous traceback with one
+count-leading-zeros per insertion run), restated in C (tests/proto/lane_proto.c) and checked against the
+oracle on the CPU."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from scrooge_amd import synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def proto():
+    so = os.path.join(HERE, "proto", "liblane_proto.so")
+    subprocess.check_call(["gcc", "-O2", "-std=c11", "-fopenmp", "-fPIC", "-shared", "-w", "-o", so,
+                           os.path.join(HERE, "proto", "lane_proto.c")])
+    return C.CDLL(so)
+
+
+class LS(C.Structure):
+    _fields_ = [("windows", C.c_uint64), ("columns", C.c_uint64), ("tb_columns", C.c_uint64)]
+
+
+CODE = np.zeros(256, np.uint8)
+CODE[ord("C")], CODE[ord("G")], CODE[ord("T")] = 1, 2, 3
+
+
+def _run(fn, t, q, head, tail):
+    tc, qc = CODE[np.frombuffer(t, np.uint8)], CODE[np.frombuffer(q, np.uint8)]
+    cap = len(t) + len(q) + 8
+    runs = (C.c_uint8 * (2 * cap))()
+    n, ed = C.c_size_t(), C.c_longlong()
+    st = fn(tc.ctypes.data_as(C.c_void_p), C.c_size_t(len(tc)), qc.ctypes.data_as(C.c_void_p), C.c_size_t(len(qc)),
+            *head, runs, C.c_size_t(cap), C.byref(n), C.byref(ed), *tail)
+    assert st == 0
+    return ed.value, bytes(runs[:2 * n.value])
+
+
+def _cases(seed):
+    T, Q = [], []
+    for prof, L, n in [("ont", 2000, 20), ("pacbio15", 2000, 12), ("illumina", 300, 30)]:
+        t, q = synth.make_pairs(n, L, prof, seed=seed + L)
+        T, Q = T + t, Q + q
+    rng = np.random.Generator(np.random.PCG64(seed))
+    for _ in range(40):                       # unrelated sequences, ragged and empty inputs
+        T.append(synth.random_seq(int(rng.integers(0, 400)), rng))
+        Q.append(synth.random_seq(int(rng.integers(0, 400)), rng))
+    for _ in range(20):                       # low-complexity sequences: long insertion/deletion runs, many ties
+        a = bytes(rng.choice(np.frombuffer(b"AC", np.uint8), int(rng.integers(1, 300))))
+        b = bytes(rng.choice(np.frombuffer(b"AC", np.uint8), int(rng.integers(1, 300))))
+        T.append(a), Q.append(b)
+    T += [b"", b"ACGT", b"A" * 200, b"A" * 10, b"ACGT" * 50]
+    Q += [b"ACGT", b"", b"A" * 10, b"A" * 200, b"TGCA" * 50]
+    return T, Q
+
+
+@pytest.mark.parametrize("W,O", [(64, 33), (64, 40), (64, 50), (64, 63), (32, 17), (48, 24), (33, 2), (2, 1), (17, 9), (64, 2), (64, 20), (50, 1)])
+def test_lane_form_matches_oracle(proto, W, O):
+    T, Q = _cases(W * 100 + O)
+    ls = LS()
+    for t, q in zip(T, Q):
+        got = _run(proto.lane_align_codes, t, q, (C.c_int(W), C.c_int(O)), (C.byref(ls),))
+        want = _run(proto.go_align_codes, t, q, (C.c_int(W), C.c_int(O)), (None,))
+        assert got == want
+    assert ls.windows > 1000
