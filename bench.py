@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--waves-per-cu", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--streams", type=int, default=2, help="pipeline depth: consecutive steps rotate over this many streams/handles")
+    ap.add_argument("--no-build", action="store_true",
+                    help="never rebuild the library (profiling: nothing may fork a compiler under rocprofv3)")
     ap.add_argument("--stats", action="store_true", help="profiling only: print kernel round/step counters")
     ap.add_argument("--ablate", type=int, default=0, help="profiling only: 1 = no TB table reads, 2 = no DC sweep")
     ap.add_argument("--serial", action="store_true",
@@ -127,8 +130,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+    if world != args.gpus:
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d): for N > 1 launch with `python -m torch.distributed.run "
+                         "--nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`"
+                         % (world, args.gpus))
+    # build (if stale) before anything initialises the GPU: a compiler must never be forked from a process that
+    # holds the device, least of all under a profiler
+    if not args.no_build:
+        scrooge_amd.build_library()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     dryrun = os.environ.get("SCRG_BENCH_DRYRUN") == "1"    # test only: all ranks on GPU 0, gloo through the host
@@ -142,10 +151,9 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=device)    # nccl == RCCL on ROCm
 
-    scrooge_amd.build_library()
     al = scrooge_amd.Aligner(local_rank)
     al.set_stream(torch.cuda.current_stream().cuda_stream)
-    n_lanes = 1 if (args.serial or args.stats or args.ablate) else 2      # software pipeline depth over streams
+    n_lanes = 1 if (args.serial or args.stats or args.ablate) else max(1, args.streams)      # software pipeline depth over streams
     kw = {}
     if args.lanes:
         kw["lanes_per_pair"] = args.lanes
@@ -215,7 +223,7 @@ def main():
     # HIP gives each priority its own hardware queues, whereas two streams of one priority can share a queue,
     # and kernels in one queue never overlap (scripts/side_stream_probe.py).
     if n_lanes > 1:
-        streams = [torch.cuda.ExternalStream(scrooge_amd.api.create_stream(local_rank, pr), device=device) for pr in (1, -1)]
+        streams = [torch.cuda.ExternalStream(scrooge_amd.api.create_stream(local_rank, pr), device=device) for pr in ([1, -1, 0, 1, -1, 0][:n_lanes])]
     else:
         streams = [torch.cuda.current_stream()]
     setup_stream = torch.cuda.current_stream()

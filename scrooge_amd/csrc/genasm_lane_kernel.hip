@@ -14,7 +14,7 @@
 // VALU instructions, there is no loop over d, and the cost of a window does not depend on its distance
 // (early termination, :278-283, has nothing left to skip).  Per text column i < W-O two dwords are kept
 // for the traceback (SENE + DENT, :63-78, :200-208, :258-267, in this form):
-//     V1 = Pv' | Ph            insertion or deletion
+//     V1 = Pv' | Ph            insertion or deletion             (kept negated, with a stop bit: see below)
 //     V0 = Pv' | ~(Ph | Xh)    insertion or substitution         (both = insertion, neither = match)
 // left-aligned: bit 31-j belongs to pattern character j.  The traceback is column-synchronous — in column
 // i the run of insertions is one count-leading-zeros over V1 & V0, then one D / X / = step moves every
@@ -22,10 +22,12 @@
 // tests/proto/lane_proto.c restates this arithmetic in C; tests/test_lane_proto.py checks it against the
 // oracle on the CPU.
 //
-// LDS holds only the CIGAR staging ring: 32 runs per lane, written out in aligned 32-byte pieces.
+// LDS holds only the CIGAR staging ring (32 runs per lane, written out in aligned 32-byte pieces) and 31
+// bytes of insertion-run lengths per lane.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "genasm_kernels.h"
 #include "genasm_device.h"
@@ -34,6 +36,7 @@ namespace scrg {
 
 constexpr int LANE_TB_COLS = 31;                 // W-O <= 31 columns can be consumed per window
 constexpr uint32_t LANE_RING_BYTES = 68;         // 32 runs + one dword: lanes land on distinct LDS banks
+constexpr uint32_t LANE_SCRATCH_BYTES = 36;      // insertion-run length of each traceback column, one byte each (+ bank skew)
 
 // truth tables (inputs a, b, c in that order)
 constexpr int TT_NE  = bitop3_table([](int x, int rh, int sh) { return x | (rh ^ sh); });          // not-equal mask
@@ -42,6 +45,9 @@ constexpr int TT_T   = bitop3_table([](int ne, int pv, int) { return ~ne & pv; }
 constexpr int TT_XH  = bitop3_table([](int sum, int pv, int ne) { return (sum ^ pv) | ~ne; });
 constexpr int TT_PH  = bitop3_table([](int mv, int xh, int pv) { return mv | ~(xh | pv); });
 constexpr int TT_PVN = bitop3_table([](int mhs, int xv, int phs) { return mhs | ~(xv | phs); });
+constexpr int TT_NOR3 = bitop3_table([](int a, int b, int c) { return ~(a | b | c); });
+constexpr int TT_NIV  = bitop3_table([](int nv1, int v0, int stop) { return nv1 | ~v0 | stop; });     // not (insertion), or the stop row
+constexpr int TT_ANDN = bitop3_table([](int a, int b, int) { return a & ~b; });
 constexpr int TT_V0  = bitop3_table([](int pvn, int ph, int xh) { return pvn | ~(ph | xh); });
 
 __device__ __forceinline__ uint32_t ffbh_u32(uint32_t v)      // count leading zeros; 0xffffffff for v == 0
@@ -55,8 +61,10 @@ __device__ __forceinline__ uint32_t ffbh_u32(uint32_t v)      // count leading z
 // (window ends, W < 64): columns >= n are skipped per lane, the table is shifted left by 64-m.
 template <bool GEN>
 __device__ __forceinline__ void lane_window_table(const Planes tw, const Planes pw, const uint32_t n, const uint32_t m,
-                                                  uint32_t (&v1)[LANE_TB_COLS], uint32_t (&v0)[LANE_TB_COLS])
+                                                  const uint32_t stop, uint32_t (&nv1)[LANE_TB_COLS], uint32_t (&v0)[LANE_TB_COLS])
 {
+    // nv1[i] = ~(V1 | stop): stop has the one bit of the row at which this lane's walk ends (jlim), so a
+    // finished lane reads "deletion" there and stays put without a test
     // reversed pattern, right-aligned: bit b <-> pattern[m-1-b] (the reference's layout, genasm_cpu.cpp:178-198);
     // whatever lies above bit m-1 never reaches the bits below it (carries and shifts only move up)
     const uint32_t sft = 64u - m;
@@ -70,7 +78,10 @@ __device__ __forceinline__ void lane_window_table(const Planes tw, const Planes 
     uint32_t pv0 = ~0u, pv1 = ~0u, mv0 = 0u, mv1 = 0u;           // D[n][j] = m-j: every vertical step is +1
     if (GEN) {
 #pragma unroll
-        for (int i = 0; i < LANE_TB_COLS; i++) v1[i] = v0[i] = ~0u;   // columns >= n: only insertions (genasm_cpu.cpp:239-245)
+        for (int i = 0; i < LANE_TB_COLS; i++) {                      // columns >= n: only insertions (genasm_cpu.cpp:239-245)
+            nv1[i] = 0u;
+            v0[i] = ~0u;
+        }
     }
 #pragma unroll
     for (int i = 63; i >= 0; i--) {
@@ -94,10 +105,10 @@ __device__ __forceinline__ void lane_window_table(const Planes tw, const Planes 
                 if (GEN) {
                     const uint64_t a = ((uint64_t)(pv1 | ph1) << 32) | (pv0 | ph0);
                     const uint64_t b = ((uint64_t)bitop3<TT_V0>(pv1, ph1, xh1) << 32) | bitop3<TT_V0>(pv0, ph0, xh0);
-                    v1[i] = (uint32_t)((a << sft) >> 32);
+                    nv1[i] = ~((uint32_t)((a << sft) >> 32) | stop);
                     v0[i] = (uint32_t)((b << sft) >> 32);
                 } else {
-                    v1[i] = pv1 | ph1;
+                    nv1[i] = bitop3<TT_NOR3>(pv1, ph1, stop);
                     v0[i] = bitop3<TT_V0>(pv1, ph1, xh1);
                 }
             }
@@ -105,13 +116,15 @@ __device__ __forceinline__ void lane_window_table(const Planes tw, const Planes 
     }
 }
 
-__global__ __launch_bounds__(64) void genasm_lane_kernel(AlignArgs a)
+__global__ __launch_bounds__(64, 3) void genasm_lane_kernel(AlignArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     char* const lds_b = reinterpret_cast<char*>(lds);
 
     const uint32_t lane = threadIdx.x;
     const uint32_t ring_b = lane * LANE_RING_BYTES;
+    const uint32_t scr_b = 64u * LANE_RING_BYTES + lane * LANE_SCRATCH_BYTES;
+    uint8_t* const lds8 = reinterpret_cast<uint8_t*>(lds);
     const uint32_t W = (uint32_t)a.W;
     const uint32_t TBL = (uint32_t)a.tb_limit;         // W - O, 1..31
 
@@ -210,13 +223,15 @@ __global__ __launch_bounds__(64) void genasm_lane_kernel(AlignArgs a)
         const uint64_t tm2 = timing ? __builtin_readcyclecounter() : 0;
 
         // ---------------- the window's table: all distances at once (genasm_cpu.cpp:210-288) ----------------
-        uint32_t v1[LANE_TB_COLS], v0[LANE_TB_COLS];
+        uint32_t nv1[LANE_TB_COLS], v0[LANE_TB_COLS];
+        const uint32_t jlim = has_pair ? min(m, TBL) : 0u;          // the walk ends when j gets here (:301, :310)
+        const uint32_t stop = 0x80000000u >> jlim;
         const bool general = __any(has_pair && (n != 64u || m != 64u));
         if (general) {
-            lane_window_table<true>(tw, pw, n, m, v1, v0);
+            lane_window_table<true>(tw, pw, n, m, stop, nv1, v0);
             st_gen++;
         } else {
-            lane_window_table<false>(tw, pw, n, m, v1, v0);
+            lane_window_table<false>(tw, pw, n, m, stop, nv1, v0);
         }
         const uint64_t tm3 = timing ? __builtin_readcyclecounter() : 0;
 
@@ -225,41 +240,79 @@ __global__ __launch_bounds__(64) void genasm_lane_kernel(AlignArgs a)
         // loop bound; i < n (:312) needs no test because columns >= n hold "insertion" in every row.  The
         // last-character rule (:336-343, insertion whenever there is budget) is what the matrix says anyway:
         // D[i][m] = 0, so an insertion is possible exactly when D[i][m-1] > 0.
+        //
+        // Pass 1 walks the columns without a branch and only records the path: per column one bit each for
+        // "no insertion run starts here" (a run's length goes to a byte of LDS), "the step out of this column
+        // is not a deletion" and "... is a substitution", pushed into three masks from the right, and the
+        // number of columns the lane was alive in.  The stop bit (row jlim) ends an insertion run and freezes
+        // a finished lane (it reads "deletion": j stays), so the loop has no min() and no test.  Pass 2 turns
+        // the masks into runs: one iteration per column at which a run starts (count-leading-zeros over the
+        // boundary mask), so its length is the number of runs of the lane with the most runs, not the number
+        // of columns.
         {
-            const uint32_t jlim = has_pair ? min(m, TBL) : 0u;
-            uint32_t j = 0, ti = 0;
-            uint32_t cur = 0xff00u;                   // run in progress: count | op << 8 (a window starts a new run, :400-403)
+            uint32_t j = 0, ti = 0, nDm = 0, Xm = 0, nIm = 0;
+            auto walk = [&](auto full_tag) {
+                constexpr bool FULL = decltype(full_tag)::value;       // W-O = 31: no per-column test of the column limit
 #pragma unroll
-            for (int i = 0; i < LANE_TB_COLS; i++) {
-                if ((uint32_t)i >= TBL) continue;      // (uniform)
-                // the insertions in a row from (i, j): leading ones of (V1 & V0) << j
-                const uint32_t iv = v1[i] & v0[i];
-                const uint32_t r = ffbh_u32(~(iv << j));
-                const uint32_t ni = min(r, jlim - j);
-                if (ni) {
-                    nr++;
-                    cur = ((uint32_t)'I' << 8) | ni;
-                    *reinterpret_cast<uint16_t*>(lds_b + ring_b + (((uint32_t)nr & 31u) << 1)) = (uint16_t)cur;
+                for (int i = 0; i < LANE_TB_COLS; i++) {
+                    if (!FULL && (uint32_t)i >= TBL) continue;         // (uniform)
+                    // the insertions in a row from (i, j): leading zeros of "not insertion, or stop" << j
+                    const uint32_t x = bitop3<TT_NIV>(nv1[i], v0[i], stop) << j;
+                    const uint32_t ni = ffbh_u32(x);
+                    lds8[scr_b + i] = (uint8_t)ni;
+                    nIm = __builtin_amdgcn_alignbit(nIm, x, 31);               // (nIm << 1) | (ni == 0)
                     j += ni;
-                    edits += ni;
+                    ti += (j < jlim) ? 1u : 0u;                                // still inside the window: one D / X / = step
+                    const uint32_t nt1 = nv1[i] << j, t0 = v0[i] << j;         // sign bits: not a deletion, substitution
+                    nDm = __builtin_amdgcn_alignbit(nDm, nt1, 31);
+                    Xm = __builtin_amdgcn_alignbit(Xm, t0, 31);
+                    uint32_t scratch;                                          // j += sign bit of nt1: a deletion (or the stop row) keeps j
+                    asm("v_add_co_u32 %1, vcc, %2, %2\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(j), "=&v"(scratch) : "v"(nt1) : "vcc");
                 }
-                if (j < jlim) {
-                    const uint32_t dm = (uint32_t)((int32_t)(v1[i] << j) >> 31);     // ~0: deletion
-                    const uint32_t xm = (uint32_t)((int32_t)(v0[i] << j) >> 31);     // ~0: substitution (if not a deletion)
-                    const uint32_t op8 = dm ? ((uint32_t)'D' << 8) : (xm ? ((uint32_t)'X' << 8) : ((uint32_t)'=' << 8));
-                    j += 1u + dm;
-                    ti++;
-                    edits -= dm | xm;
-                    const bool same = (cur & 0xff00u) == op8;
-                    nr += same ? 0 : 1;
-                    cur = same ? cur + 1u : (op8 | 1u);
-                    *reinterpret_cast<uint16_t*>(lds_b + ring_b + (((uint32_t)nr & 31u) << 1)) = (uint16_t)cur;
-                }
-                if ((i & 7) == 7) flush_pieces();      // at most 16 new runs between checks: the 32-run ring cannot wrap
-            }
-            flush_pieces();
+            };
+            if (TBL == (uint32_t)LANE_TB_COLS) walk(std::true_type{});
+            else walk(std::false_type{});
+            // column i -> bit 31-i; only the ti columns the lane was alive in count (insertion runs are exact as recorded)
+            const uint32_t nsh = 32u - min(TBL, (uint32_t)LANE_TB_COLS);
+            const uint32_t A = ~(0xffffffffu >> ti);
+            const uint32_t D = ~(nDm << nsh) & A, X = (Xm << nsh) & A;
+            const uint32_t Im = ~nIm << nsh;
+            const uint32_t B = ((D ^ (D >> 1)) | (X ^ (X >> 1)) | Im | 0x80000000u) & A;    // a D / X / = run starts here
+            const uint32_t nD = (uint32_t)__builtin_popcount(D), nX = (uint32_t)__builtin_popcount(X);
+            edits += j - ti + 2u * nD + nX;             // insertions (j - (ti - nD)) + deletions + substitutions
             ref_idx += ti;
             read_idx += j;
+
+            // Pass 2.  The next column with an event: an insertion run, then (if B) the run of steps that starts
+            // there.  Both words go to the slot after the last committed run; only committing moves on.  (A lane
+            // that is done computes garbage from column "31", which no mask ever has.)  The length byte of the
+            // next insertion run is read one iteration ahead.
+            uint32_t E = B | Im;
+            uint32_t c = ffbh_u32(E);
+            uint32_t ni = lds8[scr_b + c];
+            uint32_t nr2 = 2u * (uint32_t)nr;          // byte offset of the last committed run
+            uint32_t it = 0;
+            while (__any(E != 0u)) {
+                const uint32_t sh = 31u - c;
+                const uint32_t bit = 0x80000000u >> (c & 31u);
+                *reinterpret_cast<uint16_t*>(lds_b + ring_b + ((nr2 + 2u) & 62u)) = (uint16_t)(((uint32_t)'I' << 8) | ni);
+                nr2 += 2u * __builtin_amdgcn_ubfe(Im, sh, 1);
+                E = bitop3<TT_ANDN>(E, bit, bit);
+                const uint32_t nx = ffbh_u32(E);
+                ni = lds8[scr_b + nx];
+                const uint32_t len = min(nx, ti) - c;                       // up to the next event or the end of the walk
+                // '=' 0x3D, 'X' 0x58 = '=' + 27, 'D' 0x44 = '=' + 7
+                const uint32_t w = (((uint32_t)'=' << 8) + len) + __builtin_amdgcn_ubfe(D, sh, 1) * (7u << 8) + __builtin_amdgcn_ubfe(X, sh, 1) * (27u << 8);
+                *reinterpret_cast<uint16_t*>(lds_b + ring_b + ((nr2 + 2u) & 62u)) = (uint16_t)w;
+                nr2 += 2u * __builtin_amdgcn_ubfe(B, sh, 1);
+                c = nx;
+                if ((++it & 7u) == 7u) {                   // <= 14 new runs between checks + 1 speculative slot: the 32-run ring cannot wrap
+                    nr = (int32_t)nr2 >> 1;
+                    flush_pieces();
+                }
+            }
+            nr = (int32_t)nr2 >> 1;
+            flush_pieces();
         }
         st_rounds++;
         if (timing) {

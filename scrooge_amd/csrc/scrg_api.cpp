@@ -302,7 +302,7 @@ static bool resolve_params(const scrg_params* in, scrg_params* p)
     }
     // 11 and 12 wavefronts per CU align equally fast (the kernel is issue-bound); 11 leaves VGPRs and LDS on
     // every CU for kernels of other streams (RCCL's gather in bench.py --gpus N).  The LDS footprint caps it.
-    if (p->waves_per_cu == 0) p->waves_per_cu = p->lanes_per_pair == 1 ? 12 : 11;
+    if (p->waves_per_cu == 0) p->waves_per_cu = p->lanes_per_pair == 1 ? 16 : 11;
     const int g = p->lanes_per_pair;
     if (g == 1) return p->waves_per_cu >= 1 && p->waves_per_cu <= 32;      // no table in LDS: lds_rows is not used
     if (!(g == 4 || g == 8 || g == 16 || g == 32 || g == 64)) return false;
@@ -317,7 +317,7 @@ static bool resolve_params(const scrg_params* in, scrg_params* p)
 
 static size_t lds_bytes_for(const scrg_params& p)
 {
-    if (p.lanes_per_pair == 1) return 64 * 68;       // the CIGAR staging rings: 32 runs + 1 dword per lane
+    if (p.lanes_per_pair == 1) return 64 * (68 + 36);       // per lane: CIGAR staging ring (32 runs + 1 dword), insertion-run lengths of a window
     const size_t slots = 64 / p.lanes_per_pair;
     // per slot: CIGAR staging ring (16 dwords) + 1 scratch dword + R rows (+1 dword against bank
     // conflicts); 8 dwords of padding at the end (the traceback's speculative lanes read a little past a
