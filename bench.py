@@ -42,7 +42,10 @@ def parse():
     ap.add_argument("--waves-per-cu", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--seed", type=int, default=42)
-    ap.add_argument("--streams", type=int, default=2, help="pipeline depth: consecutive steps rotate over this many streams/handles")
+    ap.add_argument("--layout", default="auto", choices=["auto", "linear", "groups"],
+                    help="sequence layout in HBM: linear = every sequence contiguous; groups = lane-interleaved groups of 64 "
+                         "pairs (scrg_pack_planar_groups), what the one-pair-per-lane kernel reads best; auto = groups for that kernel")
+    ap.add_argument("--streams", type=int, default=4, help="pipeline depth: consecutive steps rotate over this many streams/handles")
     ap.add_argument("--no-build", action="store_true",
                     help="never rebuild the library (profiling: nothing may fork a compiler under rocprofv3)")
     ap.add_argument("--stats", action="store_true", help="profiling only: print kernel round/step counters")
@@ -177,16 +180,28 @@ def main():
     ascii_rows, tw, rw, text_len = device_pairs(torch, n, L, err, ratio, args.seed + 1000 * rank, device)
     row_words = tw + rw
     n_words = n * row_words
-    seq = torch.zeros(n_words + scrooge_amd.api.SEQ_PAD_WORDS, dtype=torch.int64, device=device)
+    groups = args.layout == "groups" or (args.layout == "auto" and p.lanes_per_pair == 1)
     bad = torch.zeros(1, dtype=torch.int32, device=device)
-    al.pack_planar(ascii_rows.view(-1), seq, bad)
-    torch.cuda.synchronize()
-    assert int(bad.item()) == 0
     cap = (2 * L + 8 + 15) // 16 * 16                 # runs per pair slice (genasm_gpu.cu:906-911), 32-byte pieces
     idx = torch.arange(n, dtype=torch.int64, device=device)
-    desc = torch.stack([idx * row_words * 32, torch.full_like(idx, text_len),
-                        (idx * row_words + tw) * 32, torch.full_like(idx, L),
-                        idx * cap, torch.full_like(idx, cap)], dim=1).contiguous()
+    sidx = idx * 0 if os.environ.get("SCRG_BENCH_SAMESEQ") else idx     # experiment only: every pair reads pair 0's sequences
+    if groups:
+        # lane-interleaved groups of 64 pairs: word w of pair p at ((p // 64) * row_words + w) * 64 + p % 64
+        G = scrooge_amd.api.GROUP
+        seq = torch.zeros((n + G - 1) // G * G * row_words + scrooge_amd.api.SEQ_PAD_WORDS_GROUPS, dtype=torch.int64, device=device)
+        al.pack_planar_groups(ascii_rows.view(-1), n, row_words, seq, bad)
+        first = (sidx // G) * row_words * G + sidx % G            # word index of the text's first word
+        desc = torch.stack([first * 32, torch.full_like(idx, text_len), (first + tw * G) * 32, torch.full_like(idx, L),
+                            idx * cap, torch.full_like(idx, cap)], dim=1).contiguous()
+        kw["text_stride_words"] = kw["read_stride_words"] = G
+    else:
+        seq = torch.zeros(n_words + scrooge_amd.api.SEQ_PAD_WORDS, dtype=torch.int64, device=device)
+        al.pack_planar(ascii_rows.view(-1), seq, bad)
+        desc = torch.stack([sidx * row_words * 32, torch.full_like(idx, text_len),
+                            (sidx * row_words + tw) * 32, torch.full_like(idx, L),
+                            idx * cap, torch.full_like(idx, cap)], dim=1).contiguous()
+    torch.cuda.synchronize()
+    assert int(bad.item()) == 0
     # result buffers, one set per pipeline lane (scrg_run = 2 bytes)
     outs = [dict(runs=torch.empty(n * cap * 2, dtype=torch.uint8, device=device),
                  ed=torch.empty(n, dtype=torch.int64, device=device),
@@ -205,11 +220,11 @@ def main():
     torch.cuda.synchronize()
     assert args.ablate or int(status.max().item()) == 0, "CIGAR slice overflow"
     total_runs = int(n_runs.sum().item())
-    denses = [torch.empty(total_runs * 2, dtype=torch.uint8, device=device) for _ in range(n_lanes)]
+    denses = [torch.empty(max(total_runs, 8) * 2, dtype=torch.uint8, device=device) for _ in range(n_lanes)]
     gather = None
     if world > 1:
         from scrooge_amd.distributed import ResultGather
-        gather = ResultGather(n, total_runs, device, dst=0)
+        gather = ResultGather(n, total_runs, device, dst=0, depth=max(2, n_lanes))
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(args.steps)]
@@ -249,7 +264,7 @@ def main():
             if world > 1:
                 # RCCL gather of scores + CIGAR runs to rank 0 over xGMI, double buffered: the gather of
                 # this step overlaps the next step's align kernel
-                gather.finish(j)                       # buffers of step j-2 are free again
+                gather.finish(j)                       # buffers of step j-DEPTH are free again
                 aligners[b].compact_runs(n, desc, o["runs"], o["n_runs"], dense_off, gather.send_runs[j % gather.DEPTH])
                 gather.start(j, o["ed"], o["n_runs"])
             else:
@@ -394,6 +409,7 @@ def main():
                                % (n, L, args.profile, p.W, p.O),
                    "pairs_per_gpu": n, "read_len": L, "text_len": text_len, "error_profile": args.profile,
                    "W": p.W, "O": p.O, "lanes_per_pair": p.lanes_per_pair, "lds_rows": p.lds_rows,
+                   "sequence_layout": "lane-interleaved groups of 64 pairs (scrg_pack_planar_groups)" if groups else "contiguous per sequence",
                    "launch": geom, "step": "align kernel + run compaction" + (" + RCCL gather of scores and CIGAR runs to rank 0 (double buffered, overlaps the next kernel)" if world > 1 else ""),
                    "pipeline": ("consecutive steps alternate between %d streams (own handle, work queue and output buffers each): "
                                 "a step's wavefronts start while the previous step's last pairs finish" % n_lanes) if n_lanes > 1

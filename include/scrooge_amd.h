@@ -61,6 +61,11 @@ typedef struct scrg_params {
     int32_t sort_by_length;  /* host entry points: issue pairs longest-read-first (the reference's
                                 callers do this themselves, src/tests.cu:375-377); results keep
                                 input order either way.  Default 1                                 */
+    int32_t text_stride_words; /* device-pointer entry points: distance, in 64-bit words, between consecutive
+                                words of one text in d_seq.  0 or 1 = contiguous; 64 = the lane-interleaved
+                                layout of scrg_pack_planar_groups() (see there).  Only lanes_per_pair = 1
+                                accepts a stride other than 1                                        */
+    int32_t read_stride_words; /* the same for the reads                                             */
     int32_t reserved[2];
 } scrg_params;
 
@@ -156,7 +161,22 @@ scrg_status scrg_align_mapping(scrg_ctx *ctx, const scrg_params *params,
 scrg_status scrg_pack_planar(scrg_ctx *ctx, const char *d_ascii, uint64_t n_words,
                              uint64_t *d_planar, uint32_t *d_bad_count);
 
-/* One alignment problem.  Offsets are in bases from the start of d_seq. */
+/* ASCII -> planar in the LANE-INTERLEAVED layout the one-pair-per-lane kernel reads best.  d_ascii holds
+ * n_rows rows of words_per_row*32 bytes each (zero padded, every sequence starting at a multiple of 32
+ * bytes within its row).  Rows are taken in groups of 64 (the pairs one wavefront aligns side by side):
+ * word w of row r is stored at d_planar[((r / 64) * words_per_row + w) * 64 + r % 64], so the 64 lanes of a
+ * wavefront, which walk their sequences at the same pace, read 512 contiguous bytes per load instead of 64
+ * separate cache lines.  A sequence that starts at byte 32*k of row r has
+ *     offset_in_bases = 32 * (((r / 64) * words_per_row + k) * 64 + r % 64)
+ * and a word stride of 64 (scrg_params.text_stride_words / read_stride_words).  d_planar needs
+ * ceil(n_rows / 64) * 64 * words_per_row words plus SCRG_SEQ_PAD_WORDS_STRIDED(64) readable words of padding. */
+scrg_status scrg_pack_planar_groups(scrg_ctx *ctx, const char *d_ascii, uint64_t n_rows, uint64_t words_per_row,
+                                    uint64_t *d_planar, uint32_t *d_bad_count);
+#define SCRG_SEQ_PAD_WORDS_STRIDED(stride) (2 * (stride) + 2)
+
+/* One alignment problem.  Offsets are in bases from the start of d_seq: base k of a sequence with offset
+ * `off` and word stride s lives in word (off / 32) + ((off % 32 + k) / 32) * s, bit (off + k) % 32 of each
+ * plane (a strided sequence therefore starts at a multiple of 32). */
 typedef struct scrg_pair_desc {
     uint64_t text_off;
     uint64_t text_len;

@@ -13,6 +13,6 @@ mkdir -p $root/gpurun_out/pmc_${tag}
 i=0
 for set in "$@"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set -d $root/gpurun_out/pmc_${tag}/p$i -o pmc --output-format csv -- python3 $root/bench.py --no-build --cpu-seconds 0 --steps 2 --warmup 0 $bargs > $root/gpurun_out/pmc_${tag}/p$i.log 2>&1
+  timeout 180 rocprofv3 --kernel-trace --pmc $set -d $root/gpurun_out/pmc_${tag}/p$i -o pmc --output-format csv -- python3 $root/bench.py --no-build --cpu-seconds 0 --steps 2 --warmup 0 $bargs > $root/gpurun_out/pmc_${tag}/p$i.log 2>&1
 done
 python3 $root/scripts/pmc_summary.py $root/gpurun_out/pmc_${tag}

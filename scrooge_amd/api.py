@@ -19,6 +19,8 @@ SCRG_ERR_HIP = 4
 SCRG_ERR_OOM = 5
 SCRG_ERR_CIGAR_OVERFLOW = 6
 SEQ_PAD_WORDS = 4
+GROUP = 64                     # rows per group of the lane-interleaved layout
+SEQ_PAD_WORDS_GROUPS = 2 * GROUP + 2
 
 
 class ScroogeError(RuntimeError):
@@ -30,7 +32,8 @@ class ScroogeError(RuntimeError):
 class Params(C.Structure):
     _fields_ = [("W", C.c_int32), ("O", C.c_int32), ("lanes_per_pair", C.c_int32),
                 ("lds_rows", C.c_int32), ("waves_per_cu", C.c_int32),
-                ("sort_by_length", C.c_int32), ("reserved", C.c_int32 * 2)]
+                ("sort_by_length", C.c_int32), ("text_stride_words", C.c_int32), ("read_stride_words", C.c_int32),
+                ("reserved", C.c_int32 * 2)]
 
 
 class PairDesc(C.Structure):
@@ -119,6 +122,7 @@ def load_library():
                                            C.POINTER(C.c_char_p), C.POINTER(u64), C.POINTER(u64),
                                            C.POINTER(u64), C.POINTER(C.POINTER(Result))]),
         "scrg_pack_planar": (C.c_int32, [vp, vp, u64, vp, vp]),
+        "scrg_pack_planar_groups": (C.c_int32, [vp, vp, u64, u64, vp, vp]),
         "scrg_align_device": (C.c_int32, [vp, C.POINTER(Params), u64, vp, vp, vp, vp, vp, vp]),
         "scrg_compact_runs": (C.c_int32, [vp, u64, vp, vp, vp, vp, vp]),
         "scrg_ascii_to_twobit": (C.c_int32, [vp, u64, vp, vp, vp, vp, vp, vp]),
@@ -138,7 +142,7 @@ EXPORTED_SYMBOLS = [
     "scrg_params_default", "scrg_params_resolve", "scrg_ctx_create", "scrg_ctx_destroy", "scrg_ctx_set_stream",
     "scrg_ctx_use_own_stream", "scrg_stream_create", "scrg_stream_destroy",
     "scrg_last_error", "scrg_status_string", "scrg_set_log", "scrg_device_count",
-    "scrg_result_free", "scrg_align_pairs", "scrg_align_mapping", "scrg_pack_planar",
+    "scrg_result_free", "scrg_align_pairs", "scrg_align_mapping", "scrg_pack_planar", "scrg_pack_planar_groups",
     "scrg_align_device", "scrg_compact_runs", "scrg_ascii_to_twobit", "scrg_query_launch",
     "scrg_last_kernel_ms", "scrg_debug_stats"]
 
@@ -312,6 +316,12 @@ class Aligner:
         n_words = ascii_u8.numel() // 32
         self._check(self.lib.scrg_pack_planar(self.h, _ptr(ascii_u8), n_words, _ptr(planar_u64),
                                               _ptr(bad_u32)))
+
+    def pack_planar_groups(self, ascii_u8, n_rows, words_per_row, planar_u64, bad_u32):
+        """ASCII rows -> planar 2-bit in the lane-interleaved layout (scrg_pack_planar_groups): word w of row r at
+        ((r // 64) * words_per_row + w) * 64 + r % 64; align with text_stride_words = read_stride_words = 64."""
+        self._check(self.lib.scrg_pack_planar_groups(self.h, _ptr(ascii_u8), int(n_rows), int(words_per_row),
+                                                     _ptr(planar_u64), _ptr(bad_u32)))
 
     def align_device(self, n_pairs, seq, pairs, runs, ed, n_runs, status, **kw):
         self._check(self.lib.scrg_align_device(self.h, C.byref(self._params(kw)), int(n_pairs),

@@ -96,6 +96,22 @@ __device__ __forceinline__ Planes load_window(const uint64_t* __restrict__ seq, 
     return r;
 }
 
+// The same for a sequence whose consecutive words are `stride` words apart (lane-interleaved groups,
+// scrg_pack_planar_groups): base k of the sequence at offset `off` lives in word off/32 + ((off%32 + k)/32)*stride.
+__device__ __forceinline__ Planes load_window_strided(const uint64_t* __restrict__ seq, uint64_t off, uint32_t k, uint32_t stride)
+{
+    const uint32_t inner = ((uint32_t)off & 31u) + k;
+    const uint64_t w = (off >> 5) + (uint64_t)(inner >> 5) * stride;
+    const uint32_t s = inner & 31u;
+    const uint64_t a = seq[w], b = seq[w + stride], c = seq[w + 2u * stride];
+    const uint32_t l0 = (uint32_t)a, l1 = (uint32_t)b, l2 = (uint32_t)c;
+    const uint32_t h0 = (uint32_t)(a >> 32), h1 = (uint32_t)(b >> 32), h2 = (uint32_t)(c >> 32);
+    Planes r;
+    r.lo = (uint64_t)__builtin_amdgcn_alignbit(l1, l0, s) | ((uint64_t)__builtin_amdgcn_alignbit(l2, l1, s) << 32);
+    r.hi = (uint64_t)__builtin_amdgcn_alignbit(h1, h0, s) | ((uint64_t)__builtin_amdgcn_alignbit(h2, h1, s) << 32);
+    return r;
+}
+
 // Conditions as 0 / ~0 masks.  Written as asm / intrinsics so that the optimiser cannot turn them
 // back into v_cmp + v_cndmask (both half rate on gfx950; v_ashrrev, v_sub and v_bitop3 are full rate).
 __device__ __forceinline__ uint32_t neg_mask(uint32_t x)      // ~0 iff (int32)x < 0

@@ -27,6 +27,8 @@ struct AlignArgs {
     int32_t W;
     int32_t tb_limit;             // W - O
     int32_t lds_rows;
+    uint32_t text_stride;         // words between consecutive words of a text / a read in seq (1 = contiguous;
+    uint32_t read_stride;         //   64 = lane-interleaved groups, scrg_pack_planar_groups; lane kernel only)
     uint64_t* stats;              // optional profiling counters {rounds, DC steps, TB macro-steps}; may be null
     int32_t debug;                // ablation switches for profiling only (params.reserved[0]); 0 in production
 };
@@ -67,6 +69,8 @@ SCRG_HD inline unsigned slot_stride_dwords(int W, int tb_limit, int lanes_per_pa
 }
 hipError_t launch_pack_planar(const char* d_ascii, uint64_t n_words, uint64_t* d_planar, uint32_t* d_bad,
                               int n_cus, hipStream_t s);
+hipError_t launch_pack_planar_groups(const char* d_ascii, uint64_t n_rows, uint64_t words_per_row, uint64_t* d_planar,
+                                     uint32_t* d_bad, int n_cus, hipStream_t s);
 hipError_t launch_ascii_to_twobit(uint64_t count, const uint64_t* d_lens, const uint64_t* d_ascii_off,
                                   const char* d_ascii, const uint64_t* d_twobit_off, uint8_t* d_twobit,
                                   uint32_t* d_bad, uint64_t max_len, hipStream_t s);

@@ -37,12 +37,12 @@ namespace scrg {
 constexpr int LANE_TB_COLS = 31;                 // W-O <= 31 columns can be consumed per window
 constexpr uint32_t LANE_RING_BYTES = 68;         // 32 runs + one dword: lanes land on distinct LDS banks
 constexpr uint32_t LANE_SCRATCH_BYTES = 36;      // insertion-run length of each traceback column, one byte each (+ bank skew)
+constexpr uint32_t LANE_WAVE_LDS_BYTES = 64u * (LANE_RING_BYTES + LANE_SCRATCH_BYTES);
 
 // truth tables (inputs a, b, c in that order)
-constexpr int TT_NE  = bitop3_table([](int x, int rh, int sh) { return x | (rh ^ sh); });          // not-equal mask
-constexpr int TT_XV  = bitop3_table([](int ne, int mv, int) { return ~ne | mv; });
-constexpr int TT_T   = bitop3_table([](int ne, int pv, int) { return ~ne & pv; });
-constexpr int TT_XH  = bitop3_table([](int sum, int pv, int ne) { return (sum ^ pv) | ~ne; });
+// (two-input operations are left to plain and/or/xor: 4-byte encodings, a v_bitop3_b32 takes 8)
+constexpr int TT_EQ  = bitop3_table([](int x, int rh, int sh) { return ~(x | (rh ^ sh)); });       // pattern character == text character
+constexpr int TT_XH  = bitop3_table([](int sum, int pv, int eq) { return (sum ^ pv) | eq; });
 constexpr int TT_PH  = bitop3_table([](int mv, int xh, int pv) { return mv | ~(xh | pv); });
 constexpr int TT_PVN = bitop3_table([](int mhs, int xv, int phs) { return mhs | ~(xv | phs); });
 constexpr int TT_NOR3 = bitop3_table([](int a, int b, int c) { return ~(a | b | c); });
@@ -57,9 +57,10 @@ __device__ __forceinline__ uint32_t ffbh_u32(uint32_t v)      // count leading z
     return r;
 }
 
-// GEN = false: every lane of the wave has a full window (n = m = 64).  GEN = true: any n, m <= 64 per lane
-// (window ends, W < 64): columns >= n are skipped per lane, the table is shifted left by 64-m.
-template <bool GEN>
+// SHORT_N / SHORT_M = false: every lane of the wave has a full text / pattern window (n = 64 / m = 64).
+// SHORT_M: any m <= 64 per lane (the last windows of a read, W < 64): the table is shifted left by 64-m.
+// SHORT_N: any n <= 64 per lane (the text ends inside the window): columns >= n are skipped per lane.
+template <bool SHORT_N, bool SHORT_M>
 __device__ __forceinline__ void lane_window_table(const Planes tw, const Planes pw, const uint32_t n, const uint32_t m,
                                                   const uint32_t stop, uint32_t (&nv1)[LANE_TB_COLS], uint32_t (&v0)[LANE_TB_COLS])
 {
@@ -69,14 +70,14 @@ __device__ __forceinline__ void lane_window_table(const Planes tw, const Planes 
     // whatever lies above bit m-1 never reaches the bits below it (carries and shifts only move up)
     const uint32_t sft = 64u - m;
     uint64_t rlo = brev64(pw.lo), rhi = brev64(pw.hi);
-    if (GEN) {
+    if (SHORT_M) {
         rlo >>= sft;
         rhi >>= sft;
     }
     const uint32_t rl0 = (uint32_t)rlo, rl1 = (uint32_t)(rlo >> 32), rh0 = (uint32_t)rhi, rh1 = (uint32_t)(rhi >> 32);
     const uint32_t tl0 = (uint32_t)tw.lo, tl1 = (uint32_t)(tw.lo >> 32), th0 = (uint32_t)tw.hi, th1 = (uint32_t)(tw.hi >> 32);
     uint32_t pv0 = ~0u, pv1 = ~0u, mv0 = 0u, mv1 = 0u;           // D[n][j] = m-j: every vertical step is +1
-    if (GEN) {
+    if (SHORT_N) {
 #pragma unroll
         for (int i = 0; i < LANE_TB_COLS; i++) {                      // columns >= n: only insertions (genasm_cpu.cpp:239-245)
             nv1[i] = 0u;
@@ -85,14 +86,14 @@ __device__ __forceinline__ void lane_window_table(const Planes tw, const Planes 
     }
 #pragma unroll
     for (int i = 63; i >= 0; i--) {
-        if (!GEN || (uint32_t)i < n) {
+        if (!SHORT_N || (uint32_t)i < n) {
             const uint32_t sl = (uint32_t)__builtin_amdgcn_sbfe((int)(i < 32 ? tl0 : tl1), i & 31, 1);
             const uint32_t sh = (uint32_t)__builtin_amdgcn_sbfe((int)(i < 32 ? th0 : th1), i & 31, 1);
-            const uint32_t ne0 = bitop3<TT_NE>(rl0 ^ sl, rh0, sh), ne1 = bitop3<TT_NE>(rl1 ^ sl, rh1, sh);
-            const uint32_t xv0 = bitop3<TT_XV>(ne0, mv0, mv0), xv1 = bitop3<TT_XV>(ne1, mv1, mv1);
-            const uint32_t t0 = bitop3<TT_T>(ne0, pv0, pv0), t1 = bitop3<TT_T>(ne1, pv1, pv1);
+            const uint32_t eq0 = bitop3<TT_EQ>(rl0 ^ sl, rh0, sh), eq1 = bitop3<TT_EQ>(rl1 ^ sl, rh1, sh);
+            const uint32_t xv0 = eq0 | mv0, xv1 = eq1 | mv1;
+            const uint32_t t0 = eq0 & pv0, t1 = eq1 & pv1;
             const uint64_t sum = add64(((uint64_t)t1 << 32) | t0, ((uint64_t)pv1 << 32) | pv0);
-            const uint32_t xh0 = bitop3<TT_XH>((uint32_t)sum, pv0, ne0), xh1 = bitop3<TT_XH>((uint32_t)(sum >> 32), pv1, ne1);
+            const uint32_t xh0 = bitop3<TT_XH>((uint32_t)sum, pv0, eq0), xh1 = bitop3<TT_XH>((uint32_t)(sum >> 32), pv1, eq1);
             const uint32_t ph0 = bitop3<TT_PH>(mv0, xh0, pv0), ph1 = bitop3<TT_PH>(mv1, xh1, pv1);
             const uint32_t mh0 = pv0 & xh0, mh1 = pv1 & xh1;
             const uint64_t phs = shl1(((uint64_t)ph1 << 32) | ph0);       // row 0 of the matrix is all zeros: 0 comes in
@@ -102,7 +103,7 @@ __device__ __forceinline__ void lane_window_table(const Planes tw, const Planes 
             mv0 = (uint32_t)phs & xv0;
             mv1 = (uint32_t)(phs >> 32) & xv1;
             if (i < LANE_TB_COLS) {
-                if (GEN) {
+                if (SHORT_M) {
                     const uint64_t a = ((uint64_t)(pv1 | ph1) << 32) | (pv0 | ph0);
                     const uint64_t b = ((uint64_t)bitop3<TT_V0>(pv1, ph1, xh1) << 32) | bitop3<TT_V0>(pv0, ph0, xh0);
                     nv1[i] = ~((uint32_t)((a << sft) >> 32) | stop);
@@ -116,14 +117,18 @@ __device__ __forceinline__ void lane_window_table(const Planes tw, const Planes 
     }
 }
 
-__global__ __launch_bounds__(64, 3) void genasm_lane_kernel(AlignArgs a)
+// Workgroups are four independent wavefronts (nothing is shared, there is no barrier): the four land on the four
+// SIMDs of one CU, so a partly filled GPU has the same number of wavefronts on every SIMD of a CU.  (Single-wave
+// workgroups were placed unevenly — 3072 of them ran no faster than 4096.)
+__global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     char* const lds_b = reinterpret_cast<char*>(lds);
 
-    const uint32_t lane = threadIdx.x;
-    const uint32_t ring_b = lane * LANE_RING_BYTES;
-    const uint32_t scr_b = 64u * LANE_RING_BYTES + lane * LANE_SCRATCH_BYTES;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave_b = (threadIdx.x >> 6) * LANE_WAVE_LDS_BYTES;      // my wavefront's part of the workgroup's LDS
+    const uint32_t ring_b = wave_b + lane * LANE_RING_BYTES;
+    const uint32_t scr_b = wave_b + 64u * LANE_RING_BYTES + lane * LANE_SCRATCH_BYTES;
     uint8_t* const lds8 = reinterpret_cast<uint8_t*>(lds);
     const uint32_t W = (uint32_t)a.W;
     const uint32_t TBL = (uint32_t)a.tb_limit;         // W - O, 1..31
@@ -138,8 +143,9 @@ __global__ __launch_bounds__(64, 3) void genasm_lane_kernel(AlignArgs a)
     uint32_t flushed = 0;              // runs below this index are in HBM (a multiple of 16)
     bool queue_empty = false;          // wave-uniform
     const bool timing = a.stats != nullptr;
-    uint64_t cy_fetch = 0, cy_setup = 0, cy_dc = 0, cy_tb = 0;
+    uint64_t cy_fetch = 0, cy_setup = 0, cy_dc = 0, cy_tb = 0, cy_p1 = 0;
     uint32_t st_rounds = 0, st_gen = 0;
+    const uint64_t rt0 = timing ? __builtin_amdgcn_s_memrealtime() : 0;      // 100 MHz wall clock: wavefront start
 
     // one 16-run piece of my ring -> my slice (two 16-byte stores); pieces past the slice's capacity are dropped
     auto write_piece = [&]() {
@@ -147,7 +153,7 @@ __global__ __launch_bounds__(64, 3) void genasm_lane_kernel(AlignArgs a)
         uint32_t w[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) w[k] = lds[rd + k];
-        if (flushed + 16u <= cigar_cap) {
+        if (flushed + 16u <= cigar_cap && !(a.debug & 16)) {          // (16: ablation, profiling only: no stores)
             uint4* const dst = reinterpret_cast<uint4*>(a.runs + cigar_off + flushed);
             dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
             dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
@@ -163,7 +169,20 @@ __global__ __launch_bounds__(64, 3) void genasm_lane_kernel(AlignArgs a)
         }
     };
 
+    // hardware wave slot on my SIMD (HW_ID bits 3:0)
+    const uint32_t wave_slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);
     for (;;) {
+        // The SIMD's arbiter issues oldest-wave-first: left alone, the first wavefront on a SIMD runs at the speed
+        // of a lone wave and the last one finishes 2.7x later, with the SIMD half idle at the end of a launch.
+        // Rotating the priorities (a different wave slot is on top every 2^15 cycles, about one round) lets the
+        // wavefronts of a SIMD progress, and finish, together.
+        if (!(a.debug & 1)) {
+            const uint32_t pr = ((uint32_t)(__builtin_readcyclecounter() >> 15) + wave_slot) & 3u;
+            if (pr == 0) __builtin_amdgcn_s_setprio(0);
+            else if (pr == 1) __builtin_amdgcn_s_setprio(1);
+            else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+            else __builtin_amdgcn_s_setprio(3);
+        }
         const uint64_t tm0 = timing ? __builtin_readcyclecounter() : 0;
         // ---------------- retire finished pairs, fetch new ones (genasm_cpu.cpp:440-460) ----------------
         for (;;) {
@@ -217,8 +236,8 @@ __global__ __launch_bounds__(64, 3) void genasm_lane_kernel(AlignArgs a)
         const uint32_t m = has_pair ? min(W, read_len - read_idx) : 1u;      // >= 1 for live pairs
         Planes tw = {0, 0}, pw = {0, 0};
         if (has_pair) {
-            tw = load_window(a.seq, text_off + ref_idx);
-            pw = load_window(a.seq, read_off + read_idx);
+            tw = load_window_strided(a.seq, text_off, ref_idx, a.text_stride);
+            pw = load_window_strided(a.seq, read_off, read_idx, a.read_stride);
         }
         const uint64_t tm2 = timing ? __builtin_readcyclecounter() : 0;
 
@@ -226,12 +245,21 @@ __global__ __launch_bounds__(64, 3) void genasm_lane_kernel(AlignArgs a)
         uint32_t nv1[LANE_TB_COLS], v0[LANE_TB_COLS];
         const uint32_t jlim = has_pair ? min(m, TBL) : 0u;          // the walk ends when j gets here (:301, :310)
         const uint32_t stop = 0x80000000u >> jlim;
-        const bool general = __any(has_pair && (n != 64u || m != 64u));
-        if (general) {
-            lane_window_table<true>(tw, pw, n, m, stop, nv1, v0);
+        const bool short_n = __any(has_pair && n != 64u), short_m = __any(has_pair && m != 64u);
+        if (a.debug & 2) {                       // ablation (profiling only): no table computation
+#pragma unroll
+            for (int i = 0; i < LANE_TB_COLS; i++) {
+                nv1[i] = ~stop;
+                v0[i] = (uint32_t)tw.lo * (uint32_t)(i + 1);
+            }
+        } else if (short_n) {
+            lane_window_table<true, true>(tw, pw, n, m, stop, nv1, v0);
+            st_gen++;
+        } else if (short_m) {
+            lane_window_table<false, true>(tw, pw, n, m, stop, nv1, v0);
             st_gen++;
         } else {
-            lane_window_table<false>(tw, pw, n, m, stop, nv1, v0);
+            lane_window_table<false, false>(tw, pw, n, m, stop, nv1, v0);
         }
         const uint64_t tm3 = timing ? __builtin_readcyclecounter() : 0;
 
@@ -270,8 +298,10 @@ __global__ __launch_bounds__(64, 3) void genasm_lane_kernel(AlignArgs a)
                     asm("v_add_co_u32 %1, vcc, %2, %2\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(j), "=&v"(scratch) : "v"(nt1) : "vcc");
                 }
             };
-            if (TBL == (uint32_t)LANE_TB_COLS) walk(std::true_type{});
+            if (a.debug & 8) { j = jlim; ti = jlim; }                    // ablation (profiling only): no walk
+            else if (TBL == (uint32_t)LANE_TB_COLS) walk(std::true_type{});
             else walk(std::false_type{});
+            if (timing) cy_p1 += __builtin_readcyclecounter() - tm3;
             // column i -> bit 31-i; only the ti columns the lane was alive in count (insertion runs are exact as recorded)
             const uint32_t nsh = 32u - min(TBL, (uint32_t)LANE_TB_COLS);
             const uint32_t A = ~(0xffffffffu >> ti);
@@ -287,7 +317,7 @@ __global__ __launch_bounds__(64, 3) void genasm_lane_kernel(AlignArgs a)
             // there.  Both words go to the slot after the last committed run; only committing moves on.  (A lane
             // that is done computes garbage from column "31", which no mask ever has.)  The length byte of the
             // next insertion run is read one iteration ahead.
-            uint32_t E = B | Im;
+            uint32_t E = (a.debug & 4) ? 0u : (B | Im);                  // (ablation, profiling only: no runs)
             uint32_t c = ffbh_u32(E);
             uint32_t ni = lds8[scr_b + c];
             uint32_t nr2 = 2u * (uint32_t)nr;          // byte offset of the last committed run
@@ -326,16 +356,25 @@ __global__ __launch_bounds__(64, 3) void genasm_lane_kernel(AlignArgs a)
     if (a.stats && lane == 0) {
         atomicAdd((unsigned long long*)&a.stats[0], (unsigned long long)st_rounds);
         atomicAdd((unsigned long long*)&a.stats[1], (unsigned long long)st_gen);
+        atomicAdd((unsigned long long*)&a.stats[2], (unsigned long long)cy_p1);
         atomicAdd((unsigned long long*)&a.stats[3], (unsigned long long)cy_fetch);
         atomicAdd((unsigned long long*)&a.stats[4], (unsigned long long)cy_setup);
         atomicAdd((unsigned long long*)&a.stats[5], (unsigned long long)cy_dc);
         atomicAdd((unsigned long long*)&a.stats[6], (unsigned long long)cy_tb);
+        // wavefront life times on the 100 MHz wall clock: sum, latest start, earliest start (as 2^62 - t), latest end
+        const uint64_t rt1 = __builtin_amdgcn_s_memrealtime();
+        atomicAdd((unsigned long long*)&a.stats[7], (unsigned long long)(rt1 - rt0));
+        atomicMax((unsigned long long*)&a.stats[8], (unsigned long long)rt0);
+        atomicMax((unsigned long long*)&a.stats[9], (unsigned long long)((1ull << 62) - rt0));
+        atomicMax((unsigned long long*)&a.stats[10], (unsigned long long)rt1);
+        atomicMax((unsigned long long*)&a.stats[11], (unsigned long long)((1ull << 62) - rt1));
     }
 }
 
 hipError_t launch_align_lane(const AlignArgs& a, int grid, size_t lds_bytes, hipStream_t s)
 {
-    hipLaunchKernelGGL(genasm_lane_kernel, dim3(grid), dim3(64), lds_bytes, s, a);
+    // grid counts wavefronts, lds_bytes is per wavefront
+    hipLaunchKernelGGL(genasm_lane_kernel, dim3((grid + 3) / 4), dim3(256), 4 * lds_bytes, s, a);
     return hipGetLastError();
 }
 

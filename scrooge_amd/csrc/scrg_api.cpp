@@ -277,9 +277,14 @@ static bool resolve_params(const scrg_params* in, scrg_params* p)
         p->lds_rows = in->lds_rows;
         p->waves_per_cu = in->waves_per_cu;
         p->sort_by_length = in->sort_by_length;
+        p->text_stride_words = in->text_stride_words;
+        p->read_stride_words = in->read_stride_words;
         p->reserved[0] = in->reserved[0];      // ablation switches and profiling counters travel with the parameters
         p->reserved[1] = in->reserved[1];
     }
+    if (p->text_stride_words == 0) p->text_stride_words = 1;
+    if (p->read_stride_words == 0) p->read_stride_words = 1;
+    if (p->text_stride_words < 1 || p->read_stride_words < 1) return false;
     if (p->W < 2 || p->W > 256) return false;
     const int tbl = p->W - p->O;
     if (tbl < 1 || p->O < 1) return false;   // O = 0 (no overlap) would let the traceback read the boundary column
@@ -305,6 +310,7 @@ static bool resolve_params(const scrg_params* in, scrg_params* p)
     if (p->waves_per_cu == 0) p->waves_per_cu = p->lanes_per_pair == 1 ? 16 : 11;
     const int g = p->lanes_per_pair;
     if (g == 1) return p->waves_per_cu >= 1 && p->waves_per_cu <= 32;      // no table in LDS: lds_rows is not used
+    if (p->text_stride_words != 1 || p->read_stride_words != 1) return false;   // strided sequences: lane kernel only
     if (!(g == 4 || g == 8 || g == 16 || g == 32 || g == 64)) return false;
     if (p->lds_rows < 1) return false;
     if (p->lds_rows > p->W + 1) p->lds_rows = p->W + 1;
@@ -361,6 +367,15 @@ scrg_status scrg_pack_planar(scrg_ctx* c, const char* d_ascii, uint64_t n_words,
     return SCRG_OK;
 }
 
+scrg_status scrg_pack_planar_groups(scrg_ctx* c, const char* d_ascii, uint64_t n_rows, uint64_t words_per_row,
+                                    uint64_t* d_planar, uint32_t* d_bad_count)
+{
+    if (!c || (n_rows && words_per_row && (!d_ascii || !d_planar)) || !d_bad_count) return SCRG_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, scrg::launch_pack_planar_groups(d_ascii, n_rows, words_per_row, d_planar, d_bad_count, c->n_cus, c->stream));
+    return SCRG_OK;
+}
+
 scrg_status scrg_align_device(scrg_ctx* c, const scrg_params* params, uint64_t n_pairs, const uint64_t* d_seq,
                               const scrg_pair_desc* d_pairs, scrg_run* d_runs, int64_t* d_edit_distance,
                               uint32_t* d_n_runs, uint32_t* d_pair_status)
@@ -401,6 +416,8 @@ scrg_status scrg_align_device(scrg_ctx* c, const scrg_params* params, uint64_t n
     a.W = p.W;
     a.tb_limit = p.W - p.O;
     a.lds_rows = p.lds_rows;
+    a.text_stride = (uint32_t)p.text_stride_words;
+    a.read_stride = (uint32_t)p.read_stride_words;
     a.debug = params ? params->reserved[0] : 0;
     a.stats = nullptr;
     if (params && params->reserved[1]) {
@@ -626,7 +643,9 @@ scrg_status run_batch(scrg_ctx* c, const scrg_params& p, std::vector<SeqRef>& se
 
     mark("descriptors (sort, build, H2D)");
     // ---- the timed region of the reference: kernel + sync (genasm_gpu.cu:939-944) ----
-    scrg_status s = scrg_align_device(c, &p, n, c->d_seq.as<uint64_t>(), c->d_pairs.as<scrg_pair_desc>(),
+    scrg_params pd = p;                   // this path packs contiguously, whatever the caller's device-layout strides say
+    pd.text_stride_words = pd.read_stride_words = 1;
+    scrg_status s = scrg_align_device(c, &pd, n, c->d_seq.as<uint64_t>(), c->d_pairs.as<scrg_pair_desc>(),
                                       c->d_runs.as<scrg_run>(), c->d_ed.as<int64_t>(), c->d_nruns.as<uint32_t>(),
                                       c->d_status.as<uint32_t>());
     if (s != SCRG_OK) return bail(s);

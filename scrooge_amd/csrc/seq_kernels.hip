@@ -53,6 +53,38 @@ __global__ __launch_bounds__(256) void pack_planar_kernel(const uint4* __restric
     if (bad) atomicAdd(bad_count, bad);
 }
 
+// The same packing into the lane-interleaved layout (scrg_pack_planar_groups): consecutive threads produce
+// consecutive OUTPUT words, i.e. the same word of 64 consecutive rows — 512 B contiguous per wave on the
+// write side, one 32-byte piece per thread on the read side.
+__global__ __launch_bounds__(256) void pack_planar_groups_kernel(const uint4* __restrict__ ascii, uint64_t n_rows,
+                                                                 uint64_t words_per_row, uint64_t* __restrict__ planar,
+                                                                 uint32_t* __restrict__ bad_count)
+{
+    uint32_t bad = 0;
+    const uint64_t n_out = ((n_rows + 63) / 64) * 64 * words_per_row;
+    for (uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; o < n_out; o += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t lane = o & 63, gw = o >> 6;                 // gw = group * words_per_row + w
+        const uint64_t row = (gw / words_per_row) * 64 + lane, w = gw % words_per_row;
+        uint64_t out = 0;
+        if (row < n_rows) {
+            const uint64_t q = row * words_per_row + w;
+            const uint4 q0 = ascii[2 * q], q1 = ascii[2 * q + 1];
+            const uint32_t v[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+            uint32_t lo = 0, hi = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                uint32_t l, h;
+                pack4(v[k], l, h, bad);
+                lo |= l << (4 * k);
+                hi |= h << (4 * k);
+            }
+            out = ((uint64_t)hi << 32) | lo;
+        }
+        planar[o] = out;
+    }
+    if (bad) atomicAdd(bad_count, bad);
+}
+
 // ----------------------------------------------------------------------------
 // Reference-layout packer (src/genasm_gpu.cu:631-685): 4 bases per byte, the
 // first base of each quad in bits 7..6; one thread per output byte, strings
@@ -165,6 +197,19 @@ hipError_t launch_pack_planar(const char* d_ascii, uint64_t n_words, uint64_t* d
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(pack_planar_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
                        reinterpret_cast<const uint4*>(d_ascii), n_words, d_planar, d_bad);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_planar_groups(const char* d_ascii, uint64_t n_rows, uint64_t words_per_row, uint64_t* d_planar,
+                                     uint32_t* d_bad, int n_cus, hipStream_t s)
+{
+    const uint64_t n_out = ((n_rows + 63) / 64) * 64 * words_per_row;
+    if (n_out == 0) return hipSuccess;
+    uint64_t blocks = (n_out + 255) / 256;
+    const uint64_t cap = (uint64_t)n_cus * 32;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(pack_planar_groups_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
+                       reinterpret_cast<const uint4*>(d_ascii), n_rows, words_per_row, d_planar, d_bad);
     return hipGetLastError();
 }
 

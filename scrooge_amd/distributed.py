@@ -98,8 +98,10 @@ class ResultGather:
 
     DEPTH = 2
 
-    def __init__(self, n_pairs, total_runs, device, dst=0, group=None):
+    def __init__(self, n_pairs, total_runs, device, dst=0, group=None, depth=None):
         self.group, self.dst = group, dst
+        if depth is not None:
+            self.DEPTH = max(1, int(depth))        # buffers in flight: one per pipelined step
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         t = torch.tensor([int(total_runs)], dtype=torch.int64, device=device)

@@ -18,7 +18,8 @@
  *     V0 = Pv' | ~(Ph | Xh)  "insertion or substitution"        (both set = insertion)
  * left-aligned so that bit 31-j belongs to pattern character j (the DENT word, :200-208).
  * The traceback is column-synchronous: in column i the run of insertions is one count-leading-zeros
- * over V1 & V0, then one D / X / = step moves to column i+1.
+ * over V1 & V0, then one D / X / = step moves to column i+1 (lane_tb below restates the kernel's two passes).
+ * For W-O > 31 (not served by the lane kernel) lane_tb_wide walks the same table cell by cell.
  */
 #include "../../oracle/genasm_oracle.c"
 
@@ -66,19 +67,63 @@ static void lane_dc(const uint8_t *t, int n, const uint8_t *q, int m, int TBL, u
     }
 }
 
-static int lp_clz64(uint64_t v) { return v ? __builtin_clzll(v) : 64; }
+static unsigned lp_ffbh32(uint32_t v) { return v ? (unsigned)__builtin_clz(v) : 0xffffffffu; }   /* v_ffbh_u32 */
+static uint32_t lp_alignbit(uint32_t hi, uint32_t lo, unsigned s) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> s); }
 
+/* The kernel's traceback (W-O <= 31), restated step by step: pass 1 walks the columns and records the path in
+ * three masks + one byte per column, pass 2 turns the masks into runs.  nv1[i] = ~(V1 | stop), v0[i] = V0 (high
+ * dwords: bit 31-j <-> pattern character j); stop has the bit of row jlim. */
 static int lane_tb(const uint64_t *V1, const uint64_t *V0, int m, int TBL, size_t *tu, size_t *pu, run_sink *out, lane_stats *ls)
 {
-    const int jlim = m < TBL ? m : TBL;            /* j < m && j < W-O, genasm_cpu.cpp:307-310 */
+    const uint32_t jlim = (uint32_t)(m < TBL ? m : TBL);    /* j < m && j < W-O, genasm_cpu.cpp:307-310 */
+    const uint32_t stop = 0x80000000u >> jlim;
+    uint32_t j = 0, ti = 0, nDm = 0, Xm = 0, nIm = 0;
+    uint8_t ilen[32];
+    for (int i = 0; i < TBL; i++) {
+        const uint32_t nv1 = ~((uint32_t)(V1[i] >> 32) | stop), v0 = (uint32_t)(V0[i] >> 32);
+        const uint32_t x = (nv1 | ~v0 | stop) << j;             /* not (insertion), or the stop row */
+        const uint32_t ni = lp_ffbh32(x);
+        ilen[i] = (uint8_t)ni;
+        nIm = lp_alignbit(nIm, x, 31);
+        j += ni;
+        ti += j < jlim;
+        const uint32_t nt1 = nv1 << j, t0 = v0 << j;
+        nDm = lp_alignbit(nDm, nt1, 31);
+        Xm = lp_alignbit(Xm, t0, 31);
+        j += nt1 >> 31;                                         /* a deletion (or the stop row) keeps j */
+        ls->tb_columns++;
+    }
+    const unsigned nsh = 32u - (unsigned)TBL;
+    const uint32_t A = ti ? ~(0xffffffffu >> ti) : 0u;
+    const uint32_t D = ~(nDm << nsh) & A, X = (Xm << nsh) & A, Im = ~nIm << nsh;
+    const uint32_t B = ((D ^ (D >> 1)) | (X ^ (X >> 1)) | Im | 0x80000000u) & A;
+    const int edits = (int)(j - ti + 2u * (unsigned)__builtin_popcount(D) + (unsigned)__builtin_popcount(X));
+    uint32_t E = B | Im;
+    while (E) {
+        const unsigned c = lp_ffbh32(E);
+        const uint32_t bit = 0x80000000u >> c;
+        if (Im & bit) sink_push(out, 'I', ilen[c]);
+        E &= ~bit;
+        unsigned nx = lp_ffbh32(E);
+        if (nx > ti) nx = ti;
+        if (B & bit) sink_push(out, (D & bit) ? 'D' : ((X & bit) ? 'X' : '='), nx - c);
+    }
+    *tu = ti; *pu = j;
+    return edits;
+}
+
+static int lp_clz64(uint64_t v) { return v ? __builtin_clzll(v) : 64; }
+
+static int lane_tb_wide(const uint64_t *V1, const uint64_t *V0, int m, int TBL, size_t *tu, size_t *pu, run_sink *out, lane_stats *ls)
+{
+    const int jlim = m < TBL ? m : TBL;
     int i = 0, j = 0, edits = 0;
-    /* the run in progress is (cur_op, cur_len); a window never merges with its neighbours (:400-403) */
     char cur = 0; unsigned cur_len = 0;
 #define LP_EVENT(op_, n_) do { if (cur == (op_)) cur_len += (n_); else { if (cur_len) sink_push(out, cur, cur_len); cur = (op_); cur_len = (n_); } } while (0)
     for (i = 0; i < TBL && j < jlim; i++) {
         ls->tb_columns++;
         const uint64_t Iv = V1[i] & V0[i];
-        int r = lp_clz64(~(Iv << j));               /* insertions in a row from (i, j) */
+        int r = lp_clz64(~(Iv << j));
         int ni = r < jlim - j ? r : jlim - j;
         if (ni) { LP_EVENT('I', (unsigned)ni); j += ni; edits += ni; }
         if (j >= jlim) break;
@@ -87,7 +132,6 @@ static int lane_tb(const uint64_t *V1, const uint64_t *V0, int m, int TBL, size_
         else if (c0) { LP_EVENT('X', 1u); j++; edits++; }
         else { LP_EVENT('=', 1u); j++; }
     }
-    /* (the loop's i++ after a D/X/= step is the text character that step consumed) */
     if (cur_len) sink_push(out, cur, cur_len);
     *tu = (size_t)i; *pu = (size_t)j;
     return edits;
@@ -106,7 +150,7 @@ int lane_align_codes(const uint8_t *text, size_t text_len, const uint8_t *read, 
         size_t m = read_len - ri < (size_t)W ? read_len - ri : (size_t)W;
         size_t tu, pu;
         lane_dc(text + ti, (int)n, read + ri, (int)m, TBL, V1, V0, ls);
-        total += lane_tb(V1, V0, (int)m, TBL, &tu, &pu, &out, ls);
+        total += (TBL <= 31 ? lane_tb : lane_tb_wide)(V1, V0, (int)m, TBL, &tu, &pu, &out, ls);
         ls->windows++;
         ti += tu; ri += pu;
     }

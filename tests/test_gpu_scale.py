@@ -20,8 +20,9 @@ def test_many_distinct_pairs_fill_every_wave(aligner, oracle):
     (this is the regime where an LDS/flat ordering bug once hid from the small tests)."""
     t, q = synth.make_pairs(30000, 600, "ont", seed=77)
     eds, cigars, _, _ = oracle.align(t, q, threads=16)
-    _same(aligner.align_pairs(t, q), eds, cigars)
-    _same(aligner.align_pairs(t, q, lds_rows=4), eds, cigars)        # heavy HBM spill of R rows
+    _same(aligner.align_pairs(t, q), eds, cigars)                                # one pair per lane (the default)
+    _same(aligner.align_pairs(t, q, lanes_per_pair=8), eds, cigars)
+    _same(aligner.align_pairs(t, q, lanes_per_pair=8, lds_rows=4), eds, cigars)  # heavy HBM spill of R rows
 
 
 def test_config1_illumina_150bp(aligner, oracle):
@@ -62,6 +63,7 @@ def test_config5_long_noisy_reads(aligner, oracle):
     t, q = synth.make_pairs(24, 50000, "pacbio15", seed=50)
     eds, cigars, st, _ = oracle.align(t, q, threads=16)
     _same(aligner.align_pairs(t, q), eds, cigars)
+    _same(aligner.align_pairs(t, q, lanes_per_pair=8), eds, cigars)
     _same(aligner.align_pairs(t, q, lanes_per_pair=64), eds, cigars)
     assert st["windows"] / 24 > 1500
 
@@ -164,7 +166,7 @@ def test_extreme_inputs(aligner, oracle):
          b"CA" * 1500, big_q[0], b"g" * 700]
     eds, cigars, st, _ = oracle.align(T, Q, threads=8)
     assert eds[0] == 5000 and eds[2] == 5000 and eds[3] == 0
-    for g, rows in [(8, 13), (8, 2), (64, 13), (16, 5)]:
+    for g, rows in [(1, 0), (8, 13), (8, 2), (64, 13), (16, 5)]:
         _same(aligner.align_pairs(T, Q, lanes_per_pair=g, lds_rows=rows), eds, cigars)
 
 
@@ -240,9 +242,10 @@ def test_bench_two_ranks_dry_run():
 
 def test_full_bench_size_two_algorithms_agree(aligner):
     """BASELINE configs[1] at full size (100k x 10 kb ONT-error pairs, generated on the GPU like bench.py):
-    the diagonal-major and the column-major window paths are two independent formulations of the same table;
-    every edit distance, run count and run must be identical between them, the edit distances must respect
-    the read length and error rate, and 500 sampled pairs must validate against their sequences."""
+    the lane-per-pair kernel (difference vectors, the default) and the diagonal-major and column-major window
+    paths of the G = 8 kernel (GenASM rows) are three independent formulations of the same table; every edit
+    distance, run count and run must be identical between them, the edit distances must respect the read
+    length and error rate, and 500 sampled pairs must validate against their sequences."""
     import torch
     import bench
     import scrooge_amd
@@ -263,8 +266,8 @@ def test_full_bench_size_two_algorithms_agree(aligner):
         desc = torch.stack([idx * (tw + rw) * 32, torch.full_like(idx, text_len), (idx * (tw + rw) + tw) * 32,
                             torch.full_like(idx, L), idx * cap, torch.full_like(idx, cap)], dim=1).contiguous()
         res = []
-        for flags in (0, 32):                                   # 32: diagonal path off
-            p = aligner.make_params()
+        for lanes, flags in ((1, 0), (8, 0), (8, 32)):           # 32: diagonal path off
+            p = aligner.make_params(lanes_per_pair=lanes)
             p.reserved[0] = flags
             keep, aligner.params = aligner.params, p
             try:
@@ -285,9 +288,10 @@ def test_full_bench_size_two_algorithms_agree(aligner):
         assert int(bad.item()) == 0
     finally:
         aligner.use_own_stream()
-    (ed0, nr0, st0, d0, off0), (ed1, nr1, st1, d1, _) = res
-    assert int(st0.max()) == 0 and int(st1.max()) == 0
-    assert torch.equal(ed0, ed1) and torch.equal(nr0, nr1) and torch.equal(d0, d1)
+    (ed0, nr0, st0, d0, off0) = res[0]
+    for (ed1, nr1, st1, d1, _) in res[1:]:
+        assert int(st0.max()) == 0 and int(st1.max()) == 0
+        assert torch.equal(ed0, ed1) and torch.equal(nr0, nr1) and torch.equal(d0, d1)
     # ~10 % of 10 kb on average (the greedy windows lose the diagonal in a few pairs, here as in the reference,
     # so there is no useful bound on the maximum)
     assert 700 < float(ed0.double().mean()) < 1300 and float((ed0 > 2000).double().mean()) < 0.01
