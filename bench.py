@@ -27,6 +27,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: HBM3E 8 TB/s
 VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9   # 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6 T int32 lane-ops/s
+VALU_INSTR_PER_ROUND = 2440                 # lane kernel, SQ_INSTS_VALU per window round (overridden by profiles/r02_pmc_sq_summary.json)
 
 
 def parse():
@@ -340,7 +341,7 @@ def main():
     runs_per_pair = total_runs / n
     # CPU leg: bounded sample, also the source of dc_cells / text_used per pair and a parity check
     cpu = None
-    dc_cells = tb_steps = text_used = None
+    dc_cells = tb_steps = text_used = windows = None
     parity = None
     if sample_rows is not None:
         from oracle.pyoracle import Oracle, Reference
@@ -352,6 +353,7 @@ def main():
         cal = min(sample_cap, max(2 * cores, 16))
         _, _, st, ns = orc.align(texts_all[:cal], reads_all[:cal], threads=cores)
         dc_cells, tb_steps, text_used = (st["dc_cells"] / cal, st["tb_steps"] / cal, st["text_used"] / cal)
+        windows = st["windows"] / cal
         rate = cal / (ns * 1e-9)
         m = int(min(sample_cap, max(cal, rate * args.cpu_seconds)))
         use_ref = Reference.available()
@@ -414,28 +416,52 @@ def main():
                    "pipeline": ("consecutive steps alternate between %d streams (own handle, work queue and output buffers each): "
                                 "a step's wavefronts start while the previous step's last pairs finish" % n_lanes) if n_lanes > 1
                                else "one stream: a step starts after the previous one has finished"},
-        "gcups": value * L * L / 1e9,
+        "gcups": value * L * L / 1e9,           # EQUIVALENT full-matrix GCUPS (pairs/s x L x L, the reference's convention, scripts/profile.py:426-427)
+        "gcups_note": "equivalent full L x L matrix cells (the reference's convention); the cells the windowed algorithm really computes are in bit_cell_gcups",
         "kernel_ms": kernel_ms,        # HIP events around one align launch that has the GPU to itself
         "kernel_pairs_per_s_per_gpu": n / (kernel_ms * 1e-3),
         "kernel_ms_events_in_timed_region": events_ms,   # pipelined launches: includes waiting for the previous launch's wavefronts to retire
         "serial": serial,              # the same step without overlap between launches, measured after the timed region
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "genasm_align_kernel<%d, false>" % p.lanes_per_pair,
+                     "kernel": "genasm_lane_kernel" if p.lanes_per_pair == 1 else "genasm_align_kernel<%d, false>" % p.lanes_per_pair,
                      "algorithmic_bytes_per_pair": bytes_per_pair,
-                     "note": "path is VALU/LDS-bound, not HBM-bound (SURVEY.md §8d); see 'valu'.  'achieved' divides by "
+                     "note": "path is VALU-issue-bound, not HBM-bound (SURVEY.md §8d); see 'valu'.  'achieved' divides by "
                              "kernel_ms" + (", the duration of a launch that has the GPU to itself" if serial is not None else "")},
         "cpu_baseline": cpu,
         "parity": parity,
         "gen_seconds": gen_s,
     }
     if dc_cells is not None:
-        lane_ops = 14 * dc_cells      # 7 64-bit logic ops per DC cell = 14 int32 lane-ops (genasm_cpu.cpp:247-251)
-        out["valu"] = {"algorithmic_lane_ops_per_pair": lane_ops, "dc_cells_per_pair": dc_cells,
-                       "tb_steps_per_pair": tb_steps,
-                       "achieved": lane_ops * value / world, "peak": VALU_PEAK_LANE_OPS,
-                       "frac": lane_ops * value / world / VALU_PEAK_LANE_OPS, "unit": "int32 lane-ops/s",
-                       "note": "per GPU, from the whole-step rate"}
+        ref_ops = 14 * dc_cells       # 7 64-bit logic ops per GenASM-DC cell = 14 int32 lane-ops (genasm_cpu.cpp:247-251)
+        if p.lanes_per_pair == 1:
+            # The lane kernel does not run the GenASM rows: per window it issues 64 text columns x 23 VALU
+            # instructions for the table (all 64 pattern rows, every distance at once), and the traceback, setup and
+            # queue code around it.  The instruction count per window round (one window of each of a wavefront's 64
+            # pairs) is measured: SQ_INSTS_VALU / rounds in profiles/ (rocprofv3 --pmc); a lane-op = one lane of one
+            # wave64 VALU instruction.  Peak = 1024 SIMDs x 32 lanes/cycle x 2.4 GHz (full-rate ops; the mix here has
+            # ~25 % half-rate ops and the chip runs this kernel at ~2.0 GHz).
+            instr = VALU_INSTR_PER_ROUND
+            try:
+                pj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_sq_summary.json")))
+                instr = pj.get("valu_instructions_per_window_round", instr)
+            except Exception:
+                pass
+            lane_ops = instr * windows      # per pair: one lane's share of every instruction of its windows' rounds
+            out["valu"] = {"issued_lane_ops_per_pair": lane_ops, "valu_instructions_per_window_round": instr,
+                           "windows_per_pair": windows, "achieved": lane_ops * value / world, "peak": VALU_PEAK_LANE_OPS,
+                           "frac": lane_ops * value / world / VALU_PEAK_LANE_OPS, "unit": "int32 lane-ops/s",
+                           "reference_formulation_lane_ops_per_pair": ref_ops,
+                           "reference_formulation_equivalent_rate": ref_ops * value / world,
+                           "dc_cells_per_pair": dc_cells, "tb_steps_per_pair": tb_steps,
+                           "note": "per GPU, from the whole-step rate; 'reference_formulation_*' prices the same pairs at the 14 "
+                                   "lane-ops per R[i][d] cell of genasm_cpu.cpp:247-251 (what round 1's kernel executed)"}
+        else:
+            out["valu"] = {"algorithmic_lane_ops_per_pair": ref_ops, "dc_cells_per_pair": dc_cells,
+                           "tb_steps_per_pair": tb_steps,
+                           "achieved": ref_ops * value / world, "peak": VALU_PEAK_LANE_OPS,
+                           "frac": ref_ops * value / world / VALU_PEAK_LANE_OPS, "unit": "int32 lane-ops/s",
+                           "note": "per GPU, from the whole-step rate"}
         out["bit_cell_gcups"] = value * dc_cells * 64 / 1e9
     print(json.dumps(out))
     if world > 1:

@@ -1,0 +1,23 @@
+#!/bin/bash
+# usage (on the GPU box, from the repo root): scripts/collect_profiles.sh <tag>
+# 1. rocprofv3 --kernel-trace --stats of the default bench command  -> gpurun_out/prof_<tag>/
+# 2. PMC passes (one counter set per pass, kernel trace only) of the same workload, one stream:
+#      HBM traffic  -> gpurun_out/pmc_<tag>_hbm/summary.json
+#      SQ counters  -> gpurun_out/pmc_<tag>_sq/summary.json
+# The library is built first and pinned with SCRG_LIB; every profiler run has its own time limit.
+tag=${1:-r02}
+root=${GRAFT_REPO_ROOT:-$(pwd)}
+python3 -c "import sys; sys.path.insert(0, '$root'); import scrooge_amd; scrooge_amd.build_library()" || exit 1
+export SCRG_LIB=$root/scrooge_amd/libscrooge_amd.so
+mkdir -p $root/gpurun_out/prof_$tag
+(cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $root/gpurun_out/prof_$tag -o prof --output-format csv -- \
+    python3 $root/bench.py --no-build > $root/gpurun_out/prof_$tag/bench.json 2> $root/gpurun_out/prof_$tag/bench.err)
+tail -c 400 $root/gpurun_out/prof_$tag/bench.json; echo
+mkdir -p $root/gpurun_out/prof_${tag}_serial
+(cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $root/gpurun_out/prof_${tag}_serial -o prof --output-format csv -- \
+    python3 $root/bench.py --no-build --serial --cpu-seconds 0 > $root/gpurun_out/prof_${tag}_serial/bench.json 2> $root/gpurun_out/prof_${tag}_serial/bench.err)
+cd $root
+# window rounds per launch (kernel counters, not under the profiler)
+python3 bench.py --no-build --stats --cpu-seconds 0 --steps 2 2> gpurun_out/prof_$tag/stats.txt > /dev/null
+scripts/pmc_run.sh ${tag}_hbm "--serial" "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ TCC_EA0_RDREQ_32B" "TCC_EA0_WRREQ TCC_EA0_WRREQ_64B" "TCC_HIT TCC_MISS TCC_REQ TCC_READ" | grep -v dispatches
+scripts/pmc_run.sh ${tag}_sq "--serial" "GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_INSTS_BRANCH SQ_ACTIVE_INST_LDS" | grep -v dispatches

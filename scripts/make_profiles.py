@@ -1,0 +1,95 @@
+"""Turn the raw profiler output of scripts/collect_profiles.sh (gpurun_out/prof_<tag>*, gpurun_out/pmc_<tag>_*) into the
+judged summaries under profiles/.   usage: python scripts/make_profiles.py <tag> [<round label, default r02>]"""
+import ast, csv, glob, json, os, sys
+
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
+go = os.path.join(root, "gpurun_out")
+pr = os.path.join(root, "profiles")
+
+
+def kernel_stats(src_dir, dst, note):
+    f = glob.glob(os.path.join(src_dir, "*kernel_stats.csv"))
+    if not f:
+        print("no kernel_stats in", src_dir)
+        return
+    rows = list(csv.DictReader(open(f[0])))
+    with open(dst, "w") as o:
+        o.write("# rocprofv3 --kernel-trace --stats summary (kernel_stats.csv), %s\n" % note)
+        w = csv.writer(o)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+        for r in rows:
+            if "scrg::" in r["Name"] or float(r["Percentage"]) >= 1.0:
+                w.writerow([r["Name"][:120], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
+                            r["MinNs"], r["MaxNs"], r["StdDev"]])
+    print(open(dst).read())
+
+
+def bench_line(path):
+    try:
+        for l in open(path):
+            if l.startswith('{"metric"'):
+                return json.loads(l)
+    except Exception:
+        pass
+    return None
+
+
+b = bench_line(os.path.join(go, "prof_%s" % tag, "bench.json"))
+kernel_stats(os.path.join(go, "prof_%s" % tag), os.path.join(pr, "%s_kernel_stats_pipelined.csv" % rnd),
+             "`python bench.py` (default command: 100k x 10kb pairs, steps rotate over 4 streams); bench line of the same run: "
+             "value %.4g pairs/s, kernel_ms %.4g (stand-alone launches after the timed region), kernel_ms_events_in_timed_region %.4g"
+             % ((b["value"], b["kernel_ms"], b["kernel_ms_events_in_timed_region"]) if b else (0, 0, 0)))
+bs = bench_line(os.path.join(go, "prof_%s_serial" % tag, "bench.json"))
+kernel_stats(os.path.join(go, "prof_%s_serial" % tag), os.path.join(pr, "%s_kernel_stats_serial.csv" % rnd),
+             "`python bench.py --serial` (one stream, every launch has the GPU to itself); bench line of the same run: "
+             "value %.4g pairs/s, kernel_ms %.4g" % ((bs["value"], bs["kernel_ms"]) if bs else (0, 0)))
+
+# rounds per launch from the --stats pass
+rounds = None
+try:
+    for l in open(os.path.join(go, "prof_%s" % tag, "stats.txt")):
+        if l.startswith("stats"):
+            rounds = ast.literal_eval(l.split(":", 1)[1].strip())["rounds"]
+except Exception as e:
+    print("no stats pass:", e)
+
+sq = json.load(open(os.path.join(go, "pmc_%s_sq" % tag, "summary.json")))
+sq.pop("_dispatches_per_counter", None)
+out = dict(sq)
+out["window_rounds_per_launch"] = rounds
+if rounds:
+    out["valu_instructions_per_window_round"] = sq["SQ_INSTS_VALU"] / rounds
+    out["salu_instructions_per_window_round"] = sq["SQ_INSTS_SALU"] / rounds
+    out["lds_instructions_per_window_round"] = sq["SQ_INSTS_LDS"] / rounds
+out["effective_clock_ghz_profiled"] = None
+out["note"] = ("per launch of genasm_lane_kernel (100k x 10kb ONT pairs, one stream, lane-interleaved layout), rocprofv3 --pmc, "
+               "averages over the 3 launches of `bench.py --serial --steps 2 --warmup 0`; a window round = one window of each of "
+               "a wavefront's 64 pairs; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles, GRBM_GUI_ACTIVE is summed over the 8 XCDs")
+json.dump(out, open(os.path.join(pr, "%s_pmc_sq_summary.json" % rnd), "w"), indent=1)
+print(json.dumps(out, indent=1))
+
+h = json.load(open(os.path.join(go, "pmc_%s_hbm" % tag, "summary.json")))
+h.pop("_dispatches_per_counter", None)
+rd = h["TCC_EA0_RDREQ"] * 128.0
+rd_fetch = h["FETCH_SIZE"] * 1024.0 * 2.0
+wr = h["TCC_EA0_WRREQ_64B"] * 64.0 + (h["TCC_EA0_WRREQ"] - h["TCC_EA0_WRREQ_64B"]) * 32.0
+wr_size = h["WRITE_SIZE"] * 1024.0
+alg = None
+if bs or b:
+    j = bs or b
+    alg = j["roofline"]["algorithmic_bytes_per_pair"] * j["config"]["pairs_per_gpu"]
+t = {"pairs": 100000, "read_len": 10000, "profile": "ont", "kernel": "genasm_lane_kernel", "round": 2,
+     "layout": "lane-interleaved groups of 64 pairs",
+     "method": "rocprofv3 --pmc, one pass per counter set (scripts/pmc_run.sh): FETCH_SIZE | WRITE_SIZE | TCC_EA0_RDREQ{,_32B} | "
+               "TCC_EA0_WRREQ{,_64B} | TCC_HIT,MISS,REQ,READ; averages over the 3 align launches of `bench.py --serial --steps 2 --warmup 0 --cpu-seconds 0`",
+     "raw": h, "read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
+     "corrections": "FETCH_SIZE (KB) x1024 x2 per MI355X_MICROARCH.md §HBM (128-B requests tallied at 64 B): %.0f MB; TCC_EA0_RDREQ x128 B = %.0f MB. "
+                    "WRITE_SIZE (KB) x1024 = %.0f MB; WRREQ sizes (64-B and 32-B requests) = %.0f MB." % (rd_fetch / 1e6, rd / 1e6, wr_size / 1e6, wr / 1e6),
+     "algorithmic_bytes_per_launch": alg,
+     "l2_hit_rate": h["TCC_HIT"] / max(1.0, h["TCC_HIT"] + h["TCC_MISS"]),
+     "note": "reads = the packed sequences once (+ descriptors); writes above 2 B/run: CIGAR pieces leave the CU as 32-byte stores, and a 64-byte "
+             "request is issued when both halves of a 64-byte block are in L2 together, otherwise each half goes out on its own"}
+json.dump(t, open(os.path.join(pr, "hbm_traffic.json"), "w"), indent=1)
+print(json.dumps({k: v for k, v in t.items() if k != "raw"}, indent=1))

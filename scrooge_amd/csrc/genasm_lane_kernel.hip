@@ -19,8 +19,8 @@
 // left-aligned: bit 31-j belongs to pattern character j.  The traceback is column-synchronous — in column
 // i the run of insertions is one count-leading-zeros over V1 & V0, then one D / X / = step moves every
 // lane to column i+1 — so the table is indexed by compile-time constants and lives in 62 VGPRs.
-// tests/proto/lane_proto.c restates this arithmetic in C; tests/test_lane_proto.py checks it against the
-// oracle on the CPU.
+// tests/proto/lane_proto.c restates this arithmetic in C; tests/test_lane_proto.py checks that restatement
+// against the reference algorithm on the CPU.
 //
 // LDS holds only the CIGAR staging ring (32 runs per lane, written out in aligned 32-byte pieces) and 31
 // bytes of insertion-run lengths per lane.

@@ -302,3 +302,65 @@ def test_full_bench_size_two_algorithms_agree(aligner):
         text = bytes(sample[k, :text_len])
         read = bytes(sample[k, tw * 32: tw * 32 + L])
         assert validate(text, read, cigar, int(ed0[k])) is None
+
+
+def _device_align(aligner, torch, seq, desc, n, cap, **kw):
+    dev = seq.device
+    runs = torch.zeros(n * cap * 2, dtype=torch.uint8, device=dev)
+    ed = torch.empty(n, dtype=torch.int64, device=dev)
+    nr = torch.empty(n, dtype=torch.int32, device=dev)
+    st = torch.empty(n, dtype=torch.int32, device=dev)
+    aligner.align_device(n, seq, desc, runs, ed, nr, st, **kw)
+    torch.cuda.synchronize()
+    h, cnt = runs.cpu().numpy(), nr.cpu().tolist()
+    cig = []
+    for k in range(n):
+        seg = h[2 * k * cap: 2 * (k * cap + cnt[k])]
+        cig.append("".join("%d%s" % (seg[2 * j], chr(seg[2 * j + 1])) for j in range(cnt[k])))
+    return ed.cpu().tolist(), cig, st.cpu().tolist()
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000])
+def test_lane_interleaved_layout(aligner, oracle, n):
+    """scrg_pack_planar_groups + word strides of 64 (the layout bench.py times): ragged texts and reads, a pair
+    count that is not a multiple of the group size, same results as the oracle and as the contiguous layout."""
+    import torch
+    import scrooge_amd
+    dev = torch.device("cuda", 0)
+    rng = np.random.Generator(np.random.PCG64(n))
+    t, q = synth.make_pairs(n, 700, "ont", seed=1000 + n)
+    for k in range(0, n, 3):                                   # ragged: cut some reads and texts short, a few empty
+        q[k] = q[k][: int(rng.integers(0, 700))]
+        t[k] = t[k][: int(rng.integers(0, len(t[k]) + 1))]
+    eds, cigars, _, _ = oracle.align(t, q, threads=8)
+    tw, rw = (max(len(x) for x in t) + 31) // 32 + 1, (700 + 31) // 32
+    rows = np.zeros((n, (tw + rw) * 32), dtype=np.uint8)
+    for k in range(n):
+        rows[k, :len(t[k])] = np.frombuffer(t[k], dtype=np.uint8)
+        rows[k, tw * 32: tw * 32 + len(q[k])] = np.frombuffer(q[k], dtype=np.uint8)
+    ascii_t = torch.from_numpy(rows).to(dev)
+    G, RW = scrooge_amd.api.GROUP, tw + rw
+    cap = (2 * 700 + 8 + 15) // 16 * 16
+    idx = torch.arange(n, dtype=torch.int64, device=dev)
+    tl = torch.tensor([len(x) for x in t], dtype=torch.int64, device=dev)
+    ql = torch.tensor([len(x) for x in q], dtype=torch.int64, device=dev)
+    bad = torch.zeros(1, dtype=torch.int32, device=dev)
+    aligner.set_stream(0)
+    try:
+        seq = torch.zeros((n + G - 1) // G * G * RW + scrooge_amd.api.SEQ_PAD_WORDS_GROUPS, dtype=torch.int64, device=dev)
+        aligner.pack_planar_groups(ascii_t.view(-1), n, RW, seq, bad)
+        first = (idx // G) * RW * G + idx % G
+        desc = torch.stack([first * 32, tl, (first + tw * G) * 32, ql, idx * cap, torch.full_like(idx, cap)], dim=1).contiguous()
+        got = _device_align(aligner, torch, seq, desc, n, cap, text_stride_words=G, read_stride_words=G)
+        assert got == (eds, cigars, [0] * n)
+        # the same batch in the contiguous layout
+        seq2 = torch.zeros(n * RW + scrooge_amd.api.SEQ_PAD_WORDS, dtype=torch.int64, device=dev)
+        aligner.pack_planar(ascii_t.view(-1), seq2, bad)
+        desc2 = torch.stack([idx * RW * 32, tl, (idx * RW + tw) * 32, ql, idx * cap, torch.full_like(idx, cap)], dim=1).contiguous()
+        assert _device_align(aligner, torch, seq2, desc2, n, cap) == got
+        assert int(bad.item()) == 0
+        # strides are a property of the one-pair-per-lane kernel only
+        with pytest.raises(scrooge_amd.ScroogeError):
+            _device_align(aligner, torch, seq, desc, n, cap, text_stride_words=G, read_stride_words=G, lanes_per_pair=8)
+    finally:
+        aligner.use_own_stream()
