@@ -321,8 +321,7 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
             uint32_t c = ffbh_u32(E);
             uint32_t ni = lds8[scr_b + c];
             uint32_t nr2 = 2u * (uint32_t)nr;          // byte offset of the last committed run
-            uint32_t it = 0;
-            while (__any(E != 0u)) {
+            auto event = [&]() {
                 const uint32_t sh = 31u - c;
                 const uint32_t bit = 0x80000000u >> (c & 31u);
                 *reinterpret_cast<uint16_t*>(lds_b + ring_b + ((nr2 + 2u) & 62u)) = (uint16_t)(((uint32_t)'I' << 8) | ni);
@@ -336,7 +335,13 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
                 *reinterpret_cast<uint16_t*>(lds_b + ring_b + ((nr2 + 2u) & 62u)) = (uint16_t)w;
                 nr2 += 2u * __builtin_amdgcn_ubfe(B, sh, 1);
                 c = nx;
-                if ((++it & 7u) == 7u) {                   // <= 14 new runs between checks + 1 speculative slot: the 32-run ring cannot wrap
+            };
+            uint32_t trips = 0;
+            while (__any(E != 0u)) {
+                event();                                   // two events per trip: half the loop branches, twice the
+                event();                                   // independent work in flight (a finished lane commits nothing)
+                if (++trips == 3u) {                       // <= 12 new runs between checks + 1 speculative slot: the 32-run ring cannot wrap
+                    trips = 0;
                     nr = (int32_t)nr2 >> 1;
                     flush_pieces();
                 }
