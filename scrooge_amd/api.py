@@ -267,7 +267,17 @@ class Aligner:
         return out
 
     # -- genasm_gpu::align_all(texts, queries)  (src/genasm_gpu.cu:982-1065) --------
-    def align_pairs(self, texts, queries, arrays=False, **kw):
+    def _finish(self, res, st, arrays, strict):
+        """Collect (and free) the library's result; a pair that overflowed its CIGAR slice is an error unless
+        strict=False, in which case the truncated result is returned and `last_status` / `status` says which pairs
+        (the C++ shim throws in the same case, scrooge_amd.hpp)."""
+        out = self._collect_arrays(res, st) if arrays else self._collect(res, st)
+        if st == SCRG_ERR_CIGAR_OVERFLOW and strict:
+            raise ScroogeError(st, (self.lib.scrg_last_error(self.h) or b"").decode() or
+                               "at least one pair overflowed its CIGAR slice")
+        return out
+
+    def align_pairs(self, texts, queries, arrays=False, strict=True, **kw):
         texts, queries = _bytes_list(texts), _bytes_list(queries)
         if len(texts) != len(queries):
             raise ValueError("texts and queries differ in length")   # reference: assert, genasm_cpu.cpp:559
@@ -280,10 +290,10 @@ class Aligner:
         st = self.lib.scrg_align_pairs(self.h, C.byref(self._params(kw)), n, tp, tl, qp, ql,
                                        C.byref(res))
         self._check(st, allow=(SCRG_ERR_CIGAR_OVERFLOW,))
-        return self._collect_arrays(res, st) if arrays else self._collect(res, st)
+        return self._finish(res, st, arrays, strict)
 
     # -- genasm_gpu::align_all(genome, reads)  (src/genasm_gpu.cu:890-980) ----------
-    def align_mapping(self, genome, reads, candidates, arrays=False, **kw):
+    def align_mapping(self, genome, reads, candidates, arrays=False, strict=True, **kw):
         """candidates[r] = list of start_in_reference for read r (forward strand)."""
         genome = genome.encode() if isinstance(genome, str) else bytes(genome)
         reads = _bytes_list(reads)
@@ -302,7 +312,7 @@ class Aligner:
         st = self.lib.scrg_align_mapping(self.h, C.byref(self._params(kw)), genome, len(genome),
                                          nr, rp, rl, co, cs, C.byref(res))
         self._check(st, allow=(SCRG_ERR_CIGAR_OVERFLOW,))
-        return self._collect_arrays(res, st) if arrays else self._collect(res, st)
+        return self._finish(res, st, arrays, strict)
 
     # -- device-pointer layer (torch tensors as plain device memory) -----------
     def set_stream(self, stream_handle):

@@ -144,6 +144,19 @@ struct scrg_ctx {
             return (ctx)->fail(e__ == hipErrorOutOfMemory ? SCRG_ERR_OOM : SCRG_ERR_HIP, #call, e__); \
     } while (0)
 
+// Host entry points never let a C++ exception cross the C boundary (std::vector growth on huge batches):
+// allocation failures become SCRG_ERR_OOM, anything else SCRG_ERR_INVALID_ARG.
+template <typename F> static scrg_status guarded(scrg_ctx* c, F&& f)
+{
+    try {
+        return f();
+    } catch (const std::bad_alloc&) {
+        return c ? c->fail(SCRG_ERR_OOM, "host allocation failed") : SCRG_ERR_OOM;
+    } catch (...) {
+        return c ? c->fail(SCRG_ERR_INVALID_ARG, "unexpected exception") : SCRG_ERR_INVALID_ARG;
+    }
+}
+
 extern "C" {
 
 void scrg_params_default(scrg_params* p)
@@ -749,7 +762,7 @@ scrg_status run_batch(scrg_ctx* c, const scrg_params& p, std::vector<SeqRef>& se
 
 }  // namespace
 
-scrg_status scrg_align_pairs(scrg_ctx* c, const scrg_params* params, uint64_t n_pairs, const char* const* texts,
+static scrg_status align_pairs_impl(scrg_ctx* c, const scrg_params* params, uint64_t n_pairs, const char* const* texts,
                              const uint64_t* text_lens, const char* const* queries, const uint64_t* query_lens,
                              scrg_result** out)
 {
@@ -780,7 +793,14 @@ scrg_status scrg_align_pairs(scrg_ctx* c, const scrg_params* params, uint64_t n_
     return run_batch(c, p, seqs, w, probs, out);
 }
 
-scrg_status scrg_align_mapping_stranded(scrg_ctx* c, const scrg_params* params, const char* genome,
+scrg_status scrg_align_pairs(scrg_ctx* c, const scrg_params* params, uint64_t n_pairs, const char* const* texts,
+                             const uint64_t* text_lens, const char* const* queries, const uint64_t* query_lens,
+                             scrg_result** out)
+{
+    return guarded(c, [&] { return align_pairs_impl(c, params, n_pairs, texts, text_lens, queries, query_lens, out); });
+}
+
+static scrg_status align_mapping_impl(scrg_ctx* c, const scrg_params* params, const char* genome,
                                         uint64_t genome_len, uint64_t n_reads, const char* const* reads,
                                         const uint64_t* read_lens, const uint64_t* cand_offsets,
                                         const uint64_t* cand_start, const uint8_t* cand_reverse, scrg_result** out)
@@ -834,6 +854,17 @@ scrg_status scrg_align_mapping_stranded(scrg_ctx* c, const scrg_params* params, 
         }
     }
     return run_batch(c, p, seqs, w, probs, out);
+}
+
+scrg_status scrg_align_mapping_stranded(scrg_ctx* c, const scrg_params* params, const char* genome,
+                                        uint64_t genome_len, uint64_t n_reads, const char* const* reads,
+                                        const uint64_t* read_lens, const uint64_t* cand_offsets,
+                                        const uint64_t* cand_start, const uint8_t* cand_reverse, scrg_result** out)
+{
+    return guarded(c, [&] {
+        return align_mapping_impl(c, params, genome, genome_len, n_reads, reads, read_lens, cand_offsets, cand_start,
+                                  cand_reverse, out);
+    });
 }
 
 scrg_status scrg_align_mapping(scrg_ctx* c, const scrg_params* params, const char* genome, uint64_t genome_len,

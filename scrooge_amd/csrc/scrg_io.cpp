@@ -10,6 +10,8 @@
 #include <fstream>
 #include <map>
 #include <sstream>
+#include <memory>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -26,9 +28,17 @@ bool slurp(const std::string& path, std::string& out, std::string& err)
     }
     f.seekg(0, std::ios::end);
     const std::streamoff n = f.tellg();
+    if (!f || n < 0) {                     // a directory or an unseekable path
+        err = "could not read file \"" + path + "\"";
+        return false;
+    }
     f.seekg(0, std::ios::beg);
     out.resize((size_t)n);
     if (n) f.read(&out[0], n);
+    if (!f) {
+        err = "could not read file \"" + path + "\"";
+        return false;
+    }
     return true;
 }
 
@@ -195,6 +205,19 @@ struct scrg_job {
     std::vector<uint64_t> pair_read;   // read index of every pair
 };
 
+// The entry points below never let a C++ exception cross the C boundary: allocation failures become
+// SCRG_ERR_OOM, anything else SCRG_ERR_INVALID_ARG.
+template <typename F> static scrg_status guarded(F&& f)
+{
+    try {
+        return f();
+    } catch (const std::bad_alloc&) {
+        return SCRG_ERR_OOM;
+    } catch (...) {
+        return SCRG_ERR_INVALID_ARG;
+    }
+}
+
 extern "C" {
 
 void scrg_job_options_default(scrg_job_options* o)
@@ -207,7 +230,7 @@ void scrg_job_options_default(scrg_job_options* o)
     o->read_length_cap = -1;
 }
 
-scrg_status scrg_job_load(const char* genome_fasta, const char* reads_fastq, const char* seeds_path,
+static scrg_status job_load_impl(const char* genome_fasta, const char* reads_fastq, const char* seeds_path,
                           const scrg_job_options* opt_in, scrg_job** out, char* err, size_t err_len)
 {
     if (!genome_fasta || !reads_fastq || !seeds_path || !out) return SCRG_ERR_INVALID_ARG;
@@ -216,10 +239,10 @@ scrg_status scrg_job_load(const char* genome_fasta, const char* reads_fastq, con
     scrg_job_options_default(&opt);
     if (opt_in) opt = *opt_in;
     std::string raw, msg;
-    scrg_job* job = new scrg_job();
+    std::unique_ptr<scrg_job> job_owner(new scrg_job());       // released to the caller on success only
+    scrg_job* job = job_owner.get();
     auto fail = [&](scrg_status s, const std::string& m) {
         set_err(err, err_len, m);
-        delete job;
         return s;
     };
 
@@ -311,8 +334,16 @@ scrg_status scrg_job_load(const char* genome_fasta, const char* reads_fastq, con
         job->cand_offsets.push_back(job->cand_start.size());
     }
     for (const std::string& s : job->read_seqs) job->read_ptrs.push_back(s.data());
-    *out = job;
+    *out = job_owner.release();
     return SCRG_OK;
+}
+
+scrg_status scrg_job_load(const char* genome_fasta, const char* reads_fastq, const char* seeds_path,
+                          const scrg_job_options* opt_in, scrg_job** out, char* err, size_t err_len)
+{
+    const scrg_status st = guarded([&] { return job_load_impl(genome_fasta, reads_fastq, seeds_path, opt_in, out, err, err_len); });
+    if (st == SCRG_ERR_OOM) set_err(err, err_len, "out of memory while loading the job");
+    return st;
 }
 
 void scrg_job_free(scrg_job* job) { delete job; }
@@ -362,7 +393,12 @@ scrg_status scrg_job_align(scrg_ctx* ctx, const scrg_params* params, const scrg_
                                        job->cand_start.data(), job->cand_reverse.data(), out);
 }
 
+static scrg_status job_write_impl(const scrg_job* job, const scrg_result* res, const char* path, int format);
 scrg_status scrg_job_write(const scrg_job* job, const scrg_result* res, const char* path, int format)
+{
+    return guarded([&] { return job_write_impl(job, res, path, format); });
+}
+static scrg_status job_write_impl(const scrg_job* job, const scrg_result* res, const char* path, int format)
 {
     if (!job || !res || !path) return SCRG_ERR_INVALID_ARG;
     if (res->n_pairs != job->cand_start.size()) return SCRG_ERR_INVALID_ARG;
