@@ -225,7 +225,8 @@ def main():
     gather = None
     if world > 1:
         from scrooge_amd.distributed import ResultGather
-        gather = ResultGather(n, total_runs, device, dst=0, depth=max(2, n_lanes))
+        packed_gather = p.W - p.O <= 63              # runs travel as one byte each; rank 0 restores scrg_run pairs
+        gather = ResultGather(n, total_runs, device, dst=0, depth=max(2, n_lanes), packed=packed_gather)
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(args.steps)]
@@ -266,7 +267,10 @@ def main():
                 # RCCL gather of scores + CIGAR runs to rank 0 over xGMI, double buffered: the gather of
                 # this step overlaps the next step's align kernel
                 gather.finish(j)                       # buffers of step j-DEPTH are free again
-                aligners[b].compact_runs(n, desc, o["runs"], o["n_runs"], dense_off, gather.send_runs[j % gather.DEPTH])
+                if packed_gather:
+                    aligners[b].compact_runs_packed(n, desc, o["runs"], o["n_runs"], dense_off, gather.send_runs[j % gather.DEPTH], **kw)
+                else:
+                    aligners[b].compact_runs(n, desc, o["runs"], o["n_runs"], dense_off, gather.send_runs[j % gather.DEPTH])
                 gather.start(j, o["ed"], o["n_runs"])
             else:
                 aligners[b].compact_runs(n, desc, o["runs"], o["n_runs"], dense_off, denses[b])
@@ -291,6 +295,16 @@ def main():
     dt = time.perf_counter() - t0
     last = (step.count - 1) % n_lanes
     ed, n_runs, dense = outs[last]["ed"], outs[last]["n_runs"], denses[last]
+    gather_check = None
+    if gather is not None and rank == 0:
+        # outside the timed region: what rank 0 holds for itself after the last step's gather (scores, counts and the
+        # runs restored from the wire format) must be what its own kernel produced
+        cnt64 = n_runs.to(torch.int64)
+        aligners[last].compact_runs(n, desc, outs[last]["runs"], n_runs, torch.cumsum(cnt64, 0) - cnt64, dense)
+        torch.cuda.synchronize()
+        ed_g, cnt_g, runs_g = gather.results(step.count - 1, 0)
+        gather_check = bool(torch.equal(ed_g, ed) and torch.equal(cnt_g, n_runs) and torch.equal(runs_g, dense[: runs_g.numel()]))
+        assert gather_check, "gathered results differ from the local ones"
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -412,7 +426,7 @@ def main():
                    "pairs_per_gpu": n, "read_len": L, "text_len": text_len, "error_profile": args.profile,
                    "W": p.W, "O": p.O, "lanes_per_pair": p.lanes_per_pair, "lds_rows": p.lds_rows,
                    "sequence_layout": "lane-interleaved groups of 64 pairs (scrg_pack_planar_groups)" if groups else "contiguous per sequence",
-                   "launch": geom, "step": "align kernel + run compaction" + (" + RCCL gather of scores and CIGAR runs to rank 0 (double buffered, overlaps the next kernel)" if world > 1 else ""),
+                   "launch": geom, "step": "align kernel + run compaction" + (" + RCCL gather of scores and CIGAR runs to rank 0 (one buffer set per pipelined step, overlaps the next kernels; runs travel as one byte each and are restored to scrg_run on rank 0 inside the timed region)" if world > 1 else ""),
                    "pipeline": ("consecutive steps alternate between %d streams (own handle, work queue and output buffers each): "
                                 "a step's wavefronts start while the previous step's last pairs finish" % n_lanes) if n_lanes > 1
                                else "one stream: a step starts after the previous one has finished"},
@@ -430,6 +444,7 @@ def main():
                              "kernel_ms" + (", the duration of a launch that has the GPU to itself" if serial is not None else "")},
         "cpu_baseline": cpu,
         "parity": parity,
+        "gather_check": gather_check,
         "gen_seconds": gen_s,
     }
     if dc_cells is not None:

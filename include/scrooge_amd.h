@@ -200,6 +200,15 @@ scrg_status scrg_compact_runs(scrg_ctx *ctx, uint64_t n_pairs, const scrg_pair_d
                               const scrg_run *d_runs, const uint32_t *d_n_runs,
                               const uint64_t *d_dense_offset, scrg_run *d_dense);
 
+/* The same gather into ONE BYTE per run — op in bits 7..6 (0 '=', 1 'X', 2 'I', 3 'D'), count in bits 5..0 — for
+ * transfers (the RCCL gather of CIGARs to one GPU moves half the bytes).  A run never spans windows, so its count
+ * is at most W-O; valid for W-O <= 63, i.e. every W <= 64 (SCRG_ERR_INVALID_ARG otherwise).  d_dense_offset is in
+ * runs (= bytes).  scrg_unpack_runs restores scrg_run pairs bit for bit; both buffers 4-byte aligned. */
+scrg_status scrg_compact_runs_packed(scrg_ctx *ctx, const scrg_params *params, uint64_t n_pairs,
+                                     const scrg_pair_desc *d_pairs, const scrg_run *d_runs, const uint32_t *d_n_runs,
+                                     const uint64_t *d_dense_offset, uint8_t *d_packed);
+scrg_status scrg_unpack_runs(scrg_ctx *ctx, uint64_t n_runs, const uint8_t *d_packed, scrg_run *d_runs);
+
 /* Reference-layout 2-bit packer, mirrors the exported kernel
  * genasm_gpu::ascii_to_twobit_strings (src/genasm_gpu.cu:631-685): 4 bases per
  * byte, first base in bits 7..6, last byte zero-padded.  Each string occupies

@@ -123,6 +123,8 @@ def load_library():
                                            C.POINTER(u64), C.POINTER(C.POINTER(Result))]),
         "scrg_pack_planar": (C.c_int32, [vp, vp, u64, vp, vp]),
         "scrg_pack_planar_groups": (C.c_int32, [vp, vp, u64, u64, vp, vp]),
+        "scrg_compact_runs_packed": (C.c_int32, [vp, vp, u64, vp, vp, vp, vp, vp]),
+        "scrg_unpack_runs": (C.c_int32, [vp, u64, vp, vp]),
         "scrg_align_device": (C.c_int32, [vp, C.POINTER(Params), u64, vp, vp, vp, vp, vp, vp]),
         "scrg_compact_runs": (C.c_int32, [vp, u64, vp, vp, vp, vp, vp]),
         "scrg_ascii_to_twobit": (C.c_int32, [vp, u64, vp, vp, vp, vp, vp, vp]),
@@ -143,7 +145,7 @@ EXPORTED_SYMBOLS = [
     "scrg_ctx_use_own_stream", "scrg_stream_create", "scrg_stream_destroy",
     "scrg_last_error", "scrg_status_string", "scrg_set_log", "scrg_device_count",
     "scrg_result_free", "scrg_align_pairs", "scrg_align_mapping", "scrg_pack_planar", "scrg_pack_planar_groups",
-    "scrg_align_device", "scrg_compact_runs", "scrg_ascii_to_twobit", "scrg_query_launch",
+    "scrg_align_device", "scrg_compact_runs", "scrg_compact_runs_packed", "scrg_unpack_runs", "scrg_ascii_to_twobit", "scrg_query_launch",
     "scrg_last_kernel_ms", "scrg_debug_stats"]
 
 
@@ -341,6 +343,15 @@ class Aligner:
     def compact_runs(self, n_pairs, pairs, runs, n_runs, dense_off, dense):
         self._check(self.lib.scrg_compact_runs(self.h, int(n_pairs), _ptr(pairs), _ptr(runs),
                                                _ptr(n_runs), _ptr(dense_off), _ptr(dense)))
+
+    def compact_runs_packed(self, n_pairs, pairs, runs, n_runs, dense_off, packed_u8, **kw):
+        """Like compact_runs, one byte per run (op << 6 | count; W-O <= 63): the transfer format of the RCCL gather."""
+        self._check(self.lib.scrg_compact_runs_packed(self.h, C.byref(self._params(kw)), int(n_pairs), _ptr(pairs),
+                                                      _ptr(runs), _ptr(n_runs), _ptr(dense_off), _ptr(packed_u8)))
+
+    def unpack_runs(self, n_runs, packed_u8, runs_u8):
+        """Restores scrg_run pairs (2 bytes each) from packed runs."""
+        self._check(self.lib.scrg_unpack_runs(self.h, int(n_runs), _ptr(packed_u8), _ptr(runs_u8)))
 
     def ascii_to_twobit(self, count, lens, ascii_off, ascii, twobit_off, twobit, bad):
         self._check(self.lib.scrg_ascii_to_twobit(self.h, int(count), _ptr(lens), _ptr(ascii_off),

@@ -484,6 +484,33 @@ scrg_status scrg_compact_runs(scrg_ctx* c, uint64_t n_pairs, const scrg_pair_des
     return SCRG_OK;
 }
 
+scrg_status scrg_compact_runs_packed(scrg_ctx* c, const scrg_params* params, uint64_t n_pairs, const scrg_pair_desc* d_pairs,
+                                     const scrg_run* d_runs, const uint32_t* d_n_runs, const uint64_t* d_dense_offset,
+                                     uint8_t* d_packed)
+{
+    if (!c) return SCRG_ERR_INVALID_ARG;
+    scrg_params p;
+    if (!resolve_params(params, &p)) return c->fail(SCRG_ERR_INVALID_ARG, "bad scrg_params");
+    if (p.W - p.O > 63) return c->fail(SCRG_ERR_INVALID_ARG, "packed runs hold counts up to 63: W-O must be <= 63");
+    if (n_pairs && (!d_pairs || !d_runs || !d_n_runs || !d_dense_offset || !d_packed))
+        return c->fail(SCRG_ERR_INVALID_ARG, "null device pointer");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, scrg::launch_compact_runs_packed(n_pairs, d_pairs, reinterpret_cast<const uint16_t*>(d_runs), d_n_runs,
+                                                d_dense_offset, d_packed, c->n_cus, c->stream));
+    return SCRG_OK;
+}
+
+scrg_status scrg_unpack_runs(scrg_ctx* c, uint64_t n_runs, const uint8_t* d_packed, scrg_run* d_runs)
+{
+    if (!c) return SCRG_ERR_INVALID_ARG;
+    if (n_runs && (!d_packed || !d_runs)) return c->fail(SCRG_ERR_INVALID_ARG, "null device pointer");
+    if ((reinterpret_cast<uintptr_t>(d_packed) & 3u) || (reinterpret_cast<uintptr_t>(d_runs) & 7u))
+        return c->fail(SCRG_ERR_INVALID_ARG, "packed runs need 4-byte, runs 8-byte alignment");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, scrg::launch_unpack_runs(n_runs, d_packed, reinterpret_cast<uint16_t*>(d_runs), c->n_cus, c->stream));
+    return SCRG_OK;
+}
+
 scrg_status scrg_ascii_to_twobit(scrg_ctx* c, uint64_t count, const uint64_t* d_lens, const uint64_t* d_ascii_off,
                                  const char* d_ascii, const uint64_t* d_twobit_off, uint8_t* d_twobit,
                                  uint32_t* d_bad_count)

@@ -188,6 +188,74 @@ __global__ __launch_bounds__(256) void compact_runs_kernel(uint64_t n_pairs, con
         if ((rem & 1u) && lane == 63) d16[cnt - 1] = s16[cnt - 1];
     }
 }
+// ----------------------------------------------------------------------------
+// Packed runs for the RCCL gather: one byte per run, op in bits 7..6 (0 '=', 1 'X', 2 'I', 3 'D'), count in
+// bits 5..0 (a run never spans windows, so its count is at most W-O <= 63 for every W <= 64).  Halves the
+// bytes a rank sends to rank 0; unpack_runs_kernel restores scrg_run pairs bit for bit.
+// ----------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t run_to_byte(uint32_t run16)
+{
+    // op char in bits 15..8: '=' 0x3D, 'X' 0x58, 'I' 0x49, 'D' 0x44 -> index (bit4, bit2) = 3, 2, 0, 1 -> code 0, 1, 2, 3
+    const uint32_t op = run16 >> 8;
+    const uint32_t idx = ((op >> 3) & 2u) | ((op >> 2) & 1u);
+    // idx 0 'I' -> 2, idx 1 'D' -> 3, idx 2 'X' -> 1, idx 3 '=' -> 0: 2-bit fields 0b00'01'11'10
+    const uint32_t code = (0x1Eu >> (2u * idx)) & 3u;
+    return (code << 6) | (run16 & 63u);
+}
+__device__ __forceinline__ uint32_t byte_to_run(uint32_t b)
+{
+    const uint32_t chars = 0x4449583Du;                           // code 0 '=', 1 'X', 2 'I', 3 'D'
+    return (((chars >> (8u * (b >> 6))) & 0xffu) << 8) | (b & 63u);
+}
+
+__global__ __launch_bounds__(256) void compact_runs_packed_kernel(uint64_t n_pairs, const scrg_pair_desc* __restrict__ pairs,
+                                                                  const uint16_t* __restrict__ runs,
+                                                                  const uint32_t* __restrict__ n_runs,
+                                                                  const uint64_t* __restrict__ dense_off,
+                                                                  uint8_t* __restrict__ dense)
+{
+    // one wavefront per pair; a lane converts four runs (8 bytes in, 4 bytes out) per iteration once the
+    // destination is dword aligned
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t p = wave; p < n_pairs; p += n_waves) {
+        const uint64_t cap = pairs[p].cigar_cap;
+        uint64_t cnt = n_runs[p];
+        if (cnt > cap) cnt = cap;
+        if (cnt == 0) continue;
+        const uint16_t* const s16 = runs + pairs[p].cigar_off;
+        uint8_t* const d8 = dense + dense_off[p];
+        uint64_t head = (uint64_t)((0u - (uint32_t)reinterpret_cast<uintptr_t>(d8)) & 3u);      // bytes up to dword alignment
+        if (head > cnt) head = cnt;
+        if (lane < head) d8[lane] = (uint8_t)run_to_byte(s16[lane]);
+        const uint64_t quads = (cnt - head) >> 2;
+        uint32_t* const d32 = reinterpret_cast<uint32_t*>(d8 + head);
+        for (uint64_t q = lane; q < quads; q += 64) {
+            const uint16_t* const s = s16 + head + 4 * q;
+            d32[q] = run_to_byte(s[0]) | (run_to_byte(s[1]) << 8) | (run_to_byte(s[2]) << 16) | (run_to_byte(s[3]) << 24);
+        }
+        const uint64_t done = head + 4 * quads;
+        if (done + lane < cnt) d8[done + lane] = (uint8_t)run_to_byte(s16[done + lane]);        // up to 3 runs
+    }
+}
+
+__global__ __launch_bounds__(256) void unpack_runs_kernel(uint64_t n, const uint8_t* __restrict__ packed, uint16_t* __restrict__ runs)
+{
+    // n runs; a thread restores four at a time where both sides are aligned (callers pass 4-byte aligned buffers)
+    const uint64_t quads = n >> 2;
+    const uint32_t* const p32 = reinterpret_cast<const uint32_t*>(packed);
+    uint2* const r64 = reinterpret_cast<uint2*>(runs);
+    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t v = p32[q];
+        uint2 o;
+        o.x = byte_to_run(v & 0xffu) | (byte_to_run((v >> 8) & 0xffu) << 16);
+        o.y = byte_to_run((v >> 16) & 0xffu) | (byte_to_run(v >> 24) << 16);
+        r64[q] = o;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3u)) runs[4 * quads + threadIdx.x] = (uint16_t)byte_to_run(packed[4 * quads + threadIdx.x]);
+}
+
 hipError_t launch_pack_planar(const char* d_ascii, uint64_t n_words, uint64_t* d_planar, uint32_t* d_bad,
                               int n_cus, hipStream_t s)
 {
@@ -237,6 +305,30 @@ hipError_t launch_compact_runs(uint64_t n_pairs, const scrg_pair_desc* d_pairs, 
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(compact_runs_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
                        n_pairs, d_pairs, d_runs, d_n_runs, d_dense_off, d_dense);
+    return hipGetLastError();
+}
+
+hipError_t launch_compact_runs_packed(uint64_t n_pairs, const scrg_pair_desc* d_pairs, const uint16_t* d_runs,
+                                      const uint32_t* d_n_runs, const uint64_t* d_dense_off, uint8_t* d_dense,
+                                      int n_cus, hipStream_t s)
+{
+    if (n_pairs == 0) return hipSuccess;
+    uint64_t blocks = (n_pairs + 3) / 4;
+    const uint64_t cap = (uint64_t)n_cus * 8;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(compact_runs_packed_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
+                       n_pairs, d_pairs, d_runs, d_n_runs, d_dense_off, d_dense);
+    return hipGetLastError();
+}
+
+hipError_t launch_unpack_runs(uint64_t n_runs, const uint8_t* d_packed, uint16_t* d_runs, int n_cus, hipStream_t s)
+{
+    if (n_runs == 0) return hipSuccess;
+    uint64_t blocks = ((n_runs >> 2) + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    const uint64_t cap = (uint64_t)n_cus * 16;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(unpack_runs_kernel, dim3((unsigned)blocks), dim3(256), 0, s, n_runs, d_packed, d_runs);
     return hipGetLastError();
 }
 

@@ -86,22 +86,26 @@ def align_pairs_sharded(aligner, texts, queries, dst=0, group=None, device=None,
 
 
 class ResultGather:
-    """Fixed-size, double-buffered gather of a batch's device results to rank `dst`
+    """Fixed-size, multi-buffered gather of a batch's device results to rank `dst`
     (bench.py: the data, hence every size, is the same each step, so buffers are allocated once
     and no size exchange happens inside the timed region).
 
-    Payload per rank: int64 edit distances [n], int32 run counts [n] and the dense scrg_run array
-    as bytes, padded to the largest total over ranks.  `start(k, ...)` enqueues the collectives
+    Payload per rank: int64 edit distances [n], int32 run counts [n] and the dense runs, padded to the
+    largest total over ranks.  With `packed=True` the runs travel as ONE byte each (scrg_compact_runs_packed:
+    op << 6 | count, valid for W-O <= 63) and rank `dst` restores scrg_run pairs with scrg_unpack_runs once a
+    step's gather has landed — half the bytes on the xGMI links into `dst`, which is what bounds N > 1 once a
+    rank produces runs faster than a link carries them.  `start(k, ...)` enqueues the collectives
     asynchronously (RCCL runs them on its own stream, after the work already enqueued on the current
-    stream), so the gather of step k overlaps the align kernel of step k+1; `finish(k)` makes the
-    current stream wait for step k's gather before its buffers are reused."""
+    stream), so the gather of step k overlaps the align kernels of the following steps; `finish(k)` makes the
+    current stream wait for step k's gather (and unpacking) before its buffers are reused."""
 
     DEPTH = 2
 
-    def __init__(self, n_pairs, total_runs, device, dst=0, group=None, depth=None):
+    def __init__(self, n_pairs, total_runs, device, dst=0, group=None, depth=None, packed=False):
         self.group, self.dst = group, dst
         if depth is not None:
             self.DEPTH = max(1, int(depth))        # buffers in flight: one per pipelined step
+        self.packed = bool(packed)
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         t = torch.tensor([int(total_runs)], dtype=torch.int64, device=device)
@@ -110,23 +114,35 @@ class ResultGather:
         self.totals = [int(x.item()) for x in sizes]
         self.cap = max(max(self.totals), 1)
         d = self.DEPTH
-        self.send_runs = [torch.zeros(self.cap * 2, dtype=torch.uint8, device=device) for _ in range(d)]
+        wire = (self.cap * (1 if self.packed else 2) + 7) // 8 * 8          # bytes on the wire per rank and step
+        self.send_runs = [torch.zeros(wire, dtype=torch.uint8, device=device) for _ in range(d)]
         self.send_ed = [torch.zeros(n_pairs, dtype=torch.int64, device=device) for _ in range(d)]
         self.send_cnt = [torch.zeros(n_pairs, dtype=torch.int32, device=device) for _ in range(d)]
         self.recv_runs = self.recv_ed = self.recv_cnt = [None] * d
+        self.runs16 = [None] * d                   # packed: the restored scrg_run bytes on dst
+        self._unpacker = None
         if self.rank == dst:
             mk = lambda shape, dt: [[torch.empty(shape, dtype=dt, device=device) for _ in range(self.world)]
                                     for _ in range(d)]
-            self.recv_runs = mk(self.cap * 2, torch.uint8)
+            self.recv_runs = mk(wire, torch.uint8)
             self.recv_ed = mk(n_pairs, torch.int64)
             self.recv_cnt = mk(n_pairs, torch.int32)
+            if self.packed:
+                from . import api
+                self.runs16 = mk(self.cap * 2 + 8, torch.uint8)
+                # unpacking runs on its own stream and handle, ordered after the collective and before buffer reuse
+                self._unpack_stream = torch.cuda.Stream(device=device)
+                self._unpacker = api.Aligner(torch.device(device).index or 0)
+                self._unpacker.set_stream(self._unpack_stream.cuda_stream)
         self.pending = [None] * d
+        self.landed = [False] * d                  # a step's data is in recv_* but not unpacked yet
         # gloo cannot gather device tensors: stage through the host (the multi-rank dry run of bench.py on a
         # box with one GPU, SCRG_BENCH_DRYRUN=1; never the measured configuration)
         self.host_stage = dist.get_backend(group) == "gloo" and torch.device(device).type == "cuda"
 
     def start(self, k, ed, n_runs):
-        """`self.send_runs[k % DEPTH]` must already hold this rank's dense runs of step k."""
+        """`self.send_runs[k % DEPTH]` must already hold this rank's dense runs of step k (packed bytes if
+        `packed`, scrg_run pairs otherwise)."""
         b = k % self.DEPTH
         self.send_ed[b].copy_(ed)
         self.send_cnt[b].copy_(n_runs)
@@ -139,11 +155,13 @@ class ResultGather:
                 if host is not None:
                     for r in range(self.world):
                         recv[r].copy_(host[r])
+            self.landed[b] = True
             return
         self.pending[b] = [
             dist.gather(self.send_ed[b], self.recv_ed[b], dst=self.dst, group=self.group, async_op=True),
             dist.gather(self.send_cnt[b], self.recv_cnt[b], dst=self.dst, group=self.group, async_op=True),
             dist.gather(self.send_runs[b], self.recv_runs[b], dst=self.dst, group=self.group, async_op=True)]
+        self.landed[b] = True
 
     def finish(self, k):
         b = k % self.DEPTH
@@ -151,12 +169,22 @@ class ResultGather:
             for w in self.pending[b]:
                 w.wait()
             self.pending[b] = None
+        if self.landed[b]:
+            self.landed[b] = False
+            if self._unpacker is not None:
+                cur = torch.cuda.current_stream()
+                self._unpack_stream.wait_stream(cur)           # (cur already waits for the collectives)
+                with torch.cuda.stream(self._unpack_stream):
+                    for r in range(self.world):
+                        self._unpacker.unpack_runs(self.totals[r], self.recv_runs[b][r], self.runs16[b][r])
+                cur.wait_stream(self._unpack_stream)
 
     def finish_all(self):
         for b in range(self.DEPTH):
             self.finish(b)
 
     def results(self, k, r):
-        """(ed, counts, run bytes) of rank r for step k, on dst (after finish(k))."""
+        """(ed, counts, scrg_run bytes) of rank r for step k, on dst (after finish(k))."""
         b = k % self.DEPTH
-        return self.recv_ed[b][r], self.recv_cnt[b][r], self.recv_runs[b][r][: 2 * self.totals[r]]
+        runs = self.runs16[b][r] if self.packed else self.recv_runs[b][r]
+        return self.recv_ed[b][r], self.recv_cnt[b][r], runs[: 2 * self.totals[r]]

@@ -364,3 +364,52 @@ def test_lane_interleaved_layout(aligner, oracle, n):
             _device_align(aligner, torch, seq, desc, n, cap, text_stride_words=G, read_stride_words=G, lanes_per_pair=8)
     finally:
         aligner.use_own_stream()
+
+
+def test_packed_runs_round_trip(aligner, oracle):
+    """scrg_compact_runs_packed (one byte per run, the RCCL transfer format) + scrg_unpack_runs reproduce
+    scrg_compact_runs bit for bit, at odd destination offsets and with empty pairs; W-O > 63 is refused."""
+    import torch
+    import scrooge_amd
+    dev = torch.device("cuda", 0)
+    t, q = synth.make_pairs(300, 1500, "pacbio15", seed=77)
+    q[5], t[9] = b"", b""                                   # no runs at all / insertions only
+    n = len(t)
+    tw, rw = (max(len(x) for x in t) + 31) // 32, (1500 + 31) // 32
+    rows = np.zeros((n, (tw + rw) * 32), dtype=np.uint8)
+    for k in range(n):
+        rows[k, :len(t[k])] = np.frombuffer(t[k], dtype=np.uint8)
+        rows[k, tw * 32: tw * 32 + len(q[k])] = np.frombuffer(q[k], dtype=np.uint8)
+    ascii_t = torch.from_numpy(rows).to(dev)
+    cap = (2 * 1500 + 8 + 15) // 16 * 16
+    idx = torch.arange(n, dtype=torch.int64, device=dev)
+    aligner.set_stream(0)
+    try:
+        seq = torch.zeros(n * (tw + rw) + scrooge_amd.api.SEQ_PAD_WORDS, dtype=torch.int64, device=dev)
+        bad = torch.zeros(1, dtype=torch.int32, device=dev)
+        aligner.pack_planar(ascii_t.view(-1), seq, bad)
+        desc = torch.stack([idx * (tw + rw) * 32, torch.tensor([len(x) for x in t], device=dev),
+                            (idx * (tw + rw) + tw) * 32, torch.tensor([len(x) for x in q], device=dev),
+                            idx * cap, torch.full_like(idx, cap)], dim=1).contiguous()
+        runs = torch.zeros(n * cap * 2, dtype=torch.uint8, device=dev)
+        ed = torch.empty(n, dtype=torch.int64, device=dev)
+        nr = torch.empty(n, dtype=torch.int32, device=dev)
+        st = torch.empty(n, dtype=torch.int32, device=dev)
+        aligner.align_device(n, seq, desc, runs, ed, nr, st)
+        cnt = nr.to(torch.int64)
+        total = int(cnt.sum().item())
+        for shift in (0, 1, 2, 3):                            # destination offsets of every alignment
+            off = torch.cumsum(cnt, 0) - cnt + shift
+            dense = torch.zeros((total + shift) * 2 + 8, dtype=torch.uint8, device=dev)
+            packed = torch.zeros((total + shift + 7) // 8 * 8 + 8, dtype=torch.uint8, device=dev)
+            back = torch.zeros((total + shift) * 2 + 8, dtype=torch.uint8, device=dev)
+            aligner.compact_runs(n, desc, runs, nr, off, dense)
+            aligner.compact_runs_packed(n, desc, runs, nr, off, packed)
+            aligner.unpack_runs(total + shift, packed, back)
+            torch.cuda.synchronize()
+            assert torch.equal(back[2 * shift: 2 * (total + shift)], dense[2 * shift: 2 * (total + shift)])
+            assert int(packed[total + shift:].max().item()) == 0            # nothing written past the end
+        with pytest.raises(scrooge_amd.ScroogeError):
+            aligner.compact_runs_packed(n, desc, runs, nr, off, packed, W=128, O=1)      # counts up to 127 do not fit 6 bits
+    finally:
+        aligner.use_own_stream()
