@@ -143,6 +143,20 @@ scrg_status scrg_align_mapping(scrg_ctx *ctx, const scrg_params *params,
                                const uint64_t *cand_offsets, const uint64_t *cand_start,
                                scrg_result **out);
 
+/* Many read batches against one reference: scrg_genome_set() stages, transfers and packs the genome ONCE and
+ * keeps it in the handle's HBM; scrg_align_mapping_resident() then aligns batches against it without touching
+ * the genome again (scrg_align_mapping re-stages it on every call, as the reference re-converts it,
+ * genasm_cpu.cpp:508).  cand_reverse may be NULL (all forward) or hold one 0/1 per candidate (1 = align the
+ * reverse complement of the read, as scrg_align_mapping_stranded in scrooge_amd_io.h).  The genome stays
+ * resident until another one is set, scrg_genome_clear() is called, or scrg_align_pairs / scrg_align_mapping
+ * reuse the handle's sequence array (scrg_align_mapping_resident then fails with SCRG_ERR_INVALID_ARG). */
+scrg_status scrg_genome_set(scrg_ctx *ctx, const char *genome, uint64_t genome_len);
+void        scrg_genome_clear(scrg_ctx *ctx);
+scrg_status scrg_align_mapping_resident(scrg_ctx *ctx, const scrg_params *params,
+                                        uint64_t n_reads, const char *const *reads, const uint64_t *read_lens,
+                                        const uint64_t *cand_offsets, const uint64_t *cand_start,
+                                        const uint8_t *cand_reverse, scrg_result **out);
+
 /* ---------------------------------------------------------------------------
  * Device-pointer entry points (inputs/outputs already resident in HBM; this is
  * what bench.py times).  All pointers below are device pointers valid on the

@@ -121,6 +121,9 @@ def load_library():
         "scrg_align_mapping": (C.c_int32, [vp, C.POINTER(Params), C.c_char_p, u64, u64,
                                            C.POINTER(C.c_char_p), C.POINTER(u64), C.POINTER(u64),
                                            C.POINTER(u64), C.POINTER(C.POINTER(Result))]),
+        "scrg_genome_set": (C.c_int32, [vp, C.c_char_p, u64]),
+        "scrg_genome_clear": (None, [vp]),
+        "scrg_align_mapping_resident": (C.c_int32, [vp, vp, u64, vp, vp, vp, vp, vp, vp]),
         "scrg_pack_planar": (C.c_int32, [vp, vp, u64, vp, vp]),
         "scrg_pack_planar_groups": (C.c_int32, [vp, vp, u64, u64, vp, vp]),
         "scrg_compact_runs_packed": (C.c_int32, [vp, vp, u64, vp, vp, vp, vp, vp]),
@@ -144,7 +147,8 @@ EXPORTED_SYMBOLS = [
     "scrg_params_default", "scrg_params_resolve", "scrg_ctx_create", "scrg_ctx_destroy", "scrg_ctx_set_stream",
     "scrg_ctx_use_own_stream", "scrg_stream_create", "scrg_stream_destroy",
     "scrg_last_error", "scrg_status_string", "scrg_set_log", "scrg_device_count",
-    "scrg_result_free", "scrg_align_pairs", "scrg_align_mapping", "scrg_pack_planar", "scrg_pack_planar_groups",
+    "scrg_result_free", "scrg_align_pairs", "scrg_align_mapping", "scrg_genome_set", "scrg_genome_clear",
+    "scrg_align_mapping_resident", "scrg_pack_planar", "scrg_pack_planar_groups",
     "scrg_align_device", "scrg_compact_runs", "scrg_compact_runs_packed", "scrg_unpack_runs", "scrg_ascii_to_twobit", "scrg_query_launch",
     "scrg_last_kernel_ms", "scrg_debug_stats"]
 
@@ -295,9 +299,20 @@ class Aligner:
         return self._finish(res, st, arrays, strict)
 
     # -- genasm_gpu::align_all(genome, reads)  (src/genasm_gpu.cu:890-980) ----------
-    def align_mapping(self, genome, reads, candidates, arrays=False, strict=True, **kw):
-        """candidates[r] = list of start_in_reference for read r (forward strand)."""
+    def set_genome(self, genome):
+        """Stage, transfer and pack a genome once; align_mapping(None, reads, candidates) then aligns batches
+        against it without touching it again (scrg_genome_set / scrg_align_mapping_resident)."""
         genome = genome.encode() if isinstance(genome, str) else bytes(genome)
+        self._check(self.lib.scrg_genome_set(self.h, genome, len(genome)))
+
+    def clear_genome(self):
+        self.lib.scrg_genome_clear(self.h)
+
+    def align_mapping(self, genome, reads, candidates, arrays=False, strict=True, **kw):
+        """candidates[r] = list of start_in_reference for read r (forward strand).  genome=None: the genome
+        left resident by set_genome()."""
+        if genome is not None:
+            genome = genome.encode() if isinstance(genome, str) else bytes(genome)
         reads = _bytes_list(reads)
         nr = len(reads)
         if len(candidates) != nr:
@@ -311,8 +326,12 @@ class Aligner:
         co = (C.c_uint64 * (nr + 1))(*offs)
         cs = (C.c_uint64 * max(len(starts), 1))(*starts)
         res = C.POINTER(Result)()
-        st = self.lib.scrg_align_mapping(self.h, C.byref(self._params(kw)), genome, len(genome),
-                                         nr, rp, rl, co, cs, C.byref(res))
+        if genome is None:
+            st = self.lib.scrg_align_mapping_resident(self.h, C.byref(self._params(kw)), nr, rp, rl, co, cs, None,
+                                                      C.byref(res))
+        else:
+            st = self.lib.scrg_align_mapping(self.h, C.byref(self._params(kw)), genome, len(genome),
+                                             nr, rp, rl, co, cs, C.byref(res))
         self._check(st, allow=(SCRG_ERR_CIGAR_OVERFLOW,))
         return self._finish(res, st, arrays, strict)
 

@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <numeric>
 #include <string>
 #include <thread>
@@ -122,6 +123,11 @@ struct scrg_ctx {
     // staging used by the host-pointer entry points
     HostPinned h_ascii;
     HostPinned h_desc;   // problem descriptors (pinned: no page faults after the first call, full-rate H2D)
+    HostPinned h_out, h_runs, h_off;   // pinned landing zones: per-pair scalars, dense runs, dense offsets (full-rate D2H / H2D;
+                                       // results are copied out to the caller's arrays in parallel)
+    // a genome kept resident by scrg_genome_set(): the first `genome_words` words of d_seq hold it, packed
+    uint64_t genome_len = 0, genome_words = 0;
+    bool genome_resident = false;
     DevBuf d_ascii, d_seq, d_pairs, d_runs, d_ed, d_nruns, d_status, d_bad, d_dense_off, d_dense;
 
     scrg_status fail(scrg_status s, const char* what, hipError_t e = hipSuccess)
@@ -156,6 +162,64 @@ template <typename F> static scrg_status guarded(scrg_ctx* c, F&& f)
         return c ? c->fail(SCRG_ERR_INVALID_ARG, "unexpected exception") : SCRG_ERR_INVALID_ARG;
     }
 }
+
+// Result arrays are recycled: a batch of millions of pairs returns hundreds of MB, and freshly mapped pages cost
+// more (first-touch faults) than filling them.  scrg_result_free() parks the big arrays here, the next call of
+// similar size takes them back.  At most 12 blocks / 2 GB are kept; everything else goes to malloc/free.
+namespace {
+struct ResultPool {
+    struct Block { void* p; size_t cap; };
+    std::mutex mu;
+    std::vector<Block> blocks;
+    size_t held = 0;
+    static constexpr size_t kMinPooled = 1u << 20, kMaxHeld = 2ull << 30, kMaxBlocks = 12;
+
+    void* get(size_t bytes, bool zero)
+    {
+        void* p = nullptr;
+        size_t cap = 0;
+        if (bytes >= kMinPooled) {
+            std::lock_guard<std::mutex> g(mu);
+            size_t best = blocks.size();
+            for (size_t i = 0; i < blocks.size(); i++)
+                if (blocks[i].cap >= bytes && blocks[i].cap <= 2 * bytes + (64u << 20) &&
+                    (best == blocks.size() || blocks[i].cap < blocks[best].cap))
+                    best = i;
+            if (best != blocks.size()) {
+                p = blocks[best].p;
+                cap = blocks[best].cap;
+                held -= cap;
+                blocks.erase(blocks.begin() + (long)best);
+            }
+        }
+        if (!p) {
+            cap = bytes >= kMinPooled ? bytes + bytes / 8 : bytes;
+            p = malloc(cap + sizeof(size_t) * 2);
+            if (!p) return nullptr;
+            static_cast<size_t*>(p)[0] = cap;
+        }
+        void* user = static_cast<char*>(p) + sizeof(size_t) * 2;
+        if (zero) memset(user, 0, bytes);
+        return user;
+    }
+    void put(void* user)
+    {
+        if (!user) return;
+        void* p = static_cast<char*>(user) - sizeof(size_t) * 2;
+        const size_t cap = static_cast<size_t*>(p)[0];
+        if (cap >= kMinPooled) {
+            std::lock_guard<std::mutex> g(mu);
+            if (blocks.size() < kMaxBlocks && held + cap <= kMaxHeld) {
+                blocks.push_back({p, cap});
+                held += cap;
+                return;
+            }
+        }
+        free(p);
+    }
+};
+ResultPool g_pool;
+}  // namespace
 
 extern "C" {
 
@@ -236,6 +300,7 @@ void scrg_ctx_destroy(scrg_ctx* c)
     c->stats.release();
     c->h_ascii.release();
     c->h_desc.release();
+    for (HostPinned* b : {&c->h_out, &c->h_runs, &c->h_off}) b->release();
     for (DevBuf* b : {&c->d_ascii, &c->d_seq, &c->d_pairs, &c->d_runs, &c->d_ed, &c->d_nruns, &c->d_status,
                       &c->d_bad, &c->d_dense_off, &c->d_dense})
         b->release();
@@ -532,12 +597,12 @@ scrg_status scrg_ascii_to_twobit(scrg_ctx* c, uint64_t count, const uint64_t* d_
 void scrg_result_free(scrg_result* r)
 {
     if (!r) return;
-    free(r->edit_distance);
-    free(r->pair_status);
-    free(r->run_offset);
-    free(r->runs);
-    free(r->cigar_offset);
-    free(r->cigar_text);
+    g_pool.put(r->edit_distance);
+    g_pool.put(r->pair_status);
+    g_pool.put(r->run_offset);
+    g_pool.put(r->runs);
+    g_pool.put(r->cigar_offset);
+    g_pool.put(r->cigar_text);
     free(r);
 }
 
@@ -565,8 +630,10 @@ struct Problem {         // one (text, read) problem in caller order
 
 // Shared tail of both host entry points: sequences are described by `seqs`
 // (each packed once, 32-base aligned), problems by `probs`.
+// `resident_words` leading words of d_seq are already packed on the device (a genome kept by scrg_genome_set):
+// they are neither staged nor transferred nor packed again; `seqs` then describes the words after them only.
 scrg_status run_batch(scrg_ctx* c, const scrg_params& p, std::vector<SeqRef>& seqs, uint64_t total_words,
-                      const std::vector<Problem>& probs, scrg_result** out)
+                      const std::vector<Problem>& probs, scrg_result** out, uint64_t resident_words = 0)
 {
     const int64_t t_begin = now_ns();
     const uint64_t n = probs.size();
@@ -587,31 +654,65 @@ scrg_status run_batch(scrg_ctx* c, const scrg_params& p, std::vector<SeqRef>& se
         scrg_result_free(r);
         return s;
     };
-    r->edit_distance = static_cast<int64_t*>(calloc(n + 1, sizeof(int64_t)));
-    r->pair_status = static_cast<uint32_t*>(calloc(n + 1, sizeof(uint32_t)));
-    r->run_offset = static_cast<uint64_t*>(calloc(n + 1, sizeof(uint64_t)));
-    r->cigar_offset = static_cast<uint64_t*>(calloc(n + 1, sizeof(uint64_t)));
+    // (every element of these four is written below; only the terminating entries need the zero)
+    r->edit_distance = static_cast<int64_t*>(g_pool.get((n + 1) * sizeof(int64_t), n < 4096));
+    r->pair_status = static_cast<uint32_t*>(g_pool.get((n + 1) * sizeof(uint32_t), n < 4096));
+    r->run_offset = static_cast<uint64_t*>(g_pool.get((n + 1) * sizeof(uint64_t), n < 4096));
+    r->cigar_offset = static_cast<uint64_t*>(g_pool.get((n + 1) * sizeof(uint64_t), n < 4096));
+    if (r->edit_distance) r->edit_distance[n] = 0;
+    if (r->pair_status) r->pair_status[n] = 0;
+    if (r->run_offset) r->run_offset[0] = r->run_offset[n] = 0;
+    if (r->cigar_offset) r->cigar_offset[0] = r->cigar_offset[n] = 0;
     if (!r->edit_distance || !r->pair_status || !r->run_offset || !r->cigar_offset)
         return bail(c->fail(SCRG_ERR_OOM, "result arrays"));
 
     // ---- stage ASCII (32 bytes per planar word, zero padded), H2D, pack ----
     const uint64_t seq_words = total_words + SCRG_SEQ_PAD_WORDS;
-    const size_t ascii_bytes = (size_t)total_words * 32;
+    const uint64_t new_words = total_words - resident_words;       // words to stage, transfer and pack in this call
+    const size_t ascii_bytes = (size_t)new_words * 32;
     if (ascii_bytes) {
         hipError_t e = c->h_ascii.ensure(ascii_bytes);
         if (e != hipSuccess) return bail(c->fail(SCRG_ERR_OOM, "pinned staging buffer", e));
         char* h = static_cast<char*>(c->h_ascii.p);
-        parallel_for(seqs.size(), [&](uint64_t s) {
-            const SeqRef& q = seqs[s];
-            char* dst = h + q.word_off * 32;
-            const uint64_t span = ((q.len + 31) / 32) * 32;
-            if (q.len && !q.revcomp) memcpy(dst, q.p, q.len);
-            if (q.len && q.revcomp)
-                for (uint64_t k = 0; k < q.len; k++) dst[k] = complement_base(q.p[q.len - 1 - k]);
-            if (span > q.len) memset(dst + q.len, 0, span - q.len);
+        // pieces of at most 4 MB, so that one long sequence (a chromosome) is copied by all threads
+        struct Piece { uint64_t seq, from, to; };
+        std::vector<Piece> pieces;
+        pieces.reserve(seqs.size());
+        const uint64_t PIECE = 4u << 20;
+        for (uint64_t s = 0; s < seqs.size(); s++) {
+            const uint64_t span = ((seqs[s].len + 31) / 32) * 32;
+            for (uint64_t a = 0; a < span || a == 0; a += PIECE) {
+                pieces.push_back({s, a, std::min(span, a + PIECE)});
+                if (span == 0) break;
+            }
+        }
+        parallel_for(pieces.size(), [&](uint64_t i) {
+            const Piece& pc = pieces[i];
+            const SeqRef& q = seqs[pc.seq];
+            char* dst = h + (q.word_off - resident_words) * 32;
+            const uint64_t data_to = std::min(pc.to, q.len);
+            if (pc.from < data_to) {
+                if (!q.revcomp) memcpy(dst + pc.from, q.p + pc.from, data_to - pc.from);
+                else
+                    for (uint64_t k = pc.from; k < data_to; k++) dst[k] = complement_base(q.p[q.len - 1 - k]);
+            }
+            if (pc.to > std::max(pc.from, q.len)) memset(dst + std::max(pc.from, q.len), 0, pc.to - std::max(pc.from, q.len));
         });
     }
     hipError_t e;
+    if (resident_words && (size_t)seq_words * 8 > c->d_seq.cap) {
+        // the sequence array has to grow: keep the resident genome (device-to-device) instead of packing it again
+        DevBuf bigger;
+        if ((e = bigger.ensure((size_t)seq_words * 8)) != hipSuccess) return bail(c->fail(SCRG_ERR_OOM, "device sequence buffer", e));
+        if ((e = hipMemcpyAsync(bigger.p, c->d_seq.p, resident_words * 8, hipMemcpyDeviceToDevice, c->stream)) != hipSuccess ||
+            (e = hipStreamSynchronize(c->stream)) != hipSuccess) {
+            bigger.release();
+            return bail(c->fail(SCRG_ERR_HIP, "moving the resident genome", e));
+        }
+        c->d_seq.release();
+        c->d_seq = bigger;
+    }
+    if (!resident_words && c->genome_resident) c->genome_resident = false;     // d_seq is about to be overwritten from word 0
     if ((e = c->d_ascii.ensure(ascii_bytes + 32)) != hipSuccess || (e = c->d_seq.ensure(seq_words * 8)) != hipSuccess ||
         (e = c->d_bad.ensure(4)) != hipSuccess)
         return bail(c->fail(SCRG_ERR_OOM, "device sequence buffers", e));
@@ -623,7 +724,7 @@ scrg_status run_batch(scrg_ctx* c, const scrg_params& p, std::vector<SeqRef>& se
     if (ascii_bytes) {
         if ((e = hipMemcpyAsync(c->d_ascii.p, c->h_ascii.p, ascii_bytes, hipMemcpyHostToDevice, c->stream)) != hipSuccess)
             return bail(c->fail(SCRG_ERR_HIP, "H2D ascii", e));
-        scrg_status s = scrg_pack_planar(c, c->d_ascii.as<char>(), total_words, c->d_seq.as<uint64_t>(),
+        scrg_status s = scrg_pack_planar(c, c->d_ascii.as<char>(), new_words, c->d_seq.as<uint64_t>() + resident_words,
                                          c->d_bad.as<uint32_t>());
         if (s != SCRG_OK) return bail(s);
     }
@@ -646,28 +747,42 @@ scrg_status run_batch(scrg_ctx* c, const scrg_params& p, std::vector<SeqRef>& se
             std::stable_sort(order.begin(), order.end(),
                              [&](uint32_t x, uint32_t y) { return probs[x].read_len > probs[y].read_len; });
     }
+    mark("  order");
     if (hipError_t eh = c->h_desc.ensure(std::max<uint64_t>(n, 1) * sizeof(scrg_pair_desc)); eh != hipSuccess)
         return bail(c->fail(SCRG_ERR_OOM, "pinned descriptor buffer", eh));
     scrg_pair_desc* const desc = static_cast<scrg_pair_desc*>(c->h_desc.p);
+    // slices: same bound as the reference's GPU list sizing (2*read_len, genasm_gpu.cu:906-911), whole 32-byte
+    // pieces; offsets by a two-level prefix sum (blocks of 64 k pairs in parallel)
     uint64_t arena = 0;
-    for (uint64_t k = 0; k < n; k++) {
-        // same bound as the reference's GPU list sizing (2*read_len, genasm_gpu.cu:906-911)
-        scrg_pair_desc& d = desc[k];
-        d.cigar_off = arena;
-        d.cigar_cap = (2 * probs[order[k]].read_len + 8 + 15) & ~(uint64_t)15;   // slices are whole 32-byte pieces
-        arena += d.cigar_cap;
+    {
+        const uint64_t BLK = 1u << 16, nb = (n + BLK - 1) / BLK;
+        std::vector<uint64_t> block_sum(nb + 1, 0);
+        parallel_for(nb, [&](uint64_t b) {
+            uint64_t acc = 0;
+            for (uint64_t k = b * BLK; k < std::min(n, (b + 1) * BLK); k++) {
+                const Problem& q = probs[order[k]];
+                scrg_pair_desc& d = desc[k];
+                d.text_off = q.text_off;
+                d.text_len = q.text_len;
+                d.read_off = q.read_off;
+                d.read_len = q.read_len;
+                d.cigar_cap = (2 * q.read_len + 8 + 15) & ~(uint64_t)15;
+                d.cigar_off = acc;
+                acc += d.cigar_cap;
+            }
+            block_sum[b + 1] = acc;
+        });
+        for (uint64_t b = 0; b < nb; b++) block_sum[b + 1] += block_sum[b];
+        arena = block_sum[nb];
+        parallel_for(nb, [&](uint64_t b) {
+            if (block_sum[b])
+                for (uint64_t k = b * BLK; k < std::min(n, (b + 1) * BLK); k++) desc[k].cigar_off += block_sum[b];
+        });
     }
-    parallel_for(n, [&](uint64_t k) {
-        const Problem& q = probs[order[k]];
-        scrg_pair_desc& d = desc[k];
-        d.text_off = q.text_off;
-        d.text_len = q.text_len;
-        d.read_off = q.read_off;
-        d.read_len = q.read_len;
-    });
+    mark("  build descriptors");
     if (n == 0) {
-        r->runs = static_cast<scrg_run*>(calloc(1, sizeof(scrg_run)));
-        r->cigar_text = static_cast<char*>(calloc(1, 1));
+        r->runs = static_cast<scrg_run*>(g_pool.get(sizeof(scrg_run), true));
+        r->cigar_text = static_cast<char*>(g_pool.get(1, true));
         r->total_ns = now_ns() - t_begin;
         *out = r;
         return SCRG_OK;
@@ -698,48 +813,74 @@ scrg_status run_batch(scrg_ctx* c, const scrg_params& p, std::vector<SeqRef>& se
 
     mark("align kernel");
     // ---- read back: per-pair scalars, then the compacted runs ----
-    std::vector<int64_t> ed(n);
-    std::vector<uint32_t> nr(n), st(n);
-    if ((e = hipMemcpyAsync(ed.data(), c->d_ed.p, n * 8, hipMemcpyDeviceToHost, c->stream)) != hipSuccess ||
-        (e = hipMemcpyAsync(nr.data(), c->d_nruns.p, n * 4, hipMemcpyDeviceToHost, c->stream)) != hipSuccess ||
-        (e = hipMemcpyAsync(st.data(), c->d_status.p, n * 4, hipMemcpyDeviceToHost, c->stream)) != hipSuccess ||
+    // (pinned landing zone: a D2H into pageable memory runs at a fraction of the link rate)
+    if ((e = c->h_out.ensure(n * 16)) != hipSuccess) return bail(c->fail(SCRG_ERR_OOM, "pinned result buffer", e));
+    int64_t* const ed = static_cast<int64_t*>(c->h_out.p);
+    uint32_t* const nr = reinterpret_cast<uint32_t*>(ed + n);
+    uint32_t* const st = nr + n;
+    if ((e = hipMemcpyAsync(ed, c->d_ed.p, n * 8, hipMemcpyDeviceToHost, c->stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(nr, c->d_nruns.p, n * 4, hipMemcpyDeviceToHost, c->stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(st, c->d_status.p, n * 4, hipMemcpyDeviceToHost, c->stream)) != hipSuccess ||
         (e = hipStreamSynchronize(c->stream)) != hipSuccess)
         return bail(c->fail(SCRG_ERR_HIP, "D2H scalars", e));
+    mark("  D2H scalars");
 
     // dense layout in caller order
-    std::vector<uint64_t> dense_off_sorted(n);
+    if ((e = c->h_off.ensure(n * 8)) != hipSuccess) return bail(c->fail(SCRG_ERR_OOM, "pinned offset buffer", e));
+    uint64_t* const dense_off_sorted = static_cast<uint64_t*>(c->h_off.p);
     {
-        std::vector<uint32_t> cnt_by_caller(n);
+        // run_offset[i] = exclusive prefix sum of the (capped) run counts in caller order: counts are scattered into
+        // run_offset itself, then a two-level scan (blocks of 64 k in parallel)
         parallel_for(n, [&](uint64_t k) {
-            cnt_by_caller[order[k]] = (uint32_t)std::min<uint64_t>(nr[k], desc[k].cigar_cap);
+            r->run_offset[order[k]] = std::min<uint64_t>(nr[k], desc[k].cigar_cap);
         });
-        uint64_t acc = 0;
-        for (uint64_t i = 0; i < n; i++) {
-            r->run_offset[i] = acc;
-            acc += cnt_by_caller[i];
-        }
-        r->run_offset[n] = acc;
+        const uint64_t BLK = 1u << 16, nb = (n + BLK - 1) / BLK;
+        std::vector<uint64_t> block_sum(nb + 1, 0);
+        parallel_for(nb, [&](uint64_t b) {
+            uint64_t acc = 0;
+            for (uint64_t i = b * BLK; i < std::min(n, (b + 1) * BLK); i++) {
+                const uint64_t cnt = r->run_offset[i];
+                r->run_offset[i] = acc;
+                acc += cnt;
+            }
+            block_sum[b + 1] = acc;
+        });
+        for (uint64_t b = 0; b < nb; b++) block_sum[b + 1] += block_sum[b];
+        parallel_for(nb, [&](uint64_t b) {
+            if (block_sum[b])
+                for (uint64_t i = b * BLK; i < std::min(n, (b + 1) * BLK); i++) r->run_offset[i] += block_sum[b];
+        });
+        r->run_offset[n] = block_sum[nb];
         parallel_for(n, [&](uint64_t k) { dense_off_sorted[k] = r->run_offset[order[k]]; });
     }
     const uint64_t total_runs = r->run_offset[n];
-    r->runs = static_cast<scrg_run*>(malloc((total_runs + 1) * sizeof(scrg_run)));
+    mark("  dense offsets");
+    r->runs = static_cast<scrg_run*>(g_pool.get((total_runs + 1) * sizeof(scrg_run), false));
     if (!r->runs) return bail(c->fail(SCRG_ERR_OOM, "runs"));
     if (total_runs) {
         if ((e = c->d_dense.ensure(total_runs * sizeof(scrg_run))) != hipSuccess)
             return bail(c->fail(SCRG_ERR_OOM, "dense runs", e));
-        if ((e = hipMemcpyAsync(c->d_dense_off.p, dense_off_sorted.data(), n * 8, hipMemcpyHostToDevice, c->stream)) !=
+        if ((e = hipMemcpyAsync(c->d_dense_off.p, dense_off_sorted, n * 8, hipMemcpyHostToDevice, c->stream)) !=
             hipSuccess)
             return bail(c->fail(SCRG_ERR_HIP, "H2D offsets", e));
         s = scrg_compact_runs(c, n, c->d_pairs.as<scrg_pair_desc>(), c->d_runs.as<scrg_run>(), c->d_nruns.as<uint32_t>(),
                               c->d_dense_off.as<uint64_t>(), c->d_dense.as<scrg_run>());
         if (s != SCRG_OK) return bail(s);
-        if ((e = hipMemcpyAsync(r->runs, c->d_dense.p, total_runs * sizeof(scrg_run), hipMemcpyDeviceToHost, c->stream)) !=
+        if ((e = c->h_runs.ensure(total_runs * sizeof(scrg_run))) != hipSuccess)
+            return bail(c->fail(SCRG_ERR_OOM, "pinned run buffer", e));
+        if ((e = hipMemcpyAsync(c->h_runs.p, c->d_dense.p, total_runs * sizeof(scrg_run), hipMemcpyDeviceToHost, c->stream)) !=
                 hipSuccess ||
             (e = hipStreamSynchronize(c->stream)) != hipSuccess)
             return bail(c->fail(SCRG_ERR_HIP, "D2H runs", e));
+        mark("  compaction + D2H runs");
+        const uint64_t bytes = total_runs * sizeof(scrg_run), CH = 1u << 20;
+        parallel_for((bytes + CH - 1) / CH, [&](uint64_t i) {
+            memcpy(reinterpret_cast<char*>(r->runs) + i * CH, static_cast<const char*>(c->h_runs.p) + i * CH,
+                   std::min<uint64_t>(CH, bytes - i * CH));
+        });
     }
 
-    mark("D2H scalars, compaction, D2H runs");
+    mark("  copy runs out");
     std::atomic<int> any_overflow{0};
     parallel_for(n, [&](uint64_t k) {
         r->edit_distance[order[k]] = ed[k];
@@ -761,12 +902,27 @@ scrg_status run_batch(scrg_ctx* c, const scrg_params& p, std::vector<SeqRef>& se
             chars_of[i] = chars;
         });
         uint64_t acc = 0;
-        for (uint64_t i = 0; i < n; i++) {
-            r->cigar_offset[i] = acc;
-            acc += chars_of[i] + 1;
+        {
+            const uint64_t BLK = 1u << 16, nb = (n + BLK - 1) / BLK;
+            std::vector<uint64_t> block_sum(nb + 1, 0);
+            parallel_for(nb, [&](uint64_t b) {
+                uint64_t a = 0;
+                for (uint64_t i = b * BLK; i < std::min(n, (b + 1) * BLK); i++) {
+                    r->cigar_offset[i] = a;
+                    a += chars_of[i] + 1;
+                }
+                block_sum[b + 1] = a;
+            });
+            for (uint64_t b = 0; b < nb; b++) block_sum[b + 1] += block_sum[b];
+            parallel_for(nb, [&](uint64_t b) {
+                if (block_sum[b])
+                    for (uint64_t i = b * BLK; i < std::min(n, (b + 1) * BLK); i++) r->cigar_offset[i] += block_sum[b];
+            });
+            acc = block_sum[nb];
         }
         r->cigar_offset[n] = acc;
-        r->cigar_text = static_cast<char*>(malloc(acc + 1));
+        mark("  text sizes");
+        r->cigar_text = static_cast<char*>(g_pool.get(acc + 1, false));
         if (!r->cigar_text) return bail(c->fail(SCRG_ERR_OOM, "cigar text"));
         parallel_for(n, [&](uint64_t i) {
             char* w = r->cigar_text + r->cigar_offset[i];
@@ -830,11 +986,17 @@ scrg_status scrg_align_pairs(scrg_ctx* c, const scrg_params* params, uint64_t n_
 static scrg_status align_mapping_impl(scrg_ctx* c, const scrg_params* params, const char* genome,
                                         uint64_t genome_len, uint64_t n_reads, const char* const* reads,
                                         const uint64_t* read_lens, const uint64_t* cand_offsets,
-                                        const uint64_t* cand_start, const uint8_t* cand_reverse, scrg_result** out)
+                                        const uint64_t* cand_start, const uint8_t* cand_reverse, scrg_result** out,
+                                        bool resident = false)
 {
     if (!c || !out) return SCRG_ERR_INVALID_ARG;
     *out = nullptr;
-    if ((genome_len && !genome) || (n_reads && (!reads || !read_lens)) || !cand_offsets)
+    if (resident) {                          // the genome scrg_genome_set() left packed at the front of d_seq
+        if (!c->genome_resident) return c->fail(SCRG_ERR_INVALID_ARG, "no resident genome: call scrg_genome_set first");
+        genome = nullptr;
+        genome_len = c->genome_len;
+    }
+    if ((!resident && genome_len && !genome) || (n_reads && (!reads || !read_lens)) || !cand_offsets)
         return c->fail(SCRG_ERR_INVALID_ARG, "null input array");
     scrg_params p;
     if (!resolve_params(params, &p)) return c->fail(SCRG_ERR_INVALID_ARG, "bad scrg_params");
@@ -848,7 +1010,7 @@ static scrg_status align_mapping_impl(scrg_ctx* c, const scrg_params* params, co
     seqs.reserve(1 + n_reads);
     std::vector<Problem> probs(n_pairs);
     uint64_t w = 0;
-    seqs.push_back({genome, genome_len, 0, false});
+    if (!resident) seqs.push_back({genome, genome_len, 0, false});
     w += (genome_len + 31) / 32;
     for (uint64_t r = 0; r < n_reads; r++) {
         if (read_lens[r] && !reads[r]) return c->fail(SCRG_ERR_INVALID_ARG, "null read pointer");
@@ -880,7 +1042,46 @@ static scrg_status align_mapping_impl(scrg_ctx* c, const scrg_params* params, co
             probs[k].read_len = read_lens[r];
         }
     }
-    return run_batch(c, p, seqs, w, probs, out);
+    return run_batch(c, p, seqs, w, probs, out, resident ? c->genome_words : 0);
+}
+
+// scrg_genome_set: stage, transfer and pack a genome once; it stays at the front of the handle's sequence
+// array until another genome is set, scrg_genome_clear() is called or a call that brings its own sequences
+// (scrg_align_pairs, scrg_align_mapping) reuses the array.
+static scrg_status genome_set_impl(scrg_ctx* c, const char* genome, uint64_t genome_len)
+{
+    if (!c || (genome_len && !genome)) return SCRG_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->genome_resident = false;
+    const uint64_t words = (genome_len + 31) / 32;
+    const size_t bytes = (size_t)words * 32;
+    hipError_t e;
+    if ((e = c->h_ascii.ensure(bytes + 32)) != hipSuccess) return c->fail(SCRG_ERR_OOM, "pinned staging buffer", e);
+    char* const h = static_cast<char*>(c->h_ascii.p);
+    const uint64_t PIECE = 4u << 20;
+    parallel_for((bytes + PIECE - 1) / PIECE, [&](uint64_t i) {
+        const uint64_t a = i * PIECE, b = std::min<uint64_t>(bytes, a + PIECE), d = std::min(b, genome_len);
+        if (a < d) memcpy(h + a, genome + a, d - a);
+        if (b > std::max(a, genome_len)) memset(h + std::max(a, genome_len), 0, b - std::max(a, genome_len));
+    });
+    if ((e = c->d_ascii.ensure(bytes + 32)) != hipSuccess || (e = c->d_seq.ensure((words + SCRG_SEQ_PAD_WORDS) * 8)) != hipSuccess ||
+        (e = c->d_bad.ensure(4)) != hipSuccess)
+        return c->fail(SCRG_ERR_OOM, "device sequence buffers", e);
+    HIP_TRY(c, hipMemsetAsync(c->d_bad.p, 0, 4, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_seq.as<uint64_t>() + words, 0, SCRG_SEQ_PAD_WORDS * 8, c->stream));
+    if (bytes) {
+        HIP_TRY(c, hipMemcpyAsync(c->d_ascii.p, h, bytes, hipMemcpyHostToDevice, c->stream));
+        scrg_status s = scrg_pack_planar(c, c->d_ascii.as<char>(), words, c->d_seq.as<uint64_t>(), c->d_bad.as<uint32_t>());
+        if (s != SCRG_OK) return s;
+    }
+    uint32_t bad = 0;
+    HIP_TRY(c, hipMemcpyAsync(&bad, c->d_bad.p, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (bad) return c->fail(SCRG_ERR_BAD_BASE, "genome contains characters other than ACGTacgt");
+    c->genome_len = genome_len;
+    c->genome_words = words;
+    c->genome_resident = true;
+    return SCRG_OK;
 }
 
 scrg_status scrg_align_mapping_stranded(scrg_ctx* c, const scrg_params* params, const char* genome,
@@ -891,6 +1092,26 @@ scrg_status scrg_align_mapping_stranded(scrg_ctx* c, const scrg_params* params, 
     return guarded(c, [&] {
         return align_mapping_impl(c, params, genome, genome_len, n_reads, reads, read_lens, cand_offsets, cand_start,
                                   cand_reverse, out);
+    });
+}
+
+scrg_status scrg_genome_set(scrg_ctx* c, const char* genome, uint64_t genome_len)
+{
+    return guarded(c, [&] { return genome_set_impl(c, genome, genome_len); });
+}
+
+void scrg_genome_clear(scrg_ctx* c)
+{
+    if (c) c->genome_resident = false;
+}
+
+scrg_status scrg_align_mapping_resident(scrg_ctx* c, const scrg_params* params, uint64_t n_reads, const char* const* reads,
+                                        const uint64_t* read_lens, const uint64_t* cand_offsets, const uint64_t* cand_start,
+                                        const uint8_t* cand_reverse, scrg_result** out)
+{
+    return guarded(c, [&] {
+        return align_mapping_impl(c, params, nullptr, 0, n_reads, reads, read_lens, cand_offsets, cand_start, cand_reverse,
+                                  out, true);
     });
 }
 

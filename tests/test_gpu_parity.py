@@ -227,3 +227,40 @@ def test_array_results_match_object_results(aligner):
         seg = arr["runs"][int(ro[i]):int(ro[i + 1])]
         assert "".join("%d%s" % (c, chr(o)) for c, o in seg) == objs[i].cigar
     assert aligner.align_pairs([], [], arrays=True)["edit_distance"].shape == (0,)
+
+
+def test_resident_genome(aligner, golden_mapping, oracle):
+    """scrg_genome_set + scrg_align_mapping_resident: the genome is staged and packed once; batches of different
+    sizes (the sequence array grows in between: the genome moves device-to-device), the same results as
+    scrg_align_mapping; a call that brings its own sequences evicts it and the next resident call fails."""
+    import scrooge_amd
+    gm = golden_mapping
+    aligner.set_genome(gm["genome"])
+    try:
+        small = aligner.align_mapping(None, gm["reads"][:3], gm["candidates"][:3])
+        n_small = sum(len(c) for c in gm["candidates"][:3])
+        _check(small, gm["ed"][:n_small], gm["cigar"][:n_small], "resident, small batch")
+        _check(aligner.align_mapping(None, gm["reads"], gm["candidates"]), gm["ed"], gm["cigar"], "resident, full batch")
+        # a much larger batch against the same resident genome
+        rng = np.random.Generator(np.random.PCG64(3))
+        G = len(gm["genome"])
+        reads, cands, texts, qs = [], [], [], []
+        for _ in range(3000):
+            s = int(rng.integers(0, max(1, G - 200)))
+            r = gm["genome"][s:s + 150]
+            r = r if isinstance(r, bytes) else r.encode()
+            reads.append(r)
+            cands.append([s, max(0, s - 2)])
+            for c in cands[-1]:
+                g = gm["genome"][c:c + 400]
+                texts.append(g if isinstance(g, bytes) else g.encode())
+                qs.append(r)
+        eds, cigars, _, _ = oracle.align(texts, qs, threads=8)
+        _check(aligner.align_mapping(None, reads, cands), eds, cigars, "resident, large batch")
+        _check(aligner.align_mapping(None, gm["reads"], gm["candidates"]), gm["ed"], gm["cigar"], "resident, again")
+        aligner.align_pairs(["ACGT"], ["ACGT"])                 # reuses the sequence array: the genome is gone
+        with pytest.raises(scrooge_amd.ScroogeError):
+            aligner.align_mapping(None, gm["reads"], gm["candidates"])
+    finally:
+        aligner.clear_genome()
+    _check(aligner.align_mapping(gm["genome"], gm["reads"], gm["candidates"]), gm["ed"], gm["cigar"], "after clear")
