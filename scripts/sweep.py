@@ -34,14 +34,14 @@ ed = torch.empty(n, dtype=torch.int64, device=dev)
 nr = torch.empty(n, dtype=torch.int32, device=dev)
 st = torch.empty(n, dtype=torch.int32, device=dev)
 name = torch.cuda.get_device_name(0)
-configs = [(64, 33, 0, 0, 0)]                                                                    # library defaults (G=8, 12 rows, 11 waves/CU; diagonal-major path on)
-configs += [(W, min(W // 2 + 1, W - 1), 8, 13, 11) for W in (16, 24, 32, 40, 48, 56)]      # W sweep, O = W/2+1 (profile.py:78)
-configs += [(64, O, 8, 13, 11) for O in (36, 40, 48, 56, 60)]                                  # O sweep at W=64 (profile.py:88-100)
-configs += [(64, O, 8, 13, 3) for O in (2, 16, 32)]                                             # small overlaps: WIDE storage
+configs = [(64, 33, 0, 0, 0)]                                                                    # library defaults (one pair per lane, 16 waves/CU)
+configs += [(W, min(W // 2 + 1, W - 1), 0, 0, 0) for W in (16, 24, 32, 40, 48, 56)]        # W sweep, O = W/2+1 (profile.py:78): lane kernel
+configs += [(64, O, 0, 0, 0) for O in (36, 40, 48, 56, 60)]                                    # O sweep at W=64 (profile.py:88-100): lane kernel
+configs += [(64, O, 8, 13, 3) for O in (2, 16, 32)]                                             # small overlaps: WIDE storage of the G=8 kernel
 configs += [(W, W // 2 + 1, 0, 0, 0) for W in (80, 96, 112, 128, 160, 192, 224, 256)]         # W sweep past one word (profile.py:180-185)
 configs += [(128, 65, 64, 0, 0), (256, 129, 64, 0, 0), (256, 129, 32, 20, 0), (128, 20, 0, 0, 0)]
-configs += [(64, 33, g, 13, w) for g, w in ((64, 16), (32, 16), (16, 16), (4, 6))]             # lane mappings
-configs += [(64, 33, 8, r, w) for r, w in ((12, 10), (12, 12), (16, 9), (8, 11))]              # LDS rows / waves per CU
+configs += [(64, 33, g, 13, w) for g, w in ((64, 16), (32, 16), (16, 16), (8, 11), (4, 6))]    # the GenASM-row lane mappings
+configs += [(64, 33, 1, 0, w) for w in (4, 8, 12, 16)]                                          # one pair per lane: waves per CU
 with open(out, "w", newline="") as f:
     wr = csv.writer(f)
     wr.writerow(["W", "O", "sene", "dent", "early termination", "threadblocks/sm", "lanes per pair", "lds rows",
