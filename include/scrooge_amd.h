@@ -242,14 +242,19 @@ scrg_status scrg_query_launch(scrg_ctx *ctx, const scrg_params *params,
  * the launch stream (milliseconds); blocks until that launch finished. */
 scrg_status scrg_last_kernel_ms(scrg_ctx *ctx, float *ms);
 
-/* Profiling aid: when params.reserved[1] != 0 the align kernel accumulates
- * {window rounds, DC sweep steps, TB macro-steps, and shader cycles summed over
- * wavefronts for fetch / window setup / DC / TB / TB loop, rounds on the
- * diagonal-major path, rounds that fell back from it, and the DC / TB cycles of
- * the diagonal-major rounds (not included in the former)} per launch; this
- * reads them back (blocks on the stream).  params.reserved[0] holds ablation
- * switches and must be 0 for correct results (32 only turns the diagonal-major
- * path off and keeps results intact). */
+/* Profiling aid: when params.reserved[1] != 0 the align kernel accumulates twelve counters per launch; this
+ * reads them back (blocks on the stream).
+ *   lanes_per_pair = 1 (genasm_lane_kernel): [0] window rounds (one window of each of a wavefront's 64 pairs),
+ *     [1] rounds that took a short-window variant, [2..6] shader cycles summed over wavefronts: traceback pass 1,
+ *     queue/fetch, window setup, table, traceback (both passes + CIGAR flush), [7] wavefront life times and
+ *     [8..11] latest start, 2^62 - earliest start, latest end, 2^62 - earliest end on the 100 MHz wall clock.
+ *   lanes_per_pair >= 4 (genasm_align_kernel): {window rounds, DC sweep steps, TB macro-steps, shader cycles for
+ *     fetch / window setup / DC / TB / TB loop, rounds on the diagonal-major path, rounds that fell back from it,
+ *     DC / TB cycles of the diagonal-major rounds (not included in the former)}.
+ * params.reserved[0] holds ablation switches for profiling and must be 0 for correct results, except:
+ *   lanes_per_pair = 1: 1 only turns the wavefront priority rotation off (results intact); 2 / 4 / 8 / 16 skip the
+ *     table, traceback pass 2, traceback pass 1, the CIGAR stores (results are wrong by design);
+ *   lanes_per_pair = 8: 32 only turns the diagonal-major path off (results intact). */
 scrg_status scrg_debug_stats(scrg_ctx *ctx, uint64_t out[12]);
 
 #ifdef __cplusplus

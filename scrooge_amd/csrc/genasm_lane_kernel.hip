@@ -37,18 +37,41 @@ namespace scrg {
 constexpr int LANE_TB_COLS = 31;                 // W-O <= 31 columns can be consumed per window
 constexpr uint32_t LANE_RING_BYTES = 68;         // 32 runs + one dword: lanes land on distinct LDS banks
 constexpr uint32_t LANE_SCRATCH_BYTES = 36;      // insertion-run length of each traceback column, one byte each (+ bank skew)
-constexpr uint32_t LANE_WAVE_LDS_BYTES = 64u * (LANE_RING_BYTES + LANE_SCRATCH_BYTES);
+#ifndef SCRG_EQ_LDS
+#define SCRG_EQ_LDS 1                            // 0: compute Eq from the text bits per column (A/B builds only)
+#endif
+constexpr uint32_t LANE_EQ_BYTES = SCRG_EQ_LDS ? 32 : 0;   // Eq of the window's pattern for each of the four bases, 8 bytes each
+constexpr uint32_t LANE_WAVE_LDS_BYTES = 64u * (LANE_RING_BYTES + LANE_SCRATCH_BYTES + LANE_EQ_BYTES);
+constexpr int LANE_EQ_AHEAD = 8;                 // Eq words are read from LDS this many columns ahead of their use
 
 // truth tables (inputs a, b, c in that order)
 // (two-input operations are left to plain and/or/xor: 4-byte encodings, a v_bitop3_b32 takes 8)
-constexpr int TT_EQ  = bitop3_table([](int x, int rh, int sh) { return ~(x | (rh ^ sh)); });       // pattern character == text character
+[[maybe_unused]] constexpr int TT_EQ  = bitop3_table([](int x, int rh, int sh) { return ~(x | (rh ^ sh)); });       // pattern character == text character
 constexpr int TT_XH  = bitop3_table([](int sum, int pv, int eq) { return (sum ^ pv) | eq; });
 constexpr int TT_PH  = bitop3_table([](int mv, int xh, int pv) { return mv | ~(xh | pv); });
 constexpr int TT_PVN = bitop3_table([](int mhs, int xv, int phs) { return mhs | ~(xv | phs); });
 constexpr int TT_NOR3 = bitop3_table([](int a, int b, int c) { return ~(a | b | c); });
 constexpr int TT_NIV  = bitop3_table([](int nv1, int v0, int stop) { return nv1 | ~v0 | stop; });     // not (insertion), or the stop row
 constexpr int TT_ANDN = bitop3_table([](int a, int b, int) { return a & ~b; });
+constexpr int TT_BFI = bitop3_table([](int a, int b, int c) { return (a & c) | (b & ~c); });       // bits of a where c is set, else b
+constexpr int TT_ANDOR = bitop3_table([](int a, int b, int c) { return (a & b) | c; });
 constexpr int TT_V0  = bitop3_table([](int pvn, int ph, int xh) { return pvn | ~(ph | xh); });
+
+// LDS accesses by 32-bit LDS address (no generic-pointer arithmetic in front of the ds instruction)
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) u32x2_t lds_u32x2_t;
+__device__ __forceinline__ uint2 lds_read64(uint32_t addr)
+{
+    const u32x2_t v = *reinterpret_cast<const lds_u32x2_t*>((uintptr_t)addr);
+    return make_uint2(v.x, v.y);
+}
+__device__ __forceinline__ void lds_write64(uint32_t addr, uint2 v)
+{
+    u32x2_t w;
+    w.x = v.x;
+    w.y = v.y;
+    *reinterpret_cast<lds_u32x2_t*>((uintptr_t)addr) = w;
+}
 
 __device__ __forceinline__ uint32_t ffbh_u32(uint32_t v)      // count leading zeros; 0xffffffff for v == 0
 {
@@ -60,9 +83,16 @@ __device__ __forceinline__ uint32_t ffbh_u32(uint32_t v)      // count leading z
 // SHORT_N / SHORT_M = false: every lane of the wave has a full text / pattern window (n = 64 / m = 64).
 // SHORT_M: any m <= 64 per lane (the last windows of a read, W < 64): the table is shifted left by 64-m.
 // SHORT_N: any n <= 64 per lane (the text ends inside the window): columns >= n are skipped per lane.
+// Eq of a column is LOOKED UP: the four possible words (pattern == A / C / G / T) are written to 32 bytes of LDS per
+// lane once per window, and a column reads the one its text character selects — address = table | 8 * character from
+// two right shifts and two v_bitop3_b32 with inline constants, the ds_read_b64 itself does not occupy the VALU.
+// (Computing it per column costs 2 v_bfe_i32 + 2 v_xor + 2 v_bitop3; the reads are issued LANE_EQ_AHEAD columns early.)
+// Slot c ^ swz of a lane holds base c, swz = (lane >> 3) & 3, so the lanes that share LDS banks (8 apart) use
+// different slots for the same base; the swizzle is folded into the text planes once per window.
 template <bool SHORT_N, bool SHORT_M>
 __device__ __forceinline__ void lane_window_table(const Planes tw, const Planes pw, const uint32_t n, const uint32_t m,
-                                                  const uint32_t stop, uint32_t (&nv1)[LANE_TB_COLS], uint32_t (&v0)[LANE_TB_COLS])
+                                                  const uint32_t stop, uint32_t (&nv1)[LANE_TB_COLS], uint32_t (&v0)[LANE_TB_COLS],
+                                                  char* const lds_b, const uint32_t eq_b, const uint32_t swz)
 {
     // nv1[i] = ~(V1 | stop): stop has the one bit of the row at which this lane's walk ends (jlim), so a
     // finished lane reads "deletion" there and stays put without a test
@@ -75,7 +105,30 @@ __device__ __forceinline__ void lane_window_table(const Planes tw, const Planes 
         rhi >>= sft;
     }
     const uint32_t rl0 = (uint32_t)rlo, rl1 = (uint32_t)(rlo >> 32), rh0 = (uint32_t)rhi, rh1 = (uint32_t)(rhi >> 32);
+#if SCRG_EQ_LDS
+    {   // base c = 2*hi + lo: Eq_c = (lo plane == c&1) & (hi plane == c>>1); slot c ^ swz
+        const uint32_t x = eq_b | (swz << 3);
+        lds_write64(x ^ 0u, make_uint2(~(rl0 | rh0), ~(rl1 | rh1)));
+        lds_write64(x ^ 8u, make_uint2(rl0 & ~rh0, rl1 & ~rh1));
+        lds_write64(x ^ 16u, make_uint2(~rl0 & rh0, ~rl1 & rh1));
+        lds_write64(x ^ 24u, make_uint2(rl0 & rh0, rl1 & rh1));
+    }
+    const uint32_t swl = 0u - (swz & 1u), swh = 0u - (swz >> 1);
+    const uint32_t tl0 = (uint32_t)tw.lo ^ swl, tl1 = (uint32_t)(tw.lo >> 32) ^ swl, th0 = (uint32_t)tw.hi ^ swh, th1 = (uint32_t)(tw.hi >> 32) ^ swh;
+    // LDS address of column i's Eq word: eq_b | 8 * (2 * hi bit + lo bit)
+    auto eq_addr = [&](int i) -> uint32_t {
+        const uint32_t tl = i < 32 ? tl0 : tl1, th = i < 32 ? th0 : th1;
+        const int b = i & 31;
+        const uint32_t u = b >= 3 ? tl >> (b - 3) : tl << (3 - b);         // lo bit -> bit 3
+        const uint32_t v = b >= 4 ? th >> (b - 4) : th << (4 - b);         // hi bit -> bit 4
+        return bitop3<TT_ANDOR>(bitop3<TT_BFI>(u, v, 8u), 24u, eq_b);
+    };
+    uint2 eqw[LANE_EQ_AHEAD];
+#pragma unroll
+    for (int k = 0; k < LANE_EQ_AHEAD; k++) eqw[k] = lds_read64(eq_addr(63 - k));
+#else
     const uint32_t tl0 = (uint32_t)tw.lo, tl1 = (uint32_t)(tw.lo >> 32), th0 = (uint32_t)tw.hi, th1 = (uint32_t)(tw.hi >> 32);
+#endif
     uint32_t pv0 = ~0u, pv1 = ~0u, mv0 = 0u, mv1 = 0u;           // D[n][j] = m-j: every vertical step is +1
     if (SHORT_N) {
 #pragma unroll
@@ -86,10 +139,18 @@ __device__ __forceinline__ void lane_window_table(const Planes tw, const Planes 
     }
 #pragma unroll
     for (int i = 63; i >= 0; i--) {
+#if SCRG_EQ_LDS
+        const uint2 eq_now = eqw[(63 - i) % LANE_EQ_AHEAD];
+        if (i - LANE_EQ_AHEAD >= 0) eqw[(63 - i) % LANE_EQ_AHEAD] = lds_read64(eq_addr(i - LANE_EQ_AHEAD));
+#endif
         if (!SHORT_N || (uint32_t)i < n) {
+#if SCRG_EQ_LDS
+            const uint32_t eq0 = eq_now.x, eq1 = eq_now.y;
+#else
             const uint32_t sl = (uint32_t)__builtin_amdgcn_sbfe((int)(i < 32 ? tl0 : tl1), i & 31, 1);
             const uint32_t sh = (uint32_t)__builtin_amdgcn_sbfe((int)(i < 32 ? th0 : th1), i & 31, 1);
             const uint32_t eq0 = bitop3<TT_EQ>(rl0 ^ sl, rh0, sh), eq1 = bitop3<TT_EQ>(rl1 ^ sl, rh1, sh);
+#endif
             const uint32_t xv0 = eq0 | mv0, xv1 = eq1 | mv1;
             const uint32_t t0 = eq0 & pv0, t1 = eq1 & pv1;
             const uint64_t sum = add64(((uint64_t)t1 << 32) | t0, ((uint64_t)pv1 << 32) | pv0);
@@ -130,6 +191,10 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
     const uint32_t ring_b = wave_b + lane * LANE_RING_BYTES;
     const uint32_t scr_b = wave_b + 64u * LANE_RING_BYTES + lane * LANE_SCRATCH_BYTES;
     uint8_t* const lds8 = reinterpret_cast<uint8_t*>(lds);
+    // (an LDS ADDRESS, a multiple of 32: the dynamic LDS starts at a multiple of 32 because nothing static precedes it)
+    const uint32_t eq_b = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds_b +
+                          wave_b + 64u * (LANE_RING_BYTES + LANE_SCRATCH_BYTES) + lane * LANE_EQ_BYTES;
+    const uint32_t swz = (lane >> 3) & 3u;
     const uint32_t W = (uint32_t)a.W;
     const uint32_t TBL = (uint32_t)a.tb_limit;         // W - O, 1..31
 
@@ -253,13 +318,13 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
                 v0[i] = (uint32_t)tw.lo * (uint32_t)(i + 1);
             }
         } else if (short_n) {
-            lane_window_table<true, true>(tw, pw, n, m, stop, nv1, v0);
+            lane_window_table<true, true>(tw, pw, n, m, stop, nv1, v0, lds_b, eq_b, swz);
             st_gen++;
         } else if (short_m) {
-            lane_window_table<false, true>(tw, pw, n, m, stop, nv1, v0);
+            lane_window_table<false, true>(tw, pw, n, m, stop, nv1, v0, lds_b, eq_b, swz);
             st_gen++;
         } else {
-            lane_window_table<false, false>(tw, pw, n, m, stop, nv1, v0);
+            lane_window_table<false, false>(tw, pw, n, m, stop, nv1, v0, lds_b, eq_b, swz);
         }
         const uint64_t tm3 = timing ? __builtin_readcyclecounter() : 0;
 
