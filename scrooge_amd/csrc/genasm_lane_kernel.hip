@@ -91,11 +91,12 @@ __device__ __forceinline__ uint32_t ffbh_u32(uint32_t v)      // count leading z
 // different slots for the same base; the swizzle is folded into the text planes once per window.
 template <bool SHORT_N, bool SHORT_M>
 __device__ __forceinline__ void lane_window_table(const Planes tw, const Planes pw, const uint32_t n, const uint32_t m,
-                                                  const uint32_t stop, uint32_t (&nv1)[LANE_TB_COLS], uint32_t (&v0)[LANE_TB_COLS],
+                                                  const uint32_t stop, uint64_t (&tab)[LANE_TB_COLS],
                                                   char* const lds_b, const uint32_t eq_b, const uint32_t swz)
 {
-    // nv1[i] = ~(V1 | stop): stop has the one bit of the row at which this lane's walk ends (jlim), so a
-    // finished lane reads "deletion" there and stays put without a test
+    // tab[i] = ~(V1 | stop) in the upper dword, V0 in the lower one (a register pair: the traceback shifts both with one
+    // 64-bit shift): stop has the one bit of the row at which this lane's walk ends (jlim), so a finished lane reads
+    // "deletion" there and stays put without a test
     // reversed pattern, right-aligned: bit b <-> pattern[m-1-b] (the reference's layout, genasm_cpu.cpp:178-198);
     // whatever lies above bit m-1 never reaches the bits below it (carries and shifts only move up)
     const uint32_t sft = 64u - m;
@@ -132,10 +133,7 @@ __device__ __forceinline__ void lane_window_table(const Planes tw, const Planes 
     uint32_t pv0 = ~0u, pv1 = ~0u, mv0 = 0u, mv1 = 0u;           // D[n][j] = m-j: every vertical step is +1
     if (SHORT_N) {
 #pragma unroll
-        for (int i = 0; i < LANE_TB_COLS; i++) {                      // columns >= n: only insertions (genasm_cpu.cpp:239-245)
-            nv1[i] = 0u;
-            v0[i] = ~0u;
-        }
+        for (int i = 0; i < LANE_TB_COLS; i++) tab[i] = 0xffffffffull;    // columns >= n: only insertions (genasm_cpu.cpp:239-245)
     }
 #pragma unroll
     for (int i = 63; i >= 0; i--) {
@@ -167,11 +165,9 @@ __device__ __forceinline__ void lane_window_table(const Planes tw, const Planes 
                 if (SHORT_M) {
                     const uint64_t a = ((uint64_t)(pv1 | ph1) << 32) | (pv0 | ph0);
                     const uint64_t b = ((uint64_t)bitop3<TT_V0>(pv1, ph1, xh1) << 32) | bitop3<TT_V0>(pv0, ph0, xh0);
-                    nv1[i] = ~((uint32_t)((a << sft) >> 32) | stop);
-                    v0[i] = (uint32_t)((b << sft) >> 32);
+                    tab[i] = ((uint64_t)(~((uint32_t)((a << sft) >> 32) | stop)) << 32) | (uint32_t)((b << sft) >> 32);
                 } else {
-                    nv1[i] = bitop3<TT_NOR3>(pv1, ph1, stop);
-                    v0[i] = bitop3<TT_V0>(pv1, ph1, xh1);
+                    tab[i] = ((uint64_t)bitop3<TT_NOR3>(pv1, ph1, stop) << 32) | bitop3<TT_V0>(pv1, ph1, xh1);
                 }
             }
         }
@@ -307,24 +303,21 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
         const uint64_t tm2 = timing ? __builtin_readcyclecounter() : 0;
 
         // ---------------- the window's table: all distances at once (genasm_cpu.cpp:210-288) ----------------
-        uint32_t nv1[LANE_TB_COLS], v0[LANE_TB_COLS];
+        uint64_t tab[LANE_TB_COLS];
         const uint32_t jlim = has_pair ? min(m, TBL) : 0u;          // the walk ends when j gets here (:301, :310)
         const uint32_t stop = 0x80000000u >> jlim;
         const bool short_n = __any(has_pair && n != 64u), short_m = __any(has_pair && m != 64u);
         if (a.debug & 2) {                       // ablation (profiling only): no table computation
 #pragma unroll
-            for (int i = 0; i < LANE_TB_COLS; i++) {
-                nv1[i] = ~stop;
-                v0[i] = (uint32_t)tw.lo * (uint32_t)(i + 1);
-            }
+            for (int i = 0; i < LANE_TB_COLS; i++) tab[i] = ((uint64_t)~stop << 32) | ((uint32_t)tw.lo * (uint32_t)(i + 1));
         } else if (short_n) {
-            lane_window_table<true, true>(tw, pw, n, m, stop, nv1, v0, lds_b, eq_b, swz);
+            lane_window_table<true, true>(tw, pw, n, m, stop, tab, lds_b, eq_b, swz);
             st_gen++;
         } else if (short_m) {
-            lane_window_table<false, true>(tw, pw, n, m, stop, nv1, v0, lds_b, eq_b, swz);
+            lane_window_table<false, true>(tw, pw, n, m, stop, tab, lds_b, eq_b, swz);
             st_gen++;
         } else {
-            lane_window_table<false, false>(tw, pw, n, m, stop, nv1, v0, lds_b, eq_b, swz);
+            lane_window_table<false, false>(tw, pw, n, m, stop, tab, lds_b, eq_b, swz);
         }
         const uint64_t tm3 = timing ? __builtin_readcyclecounter() : 0;
 
@@ -350,13 +343,16 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
                 for (int i = 0; i < LANE_TB_COLS; i++) {
                     if (!FULL && (uint32_t)i >= TBL) continue;         // (uniform)
                     // the insertions in a row from (i, j): leading zeros of "not insertion, or stop" << j
-                    const uint32_t x = bitop3<TT_NIV>(nv1[i], v0[i], stop) << j;
+                    const uint32_t x = bitop3<TT_NIV>((uint32_t)(tab[i] >> 32), (uint32_t)tab[i], stop) << j;
                     const uint32_t ni = ffbh_u32(x);
                     lds8[scr_b + i] = (uint8_t)ni;
                     nIm = __builtin_amdgcn_alignbit(nIm, x, 31);               // (nIm << 1) | (ni == 0)
                     j += ni;
                     ti += (j < jlim) ? 1u : 0u;                                // still inside the window: one D / X / = step
-                    const uint32_t nt1 = nv1[i] << j, t0 = v0[i] << j;         // sign bits: not a deletion, substitution
+                    // sign bits of both dwords after ONE 64-bit shift of the pair (what spills from v0 into the low bits of
+                    // the upper dword is never looked at): not a deletion, substitution
+                    const uint64_t both = tab[i] << j;
+                    const uint32_t nt1 = (uint32_t)(both >> 32), t0 = (uint32_t)both;
                     nDm = __builtin_amdgcn_alignbit(nDm, nt1, 31);
                     Xm = __builtin_amdgcn_alignbit(Xm, t0, 31);
                     uint32_t scratch;                                          // j += sign bit of nt1: a deletion (or the stop row) keeps j
