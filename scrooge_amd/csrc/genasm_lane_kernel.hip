@@ -94,9 +94,10 @@ __device__ __forceinline__ void lane_window_table(const Planes tw, const Planes 
                                                   const uint32_t stop, uint64_t (&tab)[LANE_TB_COLS],
                                                   char* const lds_b, const uint32_t eq_b, const uint32_t swz)
 {
-    // tab[i] = ~(V1 | stop) in the upper dword, V0 in the lower one (a register pair: the traceback shifts both with one
-    // 64-bit shift): stop has the one bit of the row at which this lane's walk ends (jlim), so a finished lane reads
-    // "deletion" there and stays put without a test
+    // tab[i] = ~(V1 | stop) in the upper dword, V0 | stop in the lower one (a register pair: the traceback shifts both
+    // with one 64-bit shift): stop has the one bit of the row at which this lane's walk ends (jlim), so a finished lane
+    // reads "deletion AND substitution" there — it stays put without a test, and the combination, which no cell of the
+    // matrix has, marks the columns it was no longer alive in
     // reversed pattern, right-aligned: bit b <-> pattern[m-1-b] (the reference's layout, genasm_cpu.cpp:178-198);
     // whatever lies above bit m-1 never reaches the bits below it (carries and shifts only move up)
     const uint32_t sft = 64u - m;
@@ -165,9 +166,9 @@ __device__ __forceinline__ void lane_window_table(const Planes tw, const Planes 
                 if (SHORT_M) {
                     const uint64_t a = ((uint64_t)(pv1 | ph1) << 32) | (pv0 | ph0);
                     const uint64_t b = ((uint64_t)bitop3<TT_V0>(pv1, ph1, xh1) << 32) | bitop3<TT_V0>(pv0, ph0, xh0);
-                    tab[i] = ((uint64_t)(~((uint32_t)((a << sft) >> 32) | stop)) << 32) | (uint32_t)((b << sft) >> 32);
+                    tab[i] = ((uint64_t)(~((uint32_t)((a << sft) >> 32) | stop)) << 32) | ((uint32_t)((b << sft) >> 32) | stop);
                 } else {
-                    tab[i] = ((uint64_t)bitop3<TT_NOR3>(pv1, ph1, stop) << 32) | bitop3<TT_V0>(pv1, ph1, xh1);
+                    tab[i] = ((uint64_t)bitop3<TT_NOR3>(pv1, ph1, stop) << 32) | (bitop3<TT_V0>(pv1, ph1, xh1) | stop);
                 }
             }
         }
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
         const bool short_n = __any(has_pair && n != 64u), short_m = __any(has_pair && m != 64u);
         if (a.debug & 2) {                       // ablation (profiling only): no table computation
 #pragma unroll
-            for (int i = 0; i < LANE_TB_COLS; i++) tab[i] = ((uint64_t)~stop << 32) | ((uint32_t)tw.lo * (uint32_t)(i + 1));
+            for (int i = 0; i < LANE_TB_COLS; i++) tab[i] = ((uint64_t)~stop << 32) | (((uint32_t)tw.lo * (uint32_t)(i + 1)) | stop);
         } else if (short_n) {
             lane_window_table<true, true>(tw, pw, n, m, stop, tab, lds_b, eq_b, swz);
             st_gen++;
@@ -336,7 +337,7 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
         // boundary mask), so its length is the number of runs of the lane with the most runs, not the number
         // of columns.
         {
-            uint32_t j = 0, ti = 0, nDm = 0, Xm = 0, nIm = 0;
+            uint32_t j = 0, ti, nDm = 0, Xm = 0, nIm = 0;
             auto walk = [&](auto full_tag) {
                 constexpr bool FULL = decltype(full_tag)::value;       // W-O = 31: no per-column test of the column limit
 #pragma unroll
@@ -348,7 +349,6 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
                     lds8[scr_b + i] = (uint8_t)ni;
                     nIm = __builtin_amdgcn_alignbit(nIm, x, 31);               // (nIm << 1) | (ni == 0)
                     j += ni;
-                    ti += (j < jlim) ? 1u : 0u;                                // still inside the window: one D / X / = step
                     // sign bits of both dwords after ONE 64-bit shift of the pair (what spills from v0 into the low bits of
                     // the upper dword is never looked at): not a deletion, substitution
                     const uint64_t both = tab[i] << j;
@@ -359,14 +359,17 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
                     asm("v_add_co_u32 %1, vcc, %2, %2\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(j), "=&v"(scratch) : "v"(nt1) : "vcc");
                 }
             };
-            if (a.debug & 8) { j = jlim; ti = jlim; }                    // ablation (profiling only): no walk
+            if (a.debug & 8) { j = jlim; nDm = ~0u; }                    // ablation (profiling only): no walk
             else if (TBL == (uint32_t)LANE_TB_COLS) walk(std::true_type{});
             else walk(std::false_type{});
             if (timing) cy_p1 += __builtin_readcyclecounter() - tm3;
             // column i -> bit 31-i; only the ti columns the lane was alive in count (insertion runs are exact as recorded)
             const uint32_t nsh = 32u - min(TBL, (uint32_t)LANE_TB_COLS);
+            // columns the lane was alive in: all before the first "deletion and substitution" (the stop row)
+            const uint32_t Draw = ~(nDm << nsh), Xraw = Xm << nsh;
+            ti = ffbh_u32((Draw & Xraw) | (0x80000000u >> min(TBL, (uint32_t)LANE_TB_COLS)));
             const uint32_t A = ~(0xffffffffu >> ti);
-            const uint32_t D = ~(nDm << nsh) & A, X = (Xm << nsh) & A;
+            const uint32_t D = Draw & A, X = Xraw & A;
             const uint32_t Im = ~nIm << nsh;
             const uint32_t B = ((D ^ (D >> 1)) | (X ^ (X >> 1)) | Im | 0x80000000u) & A;    // a D / X / = run starts here
             const uint32_t nD = (uint32_t)__builtin_popcount(D), nX = (uint32_t)__builtin_popcount(X);

@@ -72,7 +72,7 @@ static uint32_t lp_alignbit(uint32_t hi, uint32_t lo, unsigned s) { return (uint
 
 /* The kernel's traceback (W-O <= 31), restated step by step: pass 1 walks the columns and records the path in
  * three masks + one byte per column, pass 2 turns the masks into runs.  nv1[i] = ~(V1 | stop), v0[i] = V0 (high
- * dwords: bit 31-j <-> pattern character j); stop has the bit of row jlim. */
+ * dwords: bit 31-j <-> pattern character j, with the stop bit); stop has the bit of row jlim. */
 static int lane_tb(const uint64_t *V1, const uint64_t *V0, int m, int TBL, size_t *tu, size_t *pu, run_sink *out, lane_stats *ls)
 {
     const uint32_t jlim = (uint32_t)(m < TBL ? m : TBL);    /* j < m && j < W-O, genasm_cpu.cpp:307-310 */
@@ -80,13 +80,12 @@ static int lane_tb(const uint64_t *V1, const uint64_t *V0, int m, int TBL, size_
     uint32_t j = 0, ti = 0, nDm = 0, Xm = 0, nIm = 0;
     uint8_t ilen[32];
     for (int i = 0; i < TBL; i++) {
-        const uint32_t nv1 = ~((uint32_t)(V1[i] >> 32) | stop), v0 = (uint32_t)(V0[i] >> 32);
+        const uint32_t nv1 = ~((uint32_t)(V1[i] >> 32) | stop), v0 = (uint32_t)(V0[i] >> 32) | stop;
         const uint32_t x = (nv1 | ~v0 | stop) << j;             /* not (insertion), or the stop row */
         const uint32_t ni = lp_ffbh32(x);
         ilen[i] = (uint8_t)ni;
         nIm = lp_alignbit(nIm, x, 31);
         j += ni;
-        ti += j < jlim;
         const uint32_t nt1 = nv1 << j, t0 = v0 << j;
         nDm = lp_alignbit(nDm, nt1, 31);
         Xm = lp_alignbit(Xm, t0, 31);
@@ -94,8 +93,11 @@ static int lane_tb(const uint64_t *V1, const uint64_t *V0, int m, int TBL, size_
         ls->tb_columns++;
     }
     const unsigned nsh = 32u - (unsigned)TBL;
+    /* a finished lane reads "deletion and substitution" (the stop row): the first such column ends the walk */
+    const uint32_t Draw = ~(nDm << nsh), Xraw = Xm << nsh;
+    ti = lp_ffbh32((Draw & Xraw) | (0x80000000u >> TBL));
     const uint32_t A = ti ? ~(0xffffffffu >> ti) : 0u;
-    const uint32_t D = ~(nDm << nsh) & A, X = (Xm << nsh) & A, Im = ~nIm << nsh;
+    const uint32_t D = Draw & A, X = Xraw & A, Im = ~nIm << nsh;
     const uint32_t B = ((D ^ (D >> 1)) | (X ^ (X >> 1)) | Im | 0x80000000u) & A;
     const int edits = (int)(j - ti + 2u * (unsigned)__builtin_popcount(D) + (unsigned)__builtin_popcount(X));
     uint32_t E = B | Im;
