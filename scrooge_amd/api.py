@@ -78,7 +78,10 @@ def build_library(force=False):
         with open(os.path.join(HERE, ".build.lock"), "w") as lk:
             fcntl.flock(lk, fcntl.LOCK_EX)
             if force or is_stale():
-                subprocess.check_call(["make", "-C", src_dir, "--no-print-directory"] + (["-B"] if force else []))
+                # (make echoes the compiler command: keep it off stdout, which callers such as bench.py reserve for their
+                # own output)
+                subprocess.check_call(["make", "-C", src_dir, "--no-print-directory"] + (["-B"] if force else []),
+                                      stdout=sys.stderr)
     return so
 
 
