@@ -49,6 +49,14 @@ int main()
         ns = 0;
         timed = scrooge_amd::align_all(genome, reads, &ns);
         show("mapping_timed", timed, ns);
+
+        // many batches against one reference: the genome is staged and packed once
+        scrooge_amd::Handle& h = scrooge_amd::default_handle();
+        h.set_genome(genome);
+        show("resident", h.align_all(reads));
+        std::vector<Read_t> second = {r2};
+        show("resident", h.align_all(second));
+        h.clear_genome();
     } catch (const std::exception& e) {
         std::cerr << "error: " << e.what() << "\n";
         return 2;

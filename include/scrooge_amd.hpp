@@ -125,6 +125,39 @@ public:
         return collect(s, res, core_algorithm_ns);
     }
 
+    // Many read batches against one reference: set_genome() stages and packs it once and keeps it in HBM,
+    // align_all(reads) then aligns batches against it without touching it again (scrg_genome_set /
+    // scrg_align_mapping_resident; the two-argument overload above re-stages the genome on every call, as the
+    // reference re-converts it, src/genasm_cpu.cpp:508).
+    void set_genome(const Genome_t& reference)
+    {
+        scrg_status s = scrg_genome_set(ctx_, reference.content.data(), reference.content.size());
+        if (s != SCRG_OK)
+            throw std::runtime_error(std::string("scrooge_amd: ") + scrg_status_string(s) + " (" + scrg_last_error(ctx_) + ")");
+    }
+    void clear_genome() { scrg_genome_clear(ctx_); }
+
+    std::vector<Alignment_t> align_all(std::vector<Read_t>& reads, long long* core_algorithm_ns = nullptr)
+    {
+        const size_t nr = reads.size();
+        std::vector<const char*> rp(nr);
+        std::vector<uint64_t> rl(nr), off(nr + 1, 0), starts;
+        for (size_t r = 0; r < nr; r++) {
+            rp[r] = reads[r].content.data();
+            rl[r] = reads[r].content.size();
+            for (const CandidateLocation_t& loc : reads[r].locations) {
+                if (loc.start_in_reference < 0)
+                    throw std::invalid_argument("scrooge_amd::align_all: negative start_in_reference");
+                starts.push_back((uint64_t)loc.start_in_reference);
+            }
+            off[r + 1] = starts.size();
+        }
+        scrg_result* res = nullptr;
+        scrg_status s = scrg_align_mapping_resident(ctx_, &params_, nr, rp.data(), rl.data(), off.data(), starts.data(),
+                                                    nullptr, &res);
+        return collect(s, res, core_algorithm_ns);
+    }
+
 private:
     std::vector<Alignment_t> collect(scrg_status s, scrg_result* r, long long* ns)
     {

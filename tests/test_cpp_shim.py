@@ -24,6 +24,10 @@ EXPECTED = [
     "mapping_timed cigar=3X4= edit_distance=3",
     "mapping_timed cigar=12= edit_distance=0",
     "mapping_timed kernel_ns>0=1",
+    "resident cigar=7= edit_distance=0",
+    "resident cigar=3X4= edit_distance=3",
+    "resident cigar=12= edit_distance=0",
+    "resident cigar=12= edit_distance=0",
 ]
 
 
