@@ -478,7 +478,8 @@ scrg_status scrg_align_device(scrg_ctx* c, const scrg_params* params, uint64_t n
     HIP_TRY(c, c->counter.ensure(sizeof(uint32_t)));
     const size_t spill_rows = p.W > 64 ? (size_t)p.W + 1 : scrg::SPILL_ROWS;
     const size_t spill_row_dw = scrg::stored_row_dwords(p.W, p.W - p.O);
-    HIP_TRY(c, c->spill.ensure((size_t)n_waves * ppw * spill_rows * spill_row_dw * sizeof(uint32_t)));
+    if (p.lanes_per_pair != 1)           // (the one-pair-per-lane kernel keeps its table in registers: nothing spills)
+        HIP_TRY(c, c->spill.ensure((size_t)n_waves * ppw * spill_rows * spill_row_dw * sizeof(uint32_t)));
     HIP_TRY(c, hipMemsetAsync(c->counter.p, 0, sizeof(uint32_t), c->stream));
 
     scrg::AlignArgs a;

@@ -413,3 +413,50 @@ def test_packed_runs_round_trip(aligner, oracle):
             aligner.compact_runs_packed(n, desc, runs, nr, off, packed, W=128, O=1)      # counts up to 127 do not fit 6 bits
     finally:
         aligner.use_own_stream()
+
+
+def test_mapping_shape_with_mixed_strides(aligner, oracle):
+    """The read-mapping shape through the device API: one contiguous genome (text stride 1) shared by all candidates,
+    the reads in lane-interleaved groups (read stride 64), both in one sequence array."""
+    import torch
+    import scrooge_amd
+    dev = torch.device("cuda", 0)
+    rng = np.random.Generator(np.random.PCG64(21))
+    Gn = 50000
+    genome = synth.random_seq(Gn, rng)
+    gcodes = np.searchsorted(synth.BASES, np.frombuffer(genome, dtype=np.uint8)).astype(np.uint8)
+    n = 777
+    reads, starts, texts = [], [], []
+    for _ in range(n):
+        s = int(rng.integers(0, Gn - 400))
+        r = synth.BASES[synth.mutate(gcodes[s:s + 220], 0.05, (23, 31, 46), rng)[:int(rng.integers(20, 180))]].tobytes()
+        reads.append(r)
+        starts.append(s + int(rng.integers(-2, 3)) if s > 2 else s)
+        texts.append(genome[starts[-1]:])
+    eds, cigars, _, _ = oracle.align([t[:600] for t in texts], reads, threads=8)
+    G = scrooge_amd.api.GROUP
+    gw = (Gn + 31) // 32
+    rw = (180 + 31) // 32
+    g_ascii = np.zeros(gw * 32, dtype=np.uint8)
+    g_ascii[:Gn] = np.frombuffer(genome, dtype=np.uint8)
+    r_ascii = np.zeros((n, rw * 32), dtype=np.uint8)
+    for k in range(n):
+        r_ascii[k, :len(reads[k])] = np.frombuffer(reads[k], dtype=np.uint8)
+    n_groups = (n + G - 1) // G
+    seq = torch.zeros(gw + n_groups * G * rw + scrooge_amd.api.SEQ_PAD_WORDS_GROUPS, dtype=torch.int64, device=dev)
+    bad = torch.zeros(1, dtype=torch.int32, device=dev)
+    cap = (2 * 180 + 8 + 15) // 16 * 16
+    idx = torch.arange(n, dtype=torch.int64, device=dev)
+    aligner.set_stream(0)
+    try:
+        aligner.pack_planar(torch.from_numpy(g_ascii).to(dev), seq[:gw], bad)
+        aligner.pack_planar_groups(torch.from_numpy(r_ascii).to(dev).view(-1), n, rw, seq[gw:], bad)
+        first = gw + (idx // G) * rw * G + idx % G
+        st_t = torch.tensor(starts, dtype=torch.int64, device=dev)
+        desc = torch.stack([st_t, Gn - st_t, first * 32, torch.tensor([len(r) for r in reads], device=dev),
+                            idx * cap, torch.full_like(idx, cap)], dim=1).contiguous()
+        got = _device_align(aligner, torch, seq, desc, n, cap, text_stride_words=1, read_stride_words=G)
+        assert int(bad.item()) == 0
+    finally:
+        aligner.use_own_stream()
+    assert got == (eds, cigars, [0] * n)
