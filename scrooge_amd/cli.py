@@ -56,7 +56,8 @@ def main(argv=None):
         for r, cs in zip(reads, cands):
             for start, rev in cs:
                 q = r.translate(comp)[::-1] if rev else r
-                if sio.validate_alignment(genome[start:], q, alns[k].cigar, alns[k].edit_distance) != 0:
+                # the alignment consumes a prefix of the suffix: at most len(read) + edits <= 2 * len(read) characters of it
+                if sio.validate_alignment(genome[start:start + 2 * len(q) + args.W], q, alns[k].cigar, alns[k].edit_distance) != 0:
                     print("FAILED sanity check for alignment %d" % k)
                     bad += 1
                 k += 1
