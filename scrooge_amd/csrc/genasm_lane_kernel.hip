@@ -37,16 +37,12 @@ namespace scrg {
 constexpr int LANE_TB_COLS = 31;                 // W-O <= 31 columns can be consumed per window
 constexpr uint32_t LANE_RING_BYTES = 68;         // 32 runs + one dword: lanes land on distinct LDS banks
 constexpr uint32_t LANE_SCRATCH_BYTES = 36;      // insertion-run length of each traceback column, one byte each (+ bank skew)
-#ifndef SCRG_EQ_LDS
-#define SCRG_EQ_LDS 1                            // 0: compute Eq from the text bits per column (A/B builds only)
-#endif
-constexpr uint32_t LANE_EQ_BYTES = SCRG_EQ_LDS ? 32 : 0;   // Eq of the window's pattern for each of the four bases, 8 bytes each
+constexpr uint32_t LANE_EQ_BYTES = 32;           // Eq of the window's pattern for each of the four bases, 8 bytes each
 constexpr uint32_t LANE_WAVE_LDS_BYTES = 64u * (LANE_RING_BYTES + LANE_SCRATCH_BYTES + LANE_EQ_BYTES);
 constexpr int LANE_EQ_AHEAD = 8;                 // Eq words are read from LDS this many columns ahead of their use
 
 // truth tables (inputs a, b, c in that order)
 // (two-input operations are left to plain and/or/xor: 4-byte encodings, a v_bitop3_b32 takes 8)
-[[maybe_unused]] constexpr int TT_EQ  = bitop3_table([](int x, int rh, int sh) { return ~(x | (rh ^ sh)); });       // pattern character == text character
 constexpr int TT_XH  = bitop3_table([](int sum, int pv, int eq) { return (sum ^ pv) | eq; });
 constexpr int TT_PH  = bitop3_table([](int mv, int xh, int pv) { return mv | ~(xh | pv); });
 constexpr int TT_PVN = bitop3_table([](int mhs, int xv, int phs) { return mhs | ~(xv | phs); });
@@ -80,40 +76,38 @@ __device__ __forceinline__ uint32_t ffbh_u32(uint32_t v)      // count leading z
     return r;
 }
 
-// SHORT_N / SHORT_M = false: every lane of the wave has a full text / pattern window (n = 64 / m = 64).
-// SHORT_M: any m <= 64 per lane (the last windows of a read, W < 64): the table is shifted left by 64-m.
-// SHORT_N: any n <= 64 per lane (the text ends inside the window): columns >= n are skipped per lane.
+// SHORT_N = false: every lane of the wave has a full text window (n = 64); true: any n <= 64 per lane (the text ends
+// inside the window): columns >= n are skipped per lane.  Any pattern length m <= 64 is served by the same code:
+// the reversed pattern is LEFT-aligned (bit 63-k <-> pattern[k], i.e. the reference's layout genasm_cpu.cpp:178-198
+// shifted left by 64-m), the 64-m bits below it are kept neutral — Eq = 1 there (written into the table once per
+// window), Pv = Mv = 0 — so no carry starts below the pattern, "0 comes in" at its lowest bit, and the rows the
+// traceback reads are always the upper dword.
+//
 // Eq of a column is LOOKED UP: the four possible words (pattern == A / C / G / T) are written to 32 bytes of LDS per
 // lane once per window, and a column reads the one its text character selects — address = table | 8 * character from
 // two right shifts and two v_bitop3_b32 with inline constants, the ds_read_b64 itself does not occupy the VALU.
 // (Computing it per column costs 2 v_bfe_i32 + 2 v_xor + 2 v_bitop3; the reads are issued LANE_EQ_AHEAD columns early.)
 // Slot c ^ swz of a lane holds base c, swz = (lane >> 3) & 3, so the lanes that share LDS banks (8 apart) use
 // different slots for the same base; the swizzle is folded into the text planes once per window.
-template <bool SHORT_N, bool SHORT_M>
+template <bool SHORT_N>
 __device__ __forceinline__ void lane_window_table(const Planes tw, const Planes pw, const uint32_t n, const uint32_t m,
                                                   const uint32_t stop, uint64_t (&tab)[LANE_TB_COLS],
-                                                  char* const lds_b, const uint32_t eq_b, const uint32_t swz)
+                                                  const uint32_t eq_b, const uint32_t swz)
 {
     // tab[i] = ~(V1 | stop) in the upper dword, V0 | stop in the lower one (a register pair: the traceback shifts both
     // with one 64-bit shift): stop has the one bit of the row at which this lane's walk ends (jlim), so a finished lane
     // reads "deletion AND substitution" there — it stays put without a test, and the combination, which no cell of the
     // matrix has, marks the columns it was no longer alive in
-    // reversed pattern, right-aligned: bit b <-> pattern[m-1-b] (the reference's layout, genasm_cpu.cpp:178-198);
-    // whatever lies above bit m-1 never reaches the bits below it (carries and shifts only move up)
-    const uint32_t sft = 64u - m;
-    uint64_t rlo = brev64(pw.lo), rhi = brev64(pw.hi);
-    if (SHORT_M) {
-        rlo >>= sft;
-        rhi >>= sft;
-    }
+    const uint64_t rlo = brev64(pw.lo), rhi = brev64(pw.hi);
+    const uint64_t valid = ~0ull << (64u - m);                    // (m >= 1)
     const uint32_t rl0 = (uint32_t)rlo, rl1 = (uint32_t)(rlo >> 32), rh0 = (uint32_t)rhi, rh1 = (uint32_t)(rhi >> 32);
-#if SCRG_EQ_LDS
-    {   // base c = 2*hi + lo: Eq_c = (lo plane == c&1) & (hi plane == c>>1); slot c ^ swz
+    const uint32_t iv0 = ~(uint32_t)valid, iv1 = ~(uint32_t)(valid >> 32);
+    {   // base c = 2*hi + lo: Eq_c = (lo plane == c&1) & (hi plane == c>>1), and 1 below the pattern; slot c ^ swz
         const uint32_t x = eq_b | (swz << 3);
-        lds_write64(x ^ 0u, make_uint2(~(rl0 | rh0), ~(rl1 | rh1)));
-        lds_write64(x ^ 8u, make_uint2(rl0 & ~rh0, rl1 & ~rh1));
-        lds_write64(x ^ 16u, make_uint2(~rl0 & rh0, ~rl1 & rh1));
-        lds_write64(x ^ 24u, make_uint2(rl0 & rh0, rl1 & rh1));
+        lds_write64(x ^ 0u, make_uint2(~(rl0 | rh0) | iv0, ~(rl1 | rh1) | iv1));
+        lds_write64(x ^ 8u, make_uint2((rl0 & ~rh0) | iv0, (rl1 & ~rh1) | iv1));
+        lds_write64(x ^ 16u, make_uint2((~rl0 & rh0) | iv0, (~rl1 & rh1) | iv1));
+        lds_write64(x ^ 24u, make_uint2((rl0 & rh0) | iv0, (rl1 & rh1) | iv1));
     }
     const uint32_t swl = 0u - (swz & 1u), swh = 0u - (swz >> 1);
     const uint32_t tl0 = (uint32_t)tw.lo ^ swl, tl1 = (uint32_t)(tw.lo >> 32) ^ swl, th0 = (uint32_t)tw.hi ^ swh, th1 = (uint32_t)(tw.hi >> 32) ^ swh;
@@ -128,28 +122,17 @@ __device__ __forceinline__ void lane_window_table(const Planes tw, const Planes 
     uint2 eqw[LANE_EQ_AHEAD];
 #pragma unroll
     for (int k = 0; k < LANE_EQ_AHEAD; k++) eqw[k] = lds_read64(eq_addr(63 - k));
-#else
-    const uint32_t tl0 = (uint32_t)tw.lo, tl1 = (uint32_t)(tw.lo >> 32), th0 = (uint32_t)tw.hi, th1 = (uint32_t)(tw.hi >> 32);
-#endif
-    uint32_t pv0 = ~0u, pv1 = ~0u, mv0 = 0u, mv1 = 0u;           // D[n][j] = m-j: every vertical step is +1
+    uint32_t pv0 = (uint32_t)valid, pv1 = (uint32_t)(valid >> 32), mv0 = 0u, mv1 = 0u;   // D[n][j] = m-j: every vertical step is +1
     if (SHORT_N) {
 #pragma unroll
         for (int i = 0; i < LANE_TB_COLS; i++) tab[i] = 0xffffffffull;    // columns >= n: only insertions (genasm_cpu.cpp:239-245)
     }
 #pragma unroll
     for (int i = 63; i >= 0; i--) {
-#if SCRG_EQ_LDS
         const uint2 eq_now = eqw[(63 - i) % LANE_EQ_AHEAD];
         if (i - LANE_EQ_AHEAD >= 0) eqw[(63 - i) % LANE_EQ_AHEAD] = lds_read64(eq_addr(i - LANE_EQ_AHEAD));
-#endif
         if (!SHORT_N || (uint32_t)i < n) {
-#if SCRG_EQ_LDS
             const uint32_t eq0 = eq_now.x, eq1 = eq_now.y;
-#else
-            const uint32_t sl = (uint32_t)__builtin_amdgcn_sbfe((int)(i < 32 ? tl0 : tl1), i & 31, 1);
-            const uint32_t sh = (uint32_t)__builtin_amdgcn_sbfe((int)(i < 32 ? th0 : th1), i & 31, 1);
-            const uint32_t eq0 = bitop3<TT_EQ>(rl0 ^ sl, rh0, sh), eq1 = bitop3<TT_EQ>(rl1 ^ sl, rh1, sh);
-#endif
             const uint32_t xv0 = eq0 | mv0, xv1 = eq1 | mv1;
             const uint32_t t0 = eq0 & pv0, t1 = eq1 & pv1;
             const uint64_t sum = add64(((uint64_t)t1 << 32) | t0, ((uint64_t)pv1 << 32) | pv0);
@@ -162,15 +145,8 @@ __device__ __forceinline__ void lane_window_table(const Planes tw, const Planes 
             pv1 = bitop3<TT_PVN>((uint32_t)(mhs >> 32), xv1, (uint32_t)(phs >> 32));
             mv0 = (uint32_t)phs & xv0;
             mv1 = (uint32_t)(phs >> 32) & xv1;
-            if (i < LANE_TB_COLS) {
-                if (SHORT_M) {
-                    const uint64_t a = ((uint64_t)(pv1 | ph1) << 32) | (pv0 | ph0);
-                    const uint64_t b = ((uint64_t)bitop3<TT_V0>(pv1, ph1, xh1) << 32) | bitop3<TT_V0>(pv0, ph0, xh0);
-                    tab[i] = ((uint64_t)(~((uint32_t)((a << sft) >> 32) | stop)) << 32) | ((uint32_t)((b << sft) >> 32) | stop);
-                } else {
-                    tab[i] = ((uint64_t)bitop3<TT_NOR3>(pv1, ph1, stop) << 32) | (bitop3<TT_V0>(pv1, ph1, xh1) | stop);
-                }
-            }
+            if (i < LANE_TB_COLS)
+                tab[i] = ((uint64_t)bitop3<TT_NOR3>(pv1, ph1, stop) << 32) | (bitop3<TT_V0>(pv1, ph1, xh1) | stop);
         }
     }
 }
@@ -307,18 +283,15 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
         uint64_t tab[LANE_TB_COLS];
         const uint32_t jlim = has_pair ? min(m, TBL) : 0u;          // the walk ends when j gets here (:301, :310)
         const uint32_t stop = 0x80000000u >> jlim;
-        const bool short_n = __any(has_pair && n != 64u), short_m = __any(has_pair && m != 64u);
+        const bool short_n = __any(has_pair && n != 64u);
         if (a.debug & 2) {                       // ablation (profiling only): no table computation
 #pragma unroll
             for (int i = 0; i < LANE_TB_COLS; i++) tab[i] = ((uint64_t)~stop << 32) | (((uint32_t)tw.lo * (uint32_t)(i + 1)) | stop);
         } else if (short_n) {
-            lane_window_table<true, true>(tw, pw, n, m, stop, tab, lds_b, eq_b, swz);
-            st_gen++;
-        } else if (short_m) {
-            lane_window_table<false, true>(tw, pw, n, m, stop, tab, lds_b, eq_b, swz);
+            lane_window_table<true>(tw, pw, n, m, stop, tab, eq_b, swz);
             st_gen++;
         } else {
-            lane_window_table<false, false>(tw, pw, n, m, stop, tab, lds_b, eq_b, swz);
+            lane_window_table<false>(tw, pw, n, m, stop, tab, eq_b, swz);
         }
         const uint64_t tm3 = timing ? __builtin_readcyclecounter() : 0;
 

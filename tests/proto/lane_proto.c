@@ -44,13 +44,16 @@ static void lane_dc(const uint8_t *t, int n, const uint8_t *q, int m, int TBL, u
         Tlo |= (uint64_t)(tc & 1) << k; Thi |= (uint64_t)(tc >> 1) << k;
         Plo |= (uint64_t)(qc & 1) << k; Phi |= (uint64_t)(qc >> 1) << k;
     }
-    /* right-aligned reversed pattern: bit b <-> pattern[m-1-b] (the reference's own layout, genasm_cpu.cpp:178-198) */
-    const uint64_t Rlo = lp_brev64(Plo) >> (64 - m), Rhi = lp_brev64(Phi) >> (64 - m);
-    uint64_t Pv = ~0ull, Mv = 0;
+    /* reversed pattern, LEFT-aligned: bit 63-k <-> pattern[k], i.e. the reference's layout (bit b <-> pattern[m-1-b],
+     * genasm_cpu.cpp:178-198) shifted left by 64-m; the 64-m bits below the pattern are kept neutral: Eq = 1,
+     * Pv = Mv = 0, so no carry starts there and 0 comes in at the pattern's lowest bit */
+    const uint64_t Rlo = lp_brev64(Plo), Rhi = lp_brev64(Phi);
+    const uint64_t valid = ~0ull << (64 - m);
+    uint64_t Pv = valid, Mv = 0;
     for (int i = 0; i < TBL; i++) V1[i] = V0[i] = ~0ull;          /* columns >= n: only insertions */
     for (int i = n - 1; i >= 0; i--) {
         const uint64_t sl = 0ull - ((Tlo >> i) & 1), sh = 0ull - ((Thi >> i) & 1);
-        const uint64_t Eq = ~((Rlo ^ sl) | (Rhi ^ sh));           /* garbage above bit m-1 never reaches the bits below */
+        const uint64_t Eq = ~((Rlo ^ sl) | (Rhi ^ sh)) | ~valid;  /* (the kernel reads it from a 4-entry table per window) */
         const uint64_t Xv = Eq | Mv;
         const uint64_t Xh = ((((Eq & Pv) + Pv) ^ Pv) | Eq);
         const uint64_t Ph = Mv | ~(Xh | Pv);
@@ -59,8 +62,8 @@ static void lane_dc(const uint8_t *t, int n, const uint8_t *q, int m, int TBL, u
         const uint64_t Pvn = Mh1 | ~(Xv | Ph1);
         const uint64_t Mvn = Ph1 & Xv;
         if (i < TBL) {
-            V1[i] = (Pvn | Ph) << (64 - m);
-            V0[i] = (Pvn | ~(Ph | Xh)) << (64 - m);
+            V1[i] = Pvn | Ph;
+            V0[i] = Pvn | ~(Ph | Xh);
         }
         Pv = Pvn; Mv = Mvn;
         ls->columns++;
