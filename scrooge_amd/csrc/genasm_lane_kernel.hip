@@ -38,7 +38,8 @@ constexpr int LANE_TB_COLS = 31;                 // W-O <= 31 columns can be con
 constexpr uint32_t LANE_RING_BYTES = 68;         // 32 runs + one dword: lanes land on distinct LDS banks
 constexpr uint32_t LANE_SCRATCH_BYTES = 36;      // insertion-run length of each traceback column, one byte each (+ bank skew)
 constexpr uint32_t LANE_EQ_BYTES = 32;           // Eq of the window's pattern for each of the four bases, 8 bytes each
-constexpr uint32_t LANE_WAVE_LDS_BYTES = 64u * (LANE_RING_BYTES + LANE_SCRATCH_BYTES + LANE_EQ_BYTES);
+constexpr uint32_t LANE_NOMATCH_BYTES = 8;       // the Eq word of "no character matches" (columns past the end of the text)
+constexpr uint32_t LANE_WAVE_LDS_BYTES = 64u * (LANE_RING_BYTES + LANE_SCRATCH_BYTES + LANE_EQ_BYTES + LANE_NOMATCH_BYTES);
 constexpr int LANE_EQ_AHEAD = 8;                 // Eq words are read from LDS this many columns ahead of their use
 
 // truth tables (inputs a, b, c in that order)
@@ -77,7 +78,10 @@ __device__ __forceinline__ uint32_t ffbh_u32(uint32_t v)      // count leading z
 }
 
 // SHORT_N = false: every lane of the wave has a full text window (n = 64); true: any n <= 64 per lane (the text ends
-// inside the window): columns >= n are skipped per lane.  Any pattern length m <= 64 is served by the same code:
+// inside the window): columns >= n read the Eq word "no character matches", which leaves the boundary column
+// D[n][j] = m-j (genasm_cpu.cpp:239-245) as it is and gives table words that say "insertion" in every row — what the
+// reference's traceback finds there (:312) — so those columns need no predication, only a select of the address.
+// Any pattern length m <= 64 is served by the same code:
 // the reversed pattern is LEFT-aligned (bit 63-k <-> pattern[k], i.e. the reference's layout genasm_cpu.cpp:178-198
 // shifted left by 64-m), the 64-m bits below it are kept neutral — Eq = 1 there (written into the table once per
 // window), Pv = Mv = 0 — so no carry starts below the pattern, "0 comes in" at its lowest bit, and the rows the
@@ -92,7 +96,7 @@ __device__ __forceinline__ uint32_t ffbh_u32(uint32_t v)      // count leading z
 template <bool SHORT_N>
 __device__ __forceinline__ void lane_window_table(const Planes tw, const Planes pw, const uint32_t n, const uint32_t m,
                                                   const uint32_t stop, uint64_t (&tab)[LANE_TB_COLS],
-                                                  const uint32_t eq_b, const uint32_t swz)
+                                                  const uint32_t eq_b, const uint32_t nomatch_b, const uint32_t swz)
 {
     // tab[i] = ~(V1 | stop) in the upper dword, V0 | stop in the lower one (a register pair: the traceback shifts both
     // with one 64-bit shift): stop has the one bit of the row at which this lane's walk ends (jlim), so a finished lane
@@ -108,6 +112,7 @@ __device__ __forceinline__ void lane_window_table(const Planes tw, const Planes 
         lds_write64(x ^ 8u, make_uint2((rl0 & ~rh0) | iv0, (rl1 & ~rh1) | iv1));
         lds_write64(x ^ 16u, make_uint2((~rl0 & rh0) | iv0, (~rl1 & rh1) | iv1));
         lds_write64(x ^ 24u, make_uint2((rl0 & rh0) | iv0, (rl1 & rh1) | iv1));
+        if (SHORT_N) lds_write64(nomatch_b, make_uint2(iv0, iv1));
     }
     const uint32_t swl = 0u - (swz & 1u), swh = 0u - (swz >> 1);
     const uint32_t tl0 = (uint32_t)tw.lo ^ swl, tl1 = (uint32_t)(tw.lo >> 32) ^ swl, th0 = (uint32_t)tw.hi ^ swh, th1 = (uint32_t)(tw.hi >> 32) ^ swh;
@@ -117,21 +122,18 @@ __device__ __forceinline__ void lane_window_table(const Planes tw, const Planes 
         const int b = i & 31;
         const uint32_t u = b >= 3 ? tl >> (b - 3) : tl << (3 - b);         // lo bit -> bit 3
         const uint32_t v = b >= 4 ? th >> (b - 4) : th << (4 - b);         // hi bit -> bit 4
-        return bitop3<TT_ANDOR>(bitop3<TT_BFI>(u, v, 8u), 24u, eq_b);
+        const uint32_t a = bitop3<TT_ANDOR>(bitop3<TT_BFI>(u, v, 8u), 24u, eq_b);
+        return (!SHORT_N || (uint32_t)i < n) ? a : nomatch_b;
     };
     uint2 eqw[LANE_EQ_AHEAD];
 #pragma unroll
     for (int k = 0; k < LANE_EQ_AHEAD; k++) eqw[k] = lds_read64(eq_addr(63 - k));
     uint32_t pv0 = (uint32_t)valid, pv1 = (uint32_t)(valid >> 32), mv0 = 0u, mv1 = 0u;   // D[n][j] = m-j: every vertical step is +1
-    if (SHORT_N) {
-#pragma unroll
-        for (int i = 0; i < LANE_TB_COLS; i++) tab[i] = 0xffffffffull;    // columns >= n: only insertions (genasm_cpu.cpp:239-245)
-    }
 #pragma unroll
     for (int i = 63; i >= 0; i--) {
         const uint2 eq_now = eqw[(63 - i) % LANE_EQ_AHEAD];
         if (i - LANE_EQ_AHEAD >= 0) eqw[(63 - i) % LANE_EQ_AHEAD] = lds_read64(eq_addr(i - LANE_EQ_AHEAD));
-        if (!SHORT_N || (uint32_t)i < n) {
+        {
             const uint32_t eq0 = eq_now.x, eq1 = eq_now.y;
             const uint32_t xv0 = eq0 | mv0, xv1 = eq1 | mv1;
             const uint32_t t0 = eq0 & pv0, t1 = eq1 & pv1;
@@ -168,6 +170,7 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
     const uint32_t eq_b = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds_b +
                           wave_b + 64u * (LANE_RING_BYTES + LANE_SCRATCH_BYTES) + lane * LANE_EQ_BYTES;
     const uint32_t swz = (lane >> 3) & 3u;
+    const uint32_t nomatch_b = eq_b - lane * LANE_EQ_BYTES + 64u * LANE_EQ_BYTES + lane * LANE_NOMATCH_BYTES;
     const uint32_t W = (uint32_t)a.W;
     const uint32_t TBL = (uint32_t)a.tb_limit;         // W - O, 1..31
 
@@ -288,10 +291,10 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
 #pragma unroll
             for (int i = 0; i < LANE_TB_COLS; i++) tab[i] = ((uint64_t)~stop << 32) | (((uint32_t)tw.lo * (uint32_t)(i + 1)) | stop);
         } else if (short_n) {
-            lane_window_table<true>(tw, pw, n, m, stop, tab, eq_b, swz);
+            lane_window_table<true>(tw, pw, n, m, stop, tab, eq_b, nomatch_b, swz);
             st_gen++;
         } else {
-            lane_window_table<false>(tw, pw, n, m, stop, tab, eq_b, swz);
+            lane_window_table<false>(tw, pw, n, m, stop, tab, eq_b, nomatch_b, swz);
         }
         const uint64_t tm3 = timing ? __builtin_readcyclecounter() : 0;
 

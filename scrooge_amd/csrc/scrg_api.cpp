@@ -401,7 +401,7 @@ static bool resolve_params(const scrg_params* in, scrg_params* p)
 
 static size_t lds_bytes_for(const scrg_params& p)
 {
-    if (p.lanes_per_pair == 1) return 64 * (68 + 36 + 32);  // per lane: CIGAR staging ring (32 runs + 1 dword), insertion-run lengths of a window, Eq table
+    if (p.lanes_per_pair == 1) return 64 * (68 + 36 + 32 + 8);  // per lane: CIGAR staging ring (32 runs + 1 dword), insertion-run lengths of a window, Eq table (+ the "no match" word)
     const size_t slots = 64 / p.lanes_per_pair;
     // per slot: CIGAR staging ring (16 dwords) + 1 scratch dword + R rows (+1 dword against bank
     // conflicts); 8 dwords of padding at the end (the traceback's speculative lanes read a little past a

@@ -50,10 +50,11 @@ static void lane_dc(const uint8_t *t, int n, const uint8_t *q, int m, int TBL, u
     const uint64_t Rlo = lp_brev64(Plo), Rhi = lp_brev64(Phi);
     const uint64_t valid = ~0ull << (64 - m);
     uint64_t Pv = valid, Mv = 0;
-    for (int i = 0; i < TBL; i++) V1[i] = V0[i] = ~0ull;          /* columns >= n: only insertions */
-    for (int i = n - 1; i >= 0; i--) {
+    /* columns >= n (the text ends inside the window) take the Eq word "no character matches": the boundary column
+     * D[n][j] = m-j stays as it is and the table words come out as "insertion in every row" by themselves */
+    for (int i = 63; i >= 0; i--) {
         const uint64_t sl = 0ull - ((Tlo >> i) & 1), sh = 0ull - ((Thi >> i) & 1);
-        const uint64_t Eq = ~((Rlo ^ sl) | (Rhi ^ sh)) | ~valid;  /* (the kernel reads it from a 4-entry table per window) */
+        const uint64_t Eq = (i < n ? ~((Rlo ^ sl) | (Rhi ^ sh)) : 0ull) | ~valid;  /* (the kernel reads it from a table in LDS) */
         const uint64_t Xv = Eq | Mv;
         const uint64_t Xh = ((((Eq & Pv) + Pv) ^ Pv) | Eq);
         const uint64_t Ph = Mv | ~(Xh | Pv);
