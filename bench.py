@@ -379,6 +379,13 @@ def main():
                "kind": "reference" if use_ref else "port",
                "sample": "first %d of the %d pairs of this workload, kernel-only time (%s), %d OpenMP threads"
                          % (m, n, "genasm_cpu.cpp:589-591 via oracle/_ref" if use_ref else "oracle/liboracle.so", cores)}
+        # the same checker on ONE thread (SURVEY.md §8d asks for both), about two seconds' worth of pairs
+        m1 = int(min(m, max(8, cpu["value"] / max(1, cores) * 2.0)))
+        if use_ref:
+            _, _, ns1 = Reference().align(texts_all[:m1], reads_all[:m1], threads=1)
+        else:
+            _, _, _, ns1 = orc.align(texts_all[:m1], reads_all[:m1], threads=1)
+        cpu["single_thread"] = {"value": m1 / (ns1 * 1e-9), "unit": "pairs/s", "sample_pairs": m1}
         # parity of the timed GPU results on the same sample
         k = min(m, 2000)
         cnt = n_runs[:k].cpu().tolist()
