@@ -61,16 +61,38 @@ def library_path():
     return os.environ.get("SCRG_LIB") or os.path.join(HERE, "libscrooge_amd.so")
 
 
+def _source_digest(srcs):
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(srcs):
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def build_library(force=False):
-    """Compile the HIP kernels + host code for gfx950 (hipcc cross-compiles without a GPU)."""
+    """Compile the HIP kernels + host code for gfx950 (hipcc cross-compiles without a GPU).
+
+    Whether the built library is current is decided by the CONTENT of the sources (a digest kept next to the
+    library), not by modification times: a copy of the tree (the snapshot a GPU box gets) keeps the contents but
+    not necessarily the order of the time stamps, and a needless rebuild costs 20 s and needs a compiler."""
     so = library_path()
     if os.environ.get("SCRG_LIB"):
         return so
     src_dir = os.path.join(HERE, "csrc")
-    srcs = [os.path.join(src_dir, f) for f in os.listdir(src_dir)] + \
-        [os.path.join(HERE, "..", "include", "scrooge_amd.h")]
+    srcs = [os.path.join(src_dir, f) for f in os.listdir(src_dir) if not f.startswith(".")] + \
+        [os.path.join(HERE, "..", "include", "scrooge_amd.h"), os.path.join(HERE, "..", "include", "scrooge_amd_io.h")]
+    stamp = so + ".sources.sha256"
+    digest = _source_digest(srcs)
+
     def is_stale():
-        return (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
+        if not os.path.exists(so):
+            return True
+        try:
+            return open(stamp).read().strip() != digest
+        except OSError:
+            return True
 
     if force or is_stale():
         # several ranks of one job may get here at once: serialise, and re-check under the lock
@@ -79,9 +101,10 @@ def build_library(force=False):
             fcntl.flock(lk, fcntl.LOCK_EX)
             if force or is_stale():
                 # (make echoes the compiler command: keep it off stdout, which callers such as bench.py reserve for their
-                # own output)
-                subprocess.check_call(["make", "-C", src_dir, "--no-print-directory"] + (["-B"] if force else []),
-                                      stdout=sys.stderr)
+                # own output; -B because make's own idea of freshness is the time stamps)
+                subprocess.check_call(["make", "-C", src_dir, "--no-print-directory", "-B"], stdout=sys.stderr)
+                with open(stamp, "w") as fh:
+                    fh.write(digest + "\n")
     return so
 
 
