@@ -264,3 +264,42 @@ def test_resident_genome(aligner, golden_mapping, oracle):
     finally:
         aligner.clear_genome()
     _check(aligner.align_mapping(gm["genome"], gm["reads"], gm["candidates"]), gm["ed"], gm["cigar"], "after clear")
+
+
+def test_dense_run_patterns(aligner, oracle):
+    """Windows with a run boundary at (almost) every column — every other base substituted, inserted or deleted —
+    fill the CIGAR staging ring as fast as it can be filled (up to ~60 runs per window): ring wrap, piece flushes
+    inside the emission loop and slices that overflow are all on this path."""
+    rng = np.random.Generator(np.random.PCG64(5))
+    sub = {65: 67, 67: 71, 71: 84, 84: 65}
+    T, Q = [], []
+    for L in (64, 200, 1000, 5000):
+        for _ in range(6):
+            t = synth.random_seq(L + 40, rng)
+            q = bytearray(t[:L])
+            for k in range(int(rng.integers(0, 2)), L, 2):          # X = X = ...
+                q[k] = sub[q[k]]
+            T.append(t), Q.append(bytes(q))
+            q2 = bytearray()
+            for k in range(L):                                       # an insertion after every other base
+                q2.append(t[k])
+                if k % 2:
+                    q2.append(sub[t[k]])
+            T.append(t), Q.append(bytes(q2))
+            T.append(t), Q.append(bytes(t[k] for k in range(L) if k % 3))     # a deletion every third base
+            mix = bytearray()
+            for k in range(L):                                       # substitutions, insertions and deletions interleaved
+                r = k % 6
+                if r == 1:
+                    mix.append(sub[t[k]])
+                elif r == 3:
+                    mix += bytes([t[k], sub[t[k]]])
+                elif r != 5:
+                    mix.append(t[k])
+            T.append(t), Q.append(bytes(mix))
+    eds, cigars, _, _ = oracle.align(T, Q, threads=8)
+    assert max(c.count("X") + c.count("I") + c.count("D") for c in cigars) > 1500
+    for g in (1, 8):
+        _check(aligner.align_pairs(T, Q, lanes_per_pair=g), eds, cigars, "dense runs g=%d" % g)
+    e32, c32, _, _ = oracle.align(T, Q, W=32, O=17, threads=8)
+    _check(aligner.align_pairs(T, Q, W=32, O=17), e32, c32, "dense runs W=32")
