@@ -149,7 +149,14 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # test only: run the gather path on the real RCCL backend with this one rank (tests/test_gpu_scale.py)
+    force_gather = world == 1 and os.environ.get("SCRG_BENCH_FORCE_GATHER") == "1"
+    dist_on = world > 1 or force_gather
+    if force_gather:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+    elif world > 1:
         if dryrun:
             dist.init_process_group("gloo")
         else:
@@ -223,7 +230,7 @@ def main():
     total_runs = int(n_runs.sum().item())
     denses = [torch.empty(max(total_runs, 8) * 2, dtype=torch.uint8, device=device) for _ in range(n_lanes)]
     gather = None
-    if world > 1:
+    if dist_on:
         from scrooge_amd.distributed import ResultGather
         packed_gather = p.W - p.O <= 63              # runs travel as one byte each; rank 0 restores scrg_run pairs
         gather = ResultGather(n, total_runs, device, dst=0, depth=max(2, n_lanes), packed=packed_gather)
@@ -263,7 +270,7 @@ def main():
                 ev[k][1].record()
             cnt64 = o["n_runs"].to(torch.int64)
             dense_off = torch.cumsum(cnt64, 0) - cnt64
-            if world > 1:
+            if dist_on:
                 # RCCL gather of scores + CIGAR runs to rank 0 over xGMI, double buffered: the gather of
                 # this step overlaps the next step's align kernel
                 gather.finish(j)                       # buffers of step j-DEPTH are free again
@@ -280,7 +287,7 @@ def main():
         step()
     if gather is not None:
         gather.finish_all()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -289,7 +296,7 @@ def main():
     if gather is not None:
         gather.finish_all()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -305,14 +312,14 @@ def main():
         ed_g, cnt_g, runs_g = gather.results(step.count - 1, 0)
         gather_check = bool(torch.equal(ed_g, ed) and torch.equal(cnt_g, n_runs) and torch.equal(runs_g, dense[: runs_g.numel()]))
         assert gather_check, "gathered results differ from the local ones"
-    if world > 1:
+    if dist_on:
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)
     # reference point outside the timed region: the same step on ONE stream (no overlap between launches)
     serial = None
-    if n_lanes > 1 and world == 1:
+    if n_lanes > 1 and not dist_on:
         sev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(3)]
         o = outs[0]
         torch.cuda.synchronize()
@@ -433,7 +440,7 @@ def main():
                    "pairs_per_gpu": n, "read_len": L, "text_len": text_len, "error_profile": args.profile,
                    "W": p.W, "O": p.O, "lanes_per_pair": p.lanes_per_pair, "lds_rows": p.lds_rows,
                    "sequence_layout": "lane-interleaved groups of 64 pairs (scrg_pack_planar_groups)" if groups else "contiguous per sequence",
-                   "launch": geom, "step": "align kernel + run compaction" + (" + RCCL gather of scores and CIGAR runs to rank 0 (one buffer set per pipelined step, overlaps the next kernels; runs travel as one byte each and are restored to scrg_run on rank 0 inside the timed region)" if world > 1 else ""),
+                   "launch": geom, "step": "align kernel + run compaction" + (" + RCCL gather of scores and CIGAR runs to rank 0 (one buffer set per pipelined step, overlaps the next kernels; runs travel as one byte each and are restored to scrg_run on rank 0 inside the timed region)" if dist_on else ""),
                    "pipeline": ("consecutive steps alternate between %d streams (own handle, work queue and output buffers each): "
                                 "a step's wavefronts start while the previous step's last pairs finish" % n_lanes) if n_lanes > 1
                                else "one stream: a step starts after the previous one has finished"},
@@ -486,7 +493,7 @@ def main():
                            "note": "per GPU, from the whole-step rate"}
         out["bit_cell_gcups"] = value * dc_cells * 64 / 1e9
     print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

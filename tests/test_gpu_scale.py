@@ -460,3 +460,18 @@ def test_mapping_shape_with_mixed_strides(aligner, oracle):
     finally:
         aligner.use_own_stream()
     assert got == (eds, cigars, [0] * n)
+
+
+def test_bench_gather_on_rccl_single_rank():
+    """The gather path of bench.py on the real RCCL backend (a one-rank group, SCRG_BENCH_FORCE_GATHER): asynchronous
+    collectives, packed runs, unpacking on a stream of its own ordered after the collective, four steps in flight;
+    bench.py itself asserts that what rank 0 holds after the last step's gather is what its kernel produced."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SCRG_BENCH_FORCE_GATHER="1", MASTER_PORT="29579")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "9", "--warmup", "2",
+                          "--pairs", "20000", "--read-len", "3000", "--cpu-seconds", "0"],
+                         env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith('{"metric"')][0])
+    assert j["gather_check"] is True and j["value"] > 0
