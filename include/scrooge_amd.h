@@ -50,11 +50,12 @@ typedef struct scrg_params {
     int32_t W;               /* window length, 2..256; reference default 64 (genasm_cpu.cpp:7).
                                 W > 64 uses multi-word entries (src/bitvector.hpp:45-48)           */
     int32_t O;               /* window overlap, 1 <= O < W; reference default 33 (genasm_cpu.cpp:9).
-                                W-O <= 31 (e.g. the defaults) uses the compact DENT storage; larger
-                                W-O switches to whole 64-bit entries of all columns (4x the LDS per row) */
-    int32_t lanes_per_pair;  /* 64 = one pair per wavefront (lane = text column);
-                                4/8/16/32 pack 64/lanes pairs into one wavefront.  0 = default
-                                (8; for W > 64 only 32 and 64 exist, default 32)                      */
+                                W-O <= 31 (e.g. the defaults) keeps the traceback table in registers / the
+                                compact DENT rows; larger W-O needs 64-bit rows of all columns in LDS      */
+    int32_t lanes_per_pair;  /* 1 = one pair per lane, 64 pairs per wavefront (the default for W <= 64);
+                                64 = one pair per wavefront (lane = text column); 4/8/16/32 pack 64/lanes
+                                pairs into one wavefront (GenASM rows).  0 = default (1; for W > 64 only
+                                32 and 64 exist, default 32)                                          */
     int32_t lds_rows;        /* rows of the R table kept in LDS per pair (rest spills to HBM);
                                 0 = default                                                        */
     int32_t waves_per_cu;    /* persistent wavefronts launched per CU; 0 = default                */

@@ -37,7 +37,8 @@ name = torch.cuda.get_device_name(0)
 configs = [(64, 33, 0, 0, 0)]                                                                    # library defaults (one pair per lane, 16 waves/CU)
 configs += [(W, min(W // 2 + 1, W - 1), 0, 0, 0) for W in (16, 24, 32, 40, 48, 56)]        # W sweep, O = W/2+1 (profile.py:78): lane kernel
 configs += [(64, O, 0, 0, 0) for O in (36, 40, 48, 56, 60)]                                    # O sweep at W=64 (profile.py:88-100): lane kernel
-configs += [(64, O, 8, 13, 3) for O in (2, 16, 32)]                                             # small overlaps: WIDE storage of the G=8 kernel
+configs += [(64, O, 0, 0, 0) for O in (2, 16, 32)]                                              # small overlaps (W-O > 31): genasm_lane_wide_kernel
+configs += [(64, O, 8, 13, 3) for O in (2, 16, 32)]                                             # the same on the GenASM-row kernel (G=8, WIDE storage)
 configs += [(W, W // 2 + 1, 0, 0, 0) for W in (80, 96, 112, 128, 160, 192, 224, 256)]         # W sweep past one word (profile.py:180-185)
 configs += [(128, 65, 64, 0, 0), (256, 129, 64, 0, 0), (256, 129, 32, 20, 0), (128, 20, 0, 0, 0)]
 configs += [(64, 33, g, 13, w) for g, w in ((64, 16), (32, 16), (16, 16), (8, 11), (4, 6))]    # the GenASM-row lane mappings

@@ -37,6 +37,8 @@ hipError_t launch_align(int lanes_per_pair, const AlignArgs& a, int grid, size_t
 hipError_t launch_align_multiword(int lanes_per_pair, const AlignArgs& a, int grid, size_t lds_bytes, hipStream_t s);
 // lanes_per_pair = 1: one pair per lane, 64 pairs per wavefront (genasm_lane_kernel.hip; W <= 64, W-O <= 31)
 hipError_t launch_align_lane(const AlignArgs& a, int grid, size_t lds_bytes, hipStream_t s);
+// the same for W-O > 31 (genasm_lane_wide_kernel.hip): 64-bit table rows in LDS, one wavefront per workgroup
+hipError_t launch_align_lane_wide(const AlignArgs& a, int grid, size_t lds_bytes, hipStream_t s);
 
 // dwords of one stored row of R (the part the traceback can reach):
 //   W <= 64: the high dword of columns 0..31, or whole entries of all 64 columns when W-O > 31;
@@ -46,6 +48,11 @@ hipError_t launch_align_lane(const AlignArgs& a, int grid, size_t lds_bytes, hip
 #else
 #define SCRG_HD
 #endif
+// genasm_lane_wide_kernel: LDS per wavefront = CIGAR ring + run lengths + two 64-bit table words for each of the W-O
+// columns (+ bank skew)
+SCRG_HD inline unsigned lane_wide_tab_bytes(int tb_limit) { return (unsigned)tb_limit * 16u + 32u; }
+SCRG_HD inline unsigned lane_wide_lds_bytes(int tb_limit) { return 64u * (68u + 68u + lane_wide_tab_bytes(tb_limit)); }
+
 SCRG_HD inline unsigned stored_row_dwords(int W, int tb_limit)
 {
     if (W <= 64) return tb_limit > 31 ? 128u : 32u;

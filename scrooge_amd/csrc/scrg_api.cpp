@@ -377,10 +377,9 @@ static bool resolve_params(const scrg_params* in, scrg_params* p)
             p->lds_rows = (int32_t)std::min<size_t>(32, std::max<size_t>(4, fit));
         }
     } else {
-        // one pair per lane (genasm_lane_kernel.hip) wherever it applies: a window's traceback consumes at most
-        // W-O <= 31 characters; wider traceback limits take the G = 8 kernel's whole-entry storage
-        if (p->lanes_per_pair == 0) p->lanes_per_pair = tbl <= 31 ? 1 : 8;
-        if (p->lanes_per_pair == 1 && tbl > 31) return false;
+        // one pair per lane for every W <= 64: genasm_lane_kernel.hip (table in registers) while a window's traceback
+        // consumes at most W-O <= 31 characters, genasm_lane_wide_kernel.hip (64-bit rows, table in LDS) beyond
+        if (p->lanes_per_pair == 0) p->lanes_per_pair = 1;
         if (p->lds_rows == 0) p->lds_rows = 12;
     }
     // 11 and 12 wavefronts per CU align equally fast (the kernel is issue-bound); 11 leaves VGPRs and LDS on
@@ -401,6 +400,7 @@ static bool resolve_params(const scrg_params* in, scrg_params* p)
 
 static size_t lds_bytes_for(const scrg_params& p)
 {
+    if (p.lanes_per_pair == 1 && p.W - p.O > 31) return scrg::lane_wide_lds_bytes(p.W - p.O);   // 64-bit table rows, W-O columns
     if (p.lanes_per_pair == 1) return 64 * (68 + 36 + 32 + 8);  // per lane: CIGAR staging ring (32 runs + 1 dword), insertion-run lengths of a window, Eq table (+ the "no match" word)
     const size_t slots = 64 / p.lanes_per_pair;
     // per slot: CIGAR staging ring (16 dwords) + 1 scratch dword + R rows (+1 dword against bank
@@ -508,6 +508,8 @@ scrg_status scrg_align_device(scrg_ctx* c, const scrg_params* params, uint64_t n
     HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));
     if (p.W > 64)
         HIP_TRY(c, scrg::launch_align_multiword(p.lanes_per_pair, a, n_waves, (size_t)lds, c->stream));
+    else if (p.lanes_per_pair == 1 && p.W - p.O > 31)
+        HIP_TRY(c, scrg::launch_align_lane_wide(a, n_waves, (size_t)lds, c->stream));
     else if (p.lanes_per_pair == 1)
         HIP_TRY(c, scrg::launch_align_lane(a, n_waves, (size_t)lds, c->stream));
     else

@@ -41,7 +41,7 @@ def test_golden_other_knobs(aligner, name):
     from tests.conftest import load_golden
     g = load_golden(name)
     cases = g["cases"]
-    for lanes in ((1, 8, 64) if g["W"] - g["O"] <= 31 else (8, 64)):
+    for lanes in (1, 8, 64):          # (W-O > 31: the 64-bit-row variants of both formulations)
         alns = aligner.align_pairs([c["text"] for c in cases], [c["read"] for c in cases], W=g["W"], O=g["O"],
                                    lanes_per_pair=lanes)
         _check(alns, [c["ed"] for c in cases], [c["cigar"] for c in cases], "%s g=%d" % (name, lanes))
@@ -123,11 +123,11 @@ def test_other_window_settings(aligner, oracle, w, o):
 
 
 @pytest.mark.parametrize("w,o", [(64, 2), (64, 20), (64, 32), (40, 5), (33, 1), (64, 1)])
-@pytest.mark.parametrize("g", [8, 64, 16])
+@pytest.mark.parametrize("g", [1, 8, 64, 16])
 def test_small_overlap_uses_wide_storage(aligner, oracle, w, o, g):
     """W-O > 31 (e.g. the reference's O sweep down to small overlaps, scripts/profile.py:88-100; README's
     W=64,O=2 row): the traceback may consume up to W-O characters per window, so whole 64-bit entries of
-    all columns are stored (kernel variant WIDE)."""
+    all columns are stored (kernel variant WIDE; one pair per lane: genasm_lane_wide_kernel, table in LDS)."""
     t, q = synth.make_pairs(50, 400, "ont", seed=w * 31 + o)
     rng = np.random.Generator(np.random.PCG64(w + o))
     for _ in range(80):
