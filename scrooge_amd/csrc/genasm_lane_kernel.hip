@@ -1,5 +1,6 @@
 // genasm_lane_kernel.hip — the lane-per-pair aligner for gfx950 (W <= 64, W-O <= 31): every lane of a
 // wavefront aligns its own read pair, 64 pairs per wavefront, the window's traceback table in VGPRs.
+// (W-O > 31: genasm_lane_wide_kernel.hip, the same arithmetic with 64-bit table rows in LDS.)
 //
 // What is computed is the reference's windowed GenASM (src/genasm_cpu.cpp:411-438: window loop, :210-288
 // distance calculation, :290-409 traceback); how the table is held is different.  Bit j of R[i][d] is clear
@@ -10,20 +11,22 @@
 //     D[i][j+1] == d-1 ?    D[i+1][j] == d-1 ?    D[i+1][j+1] == d-1 ?
 // i.e. it only ever looks at the vertical, horizontal and diagonal DIFFERENCES of D.  Those differences
 // are what the Myers/Hyyro bit-vector recurrence carries (Pv/Mv vertical, Ph/Mh horizontal, Xh|Mv the
-// zero diagonal steps), so one text column — all 64 pattern rows and every distance d at once — costs 23
+// zero diagonal steps), so one text column — all 64 pattern rows and every distance d at once — costs 21
 // VALU instructions, there is no loop over d, and the cost of a window does not depend on its distance
 // (early termination, :278-283, has nothing left to skip).  Per text column i < W-O two dwords are kept
 // for the traceback (SENE + DENT, :63-78, :200-208, :258-267, in this form):
-//     V1 = Pv' | Ph            insertion or deletion             (kept negated, with a stop bit: see below)
+//     V1 = Pv' | Ph            insertion or deletion             (kept negated)
 //     V0 = Pv' | ~(Ph | Xh)    insertion or substitution         (both = insertion, neither = match)
-// left-aligned: bit 31-j belongs to pattern character j.  The traceback is column-synchronous — in column
-// i the run of insertions is one count-leading-zeros over V1 & V0, then one D / X / = step moves every
-// lane to column i+1 — so the table is indexed by compile-time constants and lives in 62 VGPRs.
+// left-aligned: bit 31-j belongs to pattern character j; both carry a stop bit at the row where the lane's
+// walk ends.  The traceback is column-synchronous — in column i the run of insertions is one
+// count-leading-zeros over V1 & V0, then one D / X / = step moves every lane to column i+1 — so the table
+// is indexed by compile-time constants and lives in 62 VGPRs (31 register pairs).
 // tests/proto/lane_proto.c restates this arithmetic in C; tests/test_lane_proto.py checks that restatement
 // against the reference algorithm on the CPU.
 //
-// LDS holds only the CIGAR staging ring (32 runs per lane, written out in aligned 32-byte pieces) and 31
-// bytes of insertion-run lengths per lane.
+// LDS (9.2 KB per wavefront): the CIGAR staging ring (32 runs per lane, written out in aligned 32-byte
+// pieces), 31 bytes of insertion-run lengths per lane, and the window's Eq words for the four bases (+ the
+// "no character matches" word), which the table columns look up by text character.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
