@@ -218,10 +218,10 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
     for (;;) {
         // The SIMD's arbiter issues oldest-wave-first: left alone, the first wavefront on a SIMD runs at the speed
         // of a lone wave and the last one finishes 2.7x later, with the SIMD half idle at the end of a launch.
-        // Rotating the priorities (a different wave slot is on top every 2^15 cycles, about one round) lets the
-        // wavefronts of a SIMD progress, and finish, together.
+        // Rotating the priorities (set once per round from the clock and the wave slot: a different wavefront is on top
+        // from round to round) lets the wavefronts of a SIMD progress, and finish, together.
         if (!(a.debug & 1)) {
-            const uint32_t pr = ((uint32_t)(__builtin_readcyclecounter() >> 15) + wave_slot) & 3u;
+            const uint32_t pr = ((uint32_t)(__builtin_readcyclecounter() >> 11) + wave_slot) & 3u;
             if (pr == 0) __builtin_amdgcn_s_setprio(0);
             else if (pr == 1) __builtin_amdgcn_s_setprio(1);
             else if (pr == 2) __builtin_amdgcn_s_setprio(2);
