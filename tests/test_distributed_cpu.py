@@ -53,7 +53,7 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def _worker_fixed(rank, world, port, q):
+def _worker_fixed(rank, world, port, q, depth=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -61,9 +61,10 @@ def _worker_fixed(rank, world, port, q):
         n = 5
         counts = torch.tensor([rank + 1, 0, 3, 2 * rank, 1], dtype=torch.int32)
         total = int(counts.sum())
-        g = sd.ResultGather(n, total, torch.device("cpu"), dst=0)
+        g = sd.ResultGather(n, total, torch.device("cpu"), dst=0, depth=depth)
+        assert g.DEPTH == (depth or 2)
         ed = torch.arange(n, dtype=torch.int64) * (rank + 1)
-        for k in range(5):        # double buffered, reusable across steps
+        for k in range(5):        # multi-buffered, reusable across steps
             g.finish(k)
             g.send_runs[k % g.DEPTH][: 2 * total] = torch.arange(2 * total, dtype=torch.uint8) + 10 * rank + k
             g.start(k, ed + k, counts)
@@ -80,11 +81,12 @@ def _worker_fixed(rank, world, port, q):
 
 
 @pytest.mark.timeout(180)
-def test_fixed_size_result_gather():
+@pytest.mark.parametrize("depth", [None, 4])            # 4: one buffer set per pipelined step of bench.py
+def test_fixed_size_result_gather(depth):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_fixed, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker_fixed, args=(r, 2, port, q, depth)) for r in range(2)]
     for p in procs:
         p.start()
     out = q.get(timeout=150)
