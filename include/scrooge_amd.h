@@ -123,6 +123,8 @@ typedef struct scrg_result {
     int64_t   total_ns;       /* whole call                                              */
 } scrg_result;
 
+/* (The large arrays are recycled by the library: up to 2 GB of them are kept for the next call of similar size
+ * instead of being returned to the allocator, so that a stream of batches does not fault fresh pages every time.) */
 void scrg_result_free(scrg_result *r);
 
 /* Unstructured pairwise alignment: queries[i] is consumed completely against a
