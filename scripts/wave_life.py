@@ -1,3 +1,5 @@
+"""Wavefront life times and per-phase cycles of genasm_lane_kernel from the stats line of `bench.py --stats`
+(scrg_debug_stats, lanes_per_pair = 1).  usage: wave_life.py <stderr of bench.py --stats> <wavefronts of the launch>"""
 import sys, ast
 for l in open(sys.argv[1]):
     if l.startswith('stats'):
