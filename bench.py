@@ -342,7 +342,13 @@ def main():
     if serial is not None:
         kernel_ms = serial["kernel_ms"]
 
-    if args.stats:
+    if args.stats and p.lanes_per_pair == 1:
+        st = al.debug_stats_lane()
+        r = max(1, st["rounds"])
+        for k in ("fetch", "setup", "table", "pass1", "traceback"):
+            st["cyc_per_round_" + k] = st["cycles_" + k] / r
+        print("stats(last launch):", st, file=sys.stderr)
+    elif args.stats:
         st = al.debug_stats()
         st["steps_per_round"] = st["dc_steps"] / max(1, st["rounds"])
         st["macro_per_round"] = st["tb_macro_steps"] / max(1, st["rounds"])

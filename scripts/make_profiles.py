@@ -51,7 +51,7 @@ rounds = None
 try:
     for l in open(os.path.join(go, "prof_%s" % tag, "stats.txt")):
         if l.startswith("stats"):
-            rounds = ast.literal_eval(l.split(":", 1)[1].strip())["rounds"]
+            rounds = ast.literal_eval(l.split(":", 1)[1].strip())["rounds"]        # (both kernels' stats call it that)
 except Exception as e:
     print("no stats pass:", e)
 

@@ -416,6 +416,18 @@ class Aligner:
                 "cycles_tb": int(out[6]), "cycles_tb_loop": int(out[7]), "diag_rounds": int(out[8]),
                 "diag_fallbacks": int(out[9]), "cycles_diag_dc": int(out[10]), "cycles_diag_tb": int(out[11])}
 
+    def debug_stats_lane(self):
+        """The same counters as read by the one-pair-per-lane kernel (scrooge_amd.h: scrg_debug_stats): window rounds,
+        rounds with a short text window, shader cycles per phase summed over wavefronts, wavefront life times on the
+        100 MHz wall clock."""
+        out = (C.c_uint64 * 12)()
+        self._check(self.lib.scrg_debug_stats(self.h, out))
+        o = [int(x) for x in out]
+        big = 1 << 62
+        return {"rounds": o[0], "short_text_rounds": o[1], "cycles_pass1": o[2], "cycles_fetch": o[3], "cycles_setup": o[4],
+                "cycles_table": o[5], "cycles_traceback": o[6], "life_ticks_sum": o[7], "last_start": o[8],
+                "first_start": big - o[9], "last_end": o[10], "first_end": big - o[11]}
+
     def resolved_params(self, **kw):
         """The parameters a launch with these overrides will really use (defaults filled in)."""
         out = Params()
