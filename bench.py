@@ -46,6 +46,10 @@ def parse():
     ap.add_argument("--layout", default="auto", choices=["auto", "linear", "groups"],
                     help="sequence layout in HBM: linear = every sequence contiguous; groups = lane-interleaved groups of 64 "
                          "pairs (scrg_pack_planar_groups), what the one-pair-per-lane kernel reads best; auto = groups for that kernel")
+    ap.add_argument("--gather-format", default="edits", choices=["edits", "edits-from-runs", "packed", "runs"],
+                    help="N > 1: how CIGARs travel to rank 0 — edit streams, 1 byte per edit, written by the align kernel "
+                         "itself (default; W-O <= 31) or encoded from its runs (edits-from-runs: any W/O), packed runs "
+                         "(1 byte per run, restored on rank 0 inside the timed region) or scrg_run pairs")
     ap.add_argument("--streams", type=int, default=4, help="pipeline depth: consecutive steps rotate over this many streams/handles")
     ap.add_argument("--no-build", action="store_true",
                     help="never rebuild the library (profiling: nothing may fork a compiler under rocprofv3)")
@@ -121,6 +125,22 @@ def device_pairs(torch, n, read_len, err, ratio, seed, device, slack=0.15, chunk
         out[b0:b0 + b, tw * 32: tw * 32 + read_len] = lut[read[:, :read_len].long()]
         del src, u, v, emit, pos, read, p_ins, p_keep, base, delta, ins_base
     return out, tw, rw, text_len
+
+
+STEP_TEXT = {
+    "local": "align kernel + run compaction",
+    "edits": "align kernel writing every CIGAR as an edit stream (scrg_align_device_edits: one byte per edit, a lossless "
+             "encoding the window breaks are restored from) + compaction of the streams + RCCL gather of scores and streams "
+             "to rank 0, one collective and one buffer set per pipelined step (overlaps the next kernels); rank 0 keeps the "
+             "streams, their decoding to scrg_run (scrg_decode_edit_stream) is checked for every rank's slot after the "
+             "timed region",
+    "edits-from-runs": "align kernel (runs) + edit-stream encoding (scrg_encode_edit_stream) + RCCL gather of scores and "
+                       "streams to rank 0, one collective and one buffer set per pipelined step; rank 0 keeps the streams, "
+                       "their decoding is checked for every rank's slot after the timed region",
+    "packed": "align kernel + run compaction to one byte per run + RCCL gather of scores and runs to rank 0 (one buffer set "
+              "per pipelined step); rank 0 restores scrg_run pairs inside the timed region",
+    "runs": "align kernel + run compaction + RCCL gather of scores and scrg_run pairs to rank 0 (one buffer set per pipelined step)",
+}
 
 
 def main():
@@ -230,9 +250,40 @@ def main():
     total_runs = int(n_runs.sum().item())
     denses = [torch.empty(max(total_runs, 8) * 2, dtype=torch.uint8, device=device) for _ in range(n_lanes)]
     gather = None
-    if dist_on:
+    gather_format = args.gather_format
+    if gather_format == "packed" and p.W - p.O > 63:
+        gather_format = "runs"                       # packed runs hold counts up to 63
+    stream_bytes = None
+    if gather_format == "edits" and not (p.lanes_per_pair == 1 and p.W <= 64 and p.W - p.O <= 31):
+        gather_format = "edits-from-runs"            # only the one-pair-per-lane kernel writes edit streams itself
+    edits = gather_format in ("edits", "edits-from-runs")
+    if dist_on and edits:
+        # CIGARs travel as edit streams (one byte per edit); rank 0 keeps them in that form
+        from scrooge_amd.distributed import EditStreamGather
+        if gather_format == "edits":
+            t_len = torch.empty(n, dtype=torch.int32, device=device)
+            al.align_device_edits(n, seq, desc, runs, ed, t_len, status, **kw)
+            torch.cuda.synchronize()
+            assert int(status.max().item()) == 0
+            stream_bytes = int(((t_len.to(torch.int64) + 3) // 4 * 4).sum().item())
+            al.align_device(n, seq, desc, runs, ed, n_runs, status, **kw)
+            torch.cuda.synchronize()
+        else:
+            bound = int(ed.sum().item()) + n * (L >> 6) + 4 * n + 64
+            tmp = torch.empty(bound, dtype=torch.uint8, device=device)
+            t_off = torch.empty(n, dtype=torch.int64, device=device)
+            t_len = torch.empty(n, dtype=torch.int32, device=device)
+            t_tot = torch.zeros(2, dtype=torch.int64, device=device)
+            al.encode_edit_stream(n, desc, runs, n_runs, tmp, t_off, t_len, t_tot)
+            torch.cuda.synchronize()
+            assert int(t_tot[1].item()) == 0
+            stream_bytes = int(t_tot[0].item())
+            del tmp, t_off
+        del t_len
+        gather = EditStreamGather(n, stream_bytes, device, dst=0, depth=max(2, n_lanes))
+    elif dist_on:
         from scrooge_amd.distributed import ResultGather
-        packed_gather = p.W - p.O <= 63              # runs travel as one byte each; rank 0 restores scrg_run pairs
+        packed_gather = gather_format == "packed"    # runs travel as one byte each; rank 0 restores scrg_run pairs
         gather = ResultGather(n, total_runs, device, dst=0, depth=max(2, n_lanes), packed=packed_gather)
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -246,8 +297,9 @@ def main():
     # Lane streams of different priorities (low, high; everything else, RCCL included, runs at normal priority):
     # HIP gives each priority its own hardware queues, whereas two streams of one priority can share a queue,
     # and kernels in one queue never overlap (scripts/side_stream_probe.py).
+    PRIOS = [int(x) for x in os.environ.get("SCRG_BENCH_PRIOS", "1,-1,0,1,-1,0").split(",")]      # experiment knob
     if n_lanes > 1:
-        streams = [torch.cuda.ExternalStream(scrooge_amd.api.create_stream(local_rank, pr), device=device) for pr in ([1, -1, 0, 1, -1, 0][:n_lanes])]
+        streams = [torch.cuda.ExternalStream(scrooge_amd.api.create_stream(local_rank, pr), device=device) for pr in (PRIOS[:n_lanes])]
     else:
         streams = [torch.cuda.current_stream()]
     setup_stream = torch.cuda.current_stream()
@@ -263,16 +315,41 @@ def main():
         b = j % n_lanes
         o = outs[b]
         with torch.cuda.stream(streams[b]):
+            if dist_on and gather_format == "edits":
+                # The align kernel writes every pair's CIGAR as an edit stream into the pair's slice; the slices are
+                # gathered into the step's send buffer (4-byte aligned, pair order) and one RCCL collective takes
+                # scores + streams to rank 0 over xGMI; one buffer set per pipelined step, so the gather of this step
+                # overlaps the next steps' align kernels
+                if k is not None:
+                    ev[k][0].record()
+                aligners[b].align_device_edits(n, seq, desc, o["runs"], o["ed"], o["n_runs"], o["status"], **kw)
+                if k is not None:
+                    ev[k][1].record()
+                gather.finish(j)                       # buffers of step j-DEPTH are free again
+                g = gather.buffers(j)
+                r4 = (o["n_runs"].to(torch.int64) + 3) & -4
+                boff = torch.cumsum(r4, 0) - r4
+                g["off"].copy_(boff)
+                g["len"].copy_(o["n_runs"])
+                aligners[b].compact_runs(n, desc, o["runs"], (r4 >> 1).to(torch.int32), boff >> 1, g["stream"])
+                gather.start(j, o["ed"], None)
+                return
             if k is not None:
                 ev[k][0].record()
             aligners[b].align_device(n, seq, desc, o["runs"], o["ed"], o["n_runs"], o["status"], **kw)
             if k is not None:
                 ev[k][1].record()
+            if dist_on and gather_format == "edits-from-runs":
+                # the same with the streams encoded from the kernel's runs (any W/O, any kernel)
+                gather.finish(j)
+                g = gather.buffers(j)
+                aligners[b].encode_edit_stream(n, desc, o["runs"], o["n_runs"], g["stream"], g["off"], g["len"], g["total"])
+                gather.start(j, o["ed"], o["n_runs"])
+                return
             cnt64 = o["n_runs"].to(torch.int64)
             dense_off = torch.cumsum(cnt64, 0) - cnt64
             if dist_on:
-                # RCCL gather of scores + CIGAR runs to rank 0 over xGMI, double buffered: the gather of
-                # this step overlaps the next step's align kernel
+                # the same with the runs themselves (--gather-format runs | packed)
                 gather.finish(j)                       # buffers of step j-DEPTH are free again
                 if packed_gather:
                     aligners[b].compact_runs_packed(n, desc, o["runs"], o["n_runs"], dense_off, gather.send_runs[j % gather.DEPTH], **kw)
@@ -293,6 +370,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(k)
+    t_enqueued = time.perf_counter() - t0
     if gather is not None:
         gather.finish_all()
     torch.cuda.synchronize()
@@ -301,16 +379,46 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     last = (step.count - 1) % n_lanes
+    if dist_on and gather_format == "edits" and rank == 0:
+        # (the slices of the last step hold edit streams: make the runs for the checks below, outside the timed region)
+        with torch.cuda.stream(streams[last]):
+            aligners[last].align_device(n, seq, desc, outs[last]["runs"], outs[last]["ed"], outs[last]["n_runs"], outs[last]["status"], **kw)
+        torch.cuda.synchronize()
     ed, n_runs, dense = outs[last]["ed"], outs[last]["n_runs"], denses[last]
     gather_check = None
-    if gather is not None and rank == 0:
+    if gather is not None and rank == 0 and os.environ.get("SCRG_BENCH_NOCOLL") != "1":
         # outside the timed region: what rank 0 holds for itself after the last step's gather (scores, counts and the
         # runs restored from the wire format) must be what its own kernel produced
         cnt64 = n_runs.to(torch.int64)
-        aligners[last].compact_runs(n, desc, outs[last]["runs"], n_runs, torch.cumsum(cnt64, 0) - cnt64, dense)
+        dense_off = torch.cumsum(cnt64, 0) - cnt64
+        torch.cuda.synchronize()                        # (torch's stream is not the handle's)
+        aligners[last].compact_runs(n, desc, outs[last]["runs"], n_runs, dense_off, dense)
         torch.cuda.synchronize()
-        ed_g, cnt_g, runs_g = gather.results(step.count - 1, 0)
-        gather_check = bool(torch.equal(ed_g, ed) and torch.equal(cnt_g, n_runs) and torch.equal(runs_g, dense[: runs_g.numel()]))
+        if edits:
+            # every rank's slot must decode (scrg_decode_edit_stream) into exactly the gathered number of runs for reads
+            # of this length, with as many edits as the gathered edit distance; rank 0's own slot must be, run for run,
+            # what its kernel produced
+            rl = torch.tensor([L], dtype=torch.int64, device=device)
+            gather_check = True
+            for r in range(world):
+                v = gather.results(step.count - 1, r)
+                torch.cuda.synchronize()
+                runs_g, off_g, n_bad = gather.decode(aligners[last], step.count - 1, r, rl, 0,
+                                                     counted=gather_format != "edits", **kw)
+                torch.cuda.synchronize()
+                is_edit = (v["stream"][: gather.totals[r]] >= 64).to(torch.int64)
+                csum = torch.cat([torch.zeros(1, dtype=torch.int64, device=device), torch.cumsum(is_edit, 0)])
+                n_edits = csum[v["off"] + v["len"].to(torch.int64)] - csum[v["off"]]
+                checks = {"streams_decode": n_bad == 0, "edits_equal_distance": bool(torch.equal(n_edits, v["ed"]))}
+                if r == 0:
+                    checks.update(own_scores=bool(torch.equal(v["ed"], ed) and torch.equal(v["cnt"], n_runs)),
+                                  own_runs=bool(runs_g is not None and torch.equal(runs_g[: 2 * total_runs], dense[: 2 * total_runs])))
+                if not all(checks.values()):
+                    print("gather check, slot of rank %d: %s (undecodable pairs: %d)" % (r, checks, n_bad), file=sys.stderr)
+                    gather_check = False
+        else:
+            ed_g, cnt_g, runs_g = gather.results(step.count - 1, 0)
+            gather_check = bool(torch.equal(ed_g, ed) and torch.equal(cnt_g, n_runs) and torch.equal(runs_g, dense[: runs_g.numel()]))
         assert gather_check, "gathered results differ from the local ones"
     if dist_on:
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -446,7 +554,9 @@ def main():
                    "pairs_per_gpu": n, "read_len": L, "text_len": text_len, "error_profile": args.profile,
                    "W": p.W, "O": p.O, "lanes_per_pair": p.lanes_per_pair, "lds_rows": p.lds_rows,
                    "sequence_layout": "lane-interleaved groups of 64 pairs (scrg_pack_planar_groups)" if groups else "contiguous per sequence",
-                   "launch": geom, "step": "align kernel + run compaction" + (" + RCCL gather of scores and CIGAR runs to rank 0 (one buffer set per pipelined step, overlaps the next kernels; runs travel as one byte each and are restored to scrg_run on rank 0 inside the timed region)" if dist_on else ""),
+                   "launch": geom, "step": STEP_TEXT[gather_format if dist_on else "local"],
+                   "gather": ({"format": gather_format, "bytes_per_rank_and_step": gather.wire if edits else None,
+                               "stream_bytes_per_pair": (stream_bytes / n) if stream_bytes is not None else None} if dist_on else None),
                    "pipeline": ("consecutive steps alternate between %d streams (own handle, work queue and output buffers each): "
                                 "a step's wavefronts start while the previous step's last pairs finish" % n_lanes) if n_lanes > 1
                                else "one stream: a step starts after the previous one has finished"},
@@ -465,6 +575,7 @@ def main():
         "cpu_baseline": cpu,
         "parity": parity,
         "gather_check": gather_check,
+        "host_enqueue_ms_per_step": t_enqueued / args.steps * 1e3,     # CPU time to enqueue a step (includes waiting for a free buffer set)
         "gen_seconds": gen_s,
     }
     if dc_cells is not None:

@@ -211,6 +211,20 @@ scrg_status scrg_align_device(scrg_ctx *ctx, const scrg_params *params, uint64_t
                               scrg_run *d_runs, int64_t *d_edit_distance,
                               uint32_t *d_n_runs, uint32_t *d_pair_status);
 
+/* The same alignment delivered as EDIT STREAMS (format below, "Edit stream") straight from the align kernel: pair p's
+ * stream goes to its slice — bytes [2 * cigar_off, 2 * cigar_off + 2 * cigar_cap) of d_streams, i.e. the very slice
+ * scrg_align_device would fill with runs, so descriptors and buffers can be shared —, d_stream_len[p] is its length
+ * in bytes (the bytes up to the next multiple of 4 are zero), d_pair_status[p] is 1 if it did not fit (a stream is
+ * never longer than edit distance + read_len / 64 bytes; 2 * cigar_cap >= that always fits).  The kernel does less
+ * work than for runs (it visits edits, not run boundaries) and writes a quarter of the bytes.
+ * scrg_compact_runs with d_n_runs[p] = (d_stream_len[p] + 3) / 4 * 2 and even d_dense_offset gathers the slices.
+ * One-pair-per-lane kernel only: lanes_per_pair = 1 (the default), W <= 64, W-O <= 31; SCRG_ERR_INVALID_ARG
+ * otherwise (use scrg_align_device + scrg_encode_edit_stream there).  d_streams 32-byte aligned. */
+scrg_status scrg_align_device_edits(scrg_ctx *ctx, const scrg_params *params, uint64_t n_pairs,
+                                    const uint64_t *d_seq, const scrg_pair_desc *d_pairs,
+                                    uint8_t *d_streams, int64_t *d_edit_distance,
+                                    uint32_t *d_stream_len, uint32_t *d_pair_status);
+
 /* Gathers every pair's runs from its slice into one dense array:
  * d_dense[d_dense_offset[p] + k] = d_runs[d_pairs[p].cigar_off + k]. */
 scrg_status scrg_compact_runs(scrg_ctx *ctx, uint64_t n_pairs, const scrg_pair_desc *d_pairs,
@@ -225,6 +239,46 @@ scrg_status scrg_compact_runs_packed(scrg_ctx *ctx, const scrg_params *params, u
                                      const scrg_pair_desc *d_pairs, const scrg_run *d_runs, const uint32_t *d_n_runs,
                                      const uint64_t *d_dense_offset, uint8_t *d_packed);
 scrg_status scrg_unpack_runs(scrg_ctx *ctx, uint64_t n_runs, const uint8_t *d_packed, scrg_run *d_runs);
+
+/* ---- Edit stream: the compact transfer format for CIGARs (multi-GPU gather, D2H) ----
+ * The runs of a pair carry the alignment operations AND the places where a window ended; the window breaks are a
+ * function of the operations (a window's traceback runs while j < m && i < W-O && j < W-O, genasm_cpu.cpp:307-310,
+ * and the next window starts where it stopped, :411-438), so only the operations travel, one byte per EDIT:
+ *     byte = op << 6 | len     op 1 'X', 2 'I', 3 'D': `len` matches, then that edit;
+ *                              op 0: `len + 1` matches, no edit (only inside a stretch of more than 63 matches)
+ * in alignment order; the matches after the last edit are implied by the read length.  Canonical form: P matches
+ * before an edit = P >> 6 bytes 0x3F, then the edit byte with len = P & 63.  A 10 kb read at 10 % error is ~1.0 KB
+ * (2140 runs = 4.3 KB as scrg_run, 2.1 KB packed).  Valid for every W (counts of restored runs are <= W-O <= 255).
+ *
+ * scrg_encode_edit_stream: for every pair, the stream of its runs (as scrg_align_device left them in d_runs).
+ *   Streams are placed in d_stream back to back in no particular order, each starting at a multiple of 4:
+ *   d_stream_off[p] (bytes; ~0 if the pair did not fit into stream_cap) and d_stream_len[p] say where.
+ *   d_total[0] = bytes of d_stream used (the amount to transfer), d_total[1] = pairs that did not fit.
+ *   stream_cap >= sum of edit distances + sum of (read_len >> 6) + 4 * n_pairs always suffices.
+ * scrg_decode_edit_stream: the inverse, one thread per pair.  Read lengths are taken from
+ *   d_read_len[p * read_len_stride] (stride 1: a plain array; 6: &d_pairs[0].read_len; 0: one length for all).
+ *   With d_dense == NULL it only counts: d_n_runs[p] = runs of pair p.  Otherwise d_n_runs[p] is an input, the size
+ *   of pair p's segment at d_dense + d_dense_offset[p], and the runs are written there — bit for bit the runs the
+ *   align kernel produced for W/O of `params`.  *d_bad_count is incremented for every pair whose stream is not an
+ *   alignment of a read of that length, or whose run count differs from d_n_runs[p]. */
+scrg_status scrg_encode_edit_stream(scrg_ctx *ctx, uint64_t n_pairs, const scrg_pair_desc *d_pairs,
+                                    const scrg_run *d_runs, const uint32_t *d_n_runs,
+                                    uint8_t *d_stream, uint64_t stream_cap,
+                                    uint64_t *d_stream_off, uint32_t *d_stream_len, uint64_t *d_total);
+scrg_status scrg_decode_edit_stream(scrg_ctx *ctx, const scrg_params *params, uint64_t n_pairs,
+                                    const uint8_t *d_stream, const uint64_t *d_stream_off, const uint32_t *d_stream_len,
+                                    const uint64_t *d_read_len, uint64_t read_len_stride,
+                                    const uint64_t *d_dense_offset, scrg_run *d_dense, uint32_t *d_n_runs,
+                                    uint32_t *d_bad_count);
+/* The same two conversions for ONE pair on the host (no GPU, no handle): what a receiver without a GPU, or a
+ * test, uses.  scrg_edit_stream_to_runs returns SCRG_ERR_INVALID_ARG for a malformed stream and
+ * SCRG_ERR_CIGAR_OVERFLOW if runs_cap is too small (*n_runs is the number needed either way; runs may be NULL
+ * with runs_cap 0 to ask for it).  scrg_runs_to_edit_stream likewise with stream_cap / *n_bytes. */
+scrg_status scrg_edit_stream_to_runs(const scrg_params *params, uint64_t read_len,
+                                     const uint8_t *stream, uint64_t n_bytes,
+                                     scrg_run *runs, uint64_t runs_cap, uint64_t *n_runs);
+scrg_status scrg_runs_to_edit_stream(const scrg_run *runs, uint64_t n_runs,
+                                     uint8_t *stream, uint64_t stream_cap, uint64_t *n_bytes);
 
 /* Reference-layout 2-bit packer, mirrors the exported kernel
  * genasm_gpu::ascii_to_twobit_strings (src/genasm_gpu.cu:631-685): 4 bases per

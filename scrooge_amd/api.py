@@ -154,8 +154,13 @@ def load_library():
         "scrg_pack_planar_groups": (C.c_int32, [vp, vp, u64, u64, vp, vp]),
         "scrg_compact_runs_packed": (C.c_int32, [vp, vp, u64, vp, vp, vp, vp, vp]),
         "scrg_unpack_runs": (C.c_int32, [vp, u64, vp, vp]),
+        "scrg_encode_edit_stream": (C.c_int32, [vp, u64, vp, vp, vp, vp, u64, vp, vp, vp]),
+        "scrg_decode_edit_stream": (C.c_int32, [vp, vp, u64, vp, vp, vp, vp, u64, vp, vp, vp, vp]),
+        "scrg_edit_stream_to_runs": (C.c_int32, [C.POINTER(Params), u64, vp, u64, vp, u64, C.POINTER(u64)]),
+        "scrg_runs_to_edit_stream": (C.c_int32, [vp, u64, vp, u64, C.POINTER(u64)]),
         "scrg_align_device": (C.c_int32, [vp, C.POINTER(Params), u64, vp, vp, vp, vp, vp, vp]),
         "scrg_compact_runs": (C.c_int32, [vp, u64, vp, vp, vp, vp, vp]),
+        "scrg_align_device_edits": (C.c_int32, [vp, C.POINTER(Params), u64, vp, vp, vp, vp, vp, vp]),
         "scrg_ascii_to_twobit": (C.c_int32, [vp, u64, vp, vp, vp, vp, vp, vp]),
         "scrg_query_launch": (C.c_int32, [vp, C.POINTER(Params), i32p, i32p, i32p, i32p]),
         "scrg_last_kernel_ms": (C.c_int32, [vp, C.POINTER(C.c_float)]),
@@ -175,8 +180,51 @@ EXPORTED_SYMBOLS = [
     "scrg_last_error", "scrg_status_string", "scrg_set_log", "scrg_device_count",
     "scrg_result_free", "scrg_align_pairs", "scrg_align_mapping", "scrg_genome_set", "scrg_genome_clear",
     "scrg_align_mapping_resident", "scrg_pack_planar", "scrg_pack_planar_groups",
-    "scrg_align_device", "scrg_compact_runs", "scrg_compact_runs_packed", "scrg_unpack_runs", "scrg_ascii_to_twobit", "scrg_query_launch",
+    "scrg_align_device", "scrg_align_device_edits", "scrg_compact_runs", "scrg_compact_runs_packed", "scrg_unpack_runs",
+    "scrg_encode_edit_stream", "scrg_decode_edit_stream", "scrg_edit_stream_to_runs", "scrg_runs_to_edit_stream", "scrg_ascii_to_twobit", "scrg_query_launch",
     "scrg_last_kernel_ms", "scrg_debug_stats"]
+
+
+def edit_stream_to_cigar(stream, read_len, W=64, O=33):
+    """Host-side decoder of ONE pair's edit stream (bytes) -> the CIGAR text the aligner returns for W/O
+    (scrg_edit_stream_to_runs: no GPU involved).  Raises ScroogeError for a malformed stream."""
+    lib = load_library()
+    p = Params()
+    lib.scrg_params_default(C.byref(p))
+    p.W, p.O = int(W), int(O)
+    buf = (C.c_uint8 * max(1, len(stream))).from_buffer_copy(bytes(stream) or b"\0")
+    n = C.c_uint64(0)
+    st = lib.scrg_edit_stream_to_runs(C.byref(p), int(read_len), buf, len(stream), None, 0, C.byref(n))
+    if st not in (SCRG_OK, SCRG_ERR_CIGAR_OVERFLOW):
+        raise ScroogeError(st, "malformed edit stream")
+    runs = (C.c_uint8 * (2 * max(1, n.value)))()
+    st = lib.scrg_edit_stream_to_runs(C.byref(p), int(read_len), buf, len(stream), runs, n.value, C.byref(n))
+    if st != SCRG_OK:
+        raise ScroogeError(st, "malformed edit stream")
+    return "".join("%d%s" % (runs[2 * k], chr(runs[2 * k + 1])) for k in range(n.value))
+
+
+def cigar_to_edit_stream(cigar):
+    """Host-side encoder: CIGAR text (=, X, I, D runs) -> canonical edit stream bytes (scrg_runs_to_edit_stream)."""
+    import re
+    lib = load_library()
+    items = re.findall(r"(\d+)([=XID])", cigar)
+    if "".join(a + b for a, b in items) != cigar:
+        raise ValueError("not a CIGAR of =, X, I, D runs: %r" % cigar[:40])
+    raw = bytearray()
+    for cnt, op in items:
+        c = int(cnt)
+        while c > 0:                       # scrg_run counts are one byte
+            raw += bytes((min(c, 255), ord(op)))
+            c -= 255
+    runs = (C.c_uint8 * max(1, len(raw))).from_buffer_copy(bytes(raw) or b"\0")
+    n = C.c_uint64(0)
+    lib.scrg_runs_to_edit_stream(runs, len(raw) // 2, None, 0, C.byref(n))
+    out = (C.c_uint8 * max(1, n.value))()
+    st = lib.scrg_runs_to_edit_stream(runs, len(raw) // 2, out, n.value, C.byref(n))
+    if st != SCRG_OK:
+        raise ScroogeError(st, "bad runs")
+    return bytes(out[: n.value])
 
 
 def create_stream(device=0, priority=0):
@@ -385,6 +433,13 @@ class Aligner:
                                                _ptr(seq), _ptr(pairs), _ptr(runs), _ptr(ed),
                                                _ptr(n_runs), _ptr(status)))
 
+    def align_device_edits(self, n_pairs, seq, pairs, streams_u8, ed, stream_len, status, **kw):
+        """Like align_device, but the pairs' slices receive EDIT STREAMS (one byte per edit) and stream_len their
+        lengths in bytes: the one-pair-per-lane kernel only (W <= 64, W-O <= 31)."""
+        self._check(self.lib.scrg_align_device_edits(self.h, C.byref(self._params(kw)), int(n_pairs),
+                                                     _ptr(seq), _ptr(pairs), _ptr(streams_u8), _ptr(ed),
+                                                     _ptr(stream_len), _ptr(status)))
+
     def compact_runs(self, n_pairs, pairs, runs, n_runs, dense_off, dense):
         self._check(self.lib.scrg_compact_runs(self.h, int(n_pairs), _ptr(pairs), _ptr(runs),
                                                _ptr(n_runs), _ptr(dense_off), _ptr(dense)))
@@ -397,6 +452,23 @@ class Aligner:
     def unpack_runs(self, n_runs, packed_u8, runs_u8):
         """Restores scrg_run pairs (2 bytes each) from packed runs."""
         self._check(self.lib.scrg_unpack_runs(self.h, int(n_runs), _ptr(packed_u8), _ptr(runs_u8)))
+
+    def encode_edit_stream(self, n_pairs, pairs, runs, n_runs, stream_u8, stream_off_i64, stream_len_i32, total_i64):
+        """Runs -> edit stream (one byte per edit, scrooge_amd.h): the transfer format of the RCCL gather.
+        total_i64[0] = bytes of stream_u8 used, total_i64[1] = pairs that did not fit."""
+        self._check(self.lib.scrg_encode_edit_stream(self.h, int(n_pairs), _ptr(pairs), _ptr(runs), _ptr(n_runs),
+                                                     _ptr(stream_u8), int(stream_u8.numel()), _ptr(stream_off_i64),
+                                                     _ptr(stream_len_i32), _ptr(total_i64)))
+
+    def decode_edit_stream(self, n_pairs, stream_u8, stream_off_i64, stream_len_i32, read_len_i64, read_len_stride,
+                           dense_off_i64, dense_u8, n_runs_i32, bad_i32, **kw):
+        """Edit stream -> scrg_run pairs with the window breaks of W/O restored; dense_u8 None: count only."""
+        self._check(self.lib.scrg_decode_edit_stream(self.h, C.byref(self._params(kw)), int(n_pairs), _ptr(stream_u8),
+                                                     _ptr(stream_off_i64), _ptr(stream_len_i32), _ptr(read_len_i64),
+                                                     int(read_len_stride),
+                                                     _ptr(dense_off_i64) if dense_off_i64 is not None else None,
+                                                     _ptr(dense_u8) if dense_u8 is not None else None,
+                                                     _ptr(n_runs_i32), _ptr(bad_i32)))
 
     def ascii_to_twobit(self, count, lens, ascii_off, ascii, twobit_off, twobit, bad):
         self._check(self.lib.scrg_ascii_to_twobit(self.h, int(count), _ptr(lens), _ptr(ascii_off),

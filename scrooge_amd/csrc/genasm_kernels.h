@@ -36,7 +36,8 @@ struct AlignArgs {
 hipError_t launch_align(int lanes_per_pair, const AlignArgs& a, int grid, size_t lds_bytes, hipStream_t s);
 hipError_t launch_align_multiword(int lanes_per_pair, const AlignArgs& a, int grid, size_t lds_bytes, hipStream_t s);
 // lanes_per_pair = 1: one pair per lane, 64 pairs per wavefront (genasm_lane_kernel.hip; W <= 64, W-O <= 31)
-hipError_t launch_align_lane(const AlignArgs& a, int grid, size_t lds_bytes, hipStream_t s);
+// (edits: the pairs' slices receive edit streams instead of runs, n_runs their lengths in bytes — scrg_align_device_edits)
+hipError_t launch_align_lane(const AlignArgs& a, int grid, size_t lds_bytes, hipStream_t s, bool edits = false);
 // the same for W-O > 31 (genasm_lane_wide_kernel.hip): 64-bit table rows in LDS, one wavefront per workgroup
 hipError_t launch_align_lane_wide(const AlignArgs& a, int grid, size_t lds_bytes, hipStream_t s);
 

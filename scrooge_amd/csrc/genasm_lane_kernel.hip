@@ -159,6 +159,13 @@ __device__ __forceinline__ void lane_window_table(const Planes tw, const Planes 
 // Workgroups are four independent wavefronts (nothing is shared, there is no barrier): the four land on the four
 // SIMDs of one CU, so a partly filled GPU has the same number of wavefronts on every SIMD of a CU.  (Single-wave
 // workgroups were placed unevenly — 3072 of them ran no faster than 4096.)
+//
+// EDITS = true (scrg_align_device_edits): the same alignment, delivered as an EDIT STREAM (edit_stream.h: one byte
+// per edit carrying the number of matches before it) instead of runs.  Only the second traceback pass and the
+// stores differ: it visits the columns that hold an edit (~3 per window at 10 % error instead of ~6.5 run
+// boundaries), the matches pending since the last edit are one register carried from window to window, and the
+// staging ring holds 64 bytes per lane that leave in the same aligned 32-byte pieces.
+template <bool EDITS>
 __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -184,7 +191,9 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
     uint32_t text_len = 0, read_len = 0, cigar_cap = 0;
     uint32_t ref_idx = 0, read_idx = 0, edits = 0;
     int32_t nr = -1;                   // index of the run in progress (or of the last finished one); n_runs = nr + 1
-    uint32_t flushed = 0;              // runs below this index are in HBM (a multiple of 16)
+    uint32_t flushed = 0;              // runs below this index are in HBM (a multiple of 16); EDITS: bytes, a multiple of 32
+    uint32_t pos = 0;                  // EDITS: bytes of the pair's stream so far
+    uint32_t mbase = 0;                // EDITS: matches pending at column c of the current window = mbase + c
     bool queue_empty = false;          // wave-uniform
     const bool timing = a.stats != nullptr;
     uint64_t cy_fetch = 0, cy_setup = 0, cy_dc = 0, cy_tb = 0, cy_p1 = 0;
@@ -192,22 +201,26 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
     const uint64_t rt0 = timing ? __builtin_amdgcn_s_memrealtime() : 0;      // 100 MHz wall clock: wavefront start
 
     // one 16-run piece of my ring -> my slice (two 16-byte stores); pieces past the slice's capacity are dropped
+    // (EDITS: the slice holds bytes — it starts at byte 2 * cigar_off and is 2 * cigar_cap bytes long — and a piece is
+    // 32 bytes of the stream)
     auto write_piece = [&]() {
-        const uint32_t rd = (ring_b >> 2) + ((flushed & 16u) >> 1);
+        const uint32_t rd = EDITS ? (ring_b >> 2) + ((flushed & 32u) >> 2) : (ring_b >> 2) + ((flushed & 16u) >> 1);
         uint32_t w[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) w[k] = lds[rd + k];
-        if (flushed + 16u <= cigar_cap && !(a.debug & 16)) {          // (16: ablation, profiling only: no stores)
-            uint4* const dst = reinterpret_cast<uint4*>(a.runs + cigar_off + flushed);
+        const bool room = EDITS ? flushed + 32u <= 2u * (uint64_t)cigar_cap : flushed + 16u <= cigar_cap;
+        if (room && !(a.debug & 16)) {          // (16: ablation, profiling only: no stores)
+            uint4* const dst = EDITS ? reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(a.runs + cigar_off) + flushed)
+                                     : reinterpret_cast<uint4*>(a.runs + cigar_off + flushed);
             dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
             dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
         }
-        flushed += 16u;
+        flushed += EDITS ? 32u : 16u;
     };
     // write out every piece that consists of finished runs only (the run at index nr may still grow)
     auto flush_pieces = [&]() {
         for (;;) {
-            const bool need = has_pair && nr - (int32_t)flushed >= 16;
+            const bool need = has_pair && (EDITS ? pos - flushed >= 32u : nr - (int32_t)flushed >= 16);
             if (!__any(need)) break;
             if (need) write_piece();
         }
@@ -232,7 +245,21 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
         for (;;) {
             const bool fin = has_pair && read_idx >= read_len;
             if (__any(fin)) {
-                if (fin) {
+                if (EDITS && fin) {
+                    // (the matches after the last edit are implied by the read length)
+                    while (pos - flushed >= 32u) write_piece();
+                    const uint32_t rem = pos - flushed;                      // < 32: whole dwords of the last, partial piece,
+                    const uint32_t rd = (ring_b >> 2) + ((flushed & 32u) >> 2);      // bytes past the end zeroed
+                    uint32_t* const dst = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(a.runs + cigar_off) + flushed);
+                    for (uint32_t k = 0; 4u * k < rem; k++) {
+                        const uint32_t left = rem - 4u * k;
+                        const uint32_t keep = left >= 4u ? 0xffffffffu : (0xffffffffu >> (32u - 8u * left));
+                        if (flushed + 4u * k < 2u * (uint64_t)cigar_cap) dst[k] = lds[rd + k] & keep;
+                    }
+                    a.ed[pair] = (int64_t)edits;
+                    a.n_runs[pair] = pos;
+                    a.status[pair] = pos > 2u * (uint64_t)cigar_cap ? 1u : 0u;
+                } else if (fin) {
                     const uint32_t n_runs = (uint32_t)(nr + 1);
                     while (n_runs - flushed >= 16u) write_piece();
                     // the tail: whole dwords of the last, partial piece
@@ -267,7 +294,7 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
                 read_len = (uint32_t)pd.read_len;
                 cigar_off = pd.cigar_off;
                 cigar_cap = pd.cigar_cap > 0xffffffffull ? 0xffffffffu : (uint32_t)pd.cigar_cap;
-                ref_idx = read_idx = edits = flushed = 0;
+                ref_idx = read_idx = edits = flushed = pos = mbase = 0;
                 nr = -1;
                 has_pair = true;
             }
@@ -360,6 +387,71 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
             // there.  Both words go to the slot after the last committed run; only committing moves on.  (A lane
             // that is done computes garbage from column "31", which no mask ever has.)  The length byte of the
             // next insertion run is read one iteration ahead.
+            if constexpr (EDITS) {
+                // Pass 2, edit stream.  Only columns with an edit are visited: an insertion run (before the column's
+                // step), then a deletion or substitution.  mbase + c = matches pending when column c is reached;
+                // an insertion at c leaves none at c (mbase = -c), a deletion/substitution none at c + 1.  Every byte
+                // goes to the slot after the last committed one; only committing moves on.  Two insertions and 63
+                // pending matches are handled in line, longer runs / stretches on a side path that a few per cent of
+                // the iterations take.
+                uint32_t E = (a.debug & 4) ? 0u : (D | X | Im);
+                uint32_t c = ffbh_u32(E);
+                uint32_t ni = lds8[scr_b + c];
+                auto put = [&](uint32_t at, uint32_t b) { lds8[ring_b + (at & 63u)] = (uint8_t)b; };
+                auto event = [&]() {
+                    const uint32_t sh = 31u - c;
+                    const uint32_t bit = 0x80000000u >> (c & 31u);
+                    uint32_t iB = __builtin_amdgcn_ubfe(Im, sh, 1), dx = __builtin_amdgcn_ubfe(D | X, sh, 1);
+                    const uint32_t xB = __builtin_amdgcn_ubfe(X, sh, 1);
+                    const uint32_t t = mbase + c;
+                    E = bitop3<TT_ANDN>(E, bit, bit);
+                    const uint32_t nx = ffbh_u32(E);
+                    const uint32_t step = 0xC0u - 0x80u * xB;                  // 'D' 3 << 6, 'X' 1 << 6
+                    const bool side = (iB && ni > 2u) || ((iB | dx) && t > 63u);
+                    if (__any(side)) {
+                        if (side) {
+                            auto emit = [&](uint32_t b) {
+                                put(pos, b);
+                                pos++;
+                                if (pos - flushed >= 32u) write_piece();
+                            };
+                            uint32_t tt = t;
+                            if (iB) {
+                                for (uint32_t q = tt >> 6; q; q--) emit(0x3Fu);
+                                emit(0x80u | (tt & 63u));
+                                for (uint32_t q = 1; q < ni; q++) emit(0x80u);
+                                tt = 0;
+                                mbase = 0u - c;
+                            }
+                            if (dx) {
+                                for (uint32_t q = tt >> 6; q; q--) emit(0x3Fu);
+                                emit(step | (tt & 63u));
+                                mbase = ~c;
+                            }
+                            iB = dx = 0;
+                        }
+                    }
+                    put(pos, 0x80u | (t & 63u));
+                    put(pos + 1u, 0x80u);
+                    pos += iB ? (ni > 1u ? 2u : 1u) : 0u;
+                    put(pos, step | ((iB ? 0u : t) & 63u));
+                    pos += dx;
+                    mbase = dx ? ~c : (iB ? 0u - c : mbase);
+                    ni = lds8[scr_b + nx];
+                    c = nx;
+                };
+                uint32_t trips = 0;
+                while (__any(E != 0u)) {
+                    event();
+                    event();
+                    if (++trips == 3u) {                       // <= 18 new bytes between checks + 3 speculative ones: the 64-byte ring cannot wrap
+                        trips = 0;
+                        flush_pieces();
+                    }
+                }
+                flush_pieces();
+                mbase += ti;                                   // the next window starts at its column 0
+            } else {
             uint32_t E = (a.debug & 4) ? 0u : (B | Im);                  // (ablation, profiling only: no runs)
             uint32_t c = ffbh_u32(E);
             uint32_t ni = lds8[scr_b + c];
@@ -391,6 +483,7 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
             }
             nr = (int32_t)nr2 >> 1;
             flush_pieces();
+            }
         }
         st_rounds++;
         if (timing) {
@@ -419,10 +512,11 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
     }
 }
 
-hipError_t launch_align_lane(const AlignArgs& a, int grid, size_t lds_bytes, hipStream_t s)
+hipError_t launch_align_lane(const AlignArgs& a, int grid, size_t lds_bytes, hipStream_t s, bool edits)
 {
     // grid counts wavefronts, lds_bytes is per wavefront
-    hipLaunchKernelGGL(genasm_lane_kernel, dim3((grid + 3) / 4), dim3(256), 4 * lds_bytes, s, a);
+    if (edits) hipLaunchKernelGGL(genasm_lane_kernel<true>, dim3((grid + 3) / 4), dim3(256), 4 * lds_bytes, s, a);
+    else hipLaunchKernelGGL(genasm_lane_kernel<false>, dim3((grid + 3) / 4), dim3(256), 4 * lds_bytes, s, a);
     return hipGetLastError();
 }
 

@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "genasm_kernels.h"
+#include "edit_stream.h"
 #include "../../include/scrooge_amd_io.h"
 
 namespace {
@@ -454,13 +455,16 @@ scrg_status scrg_pack_planar_groups(scrg_ctx* c, const char* d_ascii, uint64_t n
     return SCRG_OK;
 }
 
-scrg_status scrg_align_device(scrg_ctx* c, const scrg_params* params, uint64_t n_pairs, const uint64_t* d_seq,
-                              const scrg_pair_desc* d_pairs, scrg_run* d_runs, int64_t* d_edit_distance,
-                              uint32_t* d_n_runs, uint32_t* d_pair_status)
+static scrg_status align_device_impl(scrg_ctx* c, const scrg_params* params, uint64_t n_pairs, const uint64_t* d_seq,
+                                     const scrg_pair_desc* d_pairs, scrg_run* d_runs, int64_t* d_edit_distance,
+                                     uint32_t* d_n_runs, uint32_t* d_pair_status, bool edits)
 {
     if (!c) return SCRG_ERR_INVALID_ARG;
     scrg_params p;
     if (!resolve_params(params, &p)) return c->fail(SCRG_ERR_INVALID_ARG, "bad scrg_params");
+    if (edits && !(p.lanes_per_pair == 1 && p.W <= 64 && p.W - p.O <= 31))
+        return c->fail(SCRG_ERR_INVALID_ARG, "edit-stream output needs lanes_per_pair = 1, W <= 64 and W-O <= 31 "
+                                             "(otherwise: scrg_align_device + scrg_encode_edit_stream)");
     if (n_pairs > 0xfffffff0ull) return c->fail(SCRG_ERR_INVALID_ARG, "too many pairs for one launch");
     if (n_pairs && (!d_seq || !d_pairs || !d_runs || !d_edit_distance || !d_n_runs || !d_pair_status))
         return c->fail(SCRG_ERR_INVALID_ARG, "null device pointer");
@@ -511,12 +515,28 @@ scrg_status scrg_align_device(scrg_ctx* c, const scrg_params* params, uint64_t n
     else if (p.lanes_per_pair == 1 && p.W - p.O > 31)
         HIP_TRY(c, scrg::launch_align_lane_wide(a, n_waves, (size_t)lds, c->stream));
     else if (p.lanes_per_pair == 1)
-        HIP_TRY(c, scrg::launch_align_lane(a, n_waves, (size_t)lds, c->stream));
+        HIP_TRY(c, scrg::launch_align_lane(a, n_waves, (size_t)lds, c->stream, edits));
     else
         HIP_TRY(c, scrg::launch_align(p.lanes_per_pair, a, n_waves, (size_t)lds, c->stream));
     HIP_TRY(c, hipEventRecord(c->ev_stop, c->stream));
     c->have_timing = true;
     return SCRG_OK;
+}
+
+scrg_status scrg_align_device(scrg_ctx* c, const scrg_params* params, uint64_t n_pairs, const uint64_t* d_seq,
+                              const scrg_pair_desc* d_pairs, scrg_run* d_runs, int64_t* d_edit_distance,
+                              uint32_t* d_n_runs, uint32_t* d_pair_status)
+{
+    return align_device_impl(c, params, n_pairs, d_seq, d_pairs, d_runs, d_edit_distance, d_n_runs, d_pair_status, false);
+}
+
+scrg_status scrg_align_device_edits(scrg_ctx* c, const scrg_params* params, uint64_t n_pairs, const uint64_t* d_seq,
+                                    const scrg_pair_desc* d_pairs, uint8_t* d_streams, int64_t* d_edit_distance,
+                                    uint32_t* d_stream_len, uint32_t* d_pair_status)
+{
+    if (reinterpret_cast<uintptr_t>(d_streams) & 31u) return c ? c->fail(SCRG_ERR_INVALID_ARG, "d_streams needs 32-byte alignment") : SCRG_ERR_INVALID_ARG;
+    return align_device_impl(c, params, n_pairs, d_seq, d_pairs, reinterpret_cast<scrg_run*>(d_streams), d_edit_distance,
+                             d_stream_len, d_pair_status, true);
 }
 
 scrg_status scrg_last_kernel_ms(scrg_ctx* c, float* ms)
@@ -577,6 +597,78 @@ scrg_status scrg_unpack_runs(scrg_ctx* c, uint64_t n_runs, const uint8_t* d_pack
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, scrg::launch_unpack_runs(n_runs, d_packed, reinterpret_cast<uint16_t*>(d_runs), c->n_cus, c->stream));
     return SCRG_OK;
+}
+
+scrg_status scrg_encode_edit_stream(scrg_ctx* c, uint64_t n_pairs, const scrg_pair_desc* d_pairs, const scrg_run* d_runs,
+                                    const uint32_t* d_n_runs, uint8_t* d_stream, uint64_t stream_cap, uint64_t* d_stream_off,
+                                    uint32_t* d_stream_len, uint64_t* d_total)
+{
+    if (!c) return SCRG_ERR_INVALID_ARG;
+    if (!d_total) return c->fail(SCRG_ERR_INVALID_ARG, "d_total is required");
+    if (n_pairs && (!d_pairs || !d_runs || !d_n_runs || !d_stream_off || !d_stream_len || (stream_cap && !d_stream)))
+        return c->fail(SCRG_ERR_INVALID_ARG, "null device pointer");
+    if (reinterpret_cast<uintptr_t>(d_stream) & 3u) return c->fail(SCRG_ERR_INVALID_ARG, "d_stream needs 4-byte alignment");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, scrg::launch_encode_edits(n_pairs, d_pairs, reinterpret_cast<const uint16_t*>(d_runs), d_n_runs, d_stream,
+                                         stream_cap, d_stream_off, d_stream_len, d_total, c->n_cus, c->stream));
+    return SCRG_OK;
+}
+
+scrg_status scrg_decode_edit_stream(scrg_ctx* c, const scrg_params* params, uint64_t n_pairs, const uint8_t* d_stream,
+                                    const uint64_t* d_stream_off, const uint32_t* d_stream_len, const uint64_t* d_read_len,
+                                    uint64_t read_len_stride, const uint64_t* d_dense_offset, scrg_run* d_dense,
+                                    uint32_t* d_n_runs, uint32_t* d_bad_count)
+{
+    if (!c) return SCRG_ERR_INVALID_ARG;
+    scrg_params p;
+    if (!resolve_params(params, &p)) return c->fail(SCRG_ERR_INVALID_ARG, "bad scrg_params");
+    if (!d_bad_count || (n_pairs && (!d_stream_off || !d_stream_len || !d_read_len || !d_n_runs)))
+        return c->fail(SCRG_ERR_INVALID_ARG, "null device pointer");
+    if (d_dense && !d_dense_offset) return c->fail(SCRG_ERR_INVALID_ARG, "d_dense needs d_dense_offset");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, scrg::launch_decode_edits(n_pairs, (uint32_t)p.W, (uint32_t)p.O, d_stream, d_stream_off, d_stream_len,
+                                         d_read_len, read_len_stride, d_dense_offset, reinterpret_cast<uint16_t*>(d_dense),
+                                         d_n_runs, d_bad_count, c->stream));
+    return SCRG_OK;
+}
+
+scrg_status scrg_edit_stream_to_runs(const scrg_params* params, uint64_t read_len, const uint8_t* stream, uint64_t n_bytes,
+                                     scrg_run* runs, uint64_t runs_cap, uint64_t* n_runs)
+{
+    scrg_params p;
+    if (!n_runs || (n_bytes && !stream) || (runs_cap && !runs) || !resolve_params(params, &p)) return SCRG_ERR_INVALID_ARG;
+    uint64_t k = 0;
+    const uint64_t n = scrg::replay_edit_stream(stream, n_bytes, read_len, (uint32_t)p.W, (uint32_t)p.O,
+                                                [&](uint32_t op, uint64_t t) {
+                                                    if (k < runs_cap) { runs[k].count = (uint8_t)t; runs[k].op = (char)op; }
+                                                    k++;
+                                                });
+    *n_runs = n == ~0ull ? 0 : n;
+    if (n == ~0ull) return SCRG_ERR_INVALID_ARG;
+    return n > runs_cap ? SCRG_ERR_CIGAR_OVERFLOW : SCRG_OK;
+}
+
+scrg_status scrg_runs_to_edit_stream(const scrg_run* runs, uint64_t n_runs, uint8_t* stream, uint64_t stream_cap,
+                                     uint64_t* n_bytes)
+{
+    if (!n_bytes || (n_runs && !runs) || (stream_cap && !stream)) return SCRG_ERR_INVALID_ARG;
+    uint64_t k = 0, pend = 0;
+    auto put = [&](uint32_t b) {
+        if (k < stream_cap) stream[k] = (uint8_t)b;
+        k++;
+    };
+    for (uint64_t r = 0; r < n_runs; r++) {
+        const uint32_t op = (uint8_t)runs[r].op, cnt = runs[r].count;
+        if (op != '=' && op != 'X' && op != 'I' && op != 'D') return SCRG_ERR_INVALID_ARG;
+        if (op == '=' || cnt == 0) { pend += cnt; continue; }
+        const uint32_t code = scrg::edit_code_of_char(op) << 6;
+        for (uint64_t q = pend >> 6; q; q--) put(0x3F);
+        put(code | (uint32_t)(pend & 63u));
+        for (uint32_t q = 1; q < cnt; q++) put(code);
+        pend = 0;
+    }
+    *n_bytes = k;
+    return k > stream_cap ? SCRG_ERR_CIGAR_OVERFLOW : SCRG_OK;
 }
 
 scrg_status scrg_ascii_to_twobit(scrg_ctx* c, uint64_t count, const uint64_t* d_lens, const uint64_t* d_ascii_off,

@@ -11,6 +11,8 @@ Partitioning follows what the reference's callers do for load balance
 (src/tests.cu:375-377): order pairs by read length, longest first, then deal
 them round-robin so every rank sees the same length mix.
 """
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -188,3 +190,116 @@ class ResultGather:
         b = k % self.DEPTH
         runs = self.runs16[b][r] if self.packed else self.recv_runs[b][r]
         return self.recv_ed[b][r], self.recv_cnt[b][r], runs[: 2 * self.totals[r]]
+
+
+class EditStreamGather:
+    """Gather of a batch's device results to rank `dst` with the CIGARs as EDIT STREAMS (scrg_encode_edit_stream:
+    one byte per edit, ~1.0 KB for a 10 kb read at 10 % error instead of 4.3 KB of scrg_run pairs), so that what a
+    rank produces per second fits the one xGMI link it has to `dst`.
+
+    One buffer per rank and step, ONE collective per step:
+        [ int64 edit distance x n | int64 stream offset x n | int32 stream length x n | int32 run count x n | stream ]
+    `buffers(k)` hands out the views scrg_encode_edit_stream writes into; `start(k, ed, n_runs)` adds the scalars
+    and enqueues the gather asynchronously (it overlaps the align kernels of the following steps); `finish(k)`
+    makes the current stream wait for it before the buffers are reused.  `dst` keeps the streams as they arrive;
+    `decode(...)` (scrg_decode_edit_stream) restores scrg_run pairs, window breaks included, where a consumer
+    wants them.  Sizes are exchanged once: the data, hence every size, is the same each step in bench.py."""
+
+    def __init__(self, n_pairs, stream_bytes, device, dst=0, group=None, depth=2):
+        self.group, self.dst, self.n = group, dst, int(n_pairs)
+        self.DEPTH = max(1, int(depth))
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        t = torch.tensor([int(stream_bytes)], dtype=torch.int64, device=device)
+        sizes = [torch.zeros_like(t) for _ in range(self.world)]
+        dist.all_gather(sizes, t, group=group)
+        self.totals = [int(x.item()) for x in sizes]
+        self.cap = (max(max(self.totals), 8) + 7) // 8 * 8
+        n = self.n
+        self.head = 24 * n                                   # bytes of scalars in front of the stream
+        self.wire = self.head + self.cap                     # bytes per rank and step on the link
+        d = self.DEPTH
+        self.send = [torch.zeros(self.wire, dtype=torch.uint8, device=device) for _ in range(d)]
+        self.total = [torch.zeros(2, dtype=torch.int64, device=device) for _ in range(d)]
+        self.recv = [None] * d
+        if self.rank == dst:
+            self.recv = [[torch.empty(self.wire, dtype=torch.uint8, device=device) for _ in range(self.world)]
+                         for _ in range(d)]
+        self.pending = [None] * d
+        self.host_stage = dist.get_backend(group) == "gloo" and torch.device(device).type == "cuda"
+
+    def _views(self, buf):
+        n = self.n
+        return {"ed": buf[: 8 * n].view(torch.int64), "off": buf[8 * n: 16 * n].view(torch.int64),
+                "len": buf[16 * n: 20 * n].view(torch.int32), "cnt": buf[20 * n: 24 * n].view(torch.int32),
+                "stream": buf[24 * n:]}
+
+    def buffers(self, k):
+        b = k % self.DEPTH
+        v = self._views(self.send[b])
+        v["total"] = self.total[b]
+        return v
+
+    def start(self, k, ed, n_runs):
+        """The stream, offsets and lengths of step k must already be in `buffers(k)` (enqueued on the current stream)."""
+        b = k % self.DEPTH
+        v = self._views(self.send[b])
+        v["ed"].copy_(ed)
+        if n_runs is None:                 # (the align kernel wrote the streams itself: run counts were never made)
+            v["cnt"].zero_()
+        else:
+            v["cnt"].copy_(n_runs)
+        if self.host_stage:
+            torch.cuda.current_stream().synchronize()
+            host = [torch.empty(self.wire, dtype=torch.uint8) for _ in range(self.world)] if self.rank == self.dst else None
+            dist.gather(self.send[b].cpu(), host, dst=self.dst, group=self.group)
+            if host is not None:
+                for r in range(self.world):
+                    self.recv[b][r].copy_(host[r])
+            return
+        if os.environ.get("SCRG_BENCH_NOCOLL") == "1":        # experiment: everything but the collective
+            return
+        self.pending[b] = dist.gather(self.send[b], self.recv[b], dst=self.dst, group=self.group, async_op=True)
+
+    def finish(self, k):
+        b = k % self.DEPTH
+        if self.pending[b] is not None:
+            self.pending[b].wait()
+            self.pending[b] = None
+
+    def finish_all(self):
+        for b in range(self.DEPTH):
+            self.finish(b)
+
+    def results(self, k, r):
+        """Views (ed, off, len, cnt, stream) of what rank r sent for step k, on dst (after finish(k))."""
+        return self._views(self.recv[k % self.DEPTH][r])
+
+    def decode(self, aligner, k, r, read_len, read_len_stride, counted=True, **params):
+        """scrg_run bytes of rank r's pairs of step k on dst -> (dense uint8 tensor, run offsets int64, pairs whose
+        stream did not decode [to the gathered run count]).  `read_len`: int64 device tensor, see
+        scrg_decode_edit_stream.  counted=False: run counts did not travel; a counting pass makes them first."""
+        v = self.results(k, r)
+        n_bad0 = 0
+        if not counted:
+            bad0 = torch.zeros(1, dtype=torch.int32, device=v["cnt"].device)
+            if bad0.is_cuda:
+                torch.cuda.current_stream().synchronize()
+            aligner.decode_edit_stream(self.n, v["stream"], v["off"], v["len"], read_len, read_len_stride, None, None,
+                                       v["cnt"], bad0, **params)
+            if bad0.is_cuda:
+                torch.cuda.synchronize()                   # (the handle's stream need not be torch's current one)
+            n_bad0 = int(bad0.item())
+            if n_bad0:
+                return None, None, n_bad0
+        cnt64 = v["cnt"].to(torch.int64)
+        off = torch.cumsum(cnt64, 0) - cnt64
+        dense = torch.zeros(int(cnt64.sum().item()) * 2 + 8, dtype=torch.uint8, device=v["cnt"].device)
+        bad = torch.zeros(1, dtype=torch.int32, device=v["cnt"].device)
+        if dense.is_cuda:
+            torch.cuda.current_stream().synchronize()      # the handle's stream need not be torch's current one
+        aligner.decode_edit_stream(self.n, v["stream"], v["off"], v["len"], read_len, read_len_stride, off, dense,
+                                   v["cnt"], bad, **params)
+        if dense.is_cuda:
+            torch.cuda.synchronize()
+        return dense, off, int(bad.item())

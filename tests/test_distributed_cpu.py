@@ -154,3 +154,66 @@ def test_bench_generator_shapes_on_cpu():
     assert (h[:, text_len:tw * 32] == 0).all() and (h[:, tw * 32 + L:] == 0).all()
     eds, _, _, _ = Oracle().align(texts, reads)
     assert 0.06 * L < np.mean(eds) < 0.14 * L
+
+
+def _worker_edits(rank, world, port, q):
+    import os
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    from scrooge_amd import api, distributed as sd
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # each rank "aligned" its own three reads; CIGARs (W=64, O=33) -> edit streams with the host encoder
+        cigars = [["5=1X4=", "31=31=9=", "2I3="], ["1D30=1=1X29=11=", "", "31=1I30=9="]][rank]
+        read_len = [[10, 71, 5], [72, 0, 71]][rank]
+        streams = [api.cigar_to_edit_stream(c) for c in cigars]
+        n = 3
+        total = sum((len(s) + 3) // 4 * 4 for s in streams)
+        g = sd.EditStreamGather(n, total, torch.device("cpu"), dst=0, depth=2)
+        for k in range(3):
+            g.finish(k)
+            v = g.buffers(k)
+            at = 0
+            for i, s in enumerate(streams):
+                v["off"][i], v["len"][i] = at, len(s)
+                v["stream"][at: at + len(s)] = torch.frombuffer(bytearray(s), dtype=torch.uint8) if s else torch.zeros(0, dtype=torch.uint8)
+                at += (len(s) + 3) // 4 * 4
+            ed = torch.tensor([sum(1 for b in s if b >> 6) + k for s in streams], dtype=torch.int64)
+            g.start(k, ed, torch.tensor([len(c) for c in cigars], dtype=torch.int32))
+        g.finish_all()
+        if rank == 0:
+            out = []
+            for r in range(world):
+                v = g.results(2, r)
+                raw = bytes(v["stream"].tolist())
+                got = [raw[o: o + l] for o, l in zip(v["off"].tolist(), v["len"].tolist())]
+                out.append((v["ed"].tolist(), got, g.totals[r], g.wire))
+            q.put(out)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_edit_stream_gather():
+    """EditStreamGather: one fixed-size collective per step carrying scores, stream offsets/lengths and the edit
+    streams of every rank; what arrives on rank 0 decodes (host decoder) to each rank's CIGARs."""
+    from scrooge_amd import api
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_edits, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=150)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    cigars = [["5=1X4=", "31=31=9=", "2I3="], ["1D30=1=1X29=11=", "", "31=1I30=9="]]
+    read_len = [[10, 71, 5], [72, 0, 71]]
+    for r in range(2):
+        eds, streams, total, wire = out[r]
+        assert [api.edit_stream_to_cigar(s, L) for s, L in zip(streams, read_len[r])] == cigars[r]
+        assert eds == [sum(1 for b in s if b >> 6) + 2 for s in streams]
+        assert wire == 24 * 3 + 8                       # scalars + the larger rank's stream, padded to 8 bytes

@@ -1,0 +1,103 @@
+"""CPU tests of the edit-stream transfer format (include/scrooge_amd.h, scrooge_amd/csrc/edit_stream.h): the
+host encoder and the window replay of the decoder, against the reference's own CIGARs.
+
+The decoder has to put the window breaks back (runs are flushed per window and never merged,
+genasm_cpu.cpp:304-305, 400-403); these tests pin that to every committed golden fixture — all W/O the
+reference was built with — and to fresh oracle output on random, ragged and degenerate pairs."""
+import glob
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from scrooge_amd import api, synth
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def py_encode(cigar):
+    """Independent restatement of the canonical encoding, straight from the format's definition."""
+    code = {"X": 1, "I": 2, "D": 3}
+    out = bytearray()
+    pend = 0
+    for cnt, op in re.findall(r"(\d+)([=XID])", cigar):
+        c = int(cnt)
+        if op == "=":
+            pend += c
+            continue
+        out += b"\x3f" * (pend >> 6)
+        out.append(code[op] << 6 | (pend & 63))
+        out += bytes([code[op] << 6]) * (c - 1)
+        pend = 0
+    return bytes(out)
+
+
+def round_trip(cigar, read_len, ed, W, O):
+    s = api.cigar_to_edit_stream(cigar)
+    assert s == py_encode(cigar)
+    assert sum(1 for b in s if b >> 6) == ed          # one byte per edit (+ the long-match bytes, op 0)
+    assert api.edit_stream_to_cigar(s, read_len, W=W, O=O) == cigar
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "pairs_*.json"))), ids=os.path.basename)
+def test_golden_pairs_round_trip(path):
+    g = json.load(open(path))
+    for c in g["cases"]:
+        round_trip(c["cigar"], len(c["read"]), c["ed"], g["W"], g["O"])
+
+
+def test_golden_mapping_round_trip(golden_mapping):
+    g = golden_mapping
+    k = 0
+    for r, cands in zip(g["reads"], g["candidates"]):
+        for _ in cands:
+            round_trip(g["cigar"][k], len(r), g["ed"][k], 64, 33)
+            k += 1
+    assert k == len(g["cigar"])
+
+
+@pytest.mark.parametrize("W,O", [(64, 33), (64, 1), (64, 63), (32, 17), (5, 2), (2, 1), (128, 65), (256, 20), (50, 18)])
+def test_oracle_round_trip(oracle, W, O):
+    rng = np.random.Generator(np.random.PCG64(100 * W + O))
+    T, Q = [], []
+    for L, err in ((0, 0.0), (1, 0.0), (63, 0.0), (64, 0.0), (65, 0.0), (300, 0.0), (300, 0.02), (1000, 0.1), (700, 0.3),
+                   (2500, 0.15), (129, 0.05)):
+        for slack in (0.0, 0.2):
+            t, q = synth.make_pair(L, err, (23, 31, 46), rng, slack) if L else (np.zeros(5, np.uint8), np.zeros(0, np.uint8))
+            T.append(synth.BASES[t].tobytes()); Q.append(synth.BASES[q].tobytes())
+    T += [b"A" * 500, b"", b"ACGT" * 100, synth.random_seq(400, rng)]
+    Q += [b"A" * 700, b"ACGTACGTAC" * 30, b"ACGT" * 100, synth.random_seq(400, rng)]      # text runs out; empty text; exact; unrelated
+    eds, cigars, _, _ = oracle.align(T, Q, W=W, O=O)
+    for q, e, c in zip(Q, eds, cigars):
+        round_trip(c, len(q), e, W, O)
+
+
+def test_long_match_stretches():
+    # 64 q + r matches before an edit: q bytes 0x3F, then the edit byte carries r
+    for p in (0, 1, 62, 63, 64, 65, 127, 128, 129, 1000):
+        cig = ("%d=" % p if p else "") + "1X5="
+        s = api.cigar_to_edit_stream(cig)
+        assert s == b"\x3f" * (p >> 6) + bytes([1 << 6 | (p & 63)])
+        # W-O = 31: the decoder restores the window breaks
+        want = api.edit_stream_to_cigar(s, p + 6)
+        runs = re.findall(r"(\d+)([=XID])", want)
+        assert all(int(c) <= 31 for c, _ in runs)
+        assert sum(int(c) for c, op in runs if op == "=") == p + 5 and [op for _, op in runs].count("X") == 1
+    # an error-free read needs no bytes at all
+    assert api.cigar_to_edit_stream("31=31=31=7=") == b""
+    assert api.edit_stream_to_cigar(b"", 100) == "31=31=31=7="
+    assert api.edit_stream_to_cigar(b"", 0) == ""
+
+
+def test_malformed_streams_are_rejected():
+    with pytest.raises(api.ScroogeError):
+        api.edit_stream_to_cigar(bytes([1 << 6 | 5]), 3)            # 5 matches + X in a read of 3
+    with pytest.raises(api.ScroogeError):
+        api.edit_stream_to_cigar(bytes([2 << 6, 2 << 6]), 1)        # two insertions, one base
+    with pytest.raises(api.ScroogeError):
+        api.edit_stream_to_cigar(bytes([0x3F]), 10)                  # 64 matches in a read of 10
+    assert api.edit_stream_to_cigar(bytes([3 << 6]), 2) == "1D2="    # a deletion uses no read base
+    with pytest.raises(ValueError):
+        api.cigar_to_edit_stream("5M")

@@ -238,6 +238,7 @@ def test_bench_two_ranks_dry_run():
     assert len(lines) == 1, out.stdout[-2000:]              # rank 0 only
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["steps"] == 5 and j["value"] > 0 and j["scaling"] == "weak"
+    assert j["gather_check"] is True and j["config"]["gather"]["format"] == "edits"      # both ranks' slots decoded on rank 0
 
 
 def test_full_bench_size_two_algorithms_agree(aligner):
@@ -415,6 +416,130 @@ def test_packed_runs_round_trip(aligner, oracle):
         aligner.use_own_stream()
 
 
+@pytest.mark.parametrize("W,O", [(64, 33), (64, 2), (40, 9), (128, 65)])
+def test_edit_stream_round_trip(aligner, oracle, W, O):
+    """scrg_encode_edit_stream (one byte per edit, the RCCL transfer format) against the definition of the format on
+    the oracle's CIGARs, and scrg_decode_edit_stream back to the very runs scrg_compact_runs delivers (window breaks
+    restored); long error-free stretches, empty reads, empty texts, a tiny stream buffer."""
+    import torch
+    import scrooge_amd
+    from tests.test_edit_stream import py_encode
+    dev = torch.device("cuda", 0)
+    t, q = synth.make_pairs(300, 1500, "pacbio15", seed=78)
+    t2, q2 = synth.make_pairs(40, 1400, "illumina", seed=79)          # stretches of > 63 matches between edits
+    t, q = t + t2, q + q2
+    q[5], t[9] = b"", b""                                   # no runs at all / insertions only
+    q[11] = t[11][:1500]                                    # error-free: an empty stream
+    n = len(t)
+    tw, rw = (max(len(x) for x in t) + 31) // 32, (1500 + 31) // 32
+    rows = np.zeros((n, (tw + rw) * 32), dtype=np.uint8)
+    for k in range(n):
+        rows[k, :len(t[k])] = np.frombuffer(t[k], dtype=np.uint8)
+        rows[k, tw * 32: tw * 32 + len(q[k])] = np.frombuffer(q[k], dtype=np.uint8)
+    ascii_t = torch.from_numpy(rows).to(dev)
+    cap = (2 * 1500 + 8 + 15) // 16 * 16
+    idx = torch.arange(n, dtype=torch.int64, device=dev)
+    eds, cigars, _, _ = oracle.align(t, q, W=W, O=O)
+    aligner.set_stream(0)
+    try:
+        seq = torch.zeros(n * (tw + rw) + scrooge_amd.api.SEQ_PAD_WORDS, dtype=torch.int64, device=dev)
+        bad = torch.zeros(1, dtype=torch.int32, device=dev)
+        aligner.pack_planar(ascii_t.view(-1), seq, bad)
+        desc = torch.stack([idx * (tw + rw) * 32, torch.tensor([len(x) for x in t], device=dev),
+                            (idx * (tw + rw) + tw) * 32, torch.tensor([len(x) for x in q], device=dev),
+                            idx * cap, torch.full_like(idx, cap)], dim=1).contiguous()
+        runs = torch.zeros(n * cap * 2, dtype=torch.uint8, device=dev)
+        ed = torch.empty(n, dtype=torch.int64, device=dev)
+        nr = torch.empty(n, dtype=torch.int32, device=dev)
+        st = torch.empty(n, dtype=torch.int32, device=dev)
+        aligner.align_device(n, seq, desc, runs, ed, nr, st, W=W, O=O)
+        assert ed.cpu().tolist() == eds
+        want = [py_encode(c) for c in cigars]
+        need = sum((len(w) + 3) // 4 * 4 for w in want)
+        stream = torch.zeros(need + 64, dtype=torch.uint8, device=dev)
+        s_off = torch.empty(n, dtype=torch.int64, device=dev)
+        s_len = torch.empty(n, dtype=torch.int32, device=dev)
+        tot = torch.empty(2, dtype=torch.int64, device=dev)
+        aligner.encode_edit_stream(n, desc, runs, nr, stream, s_off, s_len, tot)
+        torch.cuda.synchronize()
+        assert tot.cpu().tolist() == [need, 0]
+        assert int(stream[need:].max().item()) == 0                       # nothing written past the reserved bytes
+        sh, oh, lh = stream.cpu().numpy().tobytes(), s_off.cpu().tolist(), s_len.cpu().tolist()
+        assert sorted(o for o, l in zip(oh, lh) if l) == sorted(set(o for o, l in zip(oh, lh) if l))   # no two pairs share a start
+        for k in range(n):
+            assert oh[k] % 4 == 0 and sh[oh[k]: oh[k] + lh[k]] == want[k], k
+            assert scrooge_amd.api.edit_stream_to_cigar(want[k], len(q[k]), W=W, O=O) == cigars[k]
+        # back to runs on the GPU: counts first, then the runs themselves, identical to the compaction of the originals
+        cnt32 = torch.empty(n, dtype=torch.int32, device=dev)
+        nbad = torch.zeros(1, dtype=torch.int32, device=dev)
+        aligner.decode_edit_stream(n, stream, s_off, s_len, desc.view(-1)[3:], 6, None, None, cnt32, nbad, W=W, O=O)
+        assert torch.equal(cnt32, nr) and int(nbad.item()) == 0
+        cnt = nr.to(torch.int64)
+        total = int(cnt.sum().item())
+        off = torch.cumsum(cnt, 0) - cnt
+        dense = torch.zeros(total * 2 + 8, dtype=torch.uint8, device=dev)
+        back = torch.zeros(total * 2 + 8, dtype=torch.uint8, device=dev)
+        aligner.compact_runs(n, desc, runs, nr, off, dense)
+        aligner.decode_edit_stream(n, stream, s_off, s_len, desc.view(-1)[3:], 6, off, back, cnt32, nbad, W=W, O=O)
+        torch.cuda.synchronize()
+        assert int(nbad.item()) == 0 and torch.equal(back, dense)
+        # wrong read lengths are noticed (longer: more runs than the segment holds; shorter: the edits overrun the
+        # read), and nothing is written past a pair's segment
+        for rl, least in ((desc[:, 3].contiguous() + 1000, n), (desc[:, 3].contiguous() // 2, n // 2)):
+            back.zero_()
+            nbad.zero_()
+            aligner.decode_edit_stream(n, stream, s_off, s_len, rl, 1, off, back, cnt32, nbad, W=W, O=O)
+            assert int(nbad.item()) >= least and int(back[2 * total:].max().item()) == 0
+        # the align kernel's own edit-stream output (scrg_align_device_edits): the same bytes in every pair's slice
+        if W - O <= 31 and W <= 64:
+            slices = torch.full((n * cap * 2,), 0xEE, dtype=torch.uint8, device=dev)
+            ed2 = torch.empty(n, dtype=torch.int64, device=dev)
+            ln2 = torch.empty(n, dtype=torch.int32, device=dev)
+            st2 = torch.empty(n, dtype=torch.int32, device=dev)
+            aligner.align_device_edits(n, seq, desc, slices, ed2, ln2, st2, W=W, O=O)
+            torch.cuda.synchronize()
+            assert ed2.cpu().tolist() == eds and int(st2.max().item()) == 0 and ln2.cpu().tolist() == lh
+            sl = slices.cpu().numpy().tobytes()
+            for k in range(n):
+                r4 = (lh[k] + 3) // 4 * 4
+                assert sl[2 * k * cap: 2 * k * cap + r4] == want[k] + bytes(r4 - lh[k]), k      # zero up to the next dword
+                assert sl[2 * k * cap + r4: 2 * k * cap + r4 + 4] in (b"\xee" * 4, b""), k        # and nothing after it
+            # gathered with scrg_compact_runs (two bytes per "run") at 4-byte aligned offsets, then decoded
+            r4 = (ln2.to(torch.int64) + 3) // 4 * 4
+            boff = torch.cumsum(r4, 0) - r4
+            dense_s = torch.zeros(int(r4.sum().item()) + 8, dtype=torch.uint8, device=dev)
+            aligner.compact_runs(n, desc, slices, (r4 // 2).to(torch.int32), boff // 2, dense_s)
+            back.zero_()
+            nbad.zero_()
+            aligner.decode_edit_stream(n, dense_s, boff, ln2, desc.view(-1)[3:], 6, off, back, nr, nbad, W=W, O=O)
+            torch.cuda.synchronize()
+            assert int(nbad.item()) == 0 and torch.equal(back, dense)
+            # slices too small for the stream: reported, not overrun (the neighbouring slice stays intact)
+            tiny = desc.clone()
+            tiny[:, 5] = 16
+            slices.fill_(0xEE)
+            aligner.align_device_edits(n, seq, tiny, slices, ed2, ln2, st2, W=W, O=O)
+            torch.cuda.synchronize()
+            assert ln2.cpu().tolist() == lh and st2.cpu().tolist() == [1 if l > 32 else 0 for l in lh]
+            sl = slices.cpu().numpy().tobytes()
+            for k in range(n):
+                assert sl[2 * k * cap: 2 * k * cap + min(32, (lh[k] + 3) // 4 * 4)] == (want[k] + bytes(3))[: min(32, (lh[k] + 3) // 4 * 4)], k
+                assert sl[2 * k * cap + 32: 2 * (k + 1) * cap] == b"\xee" * (2 * cap - 32), k
+        else:
+            with pytest.raises(scrooge_amd.ScroogeError):
+                aligner.align_device_edits(n, seq, desc, runs, ed, nr, st, W=W, O=O)
+        # a stream buffer that is too small: the pairs that do not fit are counted and marked, the others are intact
+        small = torch.zeros(need // 2 // 4 * 4, dtype=torch.uint8, device=dev)
+        aligner.encode_edit_stream(n, desc, runs, nr, small, s_off, s_len, tot)
+        torch.cuda.synchronize()
+        oh2, missing = s_off.cpu().tolist(), int(tot[1].item())
+        assert missing > 0 and sum(1 for o in oh2 if o == -1) == missing and s_len.cpu().tolist() == lh
+        sm = small.cpu().numpy().tobytes()
+        assert all(sm[o: o + l] == w for o, l, w in zip(oh2, lh, want) if o != -1)
+    finally:
+        aligner.use_own_stream()
+
+
 def test_mapping_shape_with_mixed_strides(aligner, oracle):
     """The read-mapping shape through the device API: one contiguous genome (text stride 1) shared by all candidates,
     the reads in lane-interleaved groups (read stride 64), both in one sequence array."""
@@ -462,16 +587,21 @@ def test_mapping_shape_with_mixed_strides(aligner, oracle):
     assert got == (eds, cigars, [0] * n)
 
 
-def test_bench_gather_on_rccl_single_rank():
+@pytest.mark.parametrize("fmt", ["edits", "edits-from-runs", "packed", "runs"])
+def test_bench_gather_on_rccl_single_rank(fmt):
     """The gather path of bench.py on the real RCCL backend (a one-rank group, SCRG_BENCH_FORCE_GATHER): asynchronous
-    collectives, packed runs, unpacking on a stream of its own ordered after the collective, four steps in flight;
-    bench.py itself asserts that what rank 0 holds after the last step's gather is what its kernel produced."""
+    collectives, four steps in flight, CIGARs as edit streams (the default: one collective per step, decoded and
+    compared after the timed region), as packed runs (unpacked on a stream of its own ordered after the collective) or
+    as scrg_run pairs; bench.py itself asserts that what rank 0 holds after the last step's gather is what its kernel
+    produced."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, SCRG_BENCH_FORCE_GATHER="1", MASTER_PORT="29579")
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "9", "--warmup", "2",
-                          "--pairs", "20000", "--read-len", "3000", "--cpu-seconds", "0"],
+                          "--pairs", "20000", "--read-len", "3000", "--cpu-seconds", "0", "--gather-format", fmt],
                          env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     j = json.loads([l for l in out.stdout.splitlines() if l.startswith('{"metric"')][0])
-    assert j["gather_check"] is True and j["value"] > 0
+    assert j["gather_check"] is True and j["value"] > 0 and j["config"]["gather"]["format"] == fmt
+    if fmt.startswith("edits"):
+        assert 0.09 * 3000 < j["config"]["gather"]["stream_bytes_per_pair"] < 0.13 * 3000       # one byte per edit at 10 % error
