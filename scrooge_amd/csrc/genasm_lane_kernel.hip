@@ -391,9 +391,9 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
                 // Pass 2, edit stream.  Only columns with an edit are visited: an insertion run (before the column's
                 // step), then a deletion or substitution.  mbase + c = matches pending when column c is reached;
                 // an insertion at c leaves none at c (mbase = -c), a deletion/substitution none at c + 1.  Every byte
-                // goes to the slot after the last committed one; only committing moves on.  Two insertions and 63
-                // pending matches are handled in line, longer runs / stretches on a side path that a few per cent of
-                // the iterations take.
+                // goes to the slot after the last committed one; only committing moves on.  Three insertions and 127
+                // pending matches are handled in line, longer runs / stretches on a side path (well under one per cent
+                // of the iterations at 10 % error).
                 uint32_t E = (a.debug & 4) ? 0u : (D | X | Im);
                 uint32_t c = ffbh_u32(E);
                 uint32_t ni = lds8[scr_b + c];
@@ -407,7 +407,9 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
                     E = bitop3<TT_ANDN>(E, bit, bit);
                     const uint32_t nx = ffbh_u32(E);
                     const uint32_t step = 0xC0u - 0x80u * xB;                  // 'D' 3 << 6, 'X' 1 << 6
-                    const bool side = (iB && ni > 2u) || ((iB | dx) && t > 63u);
+                    const uint32_t live = iB | dx;                             // (0 only for a lane that is done)
+                    uint32_t k64 = (t >> 6) * live;                            // bytes 0x3F owed before the edit byte
+                    const bool side = max(ni * iB, 2u * k64) > 3u;             // more than 3 insertions or 127 matches pending
                     if (__any(side)) {
                         if (side) {
                             auto emit = [&](uint32_t b) {
@@ -428,12 +430,16 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
                                 emit(step | (tt & 63u));
                                 mbase = ~c;
                             }
-                            iB = dx = 0;
+                            iB = dx = k64 = 0;
                         }
                     }
+                    // in line: one byte 0x3F (64..127 matches pending), up to three insertions, the step
+                    put(pos, 0x3Fu);
+                    pos += k64;
                     put(pos, 0x80u | (t & 63u));
                     put(pos + 1u, 0x80u);
-                    pos += iB ? (ni > 1u ? 2u : 1u) : 0u;
+                    put(pos + 2u, 0x80u);
+                    pos += iB ? (ni > 3u ? 3u : ni) : 0u;
                     put(pos, step | ((iB ? 0u : t) & 63u));
                     pos += dx;
                     mbase = dx ? ~c : (iB ? 0u - c : mbase);
@@ -444,7 +450,7 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
                 while (__any(E != 0u)) {
                     event();
                     event();
-                    if (++trips == 3u) {                       // <= 18 new bytes between checks + 3 speculative ones: the 64-byte ring cannot wrap
+                    if (++trips == 2u) {                       // <= 4 x 5 new bytes between checks + 4 speculative ones: the 64-byte ring cannot wrap
                         trips = 0;
                         flush_pieces();
                     }
