@@ -118,6 +118,82 @@ static int lane_tb(const uint64_t *V1, const uint64_t *V0, int m, int TBL, size_
     return edits;
 }
 
+/* The kernel's edit-stream variant of pass 2 (genasm_lane_kernel<true>): the same pass 1, then one visit per column
+ * that holds an edit.  mbase + c = matches pending when column c is reached (carried from window to window);
+ * an insertion at c leaves none at c, a deletion/substitution none at c + 1. */
+typedef struct { uint8_t *p; size_t cap, n; uint32_t mbase; } edit_sink;
+static void es_put(edit_sink *o, uint32_t b) { if (o->n < o->cap) o->p[o->n] = (uint8_t)b; o->n++; }
+
+static int lane_tb_edits(const uint64_t *V1, const uint64_t *V0, int m, int TBL, size_t *tu, size_t *pu, edit_sink *out, lane_stats *ls)
+{
+    const uint32_t jlim = (uint32_t)(m < TBL ? m : TBL);
+    const uint32_t stop = 0x80000000u >> jlim;
+    uint32_t j = 0, ti = 0, nDm = 0, Xm = 0, nIm = 0;
+    uint8_t ilen[32];
+    for (int i = 0; i < TBL; i++) {
+        const uint32_t nv1 = ~((uint32_t)(V1[i] >> 32) | stop), v0 = (uint32_t)(V0[i] >> 32) | stop;
+        const uint32_t x = (nv1 | ~v0 | stop) << j;
+        const uint32_t ni = lp_ffbh32(x);
+        ilen[i] = (uint8_t)ni;
+        nIm = lp_alignbit(nIm, x, 31);
+        j += ni;
+        const uint32_t nt1 = nv1 << j, t0 = v0 << j;
+        nDm = lp_alignbit(nDm, nt1, 31);
+        Xm = lp_alignbit(Xm, t0, 31);
+        j += nt1 >> 31;
+        ls->tb_columns++;
+    }
+    const unsigned nsh = 32u - (unsigned)TBL;
+    const uint32_t Draw = ~(nDm << nsh), Xraw = Xm << nsh;
+    ti = lp_ffbh32((Draw & Xraw) | (0x80000000u >> TBL));
+    const uint32_t A = ti ? ~(0xffffffffu >> ti) : 0u;
+    const uint32_t D = Draw & A, X = Xraw & A, Im = ~nIm << nsh;
+    const int edits = (int)(j - ti + 2u * (unsigned)__builtin_popcount(D) + (unsigned)__builtin_popcount(X));
+    uint32_t E = D | X | Im;
+    while (E) {
+        const unsigned c = lp_ffbh32(E);
+        const uint32_t bit = 0x80000000u >> c;
+        uint32_t t = out->mbase + c;
+        E &= ~bit;
+        if (Im & bit) {
+            for (uint32_t q = t >> 6; q; q--) es_put(out, 0x3F);
+            es_put(out, 0x80u | (t & 63u));
+            for (uint32_t q = 1; q < ilen[c]; q++) es_put(out, 0x80u);
+            t = 0;
+            out->mbase = 0u - c;
+        }
+        if ((D | X) & bit) {
+            for (uint32_t q = t >> 6; q; q--) es_put(out, 0x3F);
+            es_put(out, ((X & bit) ? 0x40u : 0xC0u) | (t & 63u));
+            out->mbase = ~c;
+        }
+    }
+    out->mbase += ti;
+    *tu = ti; *pu = j;
+    return edits;
+}
+
+int lane_align_edits(const uint8_t *text, size_t text_len, const uint8_t *read, size_t read_len, int W, int O,
+                     uint8_t *stream, size_t cap, size_t *n_bytes, long long *edit_distance, lane_stats *ls)
+{
+    if (W < 2 || W > 64 || O < 1 || O >= W || W - O > 31) return GO_ERR_PARAMS;
+    edit_sink out = { stream, cap, 0, 0 };
+    size_t ti = 0, ri = 0; long long total = 0;
+    const int TBL = W - O;
+    uint64_t V1[64], V0[64];
+    while (ri < read_len) {
+        size_t n = text_len - ti < (size_t)W ? text_len - ti : (size_t)W;
+        size_t m = read_len - ri < (size_t)W ? read_len - ri : (size_t)W;
+        size_t tu, pu;
+        lane_dc(text + ti, (int)n, read + ri, (int)m, TBL, V1, V0, ls);
+        total += lane_tb_edits(V1, V0, (int)m, TBL, &tu, &pu, &out, ls);
+        ls->windows++;
+        ti += tu; ri += pu;
+    }
+    *n_bytes = out.n; *edit_distance = total;
+    return out.n > cap ? GO_ERR_CAPACITY : GO_OK;
+}
+
 static int lp_clz64(uint64_t v) { return v ? __builtin_clzll(v) : 64; }
 
 static int lane_tb_wide(const uint64_t *V1, const uint64_t *V0, int m, int TBL, size_t *tu, size_t *pu, run_sink *out, lane_stats *ls)

@@ -30,7 +30,7 @@ CODE = np.zeros(256, np.uint8)
 CODE[ord("C")], CODE[ord("G")], CODE[ord("T")] = 1, 2, 3
 
 
-def _run(fn, t, q, head, tail):
+def _run(fn, t, q, head, tail, unit=2):
     tc, qc = CODE[np.frombuffer(t, np.uint8)], CODE[np.frombuffer(q, np.uint8)]
     cap = len(t) + len(q) + 8
     runs = (C.c_uint8 * (2 * cap))()
@@ -38,7 +38,7 @@ def _run(fn, t, q, head, tail):
     st = fn(tc.ctypes.data_as(C.c_void_p), C.c_size_t(len(tc)), qc.ctypes.data_as(C.c_void_p), C.c_size_t(len(qc)),
             *head, runs, C.c_size_t(cap), C.byref(n), C.byref(ed), *tail)
     assert st == 0
-    return ed.value, bytes(runs[:2 * n.value])
+    return ed.value, bytes(runs[:unit * n.value])
 
 
 def _cases(seed):
@@ -67,4 +67,20 @@ def test_lane_form_matches_oracle(proto, W, O):
         got = _run(proto.lane_align_codes, t, q, (C.c_int(W), C.c_int(O)), (C.byref(ls),))
         want = _run(proto.go_align_codes, t, q, (C.c_int(W), C.c_int(O)), (None,))
         assert got == want
+    assert ls.windows > 1000
+
+
+@pytest.mark.parametrize("W,O", [(64, 33), (64, 40), (64, 63), (32, 17), (48, 24), (2, 1), (17, 9), (33, 2)])
+def test_lane_edit_stream_form_matches_oracle(proto, oracle, W, O):
+    """The kernel's edit-stream traceback (pending matches carried across windows as mbase + column) produces the
+    canonical edit stream of the oracle's CIGAR (tests/test_edit_stream.py: py_encode)."""
+    from tests.test_edit_stream import py_encode
+    T, Q = _cases(W * 100 + O + 7)
+    T += [b"ACGT" * 300 + b"T" + b"ACGT" * 40, b"A" * 700]          # stretches of several hundred matches, then an edit
+    Q += [b"ACGT" * 300 + b"G" + b"ACGT" * 40, b"A" * 700]
+    eds, cigars, _, _ = oracle.align(T, Q, W=W, O=O)
+    ls = LS()
+    for t, q, e, c in zip(T, Q, eds, cigars):
+        ed, stream = _run(proto.lane_align_edits, t, q, (C.c_int(W), C.c_int(O)), (C.byref(ls),), unit=1)
+        assert ed == e and stream == py_encode(c)
     assert ls.windows > 1000
