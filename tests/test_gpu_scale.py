@@ -287,9 +287,31 @@ def test_full_bench_size_two_algorithms_agree(aligner):
             finally:
                 aligner.params = keep
         assert int(bad.item()) == 0
+        # a fourth formulation of the output: the kernel's edit streams (one byte per edit), and from them — by the
+        # decoder's window replay — the runs again, for all 100 000 pairs
+        (ed0, nr0, st0, d0, off0) = res[0]
+        slices = torch.zeros(n * cap * 2, dtype=torch.uint8, device=dev)
+        ed_s = torch.empty(n, dtype=torch.int64, device=dev)
+        ln = torch.empty(n, dtype=torch.int32, device=dev)
+        st_s = torch.empty(n, dtype=torch.int32, device=dev)
+        aligner.align_device_edits(n, seq, desc, slices, ed_s, ln, st_s)
+        r4 = (ln.to(torch.int64) + 3) & -4
+        boff = torch.cumsum(r4, 0) - r4
+        stream = torch.zeros(int(r4.sum().item()) + 8, dtype=torch.uint8, device=dev)
+        aligner.compact_runs(n, desc, slices, (r4 >> 1).to(torch.int32), boff >> 1, stream)
+        del slices
+        back = torch.zeros_like(d0)
+        nbad = torch.zeros(1, dtype=torch.int32, device=dev)
+        aligner.decode_edit_stream(n, stream, boff, ln, desc.view(-1)[3:], 6, off0, back, nr0, nbad)
+        torch.cuda.synchronize()
+        assert torch.equal(ed_s, ed0) and int(st_s.max()) == 0 and int(nbad.item()) == 0 and torch.equal(back, d0)
+        is_edit = (stream >= 64).to(torch.int64)
+        csum = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(is_edit, 0)])
+        assert torch.equal(csum[boff + ln.to(torch.int64)] - csum[boff], ed0)          # one byte per edit
+        assert 0.9 < float(ln.double().mean()) / float(ed0.double().mean()) < 1.02     # (+ the rare 0x3F bytes)
+        del stream, back
     finally:
         aligner.use_own_stream()
-    (ed0, nr0, st0, d0, off0) = res[0]
     for (ed1, nr1, st1, d1, _) in res[1:]:
         assert int(st0.max()) == 0 and int(st1.max()) == 0
         assert torch.equal(ed0, ed1) and torch.equal(nr0, nr1) and torch.equal(d0, d1)

@@ -47,3 +47,41 @@ for W, O in ((64, 63), (64, 40), (33, 2), (48, 24), (32, 17), (17, 9), (5, 2), (
     print("W=%d O=%d lanes=%d" % (W, O, a.resolved_params(W=W, O=O).lanes_per_pair), "mismatches:", len(bad), bad[:5])
     assert not bad
 print("soak ok")
+# the align kernel's edit-stream output (scrg_align_device_edits) on the same pairs: every stream must be the canonical
+# encoding of the oracle's CIGAR (long insertion runs and match stretches take the kernel's side path)
+import torch
+from tests.test_edit_stream import py_encode
+dev = torch.device("cuda", 0)
+a.set_stream(0)
+for W, O in ((64, 33), (48, 24), (33, 2), (64, 63)):
+    m = min(len(T), 12000)
+    e2, c2, _, _ = Oracle().align(T[:m], Q[:m], W=W, O=O, threads=16)
+    tw = (max(len(x) for x in T[:m]) + 31) // 32
+    rw = (max(len(x) for x in Q[:m]) + 31) // 32
+    rows = np.zeros((m, (tw + rw) * 32), dtype=np.uint8)
+    for k in range(m):
+        rows[k, :len(T[k])] = np.frombuffer(T[k], dtype=np.uint8)
+        rows[k, tw * 32: tw * 32 + len(Q[k])] = np.frombuffer(Q[k], dtype=np.uint8)
+    seq = torch.zeros(m * (tw + rw) + scrooge_amd.api.SEQ_PAD_WORDS, dtype=torch.int64, device=dev)
+    nbad = torch.zeros(1, dtype=torch.int32, device=dev)
+    a.pack_planar(torch.from_numpy(rows).to(dev).view(-1), seq, nbad)
+    cap = (max(len(x) for x in T[:m]) + max(len(x) for x in Q[:m]) + 8 + 15) // 16 * 16
+    idx = torch.arange(m, dtype=torch.int64, device=dev)
+    desc = torch.stack([idx * (tw + rw) * 32, torch.tensor([len(x) for x in T[:m]], device=dev),
+                        (idx * (tw + rw) + tw) * 32, torch.tensor([len(x) for x in Q[:m]], device=dev),
+                        idx * cap, torch.full_like(idx, cap)], dim=1).contiguous()
+    slices = torch.zeros(m * cap * 2, dtype=torch.uint8, device=dev)
+    ed = torch.empty(m, dtype=torch.int64, device=dev)
+    ln = torch.empty(m, dtype=torch.int32, device=dev)
+    st = torch.empty(m, dtype=torch.int32, device=dev)
+    a.align_device_edits(m, seq, desc, slices, ed, ln, st, W=W, O=O)
+    torch.cuda.synchronize()
+    sl, lh = slices.cpu().numpy(), ln.cpu().tolist()
+    assert int(st.max()) == 0 and ed.cpu().tolist() == e2
+    bad = [k for k in range(m) if sl[2 * k * cap: 2 * k * cap + lh[k]].tobytes() != py_encode(c2[k])]
+    print("edit streams W=%d O=%d: %d pairs, %d bytes, mismatches: %d %s" % (W, O, m, sum(lh), len(bad), bad[:5]))
+    assert not bad
+    for k in range(0, m, 97):
+        assert scrooge_amd.api.edit_stream_to_cigar(sl[2 * k * cap: 2 * k * cap + lh[k]].tobytes(), len(Q[k]), W=W, O=O) == c2[k]
+a.use_own_stream()
+print("edit-stream soak ok")
