@@ -16,6 +16,10 @@ tail -c 400 $root/gpurun_out/prof_$tag/bench.json; echo
 mkdir -p $root/gpurun_out/prof_${tag}_serial
 (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $root/gpurun_out/prof_${tag}_serial -o prof --output-format csv -- \
     python3 $root/bench.py --no-build --serial --cpu-seconds 0 > $root/gpurun_out/prof_${tag}_serial/bench.json 2> $root/gpurun_out/prof_${tag}_serial/bench.err)
+# the N > 1 step on this one GPU: the gather path on a one-rank RCCL group, CIGARs as edit streams written by the kernel
+mkdir -p $root/gpurun_out/prof_${tag}_gather
+(cd /tmp && export TMPDIR=/tmp && export SCRG_BENCH_FORCE_GATHER=1 && timeout 300 rocprofv3 --kernel-trace --stats -d $root/gpurun_out/prof_${tag}_gather -o prof --output-format csv -- \
+    python3 $root/bench.py --no-build --cpu-seconds 0 > $root/gpurun_out/prof_${tag}_gather/bench.json 2> $root/gpurun_out/prof_${tag}_gather/bench.err)
 cd $root
 # window rounds per launch (kernel counters, not under the profiler)
 python3 bench.py --no-build --stats --cpu-seconds 0 --steps 2 2> gpurun_out/prof_$tag/stats.txt > /dev/null

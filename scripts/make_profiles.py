@@ -46,6 +46,12 @@ kernel_stats(os.path.join(go, "prof_%s_serial" % tag), os.path.join(pr, "%s_kern
              "`python bench.py --serial` (one stream, every launch has the GPU to itself); bench line of the same run: "
              "value %.4g pairs/s, kernel_ms %.4g" % ((bs["value"], bs["kernel_ms"]) if bs else (0, 0)))
 
+bg = bench_line(os.path.join(go, "prof_%s_gather" % tag, "bench.json"))
+kernel_stats(os.path.join(go, "prof_%s_gather" % tag), os.path.join(pr, "%s_kernel_stats_gather_edits.csv" % rnd),
+             "`SCRG_BENCH_FORCE_GATHER=1 python bench.py --cpu-seconds 0`: the N > 1 step on one GPU (one-rank RCCL group) — "
+             "genasm_lane_kernel<true> writes edit streams, compaction, one gather per step; bench line of the same run: "
+             "value %.4g pairs/s, gather_check %s" % ((bg["value"], bg["gather_check"]) if bg else (0, None)))
+
 # rounds per launch from the --stats pass
 rounds = None
 try:
