@@ -528,6 +528,40 @@ def main():
         parity = {"checked_pairs": k, "bit_exact": ok, "checked_edit_distances_and_run_counts": m, "all_equal": ok_all}
         assert ok and ok_all, "GPU result differs from the CPU checker on the bench sample"
 
+    # The N > 1 step writes CIGARs as edit streams (a different, lossless output format).  For a like-for-like
+    # scaling figure the same step — align kernel with edit-stream output + compaction of the streams, pipelined
+    # over the same streams, no collective — is timed here on one GPU, after everything above (it reuses the slices).
+    edit_stream_step = None
+    if not dist_on and n_lanes > 1 and not args.ablate and p.lanes_per_pair == 1 and p.W <= 64 and p.W - p.O <= 31:
+        lens = [torch.empty(n, dtype=torch.int32, device=device) for _ in range(n_lanes)]
+        aligners[0].align_device_edits(n, seq, desc, outs[0]["runs"], outs[0]["ed"], lens[0], outs[0]["status"], **kw)
+        torch.cuda.synchronize()
+        sbytes = int(((lens[0].to(torch.int64) + 3) & -4).sum().item())
+        sdense = [torch.empty(sbytes + 8, dtype=torch.uint8, device=device) for _ in range(n_lanes)]
+
+        def edit_step(j):
+            b = j % n_lanes
+            o = outs[b]
+            with torch.cuda.stream(streams[b]):
+                aligners[b].align_device_edits(n, seq, desc, o["runs"], o["ed"], lens[b], o["status"], **kw)
+                r4 = (lens[b].to(torch.int64) + 3) & -4
+                boff = torch.cumsum(r4, 0) - r4
+                aligners[b].compact_runs(n, desc, o["runs"], (r4 >> 1).to(torch.int32), boff >> 1, sdense[b])
+
+        for j in range(args.warmup):
+            edit_step(j)
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        for j in range(args.steps):
+            edit_step(j)
+        torch.cuda.synchronize()
+        es_dt = time.perf_counter() - ts
+        edit_stream_step = {"value": n * args.steps / es_dt, "unit": "pairs/s", "ms_per_step": es_dt / args.steps * 1e3,
+                            "stream_bytes_per_pair": sbytes / n,
+                            "note": "the step of the N > 1 runs without the collective: scrg_align_device_edits + compaction "
+                                    "of the streams, same pipeline; measured after the timed region"}
+        del sdense, lens
+
     pairs_total = world * n * args.steps
     value = pairs_total / dt
     if text_used is None:
@@ -566,6 +600,7 @@ def main():
         "kernel_pairs_per_s_per_gpu": n / (kernel_ms * 1e-3),
         "kernel_ms_events_in_timed_region": events_ms,   # pipelined launches: includes waiting for the previous launch's wavefronts to retire
         "serial": serial,              # the same step without overlap between launches, measured after the timed region
+        "edit_stream_step": edit_stream_step,   # the N > 1 step (CIGARs as edit streams) on this one GPU, without the collective
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "genasm_lane_kernel" if p.lanes_per_pair == 1 else "genasm_align_kernel<%d, false>" % p.lanes_per_pair,
