@@ -97,7 +97,7 @@ SCRG_HD inline uint64_t replay_edit_stream(const uint8_t* s, uint64_t n_bytes, u
 
 hipError_t launch_encode_edits(uint64_t n_pairs, const scrg_pair_desc* d_pairs, const uint16_t* d_runs,
                                const uint32_t* d_n_runs, uint8_t* d_stream, uint64_t stream_cap, uint64_t* d_off,
-                               uint32_t* d_len, uint64_t* d_total, int n_cus, hipStream_t s);
+                               uint32_t* d_len, uint64_t* d_total, hipStream_t s);
 hipError_t launch_decode_edits(uint64_t n_pairs, uint32_t W, uint32_t O, const uint8_t* d_stream, const uint64_t* d_off,
                                const uint32_t* d_len, const uint64_t* d_read_len, uint64_t read_len_stride,
                                const uint64_t* d_dense_off, uint16_t* d_dense, uint32_t* d_n_runs, uint32_t* d_bad,

@@ -1,11 +1,14 @@
 // edit_stream_kernels.hip — CIGAR runs <-> edit stream on the GPU (format and rationale: edit_stream.h).
 //
-// encode_edits_kernel: one wavefront per pair.  The pair's runs (its slice of d_runs, as the align kernel left
-// them) are cut into 64 contiguous segments, one per lane; a lane walks its segment in registers, 8 runs per
-// 16-byte load.  Walk 1 sizes every lane's share — the only cross-lane quantity is the number of matches pending
-// when a lane's segment begins (one segmented scan over the wavefront) —, lane 0 reserves the pair's bytes with one
-// atomic on the stream cursor, walk 2 (the slice is 4 KB for a 10 kb read and still in cache) writes the bytes into
-// LDS, from where they leave as whole dwords.  2 bytes per run in, ~1 byte per edit out.
+// encode_edits_kernel: a workgroup takes a tile of 32 pairs, each of its four wavefronts 8 of them, one after the
+// other.  A pair's runs (its slice of d_runs, as the align kernel left them) are cut into 64 contiguous segments,
+// one per lane; a lane walks its segment in registers, five 16-byte loads in flight.  Walk 1 sizes every lane's
+// share — the only cross-lane quantity is the number of matches pending when a lane's segment begins (one segmented
+// scan over the wavefront) —, ONE atomic on the stream cursor reserves the bytes of the whole tile (one per pair on
+// the same address bounded the kernel at 1.3 ms per 100 k pairs), walk 2 (the slice is 4 KB for a 10 kb read and
+// still in cache) writes the bytes into LDS, from where they leave as whole dwords.  2 bytes per run in, ~1 byte
+// per edit out; 0.39 ms per 100 k x 10 kb pairs.  (The one-pair-per-lane align kernel writes edit streams itself,
+// scrg_align_device_edits; this kernel serves the configurations that only produce runs.)
 // decode_edits_kernel: one thread per pair replays the windows (edit_stream.h) — the receiving side's tool, not
 // part of a rank's step.
 #include "edit_stream.h"
@@ -236,12 +239,11 @@ __global__ __launch_bounds__(64) void decode_edits_kernel(uint64_t n_pairs, uint
 
 hipError_t launch_encode_edits(uint64_t n_pairs, const scrg_pair_desc* d_pairs, const uint16_t* d_runs,
                                const uint32_t* d_n_runs, uint8_t* d_stream, uint64_t stream_cap, uint64_t* d_off,
-                               uint32_t* d_len, uint64_t* d_total, int n_cus, hipStream_t s)
+                               uint32_t* d_len, uint64_t* d_total, hipStream_t s)
 {
     hipError_t e = hipMemsetAsync(d_total, 0, 2 * sizeof(uint64_t), s);
     if (e != hipSuccess || n_pairs == 0) return e;
     const uint64_t blocks = (n_pairs + ENC_TILE - 1) / ENC_TILE;            // one workgroup per tile of 32 pairs
-    (void)n_cus;
     hipLaunchKernelGGL(encode_edits_kernel, dim3((unsigned)blocks), dim3(256), 0, s, n_pairs, d_pairs, d_runs, d_n_runs,
                        d_stream, stream_cap, d_off, d_len, d_total);
     return hipGetLastError();

@@ -610,7 +610,7 @@ scrg_status scrg_encode_edit_stream(scrg_ctx* c, uint64_t n_pairs, const scrg_pa
     if (reinterpret_cast<uintptr_t>(d_stream) & 3u) return c->fail(SCRG_ERR_INVALID_ARG, "d_stream needs 4-byte alignment");
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, scrg::launch_encode_edits(n_pairs, d_pairs, reinterpret_cast<const uint16_t*>(d_runs), d_n_runs, d_stream,
-                                         stream_cap, d_stream_off, d_stream_len, d_total, c->n_cus, c->stream));
+                                         stream_cap, d_stream_off, d_stream_len, d_total, c->stream));
     return SCRG_OK;
 }
 
