@@ -280,7 +280,7 @@ def main():
             stream_bytes = int(t_tot[0].item())
             del tmp, t_off
         del t_len
-        gather = EditStreamGather(n, stream_bytes, device, dst=0, depth=max(2, n_lanes))
+        gather = EditStreamGather(n, stream_bytes, device, dst=0, depth=max(2, n_lanes), ordered=gather_format == "edits")
     elif dist_on:
         from scrooge_amd.distributed import ResultGather
         packed_gather = gather_format == "packed"    # runs travel as one byte each; rank 0 restores scrg_run pairs
@@ -329,10 +329,9 @@ def main():
                 g = gather.buffers(j)
                 r4 = (o["n_runs"].to(torch.int64) + 3) & -4
                 boff = torch.cumsum(r4, 0) - r4
-                g["off"].copy_(boff)
                 g["len"].copy_(o["n_runs"])
                 aligners[b].compact_runs(n, desc, o["runs"], (r4 >> 1).to(torch.int32), boff >> 1, g["stream"])
-                gather.start(j, o["ed"], None)
+                gather.start(j, o["ed"])
                 return
             if k is not None:
                 ev[k][0].record()
@@ -344,7 +343,7 @@ def main():
                 gather.finish(j)
                 g = gather.buffers(j)
                 aligners[b].encode_edit_stream(n, desc, o["runs"], o["n_runs"], g["stream"], g["off"], g["len"], g["total"])
-                gather.start(j, o["ed"], o["n_runs"])
+                gather.start(j, o["ed"])
                 return
             cnt64 = o["n_runs"].to(torch.int64)
             dense_off = torch.cumsum(cnt64, 0) - cnt64
@@ -403,15 +402,14 @@ def main():
             for r in range(world):
                 v = gather.results(step.count - 1, r)
                 torch.cuda.synchronize()
-                runs_g, off_g, n_bad = gather.decode(aligners[last], step.count - 1, r, rl, 0,
-                                                     counted=gather_format != "edits", **kw)
+                runs_g, cnt_g, off_g, n_bad = gather.decode(aligners[last], step.count - 1, r, rl, 0, **kw)
                 torch.cuda.synchronize()
                 is_edit = (v["stream"][: gather.totals[r]] >= 64).to(torch.int64)
                 csum = torch.cat([torch.zeros(1, dtype=torch.int64, device=device), torch.cumsum(is_edit, 0)])
                 n_edits = csum[v["off"] + v["len"].to(torch.int64)] - csum[v["off"]]
-                checks = {"streams_decode": n_bad == 0, "edits_equal_distance": bool(torch.equal(n_edits, v["ed"]))}
+                checks = {"streams_decode": n_bad == 0, "edits_equal_distance": bool(torch.equal(n_edits, v["ed"].to(torch.int64)))}
                 if r == 0:
-                    checks.update(own_scores=bool(torch.equal(v["ed"], ed) and torch.equal(v["cnt"], n_runs)),
+                    checks.update(own_scores=bool(torch.equal(v["ed"].to(torch.int64), ed) and torch.equal(cnt_g, n_runs)),
                                   own_runs=bool(runs_g is not None and torch.equal(runs_g[: 2 * total_runs], dense[: 2 * total_runs])))
                 if not all(checks.values()):
                     print("gather check, slot of rank %d: %s (undecodable pairs: %d)" % (r, checks, n_bad), file=sys.stderr)

@@ -193,21 +193,27 @@ class ResultGather:
 
 
 class EditStreamGather:
-    """Gather of a batch's device results to rank `dst` with the CIGARs as EDIT STREAMS (scrg_encode_edit_stream:
-    one byte per edit, ~1.0 KB for a 10 kb read at 10 % error instead of 4.3 KB of scrg_run pairs), so that what a
-    rank produces per second fits the one xGMI link it has to `dst`.
+    """Gather of a batch's device results to rank `dst` with the CIGARs as EDIT STREAMS (one byte per edit, ~1.0 KB
+    for a 10 kb read at 10 % error instead of 4.3 KB of scrg_run pairs), so that what a rank produces per second fits
+    the one xGMI link it has to `dst`.
 
     One buffer per rank and step, ONE collective per step:
-        [ int64 edit distance x n | int64 stream offset x n | int32 stream length x n | int32 run count x n | stream ]
-    `buffers(k)` hands out the views scrg_encode_edit_stream writes into; `start(k, ed, n_runs)` adds the scalars
-    and enqueues the gather asynchronously (it overlaps the align kernels of the following steps); `finish(k)`
-    makes the current stream wait for it before the buffers are reused.  `dst` keeps the streams as they arrive;
-    `decode(...)` (scrg_decode_edit_stream) restores scrg_run pairs, window breaks included, where a consumer
-    wants them.  Sizes are exchanged once: the data, hence every size, is the same each step in bench.py."""
+        ordered (streams in pair order at 4-byte aligned offsets — what scrg_align_device_edits + compaction gives):
+            [ int32 edit distance x n | int32 stream length x n | streams ]                          8 bytes per pair
+        not ordered (scrg_encode_edit_stream places the streams in no particular order):
+            [ int32 edit distance x n | int32 stream length x n | int64 stream offset x n | streams ]   16 bytes per pair
+    `buffers(k)` hands out the views the producer writes into ("len", "stream", and "off" — a scratch tensor when the
+    offsets do not travel); `start(k, ed)` adds the scores and enqueues the gather asynchronously (it overlaps the align
+    kernels of the following steps); `finish(k)` makes the current stream wait for it before the buffers are reused.
+    `dst` keeps the streams as they arrive; `results(k, r)` gives views of rank r's slot (offsets re-derived from the
+    lengths when they did not travel) and `decode(...)` (scrg_decode_edit_stream) restores scrg_run pairs, window
+    breaks included, where a consumer wants them.  Sizes are exchanged once: the data, hence every size, is the
+    same each step in bench.py."""
 
-    def __init__(self, n_pairs, stream_bytes, device, dst=0, group=None, depth=2):
+    def __init__(self, n_pairs, stream_bytes, device, dst=0, group=None, depth=2, ordered=True):
         self.group, self.dst, self.n = group, dst, int(n_pairs)
         self.DEPTH = max(1, int(depth))
+        self.ordered = bool(ordered)
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         t = torch.tensor([int(stream_bytes)], dtype=torch.int64, device=device)
@@ -216,11 +222,13 @@ class EditStreamGather:
         self.totals = [int(x.item()) for x in sizes]
         self.cap = (max(max(self.totals), 8) + 7) // 8 * 8
         n = self.n
-        self.head = 24 * n                                   # bytes of scalars in front of the stream
+        self.n8 = (n + 1) // 2 * 2                           # int32 arrays padded to a multiple of 8 bytes
+        self.head = 8 * self.n8 + (0 if self.ordered else 8 * n)      # bytes of scalars in front of the streams
         self.wire = self.head + self.cap                     # bytes per rank and step on the link
         d = self.DEPTH
         self.send = [torch.zeros(self.wire, dtype=torch.uint8, device=device) for _ in range(d)]
         self.total = [torch.zeros(2, dtype=torch.int64, device=device) for _ in range(d)]
+        self.off_scratch = [torch.zeros(n, dtype=torch.int64, device=device) for _ in range(d)] if self.ordered else None
         self.recv = [None] * d
         if self.rank == dst:
             self.recv = [[torch.empty(self.wire, dtype=torch.uint8, device=device) for _ in range(self.world)]
@@ -229,26 +237,26 @@ class EditStreamGather:
         self.host_stage = dist.get_backend(group) == "gloo" and torch.device(device).type == "cuda"
 
     def _views(self, buf):
-        n = self.n
-        return {"ed": buf[: 8 * n].view(torch.int64), "off": buf[8 * n: 16 * n].view(torch.int64),
-                "len": buf[16 * n: 20 * n].view(torch.int32), "cnt": buf[20 * n: 24 * n].view(torch.int32),
-                "stream": buf[24 * n:]}
+        n, n8 = self.n, self.n8
+        v = {"ed": buf[: 4 * n].view(torch.int32), "len": buf[4 * n8: 4 * n8 + 4 * n].view(torch.int32),
+             "stream": buf[self.head:]}
+        if not self.ordered:
+            v["off"] = buf[8 * n8: 8 * n8 + 8 * n].view(torch.int64)
+        return v
 
     def buffers(self, k):
         b = k % self.DEPTH
         v = self._views(self.send[b])
         v["total"] = self.total[b]
+        if self.ordered:
+            v["off"] = self.off_scratch[b]
         return v
 
-    def start(self, k, ed, n_runs):
-        """The stream, offsets and lengths of step k must already be in `buffers(k)` (enqueued on the current stream)."""
+    def start(self, k, ed):
+        """The streams and their lengths (and offsets, if they travel) of step k must already be in `buffers(k)`
+        (enqueued on the current stream)."""
         b = k % self.DEPTH
-        v = self._views(self.send[b])
-        v["ed"].copy_(ed)
-        if n_runs is None:                 # (the align kernel wrote the streams itself: run counts were never made)
-            v["cnt"].zero_()
-        else:
-            v["cnt"].copy_(n_runs)
+        self._views(self.send[b])["ed"].copy_(ed)            # (int64 -> int32)
         if self.host_stage:
             torch.cuda.current_stream().synchronize()
             host = [torch.empty(self.wire, dtype=torch.uint8) for _ in range(self.world)] if self.rank == self.dst else None
@@ -272,34 +280,34 @@ class EditStreamGather:
             self.finish(b)
 
     def results(self, k, r):
-        """Views (ed, off, len, cnt, stream) of what rank r sent for step k, on dst (after finish(k))."""
-        return self._views(self.recv[k % self.DEPTH][r])
+        """Views (ed, len, off, stream) of what rank r sent for step k, on dst (after finish(k)); `off` is re-derived
+        from the lengths when the streams are ordered."""
+        v = self._views(self.recv[k % self.DEPTH][r])
+        if self.ordered:
+            r4 = (v["len"].to(torch.int64) + 3) & -4
+            v["off"] = torch.cumsum(r4, 0) - r4
+        return v
 
-    def decode(self, aligner, k, r, read_len, read_len_stride, counted=True, **params):
-        """scrg_run bytes of rank r's pairs of step k on dst -> (dense uint8 tensor, run offsets int64, pairs whose
-        stream did not decode [to the gathered run count]).  `read_len`: int64 device tensor, see
-        scrg_decode_edit_stream.  counted=False: run counts did not travel; a counting pass makes them first."""
+    def decode(self, aligner, k, r, read_len, read_len_stride, **params):
+        """scrg_run bytes of rank r's pairs of step k on dst -> (dense uint8 tensor, run counts int32, run offsets
+        int64, number of pairs whose stream is not an alignment of a read of that length).  `read_len`: int64 device
+        tensor, see scrg_decode_edit_stream.  Two passes: count, then decode."""
         v = self.results(k, r)
-        n_bad0 = 0
-        if not counted:
-            bad0 = torch.zeros(1, dtype=torch.int32, device=v["cnt"].device)
-            if bad0.is_cuda:
-                torch.cuda.current_stream().synchronize()
-            aligner.decode_edit_stream(self.n, v["stream"], v["off"], v["len"], read_len, read_len_stride, None, None,
-                                       v["cnt"], bad0, **params)
-            if bad0.is_cuda:
-                torch.cuda.synchronize()                   # (the handle's stream need not be torch's current one)
-            n_bad0 = int(bad0.item())
-            if n_bad0:
-                return None, None, n_bad0
-        cnt64 = v["cnt"].to(torch.int64)
+        dev = v["len"].device
+        cnt = torch.zeros(self.n, dtype=torch.int32, device=dev)
+        bad = torch.zeros(1, dtype=torch.int32, device=dev)
+        sync = torch.cuda.synchronize if cnt.is_cuda else (lambda: None)     # the handle's stream need not be torch's
+        sync()
+        aligner.decode_edit_stream(self.n, v["stream"], v["off"], v["len"], read_len, read_len_stride, None, None,
+                                   cnt, bad, **params)
+        sync()
+        if int(bad.item()):
+            return None, cnt, None, int(bad.item())
+        cnt64 = cnt.to(torch.int64)
         off = torch.cumsum(cnt64, 0) - cnt64
-        dense = torch.zeros(int(cnt64.sum().item()) * 2 + 8, dtype=torch.uint8, device=v["cnt"].device)
-        bad = torch.zeros(1, dtype=torch.int32, device=v["cnt"].device)
-        if dense.is_cuda:
-            torch.cuda.current_stream().synchronize()      # the handle's stream need not be torch's current one
+        dense = torch.zeros(int(cnt64.sum().item()) * 2 + 8, dtype=torch.uint8, device=dev)
+        sync()
         aligner.decode_edit_stream(self.n, v["stream"], v["off"], v["len"], read_len, read_len_stride, off, dense,
-                                   v["cnt"], bad, **params)
-        if dense.is_cuda:
-            torch.cuda.synchronize()
-        return dense, off, int(bad.item())
+                                   cnt, bad, **params)
+        sync()
+        return dense, cnt, off, int(bad.item())

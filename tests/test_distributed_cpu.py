@@ -156,7 +156,7 @@ def test_bench_generator_shapes_on_cpu():
     assert 0.06 * L < np.mean(eds) < 0.14 * L
 
 
-def _worker_edits(rank, world, port, q):
+def _worker_edits(rank, world, port, q, ordered):
     import os
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -167,21 +167,22 @@ def _worker_edits(rank, world, port, q):
     try:
         # each rank "aligned" its own three reads; CIGARs (W=64, O=33) -> edit streams with the host encoder
         cigars = [["5=1X4=", "31=31=9=", "2I3="], ["1D30=1=1X29=11=", "", "31=1I30=9="]][rank]
-        read_len = [[10, 71, 5], [72, 0, 71]][rank]
         streams = [api.cigar_to_edit_stream(c) for c in cigars]
         n = 3
         total = sum((len(s) + 3) // 4 * 4 for s in streams)
-        g = sd.EditStreamGather(n, total, torch.device("cpu"), dst=0, depth=2)
+        g = sd.EditStreamGather(n, total, torch.device("cpu"), dst=0, depth=2, ordered=ordered)
+        order = [0, 1, 2] if ordered else [2, 0, 1]          # not ordered: the streams sit anywhere, offsets travel
         for k in range(3):
             g.finish(k)
             v = g.buffers(k)
             at = 0
-            for i, s in enumerate(streams):
+            for i in order:
+                s = streams[i]
                 v["off"][i], v["len"][i] = at, len(s)
                 v["stream"][at: at + len(s)] = torch.frombuffer(bytearray(s), dtype=torch.uint8) if s else torch.zeros(0, dtype=torch.uint8)
                 at += (len(s) + 3) // 4 * 4
             ed = torch.tensor([sum(1 for b in s if b >> 6) + k for s in streams], dtype=torch.int64)
-            g.start(k, ed, torch.tensor([len(c) for c in cigars], dtype=torch.int32))
+            g.start(k, ed)
         g.finish_all()
         if rank == 0:
             out = []
@@ -196,14 +197,16 @@ def _worker_edits(rank, world, port, q):
 
 
 @pytest.mark.timeout(180)
-def test_edit_stream_gather():
-    """EditStreamGather: one fixed-size collective per step carrying scores, stream offsets/lengths and the edit
-    streams of every rank; what arrives on rank 0 decodes (host decoder) to each rank's CIGARs."""
+@pytest.mark.parametrize("ordered", [True, False])
+def test_edit_stream_gather(ordered):
+    """EditStreamGather: one fixed-size collective per step carrying scores, stream lengths (and offsets, when the
+    streams are not in pair order) and the edit streams of every rank; what arrives on rank 0 decodes (host decoder)
+    to each rank's CIGARs."""
     from scrooge_amd import api
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_edits, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker_edits, args=(r, 2, port, q, ordered)) for r in range(2)]
     for p in procs:
         p.start()
     out = q.get(timeout=150)
@@ -216,4 +219,4 @@ def test_edit_stream_gather():
         eds, streams, total, wire = out[r]
         assert [api.edit_stream_to_cigar(s, L) for s, L in zip(streams, read_len[r])] == cigars[r]
         assert eds == [sum(1 for b in s if b >> 6) + 2 for s in streams]
-        assert wire == 24 * 3 + 8                       # scalars + the larger rank's stream, padded to 8 bytes
+        assert wire == (8 * 4 if ordered else 8 * 4 + 8 * 3) + 8            # scalars (int32 arrays padded to 8 bytes) + streams
