@@ -112,6 +112,25 @@ __device__ __forceinline__ Planes load_window_strided(const uint64_t* __restrict
     return r;
 }
 
+// The same in two steps, so that the loads can be issued long before the words are needed: the three words a window
+// can touch, then the funnel shifts.
+struct WindowWords { uint64_t a, b, c; uint32_t s; };
+__device__ __forceinline__ WindowWords load_window_words(const uint64_t* __restrict__ seq, uint64_t off, uint32_t k, uint32_t stride)
+{
+    const uint32_t inner = ((uint32_t)off & 31u) + k;
+    const uint64_t w = (off >> 5) + (uint64_t)(inner >> 5) * stride;
+    return WindowWords{seq[w], seq[w + stride], seq[w + 2u * stride], inner & 31u};
+}
+__device__ __forceinline__ Planes window_planes(const WindowWords& v)
+{
+    const uint32_t l0 = (uint32_t)v.a, l1 = (uint32_t)v.b, l2 = (uint32_t)v.c;
+    const uint32_t h0 = (uint32_t)(v.a >> 32), h1 = (uint32_t)(v.b >> 32), h2 = (uint32_t)(v.c >> 32);
+    Planes r;
+    r.lo = (uint64_t)__builtin_amdgcn_alignbit(l1, l0, v.s) | ((uint64_t)__builtin_amdgcn_alignbit(l2, l1, v.s) << 32);
+    r.hi = (uint64_t)__builtin_amdgcn_alignbit(h1, h0, v.s) | ((uint64_t)__builtin_amdgcn_alignbit(h2, h1, v.s) << 32);
+    return r;
+}
+
 // Conditions as 0 / ~0 masks.  Written as asm / intrinsics so that the optimiser cannot turn them
 // back into v_cmp + v_cndmask (both half rate on gfx950; v_ashrrev, v_sub and v_bitop3 are full rate).
 __device__ __forceinline__ uint32_t neg_mask(uint32_t x)      // ~0 iff (int32)x < 0

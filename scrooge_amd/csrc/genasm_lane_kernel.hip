@@ -194,6 +194,7 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
     uint32_t flushed = 0;              // runs below this index are in HBM (a multiple of 16); EDITS: bytes, a multiple of 32
     uint32_t pos = 0;                  // EDITS: bytes of the pair's stream so far
     uint32_t mbase = 0;                // EDITS: matches pending at column c of the current window = mbase + c
+    WindowWords twords = {0, 0, 0, 0}, pwords = {0, 0, 0, 0};     // the words of my next text / read window (loaded ahead)
     bool queue_empty = false;          // wave-uniform
     const bool timing = a.stats != nullptr;
     uint64_t cy_fetch = 0, cy_setup = 0, cy_dc = 0, cy_tb = 0, cy_p1 = 0;
@@ -297,6 +298,8 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
                 ref_idx = read_idx = edits = flushed = pos = mbase = 0;
                 nr = -1;
                 has_pair = true;
+                twords = load_window_words(a.seq, text_off, 0u, a.text_stride);
+                pwords = load_window_words(a.seq, read_off, 0u, a.read_stride);
             }
         }
         if (!__any(has_pair)) break;
@@ -305,10 +308,11 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
         // ---------------- window setup (genasm_cpu.cpp:417-420) ----------------
         const uint32_t n = (has_pair && ref_idx < text_len) ? min(W, text_len - ref_idx) : 0u;
         const uint32_t m = has_pair ? min(W, read_len - read_idx) : 1u;      // >= 1 for live pairs
+        // (the words were loaded when the pair was fetched, or before the previous round's second traceback pass)
         Planes tw = {0, 0}, pw = {0, 0};
         if (has_pair) {
-            tw = load_window_strided(a.seq, text_off, ref_idx, a.text_stride);
-            pw = load_window_strided(a.seq, read_off, read_idx, a.read_stride);
+            tw = window_planes(twords);
+            pw = window_planes(pwords);
         }
         const uint64_t tm2 = timing ? __builtin_readcyclecounter() : 0;
 
@@ -382,6 +386,11 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
             edits += j - ti + 2u * nD + nX;             // insertions (j - (ti - nD)) + deletions + substitutions
             ref_idx += ti;
             read_idx += j;
+            // the next window's words, asked for now: the second pass below hides the latency.  (Every lane loads: a
+            // pair that is finished reads its padding, a lane without a pair its last pair's, and the registers are
+            // not alive across the table that way.)
+            twords = load_window_words(a.seq, text_off, ref_idx, a.text_stride);
+            pwords = load_window_words(a.seq, read_off, read_idx < read_len ? read_idx : 0u, a.read_stride);     // (never past a finished read)
 
             // Pass 2.  The next column with an event: an insertion run, then (if B) the run of steps that starts
             // there.  Both words go to the slot after the last committed run; only committing moves on.  (A lane
