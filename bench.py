@@ -184,7 +184,8 @@ def main():
 
     al = scrooge_amd.Aligner(local_rank)
     al.set_stream(torch.cuda.current_stream().cuda_stream)
-    n_lanes = 1 if (args.serial or args.stats or args.ablate) else max(1, args.streams)      # software pipeline depth over streams
+    stats_pipelined = args.stats and os.environ.get("SCRG_BENCH_STATS_PIPELINED") == "1"     # counters of one launch among overlapping ones
+    n_lanes = 1 if (args.serial or (args.stats and not stats_pipelined) or args.ablate) else max(1, args.streams)      # software pipeline depth over streams
     kw = {}
     if args.lanes:
         kw["lanes_per_pair"] = args.lanes
@@ -196,6 +197,8 @@ def main():
     geom = al.query_launch(**kw)
     if args.stats:
         al.params.reserved[1] = 1
+    if os.environ.get("SCRG_BENCH_DEBUG_FLAGS"):      # experiment knob: switches of scrg_params.reserved[0] that leave the results intact
+        al.params.reserved[0] = int(os.environ["SCRG_BENCH_DEBUG_FLAGS"])
     if args.ablate:
         al.params.reserved[0] = args.ablate     # results are wrong by design; parity checks are skipped
         args.cpu_seconds = 0
@@ -425,7 +428,7 @@ def main():
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)
     # reference point outside the timed region: the same step on ONE stream (no overlap between launches)
     serial = None
-    if n_lanes > 1 and not dist_on:
+    if n_lanes > 1 and not dist_on and not args.stats:
         sev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(3)]
         o = outs[0]
         torch.cuda.synchronize()
@@ -453,6 +456,9 @@ def main():
         r = max(1, st["rounds"])
         for k in ("fetch", "setup", "table", "pass1", "traceback"):
             st["cyc_per_round_" + k] = st["cycles_" + k] / r
+        # shader clock while the kernel ran: cycles the wavefronts counted / their life time on the 100 MHz wall clock
+        busy = st["cycles_fetch"] + st["cycles_setup"] + st["cycles_table"] + st["cycles_traceback"]
+        st["shader_clock_ghz"] = busy / max(1, st["life_ticks_sum"]) * 0.1
         print("stats(last launch):", st, file=sys.stderr)
     elif args.stats:
         st = al.debug_stats()
@@ -530,7 +536,7 @@ def main():
     # scaling figure the same step — align kernel with edit-stream output + compaction of the streams, pipelined
     # over the same streams, no collective — is timed here on one GPU, after everything above (it reuses the slices).
     edit_stream_step = None
-    if not dist_on and n_lanes > 1 and not args.ablate and p.lanes_per_pair == 1 and p.W <= 64 and p.W - p.O <= 31:
+    if not dist_on and n_lanes > 1 and not args.ablate and not args.stats and p.lanes_per_pair == 1 and p.W <= 64 and p.W - p.O <= 31:
         lens = [torch.empty(n, dtype=torch.int32, device=device) for _ in range(n_lanes)]
         aligners[0].align_device_edits(n, seq, desc, outs[0]["runs"], outs[0]["ed"], lens[0], outs[0]["status"], **kw)
         torch.cuda.synchronize()

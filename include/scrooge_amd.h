@@ -309,8 +309,9 @@ scrg_status scrg_last_kernel_ms(scrg_ctx *ctx, float *ms);
  *     fetch / window setup / DC / TB / TB loop, rounds on the diagonal-major path, rounds that fell back from it,
  *     DC / TB cycles of the diagonal-major rounds (not included in the former)}.
  * params.reserved[0] holds ablation switches for profiling and must be 0 for correct results, except:
- *   lanes_per_pair = 1: 1 only turns the wavefront priority rotation off (results intact); 2 / 4 / 8 / 16 skip the
- *     table, traceback pass 2, traceback pass 1, the CIGAR stores (results are wrong by design);
+ *   lanes_per_pair = 1: 1 only turns the wavefront priority rotation off, 64 / 128 launch workgroups of one / two
+ *     wavefronts instead of four (results intact); 2 / 4 / 8 / 16 skip the table, traceback pass 2, traceback pass 1,
+ *     the CIGAR stores (results are wrong by design);
  *   lanes_per_pair = 8: 32 only turns the diagonal-major path off (results intact). */
 scrg_status scrg_debug_stats(scrg_ctx *ctx, uint64_t out[12]);
 

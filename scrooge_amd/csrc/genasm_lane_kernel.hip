@@ -530,8 +530,10 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
 hipError_t launch_align_lane(const AlignArgs& a, int grid, size_t lds_bytes, hipStream_t s, bool edits)
 {
     // grid counts wavefronts, lds_bytes is per wavefront
-    if (edits) hipLaunchKernelGGL(genasm_lane_kernel<true>, dim3((grid + 3) / 4), dim3(256), 4 * lds_bytes, s, a);
-    else hipLaunchKernelGGL(genasm_lane_kernel<false>, dim3((grid + 3) / 4), dim3(256), 4 * lds_bytes, s, a);
+    const unsigned wpg = (a.debug & 64) ? 1u : ((a.debug & 128) ? 2u : 4u);      // experiment: wavefronts per workgroup
+    const dim3 g((grid + wpg - 1) / wpg), b(64 * wpg);
+    if (edits) hipLaunchKernelGGL(genasm_lane_kernel<true>, g, b, wpg * lds_bytes, s, a);
+    else hipLaunchKernelGGL(genasm_lane_kernel<false>, g, b, wpg * lds_bytes, s, a);
     return hipGetLastError();
 }
 
