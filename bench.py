@@ -50,6 +50,8 @@ def parse():
                     help="N > 1: how CIGARs travel to rank 0 — edit streams, 1 byte per edit, written by the align kernel "
                          "itself (default; W-O <= 31) or encoded from its runs (edits-from-runs: any W/O), packed runs "
                          "(1 byte per run, restored on rank 0 inside the timed region) or scrg_run pairs")
+    ap.add_argument("--sustained-steps", type=int, default=150,
+                    help="N = 1: after the timed region, time this many more pipelined steps for the 'sustained' field (0 = skip)")
     ap.add_argument("--streams", type=int, default=4, help="pipeline depth: consecutive steps rotate over this many streams/handles")
     ap.add_argument("--no-build", action="store_true",
                     help="never rebuild the library (profiling: nothing may fork a compiler under rocprofv3)")
@@ -444,6 +446,22 @@ def main():
         serial = {"ms_per_step": (time.perf_counter() - ts) / 3 * 1e3,
                   "kernel_ms": sum(a_.elapsed_time(b_) for a_, b_ in sev) / 3}
         serial["value"] = n / (serial["ms_per_step"] * 1e-3)
+    # Reference point outside the timed region: the same pipelined step over many more steps.  K timed steps contain
+    # one pipeline fill and one drain — a 10 kb pair is ~334 dependent window rounds, so the last launch cannot finish
+    # sooner than ~2.5 ms after it starts, whatever the rate of the steps before it; at K = 20 that is ~10 % of the
+    # timed region.
+    sustained = None
+    if n_lanes > 1 and not dist_on and not args.stats and args.sustained_steps > 0:
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        for _ in range(args.sustained_steps):
+            step()
+        torch.cuda.synchronize()
+        sdt = time.perf_counter() - ts
+        sustained = {"steps": args.sustained_steps, "value": n * args.sustained_steps / sdt, "unit": "pairs/s",
+                     "ms_per_step": sdt / args.sustained_steps * 1e3}
+        last = (step.count - 1) % n_lanes
+        ed, n_runs, dense = outs[last]["ed"], outs[last]["n_runs"], denses[last]
     # duration of one align launch for the roofline line: events around a launch that has the GPU to itself.
     # (Events around a pipelined launch also contain the time its wavefronts wait for the previous launch's
     # to retire; rocprofv3 timestamps start at the first dispatch and agree with the stand-alone figure.)
@@ -604,6 +622,7 @@ def main():
         "kernel_pairs_per_s_per_gpu": n / (kernel_ms * 1e-3),
         "kernel_ms_events_in_timed_region": events_ms,   # pipelined launches: includes waiting for the previous launch's wavefronts to retire
         "serial": serial,              # the same step without overlap between launches, measured after the timed region
+        "sustained": sustained,        # the same pipelined step over many more steps (fill and drain amortised), after the timed region
         "edit_stream_step": edit_stream_step,   # the N > 1 step (CIGARs as edit streams) on this one GPU, without the collective
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
