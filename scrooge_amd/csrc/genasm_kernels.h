@@ -38,8 +38,6 @@ hipError_t launch_align_multiword(int lanes_per_pair, const AlignArgs& a, int gr
 // lanes_per_pair = 1: one pair per lane, 64 pairs per wavefront (genasm_lane_kernel.hip; W <= 64, W-O <= 31)
 // (edits: the pairs' slices receive edit streams instead of runs, n_runs their lengths in bytes — scrg_align_device_edits)
 hipError_t launch_align_lane(const AlignArgs& a, int grid, size_t lds_bytes, hipStream_t s, bool edits = false);
-// the same for W-O > 31 (genasm_lane_wide_kernel.hip): 64-bit table rows in LDS, one wavefront per workgroup
-hipError_t launch_align_lane_wide(const AlignArgs& a, int grid, size_t lds_bytes, hipStream_t s);
 
 // dwords of one stored row of R (the part the traceback can reach):
 //   W <= 64: the high dword of columns 0..31, or whole entries of all 64 columns when W-O > 31;
@@ -49,10 +47,12 @@ hipError_t launch_align_lane_wide(const AlignArgs& a, int grid, size_t lds_bytes
 #else
 #define SCRG_HD
 #endif
-// genasm_lane_wide_kernel: LDS per wavefront = CIGAR ring + run lengths + two 64-bit table words for each of the W-O
-// columns (+ bank skew)
-SCRG_HD inline unsigned lane_wide_tab_bytes(int tb_limit) { return (unsigned)tb_limit * 16u + 32u; }
-SCRG_HD inline unsigned lane_wide_lds_bytes(int tb_limit) { return 64u * (68u + 68u + lane_wide_tab_bytes(tb_limit)); }
+// genasm_lane_mw_kernel (W-O > 31 or W > 64): LDS per wavefront = CIGAR ring + one length byte for each of the W-O columns;
+// its table — two rows of (W-O)/64 + 1 64-bit words for each of the W-O columns, for 64 lanes — is a slab of HBM
+SCRG_HD inline unsigned lane_mw_len_bytes(int tb_limit) { return (((unsigned)tb_limit + 3u) & ~3u) + 4u; }
+SCRG_HD inline unsigned lane_mw_lds_bytes(int tb_limit) { return 64u * (68u + lane_mw_len_bytes(tb_limit)); }
+SCRG_HD inline size_t lane_mw_table_bytes(int tb_limit) { return (size_t)tb_limit * 2u * ((unsigned)tb_limit / 64u + 1u) * 64u * 8u; }
+hipError_t launch_align_lane_mw(const AlignArgs& a, int grid, size_t lds_bytes, hipStream_t s);
 
 SCRG_HD inline unsigned stored_row_dwords(int W, int tb_limit)
 {

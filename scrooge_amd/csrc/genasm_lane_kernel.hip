@@ -1,6 +1,6 @@
 // genasm_lane_kernel.hip — the lane-per-pair aligner for gfx950 (W <= 64, W-O <= 31): every lane of a
 // wavefront aligns its own read pair, 64 pairs per wavefront, the window's traceback table in VGPRs.
-// (W-O > 31: genasm_lane_wide_kernel.hip, the same arithmetic with 64-bit table rows in LDS.)
+// (W-O > 31 and W > 64: genasm_lane_mw_kernel.hip, the same arithmetic with multi-word rows and the table in HBM.)
 //
 // What is computed is the reference's windowed GenASM (src/genasm_cpu.cpp:411-438: window loop, :210-288
 // distance calculation, :290-409 traceback); how the table is held is different.  Bit j of R[i][d] is clear

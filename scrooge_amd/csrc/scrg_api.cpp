@@ -369,17 +369,21 @@ static bool resolve_params(const scrg_params* in, scrg_params* p)
     if (tbl < 1 || p->O < 1) return false;   // O = 0 (no overlap) would let the traceback read the boundary column
     const size_t row_bytes = (size_t)scrg::stored_row_dwords(p->W, tbl) * 4;
     if (p->W > 64) {
-        // multi-word entries (genasm_kernel_multiword.hip): slots of 32 or 64 lanes; as many rows of R
-        // in LDS as fit in about 40 KB per wavefront, the rest of a window's rows go to HBM
-        if (p->lanes_per_pair == 0) p->lanes_per_pair = 32;    // measured faster than 64 also at W = 256
-        if (p->lanes_per_pair != 32 && p->lanes_per_pair != 64) return false;
-        if (p->lds_rows == 0) {
+        // one pair per lane here too (genasm_lane_mw_kernel.hip: multi-word difference vectors, the table in HBM); the
+        // GenASM-row kernel with multi-word entries (genasm_kernel_multiword.hip) stays selectable: slots of 32 or 64
+        // lanes; as many rows of R in LDS as fit in about 40 KB per wavefront, the rest of a window's rows go to HBM
+        if (p->lanes_per_pair == 0) p->lanes_per_pair = 1;
+        if (p->lanes_per_pair != 1 && p->lanes_per_pair != 32 && p->lanes_per_pair != 64) return false;
+        if (p->lanes_per_pair == 1) {
+            if (p->lds_rows == 0) p->lds_rows = 12;                 // (not used)
+            if (p->waves_per_cu == 0) p->waves_per_cu = 8;          // two per SIMD: the kernel needs up to 256 VGPRs
+        } else if (p->lds_rows == 0) {
             const size_t fit = (40u << 10) / (row_bytes * (64 / p->lanes_per_pair));
             p->lds_rows = (int32_t)std::min<size_t>(32, std::max<size_t>(4, fit));
         }
     } else {
         // one pair per lane for every W <= 64: genasm_lane_kernel.hip (table in registers) while a window's traceback
-        // consumes at most W-O <= 31 characters, genasm_lane_wide_kernel.hip (64-bit rows, table in LDS) beyond
+        // consumes at most W-O <= 31 characters, genasm_lane_mw_kernel.hip (64-bit rows, table in HBM) beyond
         if (p->lanes_per_pair == 0) p->lanes_per_pair = 1;
         if (p->lds_rows == 0) p->lds_rows = 12;
     }
@@ -401,7 +405,8 @@ static bool resolve_params(const scrg_params* in, scrg_params* p)
 
 static size_t lds_bytes_for(const scrg_params& p)
 {
-    if (p.lanes_per_pair == 1 && p.W - p.O > 31) return scrg::lane_wide_lds_bytes(p.W - p.O);   // 64-bit table rows, W-O columns
+    if (p.lanes_per_pair == 1 && (p.W > 64 || p.W - p.O > 31))
+        return scrg::lane_mw_lds_bytes(p.W - p.O);   // genasm_lane_mw_kernel: CIGAR ring + insertion-run lengths (the table is in HBM)
     if (p.lanes_per_pair == 1) return 64 * (68 + 36 + 32 + 8);  // per lane: CIGAR staging ring (32 runs + 1 dword), insertion-run lengths of a window, Eq table (+ the "no match" word)
     const size_t slots = 64 / p.lanes_per_pair;
     // per slot: CIGAR staging ring (16 dwords) + 1 scratch dword + R rows (+1 dword against bank
@@ -482,7 +487,10 @@ static scrg_status align_device_impl(scrg_ctx* c, const scrg_params* params, uin
     HIP_TRY(c, c->counter.ensure(sizeof(uint32_t)));
     const size_t spill_rows = p.W > 64 ? (size_t)p.W + 1 : scrg::SPILL_ROWS;
     const size_t spill_row_dw = scrg::stored_row_dwords(p.W, p.W - p.O);
-    if (p.lanes_per_pair != 1)           // (the one-pair-per-lane kernel keeps its table in registers: nothing spills)
+    const bool lane_mw = p.lanes_per_pair == 1 && (p.W > 64 || p.W - p.O > 31);      // rows of more than 32 bits: genasm_lane_mw_kernel
+    if (lane_mw)                         // its window tables: one slab of HBM per wavefront
+        HIP_TRY(c, c->spill.ensure((size_t)n_waves * scrg::lane_mw_table_bytes(p.W - p.O)));
+    else if (p.lanes_per_pair != 1)      // (genasm_lane_kernel keeps its table in registers: nothing spills)
         HIP_TRY(c, c->spill.ensure((size_t)n_waves * ppw * spill_rows * spill_row_dw * sizeof(uint32_t)));
     HIP_TRY(c, hipMemsetAsync(c->counter.p, 0, sizeof(uint32_t), c->stream));
 
@@ -510,10 +518,10 @@ static scrg_status align_device_impl(scrg_ctx* c, const scrg_params* params, uin
     }
 
     HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));
-    if (p.W > 64)
+    if (lane_mw)
+        HIP_TRY(c, scrg::launch_align_lane_mw(a, n_waves, (size_t)lds, c->stream));
+    else if (p.W > 64)
         HIP_TRY(c, scrg::launch_align_multiword(p.lanes_per_pair, a, n_waves, (size_t)lds, c->stream));
-    else if (p.lanes_per_pair == 1 && p.W - p.O > 31)
-        HIP_TRY(c, scrg::launch_align_lane_wide(a, n_waves, (size_t)lds, c->stream));
     else if (p.lanes_per_pair == 1)
         HIP_TRY(c, scrg::launch_align_lane(a, n_waves, (size_t)lds, c->stream, edits));
     else

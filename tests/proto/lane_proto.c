@@ -239,3 +239,143 @@ int lane_align_codes(const uint8_t *text, size_t text_len, const uint8_t *read, 
     *n_runs = out.n; *edit_distance = total;
     return out.overflow ? GO_ERR_CAPACITY : GO_OK;
 }
+
+/* ------------------------------------------------------------------------------------------------------------
+ * W > 64 (genasm_lane_mw_kernel.hip): the same difference-vector table with multi-word vectors.  A pattern vector
+ * has NW = ceil(W/64) words, word 0 the MOST significant (bit 63-k of word w <-> pattern character 64 w + k); the
+ * traceback only looks at rows j <= W-O, so a table row keeps the top RW = (W-O)/64 + 1 words.  Two passes as in
+ * lane_tb, on RW-word masks.
+ * ---------------------------------------------------------------------------------------------------------- */
+#define MW_MAXNW 4
+#define MW_MAXRW 4
+typedef struct { uint64_t w[MW_MAXRW]; } mw_row;
+
+static mw_row mwr_shl(mw_row a, unsigned s, int RW)            /* towards word 0 */
+{
+    mw_row r = { {0} };
+    for (int k = 0; k < RW; k++) {
+        unsigned src = k + s / 64, b = s % 64;
+        uint64_t v = 0;
+        if ((int)src < RW) v = a.w[src] << b;
+        if (b && (int)src + 1 < RW) v |= a.w[src + 1] >> (64 - b);
+        r.w[k] = v;
+    }
+    return r;
+}
+static mw_row mwr_shr1(mw_row a, int RW)
+{
+    mw_row r = { {0} };
+    for (int k = 0; k < RW; k++) r.w[k] = (a.w[k] >> 1) | (k ? a.w[k - 1] << 63 : 0);
+    return r;
+}
+static unsigned mwr_clz(mw_row a, int RW)
+{
+    unsigned n = 0;
+    for (int k = 0; k < RW; k++) { if (a.w[k]) return n + (unsigned)__builtin_clzll(a.w[k]); n += 64; }
+    return n;
+}
+static mw_row mwr_bit(unsigned c, int RW) { mw_row r = { {0} }; if ((int)(c / 64) < RW) r.w[c / 64] = 0x8000000000000000ull >> (c % 64); return r; }
+static int mwr_test(mw_row a, unsigned c) { return (int)((a.w[c / 64] >> (63 - c % 64)) & 1); }
+static unsigned mwr_pop(mw_row a, int RW) { unsigned n = 0; for (int k = 0; k < RW; k++) n += (unsigned)__builtin_popcountll(a.w[k]); return n; }
+static int mwr_any(mw_row a, int RW) { for (int k = 0; k < RW; k++) if (a.w[k]) return 1; return 0; }
+
+int lane_align_codes_mw(const uint8_t *text, size_t text_len, const uint8_t *read, size_t read_len, int W, int O,
+                        go_run *runs, size_t cap, size_t *n_runs, long long *edit_distance, lane_stats *ls)
+{
+    if (W < 2 || W > 256 || O < 1 || O >= W) return GO_ERR_PARAMS;
+    const int NW = (W + 63) / 64, TBL = W - O, RW = TBL / 64 + 1;
+    run_sink out = { runs, cap, 0, 0 };
+    size_t tpos = 0, rpos = 0; long long total = 0;
+    static _Thread_local mw_row NV1[256], V0[256];
+    while (rpos < read_len) {
+        const int n = (int)(text_len - tpos < (size_t)W ? text_len - tpos : (size_t)W);
+        const int m = (int)(read_len - rpos < (size_t)W ? read_len - rpos : (size_t)W);
+        const int jlim = m < TBL ? m : TBL;
+        const mw_row stop = mwr_bit((unsigned)jlim, RW);
+        /* reversed pattern, left-aligned over NW words; valid = the top m bits */
+        uint64_t Rlo[MW_MAXNW] = {0}, Rhi[MW_MAXNW] = {0}, valid[MW_MAXNW] = {0};
+        for (int k = 0; k < 64 * NW; k++) {
+            const uint8_t qc = k < m ? read[rpos + k] : (uint8_t)((k * 7 + 3) & 3);
+            Rlo[k / 64] |= (uint64_t)(qc & 1) << (63 - k % 64);
+            Rhi[k / 64] |= (uint64_t)(qc >> 1) << (63 - k % 64);
+            if (k < m) valid[k / 64] |= 1ull << (63 - k % 64);
+        }
+        uint64_t Pv[MW_MAXNW], Mv[MW_MAXNW] = {0};
+        for (int w = 0; w < NW; w++) Pv[w] = valid[w];
+        for (int i = 64 * NW - 1; i >= 0; i--) {
+            const uint8_t tc = i < n ? text[tpos + i] : (uint8_t)((i * 5 + 1) & 3);
+            const uint64_t sl = 0ull - (uint64_t)(tc & 1), sh = 0ull - (uint64_t)(tc >> 1);
+            uint64_t Eq[MW_MAXNW], Xv[MW_MAXNW], Xh[MW_MAXNW], Ph[MW_MAXNW], Mh[MW_MAXNW], Pvn[MW_MAXNW], Mvn[MW_MAXNW];
+            unsigned carry = 0;
+            for (int w = NW - 1; w >= 0; w--) {                 /* the add: carries run from the last word to word 0 */
+                Eq[w] = (i < n ? ~((Rlo[w] ^ sl) | (Rhi[w] ^ sh)) : 0ull) | ~valid[w];
+                Xv[w] = Eq[w] | Mv[w];
+                const uint64_t t = Eq[w] & Pv[w];
+                const unsigned __int128 s = (unsigned __int128)t + Pv[w] + carry;
+                carry = (unsigned)(s >> 64);
+                Xh[w] = (((uint64_t)s) ^ Pv[w]) | Eq[w];
+                Ph[w] = Mv[w] | ~(Xh[w] | Pv[w]);
+                Mh[w] = Pv[w] & Xh[w];
+            }
+            for (int w = 0; w < NW; w++) {
+                const uint64_t ph1 = (Ph[w] << 1) | (w + 1 < NW ? Ph[w + 1] >> 63 : 0);
+                const uint64_t mh1 = (Mh[w] << 1) | (w + 1 < NW ? Mh[w + 1] >> 63 : 0);
+                Pvn[w] = mh1 | ~(Xv[w] | ph1);
+                Mvn[w] = ph1 & Xv[w];
+            }
+            if (i < TBL)
+                for (int r = 0; r < RW; r++) {
+                    NV1[i].w[r] = ~((Pvn[r] | Ph[r]) | stop.w[r]);
+                    V0[i].w[r] = (Pvn[r] | ~(Ph[r] | Xh[r])) | stop.w[r];
+                }
+            for (int w = 0; w < NW; w++) { Pv[w] = Pvn[w]; Mv[w] = Mvn[w]; }
+            ls->columns++;
+        }
+        /* pass 1 */
+        unsigned j = 0;
+        mw_row nDm = { {0} }, Xm = { {0} }, nIm = { {0} };
+        uint8_t ilen[256];
+        for (int i = 0; i < TBL; i++) {
+            mw_row x;
+            for (int r = 0; r < RW; r++) x.w[r] = NV1[i].w[r] | ~V0[i].w[r] | stop.w[r];
+            x = mwr_shl(x, j, RW);
+            const unsigned ni = mwr_clz(x, RW);
+            ilen[i] = (uint8_t)ni;
+            nIm = mwr_shl(nIm, 1, RW); nIm.w[RW - 1] |= x.w[0] >> 63;
+            j += ni;
+            const mw_row nt1 = mwr_shl(NV1[i], j, RW), t0 = mwr_shl(V0[i], j, RW);
+            nDm = mwr_shl(nDm, 1, RW); nDm.w[RW - 1] |= nt1.w[0] >> 63;
+            Xm = mwr_shl(Xm, 1, RW); Xm.w[RW - 1] |= t0.w[0] >> 63;
+            j += (unsigned)(nt1.w[0] >> 63);
+            ls->tb_columns++;
+        }
+        const unsigned nsh = 64u * (unsigned)RW - (unsigned)TBL;
+        mw_row Draw = mwr_shl(nDm, nsh, RW), Xraw = mwr_shl(Xm, nsh, RW), Im, dead, A, D, X, B, E;
+        for (int r = 0; r < RW; r++) { Draw.w[r] = ~Draw.w[r]; Im.w[r] = ~nIm.w[r]; }
+        Im = mwr_shl(Im, nsh, RW);                               /* (complemented before the shift: nothing below column TBL-1) */
+        const mw_row lim = mwr_bit((unsigned)TBL, RW);
+        for (int r = 0; r < RW; r++) dead.w[r] = (Draw.w[r] & Xraw.w[r]) | lim.w[r];
+        const unsigned ti = mwr_clz(dead, RW);
+        for (int r = 0; r < RW; r++) {                       /* A = the top ti bits */
+            const int lo = 64 * r;
+            A.w[r] = (int)ti >= lo + 64 ? ~0ull : ((int)ti <= lo ? 0ull : ~(~0ull >> (ti - (unsigned)lo)));
+        }
+        for (int r = 0; r < RW; r++) { D.w[r] = Draw.w[r] & A.w[r]; X.w[r] = Xraw.w[r] & A.w[r]; }
+        const mw_row D1 = mwr_shr1(D, RW), X1 = mwr_shr1(X, RW);
+        for (int r = 0; r < RW; r++) B.w[r] = ((D.w[r] ^ D1.w[r]) | (X.w[r] ^ X1.w[r]) | Im.w[r] | (r == 0 ? 0x8000000000000000ull : 0)) & A.w[r];
+        total += (long long)(j - ti + 2u * mwr_pop(D, RW) + mwr_pop(X, RW));
+        for (int r = 0; r < RW; r++) E.w[r] = B.w[r] | Im.w[r];
+        while (mwr_any(E, RW)) {
+            const unsigned c = mwr_clz(E, RW);
+            if (mwr_test(Im, c)) sink_push(&out, 'I', ilen[c]);
+            E.w[c / 64] &= ~(0x8000000000000000ull >> (c % 64));
+            unsigned nx = mwr_clz(E, RW);
+            if (nx > ti) nx = ti;
+            if (mwr_test(B, c)) sink_push(&out, mwr_test(D, c) ? 'D' : (mwr_test(X, c) ? 'X' : '='), nx - c);
+        }
+        ls->windows++;
+        tpos += ti; rpos += j;
+    }
+    *n_runs = out.n; *edit_distance = total;
+    return out.overflow ? GO_ERR_CAPACITY : GO_OK;
+}

@@ -47,9 +47,12 @@ def test_defaults_match_reference_knobs(lib):
     assert lib.scrg_params_resolve(p, r) == 0
     assert (r.W, r.O, r.lanes_per_pair) == (64, 33, 1) and r.lds_rows > 0 and r.waves_per_cu > 0
     p.W, p.O = 128, 65
-    assert lib.scrg_params_resolve(p, r) == 0 and r.lanes_per_pair == 32
+    assert lib.scrg_params_resolve(p, r) == 0 and r.lanes_per_pair == 1       # one pair per lane for every W
     p.W, p.O = 256, 129
-    assert lib.scrg_params_resolve(p, r) == 0 and r.lanes_per_pair == 32
+    assert lib.scrg_params_resolve(p, r) == 0 and r.lanes_per_pair == 1
+    p.lanes_per_pair = 32
+    assert lib.scrg_params_resolve(p, r) == 0 and r.lanes_per_pair == 32 and r.lds_rows > 0
+    p.lanes_per_pair = 0
     p.W, p.O = 257, 129
     assert lib.scrg_params_resolve(p, r) != 0
     p.W, p.O = 64, 0

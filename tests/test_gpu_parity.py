@@ -127,7 +127,7 @@ def test_other_window_settings(aligner, oracle, w, o):
 def test_small_overlap_uses_wide_storage(aligner, oracle, w, o, g):
     """W-O > 31 (e.g. the reference's O sweep down to small overlaps, scripts/profile.py:88-100; README's
     W=64,O=2 row): the traceback may consume up to W-O characters per window, so whole 64-bit entries of
-    all columns are stored (kernel variant WIDE; one pair per lane: genasm_lane_wide_kernel, table in LDS)."""
+    all columns are stored (kernel variant WIDE; one pair per lane: genasm_lane_mw_kernel, 64-bit rows, table in HBM)."""
     t, q = synth.make_pairs(50, 400, "ont", seed=w * 31 + o)
     rng = np.random.Generator(np.random.PCG64(w + o))
     for _ in range(80):
@@ -148,10 +148,11 @@ def test_long_reads_10kb(aligner, oracle):
 
 @pytest.mark.parametrize("name", ["pairs_w128_o65.json", "pairs_w96_o49.json", "pairs_w256_o129.json",
                                   "pairs_w192_o97.json", "pairs_w128_o20.json", "pairs_w200_o50.json"])
-@pytest.mark.parametrize("g", [32, 64])
+@pytest.mark.parametrize("g", [1, 32, 64])
 def test_golden_windows_over_64(aligner, name, g):
     """Reference fixtures built with -DCLI_W=96 ... 256 (the reference's bitvector<N> path,
-    src/bitvector.hpp:45-48): multi-word entries here (genasm_kernel_multiword.hip)."""
+    src/bitvector.hpp:45-48): one pair per lane with multi-word difference vectors (genasm_lane_mw_kernel.hip, the
+    default) and the GenASM-row kernel with multi-word entries (genasm_kernel_multiword.hip; lds_rows: its spill path)."""
     from tests.conftest import load_golden
     gd = load_golden(name)
     cases = gd["cases"]
@@ -164,8 +165,8 @@ def test_golden_windows_over_64(aligner, name, g):
 
 
 @pytest.mark.parametrize("w,o", [(128, 65), (96, 49), (100, 40), (65, 2), (128, 127), (127, 64), (80, 41),
-                                 (256, 129), (256, 1), (129, 65), (192, 64), (255, 200), (160, 81)])
-@pytest.mark.parametrize("g", [32, 64])
+                                 (256, 129), (256, 1), (129, 65), (192, 64), (255, 200), (160, 81), (130, 2), (200, 9)])
+@pytest.mark.parametrize("g", [1, 32, 64])
 def test_windows_over_64_vs_oracle(aligner, oracle, w, o, g):
     t, q = synth.make_pairs(40, 900, "ont", seed=w * 7 + o)
     a, b = synth.make_pairs(10, 2500, "pacbio15", seed=w + o)
@@ -183,7 +184,7 @@ def test_windows_over_64_vs_oracle(aligner, oracle, w, o, g):
 def test_windows_over_64_limits(aligner):
     import scrooge_amd
     with pytest.raises(scrooge_amd.ScroogeError):
-        aligner.align_pairs(["ACGT"], ["ACGT"], W=128, O=65, lanes_per_pair=8)   # slots of 32 or 64 lanes only
+        aligner.align_pairs(["ACGT"], ["ACGT"], W=128, O=65, lanes_per_pair=8)   # one pair per lane, or slots of 32 or 64 lanes
     with pytest.raises(scrooge_amd.ScroogeError):
         aligner.align_pairs(["ACGT"], ["ACGT"], W=257, O=129)
     assert aligner.align_pairs(["ACGT"], ["ACGT"], W=256, O=129) == [("4=", 0)]

@@ -84,3 +84,15 @@ def test_lane_edit_stream_form_matches_oracle(proto, oracle, W, O):
         ed, stream = _run(proto.lane_align_edits, t, q, (C.c_int(W), C.c_int(O)), (C.byref(ls),), unit=1)
         assert ed == e and stream == py_encode(c)
     assert ls.windows > 1000
+
+
+@pytest.mark.parametrize("W,O", [(128, 65), (96, 49), (80, 41), (256, 129), (192, 97), (128, 20), (200, 50), (65, 1), (128, 64), (129, 1)])
+def test_lane_multiword_form_matches_oracle(proto, W, O):
+    """The same table with multi-word vectors (W > 64: genasm_lane_mw_kernel.hip), rows of (W-O)/64 + 1 words."""
+    T, Q = _cases(W * 100 + O + 3)
+    ls = LS()
+    for t, q in zip(T, Q):
+        got = _run(proto.lane_align_codes_mw, t, q, (C.c_int(W), C.c_int(O)), (C.byref(ls),))
+        want = _run(proto.go_align_codes, t, q, (C.c_int(W), C.c_int(O)), (None,))
+        assert got == want
+    assert ls.windows > 300
