@@ -48,14 +48,14 @@ enum {
 /* Tunables.  Zero-initialise and call scrg_params_default(). */
 typedef struct scrg_params {
     int32_t W;               /* window length, 2..256; reference default 64 (genasm_cpu.cpp:7).
-                                W > 64 uses multi-word entries (src/bitvector.hpp:45-48)           */
+                                W > 64 uses multi-word vectors (src/bitvector.hpp:45-48)           */
     int32_t O;               /* window overlap, 1 <= O < W; reference default 33 (genasm_cpu.cpp:9).
-                                W-O <= 31 (e.g. the defaults) keeps the traceback table in registers / the
-                                compact DENT rows; larger W-O needs 64-bit rows of all columns in LDS      */
-    int32_t lanes_per_pair;  /* 1 = one pair per lane, 64 pairs per wavefront (the default for W <= 64);
+                                W <= 64 with W-O <= 31 (e.g. the defaults) keeps the traceback table in registers;
+                                larger W-O or W needs table rows of 64 to 256 bits, kept in HBM               */
+    int32_t lanes_per_pair;  /* 1 = one pair per lane, 64 pairs per wavefront (the default for every W);
                                 64 = one pair per wavefront (lane = text column); 4/8/16/32 pack 64/lanes
-                                pairs into one wavefront (GenASM rows).  0 = default (1; for W > 64 only
-                                32 and 64 exist, default 32)                                          */
+                                pairs into one wavefront (GenASM rows; for W > 64 only 32 and 64 exist).
+                                0 = default                                                          */
     int32_t lds_rows;        /* rows of the R table kept in LDS per pair (rest spills to HBM);
                                 0 = default                                                        */
     int32_t waves_per_cu;    /* persistent wavefronts launched per CU; 0 = default                */
