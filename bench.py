@@ -259,8 +259,8 @@ def main():
     if gather_format == "packed" and p.W - p.O > 63:
         gather_format = "runs"                       # packed runs hold counts up to 63
     stream_bytes = None
-    if gather_format == "edits" and not (p.lanes_per_pair == 1 and p.W <= 64 and p.W - p.O <= 31):
-        gather_format = "edits-from-runs"            # only the one-pair-per-lane kernel writes edit streams itself
+    if gather_format == "edits" and p.lanes_per_pair != 1:
+        gather_format = "edits-from-runs"            # only the one-pair-per-lane kernels write edit streams themselves
     edits = gather_format in ("edits", "edits-from-runs")
     if dist_on and edits:
         # CIGARs travel as edit streams (one byte per edit); rank 0 keeps them in that form
@@ -554,7 +554,7 @@ def main():
     # scaling figure the same step — align kernel with edit-stream output + compaction of the streams, pipelined
     # over the same streams, no collective — is timed here on one GPU, after everything above (it reuses the slices).
     edit_stream_step = None
-    if not dist_on and n_lanes > 1 and not args.ablate and not args.stats and p.lanes_per_pair == 1 and p.W <= 64 and p.W - p.O <= 31:
+    if not dist_on and n_lanes > 1 and not args.ablate and not args.stats and p.lanes_per_pair == 1:
         lens = [torch.empty(n, dtype=torch.int32, device=device) for _ in range(n_lanes)]
         aligners[0].align_device_edits(n, seq, desc, outs[0]["runs"], outs[0]["ed"], lens[0], outs[0]["status"], **kw)
         torch.cuda.synchronize()

@@ -218,8 +218,8 @@ scrg_status scrg_align_device(scrg_ctx *ctx, const scrg_params *params, uint64_t
  * never longer than edit distance + read_len / 64 bytes; 2 * cigar_cap >= that always fits).  The kernel does less
  * work than for runs (it visits edits, not run boundaries) and writes a quarter of the bytes.
  * scrg_compact_runs with d_n_runs[p] = (d_stream_len[p] + 3) / 4 * 2 and even d_dense_offset gathers the slices.
- * One-pair-per-lane kernel only: lanes_per_pair = 1 (the default), W <= 64, W-O <= 31; SCRG_ERR_INVALID_ARG
- * otherwise (use scrg_align_device + scrg_encode_edit_stream there).  d_streams 32-byte aligned. */
+ * One-pair-per-lane kernels only: lanes_per_pair = 1 (the default for every W and O); SCRG_ERR_INVALID_ARG for the
+ * GenASM-row mappings (use scrg_align_device + scrg_encode_edit_stream there).  d_streams 32-byte aligned. */
 scrg_status scrg_align_device_edits(scrg_ctx *ctx, const scrg_params *params, uint64_t n_pairs,
                                     const uint64_t *d_seq, const scrg_pair_desc *d_pairs,
                                     uint8_t *d_streams, int64_t *d_edit_distance,

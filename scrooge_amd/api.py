@@ -435,7 +435,7 @@ class Aligner:
 
     def align_device_edits(self, n_pairs, seq, pairs, streams_u8, ed, stream_len, status, **kw):
         """Like align_device, but the pairs' slices receive EDIT STREAMS (one byte per edit) and stream_len their
-        lengths in bytes: the one-pair-per-lane kernel only (W <= 64, W-O <= 31)."""
+        lengths in bytes: the one-pair-per-lane kernels only (lanes_per_pair = 1, the default for every W/O)."""
         self._check(self.lib.scrg_align_device_edits(self.h, C.byref(self._params(kw)), int(n_pairs),
                                                      _ptr(seq), _ptr(pairs), _ptr(streams_u8), _ptr(ed),
                                                      _ptr(stream_len), _ptr(status)))

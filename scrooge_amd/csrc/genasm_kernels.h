@@ -52,7 +52,7 @@ hipError_t launch_align_lane(const AlignArgs& a, int grid, size_t lds_bytes, hip
 SCRG_HD inline unsigned lane_mw_len_bytes(int tb_limit) { return (((unsigned)tb_limit + 3u) & ~3u) + 4u; }
 SCRG_HD inline unsigned lane_mw_lds_bytes(int tb_limit) { return 64u * (68u + lane_mw_len_bytes(tb_limit)); }
 SCRG_HD inline size_t lane_mw_table_bytes(int tb_limit) { return (size_t)tb_limit * 2u * ((unsigned)tb_limit / 64u + 1u) * 64u * 8u; }
-hipError_t launch_align_lane_mw(const AlignArgs& a, int grid, size_t lds_bytes, hipStream_t s);
+hipError_t launch_align_lane_mw(const AlignArgs& a, int grid, size_t lds_bytes, hipStream_t s, bool edits = false);
 
 SCRG_HD inline unsigned stored_row_dwords(int W, int tb_limit)
 {

@@ -124,7 +124,9 @@ template <int RW> __device__ __forceinline__ uint32_t row_pop(const Row<RW>& a)
 
 }  // namespace
 
-template <int NW, int RW>
+// EDITS = true (scrg_align_device_edits): the alignment leaves as an edit stream (edit_stream.h: one byte per edit
+// carrying the number of matches before it) instead of runs; see genasm_lane_kernel<true>.
+template <int NW, int RW, bool EDITS>
 __global__ __launch_bounds__(64) void genasm_lane_mw_kernel(AlignArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -146,20 +148,26 @@ __global__ __launch_bounds__(64) void genasm_lane_mw_kernel(AlignArgs a)
     uint32_t text_len = 0, read_len = 0, cigar_cap = 0;
     uint32_t ref_idx = 0, read_idx = 0, edits = 0;
     int32_t nr = -1;                   // index of the last committed run; n_runs = nr + 1
-    uint32_t flushed = 0;              // runs below this index are in HBM (a multiple of 16)
+    uint32_t flushed = 0;              // runs below this index are in HBM (a multiple of 16); EDITS: bytes, a multiple of 32
+    uint32_t pos = 0;                  // EDITS: bytes of the pair's stream so far
+    uint32_t mbase = 0;                // EDITS: matches pending at column c of the current window = mbase + c
     bool queue_empty = false;          // wave-uniform
 
+    // (EDITS: the slice holds bytes — it starts at byte 2 * cigar_off and is 2 * cigar_cap bytes long — and a piece is
+    // 32 bytes of the stream)
     auto write_piece = [&]() {
-        const uint32_t rd = (ring_b >> 2) + ((flushed & 16u) >> 1);
+        const uint32_t rd = EDITS ? (ring_b >> 2) + ((flushed & 32u) >> 2) : (ring_b >> 2) + ((flushed & 16u) >> 1);
         uint32_t w[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) w[k] = lds[rd + k];
-        if (flushed + 16u <= cigar_cap) {
-            uint4* const dst = reinterpret_cast<uint4*>(a.runs + cigar_off + flushed);
+        const bool room = EDITS ? flushed + 32u <= 2u * (uint64_t)cigar_cap : flushed + 16u <= cigar_cap;
+        if (room) {
+            uint4* const dst = EDITS ? reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(a.runs + cigar_off) + flushed)
+                                     : reinterpret_cast<uint4*>(a.runs + cigar_off + flushed);
             dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
             dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
         }
-        flushed += 16u;
+        flushed += EDITS ? 32u : 16u;
     };
     auto flush_pieces = [&]() {
         for (;;) {
@@ -172,13 +180,31 @@ __global__ __launch_bounds__(64) void genasm_lane_mw_kernel(AlignArgs a)
         nr++;
         *reinterpret_cast<uint16_t*>(lds_b + ring_b + (((uint32_t)nr & 31u) << 1)) = (uint16_t)(count | (op << 8));
     };
+    auto emit = [&](uint32_t b) {          // EDITS: one byte of the stream; whole pieces leave at once
+        lds8[ring_b + (pos & 63u)] = (uint8_t)b;
+        pos++;
+        if (pos - flushed >= 32u) write_piece();
+    };
 
     for (;;) {
         // ---------------- retire finished pairs, fetch new ones (genasm_cpu.cpp:440-460) ----------------
         for (;;) {
             const bool fin = has_pair && read_idx >= read_len;
             if (__any(fin)) {
-                if (fin) {
+                if (EDITS && fin) {
+                    // (the matches after the last edit are implied by the read length; fewer than 32 bytes are staged)
+                    const uint32_t rem = pos - flushed;
+                    const uint32_t rd = (ring_b >> 2) + ((flushed & 32u) >> 2);
+                    uint32_t* const dst = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(a.runs + cigar_off) + flushed);
+                    for (uint32_t k = 0; 4u * k < rem; k++) {
+                        const uint32_t left = rem - 4u * k;
+                        const uint32_t keep = left >= 4u ? 0xffffffffu : (0xffffffffu >> (32u - 8u * left));
+                        if (flushed + 4u * k < 2u * (uint64_t)cigar_cap) dst[k] = lds[rd + k] & keep;
+                    }
+                    a.ed[pair] = (int64_t)edits;
+                    a.n_runs[pair] = pos;
+                    a.status[pair] = pos > 2u * (uint64_t)cigar_cap ? 1u : 0u;
+                } else if (fin) {
                     const uint32_t n_runs = (uint32_t)(nr + 1);
                     while (n_runs - flushed >= 16u) write_piece();
                     const uint32_t rem = n_runs - flushed;
@@ -211,7 +237,7 @@ __global__ __launch_bounds__(64) void genasm_lane_mw_kernel(AlignArgs a)
                 read_len = (uint32_t)pd.read_len;
                 cigar_off = pd.cigar_off;
                 cigar_cap = pd.cigar_cap > 0xffffffffull ? 0xffffffffu : (uint32_t)pd.cigar_cap;
-                ref_idx = read_idx = edits = flushed = 0;
+                ref_idx = read_idx = edits = flushed = pos = mbase = 0;
                 nr = -1;
                 has_pair = true;
             }
@@ -343,6 +369,37 @@ __global__ __launch_bounds__(64) void genasm_lane_mw_kernel(AlignArgs a)
             ref_idx += ti;
             read_idx += j;
 
+            if constexpr (EDITS) {
+                // the columns that hold an edit: an insertion run (before the column's step), then a deletion or a
+                // substitution; mbase + c = matches pending when column c is reached
+                Row<RW> Ev;
+#pragma unroll
+                for (int r = 0; r < RW; r++) Ev.w[r] = D.w[r] | X.w[r] | Im.w[r];
+                while (__any(row_any<RW>(Ev))) {
+                    if (row_any<RW>(Ev)) {
+                        const uint32_t c = row_clz<RW>(Ev);
+                        const Row<RW> bit = row_bit<RW>(c);
+#pragma unroll
+                        for (int r = 0; r < RW; r++) Ev.w[r] &= ~bit.w[r];
+                        uint32_t t = mbase + c;
+                        if (row_test<RW>(Im, c)) {
+                            const uint32_t ni = lds8[len_b + c];
+                            for (uint32_t q = t >> 6; q; q--) emit(0x3Fu);
+                            emit(0x80u | (t & 63u));
+                            for (uint32_t q = 1; q < ni; q++) emit(0x80u);
+                            t = 0;
+                            mbase = 0u - c;
+                        }
+                        const bool isD = row_test<RW>(D, c), isX = row_test<RW>(X, c);
+                        if (isD || isX) {
+                            for (uint32_t q = t >> 6; q; q--) emit(0x3Fu);
+                            emit((isX ? 0x40u : 0xC0u) | (t & 63u));
+                            mbase = ~c;
+                        }
+                    }
+                }
+                mbase += ti;
+            } else
             while (__any(row_any<RW>(E))) {
                 if (row_any<RW>(E)) {
                     const uint32_t c = row_clz<RW>(E);
@@ -360,22 +417,23 @@ __global__ __launch_bounds__(64) void genasm_lane_mw_kernel(AlignArgs a)
     }
 }
 
-template <int NW, int RW> static hipError_t launch_mw(const AlignArgs& a, int grid, size_t lds_bytes, hipStream_t s)
+template <int NW, int RW> static hipError_t launch_mw(const AlignArgs& a, int grid, size_t lds_bytes, hipStream_t s, bool edits)
 {
-    hipLaunchKernelGGL((genasm_lane_mw_kernel<NW, RW>), dim3(grid), dim3(64), lds_bytes, s, a);
+    if (edits) hipLaunchKernelGGL((genasm_lane_mw_kernel<NW, RW, true>), dim3(grid), dim3(64), lds_bytes, s, a);
+    else hipLaunchKernelGGL((genasm_lane_mw_kernel<NW, RW, false>), dim3(grid), dim3(64), lds_bytes, s, a);
     return hipGetLastError();
 }
 
-hipError_t launch_align_lane_mw(const AlignArgs& a, int grid, size_t lds_bytes, hipStream_t s)
+hipError_t launch_align_lane_mw(const AlignArgs& a, int grid, size_t lds_bytes, hipStream_t s, bool edits)
 {
     const int nw = a.W <= 64 ? 1 : (a.W <= 128 ? 2 : 4), rw = a.tb_limit / 64 + 1;
-    if (nw == 1 && rw == 1) return launch_mw<1, 1>(a, grid, lds_bytes, s);
-    if (nw == 2 && rw == 1) return launch_mw<2, 1>(a, grid, lds_bytes, s);
-    if (nw == 2 && rw == 2) return launch_mw<2, 2>(a, grid, lds_bytes, s);
-    if (nw == 4 && rw == 1) return launch_mw<4, 1>(a, grid, lds_bytes, s);
-    if (nw == 4 && rw == 2) return launch_mw<4, 2>(a, grid, lds_bytes, s);
-    if (nw == 4 && rw == 3) return launch_mw<4, 3>(a, grid, lds_bytes, s);
-    if (nw == 4 && rw == 4) return launch_mw<4, 4>(a, grid, lds_bytes, s);
+    if (nw == 1 && rw == 1) return launch_mw<1, 1>(a, grid, lds_bytes, s, edits);
+    if (nw == 2 && rw == 1) return launch_mw<2, 1>(a, grid, lds_bytes, s, edits);
+    if (nw == 2 && rw == 2) return launch_mw<2, 2>(a, grid, lds_bytes, s, edits);
+    if (nw == 4 && rw == 1) return launch_mw<4, 1>(a, grid, lds_bytes, s, edits);
+    if (nw == 4 && rw == 2) return launch_mw<4, 2>(a, grid, lds_bytes, s, edits);
+    if (nw == 4 && rw == 3) return launch_mw<4, 3>(a, grid, lds_bytes, s, edits);
+    if (nw == 4 && rw == 4) return launch_mw<4, 4>(a, grid, lds_bytes, s, edits);
     return hipErrorInvalidValue;
 }
 

@@ -467,9 +467,9 @@ static scrg_status align_device_impl(scrg_ctx* c, const scrg_params* params, uin
     if (!c) return SCRG_ERR_INVALID_ARG;
     scrg_params p;
     if (!resolve_params(params, &p)) return c->fail(SCRG_ERR_INVALID_ARG, "bad scrg_params");
-    if (edits && !(p.lanes_per_pair == 1 && p.W <= 64 && p.W - p.O <= 31))
-        return c->fail(SCRG_ERR_INVALID_ARG, "edit-stream output needs lanes_per_pair = 1, W <= 64 and W-O <= 31 "
-                                             "(otherwise: scrg_align_device + scrg_encode_edit_stream)");
+    if (edits && p.lanes_per_pair != 1)
+        return c->fail(SCRG_ERR_INVALID_ARG, "edit-stream output needs lanes_per_pair = 1, the default "
+                                             "(the GenASM-row mappings: scrg_align_device + scrg_encode_edit_stream)");
     if (n_pairs > 0xfffffff0ull) return c->fail(SCRG_ERR_INVALID_ARG, "too many pairs for one launch");
     if (n_pairs && (!d_seq || !d_pairs || !d_runs || !d_edit_distance || !d_n_runs || !d_pair_status))
         return c->fail(SCRG_ERR_INVALID_ARG, "null device pointer");
@@ -519,7 +519,7 @@ static scrg_status align_device_impl(scrg_ctx* c, const scrg_params* params, uin
 
     HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));
     if (lane_mw)
-        HIP_TRY(c, scrg::launch_align_lane_mw(a, n_waves, (size_t)lds, c->stream));
+        HIP_TRY(c, scrg::launch_align_lane_mw(a, n_waves, (size_t)lds, c->stream, edits));
     else if (p.W > 64)
         HIP_TRY(c, scrg::launch_align_multiword(p.lanes_per_pair, a, n_waves, (size_t)lds, c->stream));
     else if (p.lanes_per_pair == 1)

@@ -438,7 +438,7 @@ def test_packed_runs_round_trip(aligner, oracle):
         aligner.use_own_stream()
 
 
-@pytest.mark.parametrize("W,O", [(64, 33), (64, 2), (40, 9), (128, 65)])
+@pytest.mark.parametrize("W,O", [(64, 33), (64, 2), (40, 9), (128, 65), (200, 50), (256, 1)])
 def test_edit_stream_round_trip(aligner, oracle, W, O):
     """scrg_encode_edit_stream (one byte per edit, the RCCL transfer format) against the definition of the format on
     the oracle's CIGARs, and scrg_decode_edit_stream back to the very runs scrg_compact_runs delivers (window breaks
@@ -513,7 +513,7 @@ def test_edit_stream_round_trip(aligner, oracle, W, O):
             aligner.decode_edit_stream(n, stream, s_off, s_len, rl, 1, off, back, cnt32, nbad, W=W, O=O)
             assert int(nbad.item()) >= least and int(back[2 * total:].max().item()) == 0
         # the align kernel's own edit-stream output (scrg_align_device_edits): the same bytes in every pair's slice
-        if W - O <= 31 and W <= 64:
+        if True:              # (every W/O: genasm_lane_kernel<true> or genasm_lane_mw_kernel<.., true>)
             slices = torch.full((n * cap * 2,), 0xEE, dtype=torch.uint8, device=dev)
             ed2 = torch.empty(n, dtype=torch.int64, device=dev)
             ln2 = torch.empty(n, dtype=torch.int32, device=dev)
@@ -547,9 +547,8 @@ def test_edit_stream_round_trip(aligner, oracle, W, O):
             for k in range(n):
                 assert sl[2 * k * cap: 2 * k * cap + min(32, (lh[k] + 3) // 4 * 4)] == (want[k] + bytes(3))[: min(32, (lh[k] + 3) // 4 * 4)], k
                 assert sl[2 * k * cap + 32: 2 * (k + 1) * cap] == b"\xee" * (2 * cap - 32), k
-        else:
-            with pytest.raises(scrooge_amd.ScroogeError):
-                aligner.align_device_edits(n, seq, desc, runs, ed, nr, st, W=W, O=O)
+        with pytest.raises(scrooge_amd.ScroogeError):          # the one-pair-per-lane kernels only
+            aligner.align_device_edits(n, seq, desc, runs, ed, nr, st, W=W, O=O, lanes_per_pair=64)
         # a stream buffer that is too small: the pairs that do not fit are counted and marked, the others are intact
         small = torch.zeros(need // 2 // 4 * 4, dtype=torch.uint8, device=dev)
         aligner.encode_edit_stream(n, desc, runs, nr, small, s_off, s_len, tot)

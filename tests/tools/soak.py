@@ -53,7 +53,7 @@ import torch
 from tests.test_edit_stream import py_encode
 dev = torch.device("cuda", 0)
 a.set_stream(0)
-for W, O in ((64, 33), (48, 24), (33, 2), (64, 63)):
+for W, O in ((64, 33), (48, 24), (33, 2), (64, 63), (64, 2), (50, 18), (128, 65), (256, 100)):
     m = min(len(T), 12000)
     e2, c2, _, _ = Oracle().align(T[:m], Q[:m], W=W, O=O, threads=16)
     tw = (max(len(x) for x in T[:m]) + 31) // 32
