@@ -10,7 +10,7 @@
 //
 // The table (two RW-word rows for each of the W-O columns: 1 to 16 KB per lane) lives in HBM, one slab per wavefront,
 // word-interleaved over the lanes so that a store or load of the wavefront is 512 contiguous bytes; the first
-// traceback pass reads it back four columns at a time.  LDS holds the CIGAR staging ring and the insertion-run
+// traceback pass reads it back four to sixteen columns at a time.  LDS holds the CIGAR staging ring and the insertion-run
 // lengths only.  Written with plain 64-bit operations (this is the knob-sweep configuration, scripts/profile.py:180-185,
 // not the tuned one); tests/proto/lane_proto.c (lane_align_codes_mw) restates the arithmetic and is checked against
 // the reference algorithm on the CPU (tests/test_lane_proto.py).
@@ -314,10 +314,11 @@ __global__ __launch_bounds__(64) void genasm_lane_mw_kernel(AlignArgs a)
         {
             uint32_t j = 0;
             Row<RW> nDm = row_zero<RW>(), Xm = row_zero<RW>(), nIm = row_zero<RW>();
-            for (uint32_t i0 = 0; i0 < TBL; i0 += 4) {
-                Row<RW> nv1[4], v0[4];
+            constexpr int CH = RW == 1 ? 16 : (RW == 2 ? 8 : 4);    // columns in flight: the loads do not depend on the walk
+            for (uint32_t i0 = 0; i0 < TBL; i0 += CH) {
+                Row<RW> nv1[CH], v0[CH];
 #pragma unroll
-                for (int q = 0; q < 4; q++) {                       // the loads do not depend on the walk: four columns in flight
+                for (int q = 0; q < CH; q++) {
                     const uint32_t i = min(i0 + (uint32_t)q, TBL - 1u);
 #pragma unroll
                     for (int r = 0; r < RW; r++) {
@@ -326,9 +327,9 @@ __global__ __launch_bounds__(64) void genasm_lane_mw_kernel(AlignArgs a)
                     }
                 }
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
+                for (int q = 0; q < CH; q++) {
                     const uint32_t i = i0 + (uint32_t)q;
-                    if (i >= TBL) break;                             // (uniform)
+                    if (i >= TBL) continue;                          // (uniform)
                     Row<RW> x;
 #pragma unroll
                     for (int r = 0; r < RW; r++) x.w[r] = nv1[q].w[r] | ~v0[q].w[r] | stop.w[r];   // not (insertion), or the stop row
