@@ -50,6 +50,9 @@ def parse():
                     help="N > 1: how CIGARs travel to rank 0 — edit streams, 1 byte per edit, written by the align kernel "
                          "itself (default; W-O <= 31) or encoded from its runs (edits-from-runs: any W/O), packed runs "
                          "(1 byte per run, restored on rank 0 inside the timed region) or scrg_run pairs")
+    ap.add_argument("--gather-root", default="rotate", choices=["rotate", "0"],
+                    help="N > 1, edit streams: the rank a step's results are gathered to — step k to rank k mod N (default: "
+                         "every GPU receives one step in N, a consumer per GPU) or always rank 0")
     ap.add_argument("--sustained-steps", type=int, default=150,
                     help="N = 1: after the timed region, time this many more pipelined steps for the 'sustained' field (0 = skip)")
     ap.add_argument("--streams", type=int, default=4, help="pipeline depth: consecutive steps rotate over this many streams/handles")
@@ -133,12 +136,12 @@ STEP_TEXT = {
     "local": "align kernel + run compaction",
     "edits": "align kernel writing every CIGAR as an edit stream (scrg_align_device_edits: one byte per edit, a lossless "
              "encoding the window breaks are restored from) + compaction of the streams + RCCL gather of scores and streams "
-             "to rank 0, one collective and one buffer set per pipelined step (overlaps the next kernels); rank 0 keeps the "
-             "streams, their decoding to scrg_run (scrg_decode_edit_stream) is checked for every rank's slot after the "
-             "timed region",
+             "to the step's root (config.gather.root), one collective and one buffer set per pipelined step (overlaps the "
+             "next kernels); the root keeps the streams, their decoding to scrg_run (scrg_decode_edit_stream) is checked for "
+             "every rank's slot of the last step after the timed region",
     "edits-from-runs": "align kernel (runs) + edit-stream encoding (scrg_encode_edit_stream) + RCCL gather of scores and "
-                       "streams to rank 0, one collective and one buffer set per pipelined step; rank 0 keeps the streams, "
-                       "their decoding is checked for every rank's slot after the timed region",
+                       "streams to the step's root (config.gather.root), one collective and one buffer set per pipelined step; the "
+                       "root keeps the streams, their decoding is checked for every rank's slot after the timed region",
     "packed": "align kernel + run compaction to one byte per run + RCCL gather of scores and runs to rank 0 (one buffer set "
               "per pipelined step); rank 0 restores scrg_run pairs inside the timed region",
     "runs": "align kernel + run compaction + RCCL gather of scores and scrg_run pairs to rank 0 (one buffer set per pipelined step)",
@@ -285,7 +288,8 @@ def main():
             stream_bytes = int(t_tot[0].item())
             del tmp, t_off
         del t_len
-        gather = EditStreamGather(n, stream_bytes, device, dst=0, depth=max(2, n_lanes), ordered=gather_format == "edits")
+        gather = EditStreamGather(n, stream_bytes, device, dst="rotate" if args.gather_root == "rotate" else 0,
+                                  depth=max(2, n_lanes), ordered=gather_format == "edits")
     elif dist_on:
         from scrooge_amd.distributed import ResultGather
         packed_gather = gather_format == "packed"    # runs travel as one byte each; rank 0 restores scrg_run pairs
@@ -383,15 +387,17 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     last = (step.count - 1) % n_lanes
-    if dist_on and gather_format == "edits" and rank == 0:
+    # the rank that holds the last step's gathered results checks them (rank 0 unless the root rotates)
+    check_rank = gather.root_of(step.count - 1) if (gather is not None and edits) else 0
+    if dist_on and gather_format == "edits" and rank == check_rank:
         # (the slices of the last step hold edit streams: make the runs for the checks below, outside the timed region)
         with torch.cuda.stream(streams[last]):
             aligners[last].align_device(n, seq, desc, outs[last]["runs"], outs[last]["ed"], outs[last]["n_runs"], outs[last]["status"], **kw)
         torch.cuda.synchronize()
     ed, n_runs, dense = outs[last]["ed"], outs[last]["n_runs"], denses[last]
     gather_check = None
-    if gather is not None and rank == 0 and os.environ.get("SCRG_BENCH_NOCOLL") != "1":
-        # outside the timed region: what rank 0 holds for itself after the last step's gather (scores, counts and the
+    if gather is not None and rank == check_rank and os.environ.get("SCRG_BENCH_NOCOLL") != "1":
+        # outside the timed region: what the root holds for itself after the last step's gather (scores, counts and the
         # runs restored from the wire format) must be what its own kernel produced
         cnt64 = n_runs.to(torch.int64)
         dense_off = torch.cumsum(cnt64, 0) - cnt64
@@ -399,9 +405,8 @@ def main():
         aligners[last].compact_runs(n, desc, outs[last]["runs"], n_runs, dense_off, dense)
         torch.cuda.synchronize()
         if edits:
-            # every rank's slot must decode (scrg_decode_edit_stream) into exactly the gathered number of runs for reads
-            # of this length, with as many edits as the gathered edit distance; rank 0's own slot must be, run for run,
-            # what its kernel produced
+            # every rank's slot must decode (scrg_decode_edit_stream) into runs for reads of this length, with as many
+            # edits as the gathered edit distance; the root's own slot must be, run for run, what its kernel produced
             rl = torch.tensor([L], dtype=torch.int64, device=device)
             gather_check = True
             for r in range(world):
@@ -413,16 +418,21 @@ def main():
                 csum = torch.cat([torch.zeros(1, dtype=torch.int64, device=device), torch.cumsum(is_edit, 0)])
                 n_edits = csum[v["off"] + v["len"].to(torch.int64)] - csum[v["off"]]
                 checks = {"streams_decode": n_bad == 0, "edits_equal_distance": bool(torch.equal(n_edits, v["ed"].to(torch.int64)))}
-                if r == 0:
+                if r == rank:
                     checks.update(own_scores=bool(torch.equal(v["ed"].to(torch.int64), ed) and torch.equal(cnt_g, n_runs)),
                                   own_runs=bool(runs_g is not None and torch.equal(runs_g[: 2 * total_runs], dense[: 2 * total_runs])))
                 if not all(checks.values()):
-                    print("gather check, slot of rank %d: %s (undecodable pairs: %d)" % (r, checks, n_bad), file=sys.stderr)
+                    print("gather check on rank %d, slot of rank %d: %s (undecodable pairs: %d)" % (rank, r, checks, n_bad), file=sys.stderr)
                     gather_check = False
         else:
             ed_g, cnt_g, runs_g = gather.results(step.count - 1, 0)
             gather_check = bool(torch.equal(ed_g, ed) and torch.equal(cnt_g, n_runs) and torch.equal(runs_g, dense[: runs_g.numel()]))
-        assert gather_check, "gathered results differ from the local ones"
+    if dist_on and world > 1 and gather is not None:
+        # the verdict travels to rank 0, which prints the line
+        flag = torch.tensor([1 if gather_check in (True, None) else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        gather_check = bool(int(flag.item()))
+    assert gather_check in (True, None), "gathered results differ from the local ones"
     if dist_on:
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -611,7 +621,8 @@ def main():
                    "W": p.W, "O": p.O, "lanes_per_pair": p.lanes_per_pair, "lds_rows": p.lds_rows,
                    "sequence_layout": "lane-interleaved groups of 64 pairs (scrg_pack_planar_groups)" if groups else "contiguous per sequence",
                    "launch": geom, "step": STEP_TEXT[gather_format if dist_on else "local"],
-                   "gather": ({"format": gather_format, "bytes_per_rank_and_step": gather.wire if edits else None,
+                   "gather": ({"format": gather_format, "root": ("step k to rank k mod N" if (edits and args.gather_root == "rotate") else "rank 0"),
+                               "bytes_per_rank_and_step": gather.wire if edits else None,
                                "stream_bytes_per_pair": (stream_bytes / n) if stream_bytes is not None else None} if dist_on else None),
                    "pipeline": ("consecutive steps alternate between %d streams (own handle, work queue and output buffers each): "
                                 "a step's wavefronts start while the previous step's last pairs finish" % n_lanes) if n_lanes > 1

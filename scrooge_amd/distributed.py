@@ -208,10 +208,17 @@ class EditStreamGather:
     `dst` keeps the streams as they arrive; `results(k, r)` gives views of rank r's slot (offsets re-derived from the
     lengths when they did not travel) and `decode(...)` (scrg_decode_edit_stream) restores scrg_run pairs, window
     breaks included, where a consumer wants them.  Sizes are exchanged once: the data, hence every size, is the
-    same each step in bench.py."""
+    same each step in bench.py.
+
+    `dst` may be "rotate": step k is gathered to rank k mod world, so that every rank receives one step in `world`
+    (a consumer per GPU: each batch's results end up complete on one GPU, and the link into any one GPU carries a
+    step's results only every `world`-th step); every rank then holds receive buffers, and `results` / `decode` of
+    step k are valid on `root_of(k)`."""
 
     def __init__(self, n_pairs, stream_bytes, device, dst=0, group=None, depth=2, ordered=True):
-        self.group, self.dst, self.n = group, dst, int(n_pairs)
+        self.group, self.n = group, int(n_pairs)
+        self.rotate = dst == "rotate"
+        self.dst = 0 if self.rotate else int(dst)
         self.DEPTH = max(1, int(depth))
         self.ordered = bool(ordered)
         self.world = dist.get_world_size(group)
@@ -230,11 +237,15 @@ class EditStreamGather:
         self.total = [torch.zeros(2, dtype=torch.int64, device=device) for _ in range(d)]
         self.off_scratch = [torch.zeros(n, dtype=torch.int64, device=device) for _ in range(d)] if self.ordered else None
         self.recv = [None] * d
-        if self.rank == dst:
+        if self.rotate or self.rank == self.dst:
             self.recv = [[torch.empty(self.wire, dtype=torch.uint8, device=device) for _ in range(self.world)]
                          for _ in range(d)]
         self.pending = [None] * d
         self.host_stage = dist.get_backend(group) == "gloo" and torch.device(device).type == "cuda"
+
+    def root_of(self, k):
+        """The rank step k is gathered to."""
+        return k % self.world if self.rotate else self.dst
 
     def _views(self, buf):
         n, n8 = self.n, self.n8
@@ -256,18 +267,20 @@ class EditStreamGather:
         """The streams and their lengths (and offsets, if they travel) of step k must already be in `buffers(k)`
         (enqueued on the current stream)."""
         b = k % self.DEPTH
+        dst = self.root_of(k)
         self._views(self.send[b])["ed"].copy_(ed)            # (int64 -> int32)
         if self.host_stage:
             torch.cuda.current_stream().synchronize()
-            host = [torch.empty(self.wire, dtype=torch.uint8) for _ in range(self.world)] if self.rank == self.dst else None
-            dist.gather(self.send[b].cpu(), host, dst=self.dst, group=self.group)
+            host = [torch.empty(self.wire, dtype=torch.uint8) for _ in range(self.world)] if self.rank == dst else None
+            dist.gather(self.send[b].cpu(), host, dst=dst, group=self.group)
             if host is not None:
                 for r in range(self.world):
                     self.recv[b][r].copy_(host[r])
             return
         if os.environ.get("SCRG_BENCH_NOCOLL") == "1":        # experiment: everything but the collective
             return
-        self.pending[b] = dist.gather(self.send[b], self.recv[b], dst=self.dst, group=self.group, async_op=True)
+        self.pending[b] = dist.gather(self.send[b], self.recv[b] if self.rank == dst else None, dst=dst, group=self.group,
+                                      async_op=True)
 
     def finish(self, k):
         b = k % self.DEPTH
@@ -280,8 +293,8 @@ class EditStreamGather:
             self.finish(b)
 
     def results(self, k, r):
-        """Views (ed, len, off, stream) of what rank r sent for step k, on dst (after finish(k)); `off` is re-derived
-        from the lengths when the streams are ordered."""
+        """Views (ed, len, off, stream) of what rank r sent for step k, on root_of(k) (after finish(k)); `off` is
+        re-derived from the lengths when the streams are ordered."""
         v = self._views(self.recv[k % self.DEPTH][r])
         if self.ordered:
             r4 = (v["len"].to(torch.int64) + 3) & -4

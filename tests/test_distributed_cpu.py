@@ -220,3 +220,52 @@ def test_edit_stream_gather(ordered):
         assert [api.edit_stream_to_cigar(s, L) for s, L in zip(streams, read_len[r])] == cigars[r]
         assert eds == [sum(1 for b in s if b >> 6) + 2 for s in streams]
         assert wire == (8 * 4 if ordered else 8 * 4 + 8 * 3) + 8            # scalars (int32 arrays padded to 8 bytes) + streams
+
+
+def _worker_rotate(rank, world, port, q):
+    import os
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    from scrooge_amd import distributed as sd
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = 2
+        g = sd.EditStreamGather(n, 8, torch.device("cpu"), dst="rotate", depth=2)
+        seen = {}
+        for k in range(5):
+            g.finish(k)
+            v = g.buffers(k)
+            v["len"][:] = torch.tensor([3, 1], dtype=torch.int32)
+            v["stream"][:8] = torch.tensor([10 * rank + k, 1, 2, 0, 99, 0, 0, 0], dtype=torch.uint8)
+            g.start(k, torch.tensor([100 * rank + k, 7], dtype=torch.int64))
+            assert g.root_of(k) == k % world
+        g.finish_all()
+        for k in (3, 4):                                   # the two steps whose buffers are still there
+            if g.root_of(k) == rank:
+                seen[k] = [(g.results(k, r)["ed"].tolist(), g.results(k, r)["stream"][:5].tolist(), g.results(k, r)["off"].tolist())
+                           for r in range(world)]
+        q.put((rank, seen))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_edit_stream_gather_rotating_root():
+    """dst="rotate": step k lands on rank k mod world — every rank receives, every rank sends."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_rotate, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=150) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert list(got[0].keys()) == [4] and list(got[1].keys()) == [3]          # step 4 -> rank 0, step 3 -> rank 1
+    for rank, k in ((0, 4), (1, 3)):
+        for r in range(2):
+            ed, stream, off = got[rank][k][r]
+            assert ed == [100 * r + k, 7] and stream == [10 * r + k, 1, 2, 0, 99] and off == [0, 4]

@@ -222,7 +222,8 @@ def test_two_handles_on_two_streams_overlap(oracle):
         a.close()
 
 
-def test_bench_two_ranks_dry_run():
+@pytest.mark.parametrize("root", ["rotate", "0"])
+def test_bench_two_ranks_dry_run(root):
     """bench.py's multi-rank control flow (two pipeline lanes, double-buffered gather, barriers, rank 0
     printing) with two processes on this one GPU: gloo through the host instead of RCCL (SCRG_BENCH_DRYRUN),
     so only the logic is checked, not the speed."""
@@ -231,14 +232,17 @@ def test_bench_two_ranks_dry_run():
     env = dict(os.environ, SCRG_BENCH_DRYRUN="1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
-                          "--gpus", "2", "--steps", "5", "--warmup", "1", "--pairs", "6000", "--read-len", "2000"],
+                          "--gpus", "2", "--steps", "5", "--warmup", "1", "--pairs", "6000", "--read-len", "2000",
+                          "--gather-root", root],
                          env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
     assert len(lines) == 1, out.stdout[-2000:]              # rank 0 only
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["steps"] == 5 and j["value"] > 0 and j["scaling"] == "weak"
-    assert j["gather_check"] is True and j["config"]["gather"]["format"] == "edits"      # both ranks' slots decoded on rank 0
+    # both ranks' slots of the last step decoded on its root (rank 1 when the root rotates: 6 steps), the verdict sent to rank 0
+    assert j["gather_check"] is True and j["config"]["gather"]["format"] == "edits"
+    assert j["config"]["gather"]["root"] == ("rank 0" if root == "0" else "step k to rank k mod N")
 
 
 def test_full_bench_size_two_algorithms_agree(aligner):
