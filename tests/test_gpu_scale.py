@@ -222,8 +222,8 @@ def test_two_handles_on_two_streams_overlap(oracle):
         a.close()
 
 
-@pytest.mark.parametrize("root", ["rotate", "0"])
-def test_bench_two_ranks_dry_run(root):
+@pytest.mark.parametrize("gather_root", ["rotate", "0"])
+def test_bench_two_ranks_dry_run(gather_root):
     """bench.py's multi-rank control flow (two pipeline lanes, double-buffered gather, barriers, rank 0
     printing) with two processes on this one GPU: gloo through the host instead of RCCL (SCRG_BENCH_DRYRUN),
     so only the logic is checked, not the speed."""
@@ -233,7 +233,7 @@ def test_bench_two_ranks_dry_run(root):
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
                           "--gpus", "2", "--steps", "5", "--warmup", "1", "--pairs", "6000", "--read-len", "2000",
-                          "--gather-root", root],
+                          "--gather-root", gather_root],
                          env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
@@ -242,7 +242,7 @@ def test_bench_two_ranks_dry_run(root):
     assert j["n_gpus"] == 2 and j["steps"] == 5 and j["value"] > 0 and j["scaling"] == "weak"
     # both ranks' slots of the last step decoded on its root (rank 1 when the root rotates: 6 steps), the verdict sent to rank 0
     assert j["gather_check"] is True and j["config"]["gather"]["format"] == "edits"
-    assert j["config"]["gather"]["root"] == ("rank 0" if root == "0" else "step k to rank k mod N")
+    assert j["config"]["gather"]["root"] == ("rank 0" if gather_root == "0" else "step k to rank k mod N")
 
 
 def test_full_bench_size_two_algorithms_agree(aligner):
