@@ -290,6 +290,7 @@ def main():
         del t_len
         gather = EditStreamGather(n, stream_bytes, device, dst="rotate" if args.gather_root == "rotate" else 0,
                                   depth=max(2, n_lanes), ordered=gather_format == "edits")
+        gather.prime()                               # (set-up: connections to every root exist before anything is timed)
     elif dist_on:
         from scrooge_amd.distributed import ResultGather
         packed_gather = gather_format == "packed"    # runs travel as one byte each; rank 0 restores scrg_run pairs

@@ -247,6 +247,17 @@ class EditStreamGather:
         """The rank step k is gathered to."""
         return k % self.world if self.rotate else self.dst
 
+    def prime(self):
+        """One full-size gather to every root that will be used, outside any timed region: RCCL sets up its
+        point-to-point connections (per pair of ranks, and channel by channel as message sizes ask for them) on first
+        use, and with a rotating root the first `world` steps would otherwise each pay for seven new ones."""
+        if self.host_stage or os.environ.get("SCRG_BENCH_NOCOLL") == "1":
+            return
+        for dst in (range(self.world) if self.rotate else [self.dst]):
+            dist.gather(self.send[0], self.recv[0] if self.rank == dst else None, dst=dst, group=self.group)
+        if self.send[0].is_cuda:
+            torch.cuda.synchronize()
+
     def _views(self, buf):
         n, n8 = self.n, self.n8
         v = {"ed": buf[: 4 * n].view(torch.int32), "len": buf[4 * n8: 4 * n8 + 4 * n].view(torch.int32),
