@@ -37,10 +37,11 @@ for kw in ({}, {"sort_by_length": 0}, {"lanes_per_pair": 8, "lds_rows": 7}):
     bad = [i for i in range(len(T)) if got[i].edit_distance != eds[i] or got[i].cigar != cigars[i]]
     print(kw, "gpu %.1fs" % (time.time() - t0), "mismatches:", len(bad), bad[:5])
     assert not bad
-# other window settings of the one-pair-per-lane kernels (W <= 64), on a slice of the same pairs
+# other window settings of the one-pair-per-lane kernels, on a slice of the same pairs
 m = min(len(T), 20000)
 for W, O in ((64, 63), (64, 40), (33, 2), (48, 24), (32, 17), (17, 9), (5, 2), (2, 1), (63, 32), (40, 9),
-             (64, 2), (64, 20), (64, 1), (64, 32), (40, 5), (33, 1), (50, 18)):        # the last row: W-O > 31
+             (64, 2), (64, 20), (64, 1), (64, 32), (40, 5), (33, 1), (50, 18),         # this row: W-O > 31
+             (128, 65), (96, 49), (256, 129), (200, 50), (130, 1)):                      # W > 64: multi-word vectors
     e2, c2, _, _ = Oracle().align(T[:m], Q[:m], W=W, O=O, threads=16)
     got = a.align_pairs(T[:m], Q[:m], W=W, O=O)
     bad = [i for i in range(m) if got[i].edit_distance != e2[i] or got[i].cigar != c2[i]]
