@@ -84,11 +84,13 @@ int64_t now_ns()
                std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-template <typename F> void parallel_for(uint64_t n, F f)
+// (heavy = true: every index is a block of work — a few of them are worth the threads)
+template <typename F> void parallel_for(uint64_t n, F f, bool heavy = false)
 {
     unsigned hw = std::thread::hardware_concurrency();
     unsigned nt = hw ? std::min(hw, 16u) : 4u;
-    if (n < 64 || nt <= 1) {
+    if (heavy) nt = (unsigned)std::min<uint64_t>(nt, n);
+    if (n < (heavy ? 2u : 64u) || nt <= 1) {
         for (uint64_t i = 0; i < n; i++) f(i);
         return;
     }
@@ -800,7 +802,7 @@ scrg_status run_batch(scrg_ctx* c, const scrg_params& p, std::vector<SeqRef>& se
                     for (uint64_t k = pc.from; k < data_to; k++) dst[k] = complement_base(q.p[q.len - 1 - k]);
             }
             if (pc.to > std::max(pc.from, q.len)) memset(dst + std::max(pc.from, q.len), 0, pc.to - std::max(pc.from, q.len));
-        });
+        }, true);
     }
     hipError_t e;
     if (resident_words && (size_t)seq_words * 8 > c->d_seq.cap) {
@@ -841,11 +843,22 @@ scrg_status run_batch(scrg_ctx* c, const scrg_params& p, std::vector<SeqRef>& se
 
     // ---- problem descriptors, longest read first (src/tests.cu:375-377) ----
     std::vector<uint32_t> order(n);
-    std::iota(order.begin(), order.end(), 0u);
+    std::atomic<int> unsorted{0};
+    {
+        // identity, and at the same time: is the batch already in issue order?  (read sets of one length, or sorted
+        // ones, need no sort: 4 M comparisons instead of 90 M)
+        const uint64_t BLK = 1u << 16, nb = (n + BLK - 1) / BLK;
+        parallel_for(nb, [&](uint64_t b) {
+            bool ok = true;
+            for (uint64_t k = b * BLK; k < std::min(n, (b + 1) * BLK); k++) {
+                order[k] = (uint32_t)k;
+                if (k && probs[k - 1].read_len < probs[k].read_len) ok = false;
+            }
+            if (!ok) unsorted.store(1, std::memory_order_relaxed);
+        }, true);
+    }
     if (p.sort_by_length) {
-        // (read sets of one length, or already sorted ones, need no sort: 4 M comparisons instead of 90 M)
-        bool sorted = true;
-        for (uint64_t k = 1; k < n && sorted; k++) sorted = probs[k - 1].read_len >= probs[k].read_len;
+        const bool sorted = unsorted.load() == 0;
         if (!sorted)
             std::stable_sort(order.begin(), order.end(),
                              [&](uint32_t x, uint32_t y) { return probs[x].read_len > probs[y].read_len; });
@@ -874,13 +887,13 @@ scrg_status run_batch(scrg_ctx* c, const scrg_params& p, std::vector<SeqRef>& se
                 acc += d.cigar_cap;
             }
             block_sum[b + 1] = acc;
-        });
+        }, true);
         for (uint64_t b = 0; b < nb; b++) block_sum[b + 1] += block_sum[b];
         arena = block_sum[nb];
         parallel_for(nb, [&](uint64_t b) {
             if (block_sum[b])
                 for (uint64_t k = b * BLK; k < std::min(n, (b + 1) * BLK); k++) desc[k].cigar_off += block_sum[b];
-        });
+        }, true);
     }
     mark("  build descriptors");
     if (n == 0) {
@@ -947,12 +960,12 @@ scrg_status run_batch(scrg_ctx* c, const scrg_params& p, std::vector<SeqRef>& se
                 acc += cnt;
             }
             block_sum[b + 1] = acc;
-        });
+        }, true);
         for (uint64_t b = 0; b < nb; b++) block_sum[b + 1] += block_sum[b];
         parallel_for(nb, [&](uint64_t b) {
             if (block_sum[b])
                 for (uint64_t i = b * BLK; i < std::min(n, (b + 1) * BLK); i++) r->run_offset[i] += block_sum[b];
-        });
+        }, true);
         r->run_offset[n] = block_sum[nb];
         parallel_for(n, [&](uint64_t k) { dense_off_sorted[k] = r->run_offset[order[k]]; });
     }
@@ -980,7 +993,7 @@ scrg_status run_batch(scrg_ctx* c, const scrg_params& p, std::vector<SeqRef>& se
         parallel_for((bytes + CH - 1) / CH, [&](uint64_t i) {
             memcpy(reinterpret_cast<char*>(r->runs) + i * CH, static_cast<const char*>(c->h_runs.p) + i * CH,
                    std::min<uint64_t>(CH, bytes - i * CH));
-        });
+        }, true);
     }
 
     mark("  copy runs out");
@@ -1015,12 +1028,12 @@ scrg_status run_batch(scrg_ctx* c, const scrg_params& p, std::vector<SeqRef>& se
                     a += chars_of[i] + 1;
                 }
                 block_sum[b + 1] = a;
-            });
+            }, true);
             for (uint64_t b = 0; b < nb; b++) block_sum[b + 1] += block_sum[b];
             parallel_for(nb, [&](uint64_t b) {
                 if (block_sum[b])
                     for (uint64_t i = b * BLK; i < std::min(n, (b + 1) * BLK); i++) r->cigar_offset[i] += block_sum[b];
-            });
+            }, true);
             acc = block_sum[nb];
         }
         r->cigar_offset[n] = acc;
@@ -1166,7 +1179,7 @@ static scrg_status genome_set_impl(scrg_ctx* c, const char* genome, uint64_t gen
         const uint64_t a = i * PIECE, b = std::min<uint64_t>(bytes, a + PIECE), d = std::min(b, genome_len);
         if (a < d) memcpy(h + a, genome + a, d - a);
         if (b > std::max(a, genome_len)) memset(h + std::max(a, genome_len), 0, b - std::max(a, genome_len));
-    });
+    }, true);
     if ((e = c->d_ascii.ensure(bytes + 32)) != hipSuccess || (e = c->d_seq.ensure((words + SCRG_SEQ_PAD_WORDS) * 8)) != hipSuccess ||
         (e = c->d_bad.ensure(4)) != hipSuccess)
         return c->fail(SCRG_ERR_OOM, "device sequence buffers", e);
