@@ -1007,25 +1007,35 @@ scrg_status run_batch(scrg_ctx* c, const scrg_params& p, std::vector<SeqRef>& se
 
     // ---- "%d%c" text, as genasm_cpu.cpp:387-403 ----
     {
-        // length of every pair's text (in parallel: this pass touches every run), then the offsets
-        std::vector<uint64_t> chars_of(n);
-        parallel_for(n, [&](uint64_t i) {
-            uint64_t chars = 0;
-            for (uint64_t k = r->run_offset[i]; k < r->run_offset[i + 1]; k++) {
-                const unsigned cnt = r->runs[k].count;
-                chars += (cnt >= 100 ? 4 : (cnt >= 10 ? 3 : 2));
+        // (decimal digits of a count: from a table — the low bytes of `word` are the digits, `len` of them)
+        struct DigitLut {
+            uint32_t word[256];
+            uint8_t len[256];
+            DigitLut()
+            {
+                for (unsigned v = 0; v < 256; v++) {
+                    char d[4];
+                    const int l = snprintf(d, sizeof d, "%u", v);
+                    uint32_t w = 0;
+                    for (int k = 0; k < l; k++) w |= (uint32_t)(uint8_t)d[k] << (8 * k);
+                    word[v] = w;
+                    len[v] = (uint8_t)l;
+                }
             }
-            chars_of[i] = chars;
-        });
+        };
+        static const DigitLut dig;
         uint64_t acc = 0;
         {
-            const uint64_t BLK = 1u << 16, nb = (n + BLK - 1) / BLK;
+            // length of every pair's text and its offset within its block in one pass over the runs, then the block sums
+            const uint64_t BLK = 1u << 13, nb = (n + BLK - 1) / BLK;
             std::vector<uint64_t> block_sum(nb + 1, 0);
             parallel_for(nb, [&](uint64_t b) {
                 uint64_t a = 0;
                 for (uint64_t i = b * BLK; i < std::min(n, (b + 1) * BLK); i++) {
+                    uint64_t chars = 0;
+                    for (uint64_t k = r->run_offset[i]; k < r->run_offset[i + 1]; k++) chars += dig.len[r->runs[k].count] + 1u;
                     r->cigar_offset[i] = a;
-                    a += chars_of[i] + 1;
+                    a += chars + 1;
                 }
                 block_sum[b + 1] = a;
             }, true);
@@ -1042,12 +1052,19 @@ scrg_status run_batch(scrg_ctx* c, const scrg_params& p, std::vector<SeqRef>& se
         if (!r->cigar_text) return bail(c->fail(SCRG_ERR_OOM, "cigar text"));
         parallel_for(n, [&](uint64_t i) {
             char* w = r->cigar_text + r->cigar_offset[i];
-            for (uint64_t k = r->run_offset[i]; k < r->run_offset[i + 1]; k++) {
-                unsigned cnt = r->runs[k].count;
-                if (cnt >= 100) *w++ = (char)('0' + cnt / 100);
-                if (cnt >= 10) *w++ = (char)('0' + (cnt / 10) % 10);
-                *w++ = (char)('0' + cnt % 10);
-                *w++ = r->runs[k].op;
+            const uint64_t k0 = r->run_offset[i], k1 = r->run_offset[i + 1];
+            // every run but the last: one 4-byte store (digits + op; the one or two bytes too many land where the next
+            // run of the same pair is written afterwards); the last run byte by byte — the next pair may be another thread's
+            for (uint64_t k = k0; k + 1 < k1; k++) {
+                const unsigned cnt = r->runs[k].count, l = dig.len[cnt];
+                const uint32_t v = dig.word[cnt] | ((uint32_t)(uint8_t)r->runs[k].op << (8 * l));
+                memcpy(w, &v, 4);
+                w += l + 1;
+            }
+            if (k1 > k0) {
+                const unsigned cnt = r->runs[k1 - 1].count, l = dig.len[cnt];
+                for (unsigned q = 0; q < l; q++) *w++ = (char)(dig.word[cnt] >> (8 * q));
+                *w++ = r->runs[k1 - 1].op;
             }
             *w = '\0';
         });
