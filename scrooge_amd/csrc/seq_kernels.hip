@@ -295,6 +295,37 @@ hipError_t launch_ascii_to_twobit(uint64_t count, const uint64_t* d_lens, const 
     return hipGetLastError();
 }
 
+// The same gather for batches of SHORT alignments (a few runs per pair: 150 bp reads): one pair per lane instead
+// of one per wavefront.
+__global__ __launch_bounds__(256) void compact_runs_small_kernel(uint64_t n_pairs, const scrg_pair_desc* __restrict__ pairs,
+                                                                 const uint16_t* __restrict__ runs,
+                                                                 const uint32_t* __restrict__ n_runs,
+                                                                 const uint64_t* __restrict__ dense_off,
+                                                                 uint16_t* __restrict__ dense)
+{
+    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n_pairs; p += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t cap = pairs[p].cigar_cap;
+        uint64_t cnt = n_runs[p];
+        if (cnt > cap) cnt = cap;
+        const uint16_t* const s = runs + pairs[p].cigar_off;
+        uint16_t* const d = dense + dense_off[p];
+        for (uint64_t k = 0; k < cnt; k++) d[k] = s[k];
+    }
+}
+
+hipError_t launch_compact_runs_small(uint64_t n_pairs, const scrg_pair_desc* d_pairs, const uint16_t* d_runs,
+                                     const uint32_t* d_n_runs, const uint64_t* d_dense_off, uint16_t* d_dense,
+                                     int n_cus, hipStream_t s)
+{
+    if (n_pairs == 0) return hipSuccess;
+    uint64_t blocks = (n_pairs + 255) / 256;
+    const uint64_t cap = (uint64_t)n_cus * 16;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(compact_runs_small_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
+                       n_pairs, d_pairs, d_runs, d_n_runs, d_dense_off, d_dense);
+    return hipGetLastError();
+}
+
 hipError_t launch_compact_runs(uint64_t n_pairs, const scrg_pair_desc* d_pairs, const uint16_t* d_runs,
                                const uint32_t* d_n_runs, const uint64_t* d_dense_off, uint16_t* d_dense,
                                int n_cus, hipStream_t s)
