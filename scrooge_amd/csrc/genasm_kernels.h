@@ -86,10 +86,6 @@ hipError_t launch_compact_runs(uint64_t n_pairs, const scrg_pair_desc* d_pairs, 
                                const uint32_t* d_n_runs, const uint64_t* d_dense_off, uint16_t* d_dense,
                                int n_cus, hipStream_t s);
 
-// (for batches with only a few runs per pair: one pair per lane)
-hipError_t launch_compact_runs_small(uint64_t n_pairs, const scrg_pair_desc* d_pairs, const uint16_t* d_runs,
-                                     const uint32_t* d_n_runs, const uint64_t* d_dense_off, uint16_t* d_dense,
-                                     int n_cus, hipStream_t s);
 hipError_t launch_compact_runs_packed(uint64_t n_pairs, const scrg_pair_desc* d_pairs, const uint16_t* d_runs,
                                       const uint32_t* d_n_runs, const uint64_t* d_dense_off, uint8_t* d_dense,
                                       int n_cus, hipStream_t s);

@@ -979,16 +979,9 @@ scrg_status run_batch(scrg_ctx* c, const scrg_params& p, std::vector<SeqRef>& se
         if ((e = hipMemcpyAsync(c->d_dense_off.p, dense_off_sorted, n * 8, hipMemcpyHostToDevice, c->stream)) !=
             hipSuccess)
             return bail(c->fail(SCRG_ERR_HIP, "H2D offsets", e));
-        if (total_runs < 16 * n) {       // short alignments (150 bp reads: ~3 runs per pair): one pair per lane
-            if ((e = scrg::launch_compact_runs_small(n, c->d_pairs.as<scrg_pair_desc>(), c->d_runs.as<uint16_t>(),
-                                                     c->d_nruns.as<uint32_t>(), c->d_dense_off.as<uint64_t>(),
-                                                     c->d_dense.as<uint16_t>(), c->n_cus, c->stream)) != hipSuccess)
-                return bail(c->fail(SCRG_ERR_HIP, "compaction", e));
-        } else {
-            s = scrg_compact_runs(c, n, c->d_pairs.as<scrg_pair_desc>(), c->d_runs.as<scrg_run>(), c->d_nruns.as<uint32_t>(),
-                                  c->d_dense_off.as<uint64_t>(), c->d_dense.as<scrg_run>());
-            if (s != SCRG_OK) return bail(s);
-        }
+        s = scrg_compact_runs(c, n, c->d_pairs.as<scrg_pair_desc>(), c->d_runs.as<scrg_run>(), c->d_nruns.as<uint32_t>(),
+                              c->d_dense_off.as<uint64_t>(), c->d_dense.as<scrg_run>());
+        if (s != SCRG_OK) return bail(s);
         if ((e = c->h_runs.ensure(total_runs * sizeof(scrg_run))) != hipSuccess)
             return bail(c->fail(SCRG_ERR_OOM, "pinned run buffer", e));
         if ((e = hipMemcpyAsync(c->h_runs.p, c->d_dense.p, total_runs * sizeof(scrg_run), hipMemcpyDeviceToHost, c->stream)) !=

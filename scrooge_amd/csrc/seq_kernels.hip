@@ -139,23 +139,44 @@ __global__ __launch_bounds__(256) void compact_runs_kernel(uint64_t n_pairs, con
                                                            const uint16_t* __restrict__ runs,
                                                            const uint32_t* __restrict__ n_runs,
                                                            const uint64_t* __restrict__ dense_off,
-                                                           uint16_t* __restrict__ dense)
+                                                           uint16_t* __restrict__ dense, uint32_t split)
 {
-    // One wavefront per pair.  The slice starts 32-byte aligned, the destination at any run (2-byte)
+    // Long alignments: one wavefront per pair.  The slice starts 32-byte aligned, the destination at any run (2-byte)
     // boundary: an odd destination run index means every output dword straddles two source dwords
     // (v_alignbit by 16).  The bulk moves 16 bytes per lane with 16-byte aligned stores.
+    // Pairs are taken 64 at a time: if none of the 64 has more than 16 runs (150 bp reads have ~3), every lane copies
+    // its own pair; otherwise they are copied one after the other by whole wavefronts — `split` wavefronts share a
+    // group of 64 (each takes every split-th pair), so that a batch of few, long alignments still fills the GPU.
     const uint32_t lane = threadIdx.x & 63;
-    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    for (uint64_t p = wave; p < n_pairs; p += n_waves) {
-        const uint64_t cap = pairs[p].cigar_cap;
-        uint64_t cnt = n_runs[p];
-        if (cnt > cap) cnt = cap;
+    const uint64_t wave_all = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t wave = wave_all / split, n_waves = (((uint64_t)gridDim.x * blockDim.x) >> 6) / split;
+    const uint32_t sub = (uint32_t)(wave_all % split);
+    for (uint64_t g0 = wave * 64; g0 < n_pairs; g0 += n_waves * 64) {
+      const uint64_t mine = g0 + lane;
+      uint64_t my_cnt = 0, my_src = 0, my_dst = 0;
+      if (mine < n_pairs) {
+          const uint64_t cap = pairs[mine].cigar_cap;
+          my_cnt = n_runs[mine];
+          if (my_cnt > cap) my_cnt = cap;
+          my_src = pairs[mine].cigar_off;
+          my_dst = dense_off[mine];
+      }
+      if (!__any(my_cnt > 16)) {
+          if (sub == 0) {
+              const uint16_t* const s = runs + my_src;
+              uint16_t* const d = dense + my_dst;
+              for (uint64_t k = 0; k < my_cnt; k++) d[k] = s[k];
+          }
+          continue;
+      }
+      for (uint32_t q = sub; q < 64 && g0 + q < n_pairs; q += split) {
+        uint64_t cnt = __shfl(my_cnt, (int)q, 64);
         if (cnt == 0) continue;
-        const uint16_t* const s16 = runs + pairs[p].cigar_off;
+        const uint64_t src_off = __shfl(my_src, (int)q, 64), dst_off = __shfl(my_dst, (int)q, 64);
+        const uint16_t* const s16 = runs + src_off;
         const uint32_t* const s32 = reinterpret_cast<const uint32_t*>(s16);
-        uint16_t* const d16 = dense + dense_off[p];
-        const uint32_t odd = (uint32_t)(dense_off[p] & 1u);          // the first run goes out alone, the rest is dword aligned
+        uint16_t* const d16 = dense + dst_off;
+        const uint32_t odd = (uint32_t)(dst_off & 1u);          // the first run goes out alone, the rest is dword aligned
         if (odd && lane == 0) d16[0] = s16[0];
         const uint64_t rem = cnt - odd;
         const uint64_t nd = rem >> 1;                                  // whole output dwords
@@ -186,6 +207,7 @@ __global__ __launch_bounds__(256) void compact_runs_kernel(uint64_t n_pairs, con
         const uint64_t done = head + 4 * groups;
         if (done + lane < nd) d32[done + lane] = out_dword(done + lane);          // up to 3 dwords
         if ((rem & 1u) && lane == 63) d16[cnt - 1] = s16[cnt - 1];
+      }
     }
 }
 // ----------------------------------------------------------------------------
@@ -295,47 +317,21 @@ hipError_t launch_ascii_to_twobit(uint64_t count, const uint64_t* d_lens, const 
     return hipGetLastError();
 }
 
-// The same gather for batches of SHORT alignments (a few runs per pair: 150 bp reads): one pair per lane instead
-// of one per wavefront.
-__global__ __launch_bounds__(256) void compact_runs_small_kernel(uint64_t n_pairs, const scrg_pair_desc* __restrict__ pairs,
-                                                                 const uint16_t* __restrict__ runs,
-                                                                 const uint32_t* __restrict__ n_runs,
-                                                                 const uint64_t* __restrict__ dense_off,
-                                                                 uint16_t* __restrict__ dense)
-{
-    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n_pairs; p += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t cap = pairs[p].cigar_cap;
-        uint64_t cnt = n_runs[p];
-        if (cnt > cap) cnt = cap;
-        const uint16_t* const s = runs + pairs[p].cigar_off;
-        uint16_t* const d = dense + dense_off[p];
-        for (uint64_t k = 0; k < cnt; k++) d[k] = s[k];
-    }
-}
-
-hipError_t launch_compact_runs_small(uint64_t n_pairs, const scrg_pair_desc* d_pairs, const uint16_t* d_runs,
-                                     const uint32_t* d_n_runs, const uint64_t* d_dense_off, uint16_t* d_dense,
-                                     int n_cus, hipStream_t s)
-{
-    if (n_pairs == 0) return hipSuccess;
-    uint64_t blocks = (n_pairs + 255) / 256;
-    const uint64_t cap = (uint64_t)n_cus * 16;
-    if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(compact_runs_small_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
-                       n_pairs, d_pairs, d_runs, d_n_runs, d_dense_off, d_dense);
-    return hipGetLastError();
-}
-
 hipError_t launch_compact_runs(uint64_t n_pairs, const scrg_pair_desc* d_pairs, const uint16_t* d_runs,
                                const uint32_t* d_n_runs, const uint64_t* d_dense_off, uint16_t* d_dense,
                                int n_cus, hipStream_t s)
 {
     if (n_pairs == 0) return hipSuccess;
-    uint64_t blocks = (n_pairs + 3) / 4;
+    // groups of 64 pairs; up to 8 wavefronts share a group while there are fewer groups than the GPU has room for
+    const uint64_t groups = (n_pairs + 63) / 64, room = (uint64_t)n_cus * 32;
+    uint32_t split = 1;
+    while (split < 8 && groups * split * 2 <= room) split *= 2;
+    uint64_t blocks = (groups * split + 3) / 4;                  // four wavefronts per workgroup
     const uint64_t cap = (uint64_t)n_cus * 8;
     if (blocks > cap) blocks = cap;
+    if (split == 8 && (blocks & 1)) blocks++;                    // (the wavefronts of a launch: a multiple of `split`)
     hipLaunchKernelGGL(compact_runs_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
-                       n_pairs, d_pairs, d_runs, d_n_runs, d_dense_off, d_dense);
+                       n_pairs, d_pairs, d_runs, d_n_runs, d_dense_off, d_dense, split);
     return hipGetLastError();
 }
 
