@@ -101,3 +101,23 @@ def test_malformed_streams_are_rejected():
     assert api.edit_stream_to_cigar(bytes([3 << 6]), 2) == "1D2="    # a deletion uses no read base
     with pytest.raises(ValueError):
         api.cigar_to_edit_stream("5M")
+
+
+def test_c_example_runs_without_a_gpu():
+    """examples/edit_stream_example.c: plain C against the C ABI (gcc, no HIP in the program), the host conversions only."""
+    import subprocess
+    import scrooge_amd
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    scrooge_amd.build_library()
+    libdir = os.path.join(root, "scrooge_amd")
+    exe = "/tmp/scrg_edit_stream_example"
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "examples", "edit_stream_example.c"),
+                           "-L" + libdir, "-lscrooge_amd", "-Wl,-rpath," + libdir, "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = out.stdout.splitlines()
+    assert lines[0] == "runs   31=9=1X21=6=1D24=8="
+    assert lines[1] == "stream 2 bytes: 68 db"            # X after 40 matches: 1 << 6 | 40; D after 27: 3 << 6 | 27
+    assert lines[2] == "decoded 31=9=1X21=6=1D24=8="
+    assert lines[3].startswith("W32/O17 15=") and lines[-1] == "ok"
