@@ -779,20 +779,11 @@ scrg_status run_batch(scrg_ctx* c, const scrg_params& p, std::vector<SeqRef>& se
         hipError_t e = c->h_ascii.ensure(ascii_bytes);
         if (e != hipSuccess) return bail(c->fail(SCRG_ERR_OOM, "pinned staging buffer", e));
         char* h = static_cast<char*>(c->h_ascii.p);
-        // pieces of at most 4 MB, so that one long sequence (a chromosome) is copied by all threads
+        // sequences of up to 4 MB are copied whole, one per index; longer ones (a chromosome) are cut into pieces of
+        // 4 MB so that all threads share them
         struct Piece { uint64_t seq, from, to; };
-        std::vector<Piece> pieces;
-        pieces.reserve(seqs.size());
         const uint64_t PIECE = 4u << 20;
-        for (uint64_t s = 0; s < seqs.size(); s++) {
-            const uint64_t span = ((seqs[s].len + 31) / 32) * 32;
-            for (uint64_t a = 0; a < span || a == 0; a += PIECE) {
-                pieces.push_back({s, a, std::min(span, a + PIECE)});
-                if (span == 0) break;
-            }
-        }
-        parallel_for(pieces.size(), [&](uint64_t i) {
-            const Piece& pc = pieces[i];
+        auto copy_piece = [&](const Piece& pc) {
             const SeqRef& q = seqs[pc.seq];
             char* dst = h + (q.word_off - resident_words) * 32;
             const uint64_t data_to = std::min(pc.to, q.len);
@@ -802,7 +793,18 @@ scrg_status run_batch(scrg_ctx* c, const scrg_params& p, std::vector<SeqRef>& se
                     for (uint64_t k = pc.from; k < data_to; k++) dst[k] = complement_base(q.p[q.len - 1 - k]);
             }
             if (pc.to > std::max(pc.from, q.len)) memset(dst + std::max(pc.from, q.len), 0, pc.to - std::max(pc.from, q.len));
-        }, true);
+        };
+        std::vector<Piece> pieces;                      // of the long sequences only
+        for (uint64_t s = 0; s < seqs.size(); s++) {
+            const uint64_t span = ((seqs[s].len + 31) / 32) * 32;
+            if (span > PIECE)
+                for (uint64_t a = 0; a < span; a += PIECE) pieces.push_back({s, a, std::min(span, a + PIECE)});
+        }
+        parallel_for(pieces.size(), [&](uint64_t i) { copy_piece(pieces[i]); }, true);
+        parallel_for(seqs.size(), [&](uint64_t s) {
+            const uint64_t span = ((seqs[s].len + 31) / 32) * 32;
+            if (span <= PIECE && span) copy_piece(Piece{s, 0, span});
+        });
     }
     hipError_t e;
     if (resident_words && (size_t)seq_words * 8 > c->d_seq.cap) {
