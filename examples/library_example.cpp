@@ -19,7 +19,7 @@ static void show(const char* what, const std::vector<Alignment_t>& alns, long lo
 
 int main()
 {
-    scrooge_amd::enabled_algorithm_log(false);
+    scrooge_amd::enabled_algorithm_log = false;
     try {
         // pairwise interface: queries[i] against texts[i]
         std::vector<std::string> texts = {"ACGTACGT", "AAAACCCCGGGGTTTT"};

@@ -11,7 +11,7 @@
  *   __global__ genasm_gpu::ascii_to_twobit_strings(count, lens, ascii, twobit)
  *       -> scrg_ascii_to_twobit()          (same byte layout, src/genasm_gpu.cu:631-685)
  *   genasm_gpu::enabled_algorithm_log
- *       -> scrg_set_log()
+ *       -> scrg_set_log() / scrg_get_log()
  *
  * include/scrooge_amd.hpp rebuilds the reference's C++ signatures on top of
  * these entry points.  Everything here is plain pointers and sizes; the
@@ -103,6 +103,7 @@ const char *scrg_last_error(const scrg_ctx *ctx);
 const char *scrg_status_string(scrg_status s);
 /* mirrors genasm_gpu::enabled_algorithm_log (src/genasm_gpu.hpp:6) */
 void        scrg_set_log(int enabled);
+int         scrg_get_log(void);
 int         scrg_device_count(void);
 
 /* ---------------------------------------------------------------------------

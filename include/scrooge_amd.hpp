@@ -6,10 +6,12 @@
 //     #include "genasm_gpu.hpp"                 ->  #include "scrooge_amd.hpp"
 //     genasm_gpu::align_all(genome, reads)      ->  scrooge_amd::align_all(genome, reads)
 //     genasm_gpu::align_all(texts, queries)     ->  scrooge_amd::align_all(texts, queries)
-//     genasm_gpu::enabled_algorithm_log = false ->  scrooge_amd::enabled_algorithm_log(false)
+//     genasm_gpu::enabled_algorithm_log = false ->  scrooge_amd::enabled_algorithm_log = false
 //
-// (or define SCROOGE_AMD_AS_GENASM_GPU before including to get a
-// `namespace genasm_gpu` alias and keep the call sites untouched).
+// Callers that must compile UNCHANGED include the headers of the reference's own names instead:
+// include/compat/genasm_gpu.hpp and include/compat/genasm_cpu.hpp declare `namespace genasm_gpu` / `genasm_cpu`
+// with exactly the reference's overloads on top of this file (tests/test_reference_callers.py compiles the
+// reference's src/library_example.cu against them as it is).
 //
 // Semantics kept from the reference: result k belongs to the k-th (read,
 // location) in nested order / the k-th string pair; texts[i] is the target,
@@ -190,7 +192,23 @@ inline Handle& default_handle()
     return h;
 }
 
-inline void enabled_algorithm_log(bool on) { scrg_set_log(on ? 1 : 0); }
+// The reference exports an assignable `extern bool enabled_algorithm_log` per namespace (src/genasm_gpu.hpp:6,
+// src/genasm_cpu.hpp:5) and its callers write `genasm_gpu::enabled_algorithm_log = verbose;`
+// (src/library_example.cu:91-92, src/tests.cu:791-792).  The switch itself lives inside the shared library
+// (scrg_set_log), so the name here is an object that forwards: assignable from and convertible to bool.
+// (The call form enabled_algorithm_log(false) of earlier versions of this header still works.)
+struct LogSwitch {
+    LogSwitch& operator=(bool on)
+    {
+        scrg_set_log(on ? 1 : 0);
+        return *this;
+    }
+    void operator()(bool on) const { scrg_set_log(on ? 1 : 0); }
+    operator bool() const { return scrg_get_log() != 0; }
+    LogSwitch() = default;
+    LogSwitch(const LogSwitch&) = delete;
+};
+inline LogSwitch enabled_algorithm_log;
 
 // src/genasm_gpu.hpp:7
 inline std::vector<Alignment_t> align_all(Genome_t& reference, std::vector<Read_t>& reads,
@@ -221,5 +239,7 @@ inline std::vector<Alignment_t> align_all(std::vector<std::string>& texts, std::
 }  // namespace scrooge_amd
 
 #ifdef SCROOGE_AMD_AS_GENASM_GPU
+// (kept for callers of earlier versions of this header; include/compat/genasm_gpu.hpp is the drop-in form: an alias
+// also exposes the `threads` overloads, which makes align_all(texts, queries, NULL) ambiguous)
 namespace genasm_gpu = scrooge_amd;
 #endif

@@ -253,6 +253,7 @@ const char* scrg_status_string(scrg_status s)
 }
 
 void scrg_set_log(int enabled) { g_log.store(enabled ? 1 : 0); }
+int scrg_get_log(void) { return g_log.load(); }
 
 int scrg_device_count(void)
 {
