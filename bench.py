@@ -167,6 +167,9 @@ def main():
     # holds the device, least of all under a profiler
     if not args.no_build:
         scrooge_amd.build_library()
+        if args.cpu_seconds > 0 and rank == 0:
+            from oracle.pyoracle import build as build_oracle      # the checker of the CPU leg: compiled now, only loaded later
+            build_oracle()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     dryrun = os.environ.get("SCRG_BENCH_DRYRUN") == "1"    # test only: all ranks on GPU 0, gloo through the host
@@ -207,6 +210,11 @@ def main():
     if args.ablate:
         al.params.reserved[0] = args.ablate     # results are wrong by design; parity checks are skipped
         args.cpu_seconds = 0
+        try:
+            al.resolved_params()
+        except scrooge_amd.ScroogeError:
+            raise SystemExit("--ablate needs a library built with -DSCRG_ABLATE (scripts/ab.sh build ablate -DSCRG_ABLATE; "
+                             "SCRG_LIB=ab_libs/lib_ablate.so): the shipped library has no ablation code paths")
 
     # ---------------- synthetic batch, generated and packed on the GPU ----------------
     n = args.pairs
@@ -517,7 +525,7 @@ def main():
         texts_all = [rows[i, :text_len].tobytes() for i in range(sample_cap)]
         reads_all = [rows[i, tw * 32: tw * 32 + L].tobytes() for i in range(sample_cap)]
         cores = usable_cores()
-        orc = Oracle()
+        orc = Oracle(allow_compile=False)          # (built before the GPU was initialised, or prebuilt: never compile from here)
         cal = min(sample_cap, max(2 * cores, 16))
         _, _, st, ns = orc.align(texts_all[:cal], reads_all[:cal], threads=cores)
         dc_cells, tb_steps, text_used = (st["dc_cells"] / cal, st["tb_steps"] / cal, st["text_used"] / cal)

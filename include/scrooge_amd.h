@@ -67,7 +67,9 @@ typedef struct scrg_params {
                                 layout of scrg_pack_planar_groups() (see there).  Only lanes_per_pair = 1
                                 accepts a stride other than 1                                        */
     int32_t read_stride_words; /* the same for the reads                                             */
-    int32_t reserved[2];
+    int32_t reserved[2];     /* [0]: experiment switches, 0 unless profiling (see scrg_debug_stats: unknown bits are
+                                rejected with SCRG_ERR_INVALID_ARG, so an uninitialised struct cannot silently
+                                change results); [1]: non-zero = collect the kernel's profiling counters    */
 } scrg_params;
 
 void scrg_params_default(scrg_params *p);
@@ -125,8 +127,11 @@ typedef struct scrg_result {
 } scrg_result;
 
 /* (The large arrays are recycled by the library: up to 2 GB of them are kept for the next call of similar size
- * instead of being returned to the allocator, so that a stream of batches does not fault fresh pages every time.) */
+ * instead of being returned to the allocator, so that a stream of batches does not fault fresh pages every time.
+ * scrg_result_pool_trim() returns the parked arrays to the allocator; destroying the last handle does the same.
+ * Recycled arrays are NOT zeroed: every element a result publishes is written by the call that publishes it.) */
 void scrg_result_free(scrg_result *r);
+void scrg_result_pool_trim(void);
 
 /* Unstructured pairwise alignment: queries[i] is consumed completely against a
  * prefix of texts[i] (reference: genasm_gpu.cu:982-1065; returns all n results,
@@ -309,11 +314,12 @@ scrg_status scrg_last_kernel_ms(scrg_ctx *ctx, float *ms);
  *   lanes_per_pair >= 4 (genasm_align_kernel): {window rounds, DC sweep steps, TB macro-steps, shader cycles for
  *     fetch / window setup / DC / TB / TB loop, rounds on the diagonal-major path, rounds that fell back from it,
  *     DC / TB cycles of the diagonal-major rounds (not included in the former)}.
- * params.reserved[0] holds ablation switches for profiling and must be 0 for correct results, except:
- *   lanes_per_pair = 1: 1 only turns the wavefront priority rotation off, 64 / 128 launch workgroups of one / two
- *     wavefronts instead of four (results intact); 2 / 4 / 8 / 16 skip the table, traceback pass 2, traceback pass 1,
- *     the CIGAR stores (results are wrong by design);
- *   lanes_per_pair = 8: 32 only turns the diagonal-major path off (results intact). */
+ * params.reserved[0] holds experiment switches; scrg_params_resolve() and every entry point REJECT any bit other
+ * than the ones that leave the results intact:
+ *   lanes_per_pair = 1: 1 turns the wavefront priority rotation off, 64 / 128 launch workgroups of one / two
+ *     wavefronts instead of four;  lanes_per_pair = 8: 32 turns the diagonal-major path off.
+ * (Ablation switches — skip the table, a traceback pass, the stores; results wrong by design — exist only in a
+ * library built with -DSCRG_ABLATE for profiling, scripts/ab.sh; the shipped library has no such code path.) */
 scrg_status scrg_debug_stats(scrg_ctx *ctx, uint64_t out[12]);
 
 #ifdef __cplusplus

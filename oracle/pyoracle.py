@@ -21,13 +21,46 @@ class GoStats(C.Structure):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
 
 
-def build(force=False):
-    """Compile liboracle.so (and _ref when /root/reference is present)."""
+def _digest():
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("genasm_oracle.c", "genasm_oracle_core.inc", "genasm_oracle.h", "Makefile", "ref_driver.cpp"):
+        with open(os.path.join(HERE, f), "rb") as fh:
+            h.update(f.encode())
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def is_stale():
+    """Decided by the CONTENT of the sources (a digest kept next to the library), never by modification times: the
+    snapshot a GPU box gets keeps contents, not the order of time stamps (same rule as scrooge_amd.build_library)."""
     so = os.path.join(HERE, "liboracle.so")
-    if force or not os.path.exists(so) or \
-            os.path.getmtime(so) < os.path.getmtime(os.path.join(HERE, "genasm_oracle.c")):
-        subprocess.check_call(["make", "-C", HERE, "--no-print-directory"],
-                              stdout=subprocess.DEVNULL)
+    if not os.path.exists(so):
+        return True
+    try:
+        return open(so + ".sources.sha256").read().strip() != _digest()
+    except OSError:
+        return True
+
+
+def build(force=False, allow_compile=True):
+    """Compile liboracle.so (and _ref when /root/reference is present) if its sources changed.
+
+    allow_compile=False never forks a compiler: a stale or missing library is an error.  Callers that initialise a
+    GPU (bench.py, anything under rocprofv3) build BEFORE the first HIP call and pass False afterwards — a compiler
+    must never be forked from a process that holds the device."""
+    so = os.path.join(HERE, "liboracle.so")
+    if force or is_stale():
+        if not allow_compile:
+            raise RuntimeError("oracle/liboracle.so is missing or older than its sources and building is not allowed here "
+                               "(run `python -c 'from oracle.pyoracle import build; build()'` first)")
+        import fcntl
+        with open(os.path.join(HERE, ".build.lock"), "w") as lk:
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            if force or is_stale():
+                subprocess.check_call(["make", "-C", HERE, "--no-print-directory", "-B"], stdout=subprocess.DEVNULL)
+                with open(so + ".sources.sha256", "w") as fh:
+                    fh.write(_digest() + "\n")
     return so
 
 
@@ -51,8 +84,8 @@ def _marshal(texts, reads):
 
 
 class Oracle:
-    def __init__(self):
-        self.lib = C.CDLL(build())
+    def __init__(self, allow_compile=True):
+        self.lib = C.CDLL(build(allow_compile=allow_compile))
         self.lib.go_align_batch_ascii.restype = C.c_int
         self.lib.go_align_batch_ascii.argtypes = [
             C.c_size_t, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64),

@@ -4,10 +4,12 @@
 # 2. PMC passes (one counter set per pass, kernel trace only) of the same workload, one stream:
 #      HBM traffic  -> gpurun_out/pmc_<tag>_hbm/summary.json
 #      SQ counters  -> gpurun_out/pmc_<tag>_sq/summary.json
-# The library is built first and pinned with SCRG_LIB; every profiler run has its own time limit.
+# The library AND the oracle (the CPU leg of the default bench command) are built first, the library is pinned with
+# SCRG_LIB, and bench.py --no-build loads both without ever forking a compiler (oracle/pyoracle.py: allow_compile=False);
+# every profiler run has its own time limit.
 tag=${1:-r02}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
-python3 -c "import sys; sys.path.insert(0, '$root'); import scrooge_amd; scrooge_amd.build_library()" || exit 1
+python3 -c "import sys; sys.path.insert(0, '$root'); import scrooge_amd; scrooge_amd.build_library(); from oracle.pyoracle import build; build()" || exit 1
 export SCRG_LIB=$root/scrooge_amd/libscrooge_amd.so
 mkdir -p $root/gpurun_out/prof_$tag
 (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $root/gpurun_out/prof_$tag -o prof --output-format csv -- \

@@ -142,6 +142,7 @@ def load_library():
         "scrg_get_log": (C.c_int, []),
         "scrg_device_count": (C.c_int, []),
         "scrg_result_free": (None, [C.POINTER(Result)]),
+        "scrg_result_pool_trim": (None, []),
         "scrg_align_pairs": (C.c_int32, [vp, C.POINTER(Params), u64, C.POINTER(C.c_char_p),
                                          C.POINTER(u64), C.POINTER(C.c_char_p), C.POINTER(u64),
                                          C.POINTER(C.POINTER(Result))]),
@@ -179,7 +180,7 @@ EXPORTED_SYMBOLS = [
     "scrg_params_default", "scrg_params_resolve", "scrg_ctx_create", "scrg_ctx_destroy", "scrg_ctx_set_stream",
     "scrg_ctx_use_own_stream", "scrg_stream_create", "scrg_stream_destroy",
     "scrg_last_error", "scrg_status_string", "scrg_set_log", "scrg_get_log", "scrg_device_count",
-    "scrg_result_free", "scrg_align_pairs", "scrg_align_mapping", "scrg_genome_set", "scrg_genome_clear",
+    "scrg_result_free", "scrg_result_pool_trim", "scrg_align_pairs", "scrg_align_mapping", "scrg_genome_set", "scrg_genome_clear",
     "scrg_align_mapping_resident", "scrg_pack_planar", "scrg_pack_planar_groups",
     "scrg_align_device", "scrg_align_device_edits", "scrg_compact_runs", "scrg_compact_runs_packed", "scrg_unpack_runs",
     "scrg_encode_edit_stream", "scrg_decode_edit_stream", "scrg_edit_stream_to_runs", "scrg_runs_to_edit_stream", "scrg_ascii_to_twobit", "scrg_query_launch",

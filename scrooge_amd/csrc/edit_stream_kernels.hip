@@ -125,8 +125,8 @@ __global__ __launch_bounds__(256) void encode_edits_kernel(uint64_t n_pairs, con
             // corrected below once the matches pending from the lanes before are known
             walk_segment(sg.my, sg.mine, [&](uint32_t run) {
                 const uint32_t n = run & 0xffu;
-                const bool e = (run >> 8) != (uint32_t)'=';
-                const uint32_t t = (n > 1u ? n : 1u) + (pend >> 6);
+                const bool e = (run >> 8) != (uint32_t)'=' && n != 0u;       // (a run of count 0 is no run: scrg_runs_to_edit_stream skips it too)
+                const uint32_t t = n + (pend >> 6);
                 nb += e ? t : 0u;
                 lead = (e && !has) ? pend : lead;
                 has |= e ? 1u : 0u;
@@ -182,8 +182,8 @@ __global__ __launch_bounds__(256) void encode_edits_kernel(uint64_t n_pairs, con
             // edit bytes.  The edit byte is stored by every lane that has one; the rare rest takes a side path.
             walk_segment(sg.my, sg.mine, [&](uint32_t run) {
                 const uint32_t n = run & 0xffu, op = run >> 8;
-                const bool e = op != (uint32_t)'=';
-                const uint32_t nn = n > 1u ? n : 1u;
+                const bool e = op != (uint32_t)'=' && n != 0u;
+                const uint32_t nn = n;
                 const uint32_t c = pm >> 6;
                 // 'X' 0x58, 'I' 0x49, 'D' 0x44 -> 1, 2, 3: two bits of a constant at position op & 31 (24, 9, 4)
                 const uint32_t code = ((0x01000430u >> (op & 31u)) & 3u) << 6;

@@ -30,8 +30,23 @@ struct AlignArgs {
     uint32_t text_stride;         // words between consecutive words of a text / a read in seq (1 = contiguous;
     uint32_t read_stride;         //   64 = lane-interleaved groups, scrg_pack_planar_groups; lane kernel only)
     uint64_t* stats;              // optional profiling counters {rounds, DC steps, TB macro-steps}; may be null
-    int32_t debug;                // ablation switches for profiling only (params.reserved[0]); 0 in production
+    int32_t debug;                // experiment switches (params.reserved[0]); see SCRG_SAFE_SWITCHES / SCRG_ABL below
 };
+
+// scrg_params.reserved[0].  The switches that leave the results intact exist in every build: 1 (one pair per lane: no
+// wavefront priority rotation), 32 (lanes_per_pair = 8: no diagonal-major path), 64 / 128 (one pair per lane:
+// workgroups of one / two wavefronts).  The ABLATION switches (2, 4, 8, 16, and 1 for the GenASM-row kernel: skip the
+// table, the runs, the walk, the stores — results are wrong by design) are compiled in only with -DSCRG_ABLATE
+// (scripts/ab.sh build ablate -DSCRG_ABLATE; bench.py --ablate): the shipped library has no code path that produces
+// wrong results on request, and scrg_params_resolve() rejects any other bit.
+constexpr int32_t SCRG_SAFE_SWITCHES = 1 | 32 | 64 | 128;
+#ifdef SCRG_ABLATE
+#define SCRG_ABL(args, bit) (((args).debug & (bit)) != 0)
+constexpr int32_t SCRG_ALLOWED_SWITCHES = 0xff;
+#else
+#define SCRG_ABL(args, bit) false
+constexpr int32_t SCRG_ALLOWED_SWITCHES = SCRG_SAFE_SWITCHES;
+#endif
 
 hipError_t launch_align(int lanes_per_pair, const AlignArgs& a, int grid, size_t lds_bytes, hipStream_t s);
 hipError_t launch_align_multiword(int lanes_per_pair, const AlignArgs& a, int grid, size_t lds_bytes, hipStream_t s);

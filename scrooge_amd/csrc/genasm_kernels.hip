@@ -351,7 +351,7 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
                             const bool need = found && (upto & ~15u) > flushed;
                             if (!__any(need)) break;
                             if (need) {
-                                if (!(a.debug & 4)) {
+                                if (!SCRG_ABL(a, 4)) {
                                     const uint32_t piece = ((flushed >> 4) & 1u) * 8u;
                                     uint32_t* const dst = reinterpret_cast<uint32_t*>(a.runs + cigar_off + flushed);
                                     for (uint32_t k = (uint32_t)t; k < 8u; k += (uint32_t)G) dst[k] = lds[obuf + piece + k];
@@ -589,7 +589,7 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
             d++;
             step++;
         };
-        if (!(a.debug & 2)) {
+        if (!SCRG_ABL(a, 2)) {
             while (!all_done) {
                 dc_step(pA, psA, rnA, rnsA, pB, psB, rnB, rnsB);
                 if (all_done) break;
@@ -627,7 +627,7 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
                 if (en && !same && cur_cnt != 0) {             // run ended: stage {count, op}
                     if (n_runs < cigar_cap) {
                         if (leader) lds16[2u * obuf + (n_runs & 31u)] = (uint16_t)(cur_cnt | (cur_op << 8));
-                        if ((n_runs & 15u) == 15u && !(a.debug & 4)) {   // 16 runs complete: one 32-byte store per slot
+                        if ((n_runs & 15u) == 15u && !SCRG_ABL(a, 4)) {   // 16 runs complete: one 32-byte store per slot
                             const uint32_t piece = ((n_runs >> 4) & 1u) * 8u;
                             uint32_t* const dst = reinterpret_cast<uint32_t*>(a.runs + cigar_off + (n_runs - 15u));
                             for (uint32_t k = (uint32_t)t; k < 8u; k += (uint32_t)G) dst[k] = lds[obuf + piece + k];
@@ -683,7 +683,7 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
                 const bool sub = room && tl && (last || ((e1 >> sh) & 1ull) == 0ull);
                 uint32_t ev = ins ? 1u : (del ? 2u : (sub ? 3u : 0u));     // priority I, D, X, = (:346-370)
                 ev = pos_ok ? ev : 4u;                           // 4 = the window's walk ends here
-                if (a.debug & 1) ev = pos_ok ? 0u : 4u;
+                if (SCRG_ABL(a, 1)) ev = pos_ok ? 0u : 4u;
                 const uint32_t key = (act && ev) ? (((uint32_t)t << 3) | ev) : 0xffffu;
                 const uint32_t kmin = slot_min<G>(key);
                 const bool none = kmin == 0xffffu;
@@ -749,7 +749,7 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
             auto flush_pieces = [&](uint32_t before2) {
                 const uint32_t crossed = (before2 ^ nr2) & 32u;                        // bit 5 of 2*n flips every 16 runs
                 if (__any(crossed != 0u)) {
-                    if (crossed && !(a.debug & 4)) {
+                    if (crossed && !SCRG_ABL(a, 4)) {
                         const uint32_t first = (nr2 >> 5) * 16u - 16u;                 // first run of the completed piece
                         if (first + 16u <= cigar_cap) {
                             const uint32_t piece = ((first >> 4) & 1u) * 8u;
@@ -788,7 +788,7 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
                 const uint32_t is_edit = ((c & 3u) + 3u) >> 2;                // 1 for I/D/X
                 const uint32_t inc_i = (c >> 1) & 1u, inc_j = c & 1u;
 
-                if (!(a.debug & 16)) {
+                if (!SCRG_ABL(a, 16)) {
                 emit(nz_mask(n_eq), (uint32_t)'=' << 8, n_eq);
                 // 'I' 0x49, 'D' 0x44, 'X' 0x58 in a table word indexed by the code
                 emit(0u - is_edit, ((0x58444900u >> ((c & 3u) * 8u)) & 0xffu) << 8, 1u);
@@ -818,7 +818,7 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
                 read_idx += (uint32_t)TBL - jrem;
             }
         };
-        const bool fast_ok = !WIDE && !spilled && !__any(has_pair && (m <= (uint32_t)TBL || n < (uint32_t)TBL)) && !(a.debug & 8);
+        const bool fast_ok = !WIDE && !spilled && !__any(has_pair && (m <= (uint32_t)TBL || n < (uint32_t)TBL)) && !SCRG_ABL(a, 8);
         if (fast_ok) traceback_fast();
         else if (spilled) traceback(std::true_type{});
         else traceback(std::false_type{});

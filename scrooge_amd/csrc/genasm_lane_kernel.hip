@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
 #pragma unroll
         for (int k = 0; k < 8; k++) w[k] = lds[rd + k];
         const bool room = EDITS ? flushed + 32u <= 2u * (uint64_t)cigar_cap : flushed + 16u <= cigar_cap;
-        if (room && !(a.debug & 16)) {          // (16: ablation, profiling only: no stores)
+        if (room && !SCRG_ABL(a, 16)) {          // (16: ablation, profiling only: no stores)
             uint4* const dst = EDITS ? reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(a.runs + cigar_off) + flushed)
                                      : reinterpret_cast<uint4*>(a.runs + cigar_off + flushed);
             dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
         const uint32_t jlim = has_pair ? min(m, TBL) : 0u;          // the walk ends when j gets here (:301, :310)
         const uint32_t stop = 0x80000000u >> jlim;
         const bool short_n = __any(has_pair && n != 64u);
-        if (a.debug & 2) {                       // ablation (profiling only): no table computation
+        if (SCRG_ABL(a, 2)) {                       // ablation (profiling only): no table computation
 #pragma unroll
             for (int i = 0; i < LANE_TB_COLS; i++) tab[i] = ((uint64_t)~stop << 32) | (((uint32_t)tw.lo * (uint32_t)(i + 1)) | stop);
         } else if (short_n) {
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
                     asm("v_add_co_u32 %1, vcc, %2, %2\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(j), "=&v"(scratch) : "v"(nt1) : "vcc");
                 }
             };
-            if (a.debug & 8) { j = jlim; nDm = ~0u; }                    // ablation (profiling only): no walk
+            if (SCRG_ABL(a, 8)) { j = jlim; nDm = ~0u; }                    // ablation (profiling only): no walk
             else if (TBL == (uint32_t)LANE_TB_COLS) walk(std::true_type{});
             else walk(std::false_type{});
             if (timing) cy_p1 += __builtin_readcyclecounter() - tm3;
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
                 // goes to the slot after the last committed one; only committing moves on.  Three insertions and 127
                 // pending matches are handled in line, longer runs / stretches on a side path (well under one per cent
                 // of the iterations at 10 % error).
-                uint32_t E = (a.debug & 4) ? 0u : (D | X | Im);
+                uint32_t E = SCRG_ABL(a, 4) ? 0u : (D | X | Im);
                 uint32_t c = ffbh_u32(E);
                 uint32_t ni = lds8[scr_b + c];
                 auto put = [&](uint32_t at, uint32_t b) { lds8[ring_b + (at & 63u)] = (uint8_t)b; };
@@ -467,7 +467,7 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
                 flush_pieces();
                 mbase += ti;                                   // the next window starts at its column 0
             } else {
-            uint32_t E = (a.debug & 4) ? 0u : (B | Im);                  // (ablation, profiling only: no runs)
+            uint32_t E = SCRG_ABL(a, 4) ? 0u : (B | Im);                  // (ablation, profiling only: no runs)
             uint32_t c = ffbh_u32(E);
             uint32_t ni = lds8[scr_b + c];
             uint32_t nr2 = 2u * (uint32_t)nr;          // byte offset of the last committed run

@@ -28,6 +28,10 @@
 namespace {
 
 std::atomic<int> g_log{0};
+std::atomic<int> g_live_ctx{0};          // handles alive: the result pool is emptied when the last one goes
+// the work queue is a 32-bit counter and every wavefront over-asks by up to 64 once it is empty (at most 32 wavefronts
+// on each of at most 1024 CUs): leave room for that, or the counter could wrap and hand out low indices a second time
+constexpr uint64_t kMaxPairsPerLaunch = 0xffffffffull - 64ull * 32ull * 1024ull;
 
 struct DevBuf {
     void* p = nullptr;
@@ -220,6 +224,13 @@ struct ResultPool {
         }
         free(p);
     }
+    void trim()
+    {
+        std::lock_guard<std::mutex> g(mu);
+        for (Block& b : blocks) free(b.p);
+        blocks.clear();
+        held = 0;
+    }
 };
 ResultPool g_pool;
 }  // namespace
@@ -287,6 +298,7 @@ scrg_status scrg_ctx_create(int device, scrg_ctx** out)
         return SCRG_ERR_HIP;
     }
     c->stream = c->own_stream;
+    g_live_ctx.fetch_add(1);
     if (g_log.load())
         fprintf(stderr, "[scrooge_amd] device %d: %s, %d CUs, arch %s\n", device, prop.name, c->n_cus,
                 prop.gcnArchName);
@@ -312,6 +324,7 @@ void scrg_ctx_destroy(scrg_ctx* c)
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
+    if (g_live_ctx.fetch_sub(1) == 1) g_pool.trim();      // last handle gone: give the recycled result arrays back
 }
 
 scrg_status scrg_ctx_set_stream(scrg_ctx* c, void* hip_stream)
@@ -364,6 +377,8 @@ static bool resolve_params(const scrg_params* in, scrg_params* p)
         p->reserved[0] = in->reserved[0];      // ablation switches and profiling counters travel with the parameters
         p->reserved[1] = in->reserved[1];
     }
+    // experiment switches: only those that leave the results intact, unless this is an ablation build (genasm_kernels.h)
+    if (p->reserved[0] & ~scrg::SCRG_ALLOWED_SWITCHES) return false;
     if (p->text_stride_words == 0) p->text_stride_words = 1;
     if (p->read_stride_words == 0) p->read_stride_words = 1;
     if (p->text_stride_words < 1 || p->read_stride_words < 1) return false;
@@ -473,7 +488,7 @@ static scrg_status align_device_impl(scrg_ctx* c, const scrg_params* params, uin
     if (edits && p.lanes_per_pair != 1)
         return c->fail(SCRG_ERR_INVALID_ARG, "edit-stream output needs lanes_per_pair = 1, the default "
                                              "(the GenASM-row mappings: scrg_align_device + scrg_encode_edit_stream)");
-    if (n_pairs > 0xfffffff0ull) return c->fail(SCRG_ERR_INVALID_ARG, "too many pairs for one launch");
+    if (n_pairs > kMaxPairsPerLaunch) return c->fail(SCRG_ERR_INVALID_ARG, "too many pairs for one launch");
     if (n_pairs && (!d_seq || !d_pairs || !d_runs || !d_edit_distance || !d_n_runs || !d_pair_status))
         return c->fail(SCRG_ERR_INVALID_ARG, "null device pointer");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -512,7 +527,7 @@ static scrg_status align_device_impl(scrg_ctx* c, const scrg_params* params, uin
     a.lds_rows = p.lds_rows;
     a.text_stride = (uint32_t)p.text_stride_words;
     a.read_stride = (uint32_t)p.read_stride_words;
-    a.debug = params ? params->reserved[0] : 0;
+    a.debug = p.reserved[0];
     a.stats = nullptr;
     if (params && params->reserved[1]) {
         HIP_TRY(c, c->stats.ensure(12 * sizeof(uint64_t)));
@@ -700,6 +715,8 @@ scrg_status scrg_ascii_to_twobit(scrg_ctx* c, uint64_t count, const uint64_t* d_
 // ---------------------------------------------------------------------------
 // host-pointer entry points
 // ---------------------------------------------------------------------------
+void scrg_result_pool_trim(void) { g_pool.trim(); }
+
 void scrg_result_free(scrg_result* r)
 {
     if (!r) return;
@@ -739,7 +756,7 @@ struct Problem {         // one (text, read) problem in caller order
 // `resident_words` leading words of d_seq are already packed on the device (a genome kept by scrg_genome_set):
 // they are neither staged nor transferred nor packed again; `seqs` then describes the words after them only.
 scrg_status run_batch(scrg_ctx* c, const scrg_params& p, std::vector<SeqRef>& seqs, uint64_t total_words,
-                      const std::vector<Problem>& probs, scrg_result** out, uint64_t resident_words = 0)
+                      const std::vector<Problem>& probs, scrg_result** out, uint64_t resident_words = 0, bool resident = false)
 {
     const int64_t t_begin = now_ns();
     const uint64_t n = probs.size();
@@ -820,7 +837,7 @@ scrg_status run_batch(scrg_ctx* c, const scrg_params& p, std::vector<SeqRef>& se
         c->d_seq.release();
         c->d_seq = bigger;
     }
-    if (!resident_words && c->genome_resident) c->genome_resident = false;     // d_seq is about to be overwritten from word 0
+    if (!resident) c->genome_resident = false;     // d_seq is about to be overwritten from word 0
     if ((e = c->d_ascii.ensure(ascii_bytes + 32)) != hipSuccess || (e = c->d_seq.ensure(seq_words * 8)) != hipSuccess ||
         (e = c->d_bad.ensure(4)) != hipSuccess)
         return bail(c->fail(SCRG_ERR_OOM, "device sequence buffers", e));
@@ -1091,7 +1108,7 @@ static scrg_status align_pairs_impl(scrg_ctx* c, const scrg_params* params, uint
         return c->fail(SCRG_ERR_INVALID_ARG, "null input array");
     scrg_params p;
     if (!resolve_params(params, &p)) return c->fail(SCRG_ERR_INVALID_ARG, "bad scrg_params");
-    if (n_pairs > 0xfffffff0ull) return c->fail(SCRG_ERR_INVALID_ARG, "too many pairs");
+    if (n_pairs > kMaxPairsPerLaunch) return c->fail(SCRG_ERR_INVALID_ARG, "too many pairs");
 
     std::vector<SeqRef> seqs(2 * n_pairs);
     std::vector<Problem> probs(n_pairs);
@@ -1137,7 +1154,7 @@ static scrg_status align_mapping_impl(scrg_ctx* c, const scrg_params* params, co
     scrg_params p;
     if (!resolve_params(params, &p)) return c->fail(SCRG_ERR_INVALID_ARG, "bad scrg_params");
     const uint64_t n_pairs = cand_offsets[n_reads];
-    if (n_pairs > 0xfffffff0ull) return c->fail(SCRG_ERR_INVALID_ARG, "too many pairs");
+    if (n_pairs > kMaxPairsPerLaunch) return c->fail(SCRG_ERR_INVALID_ARG, "too many pairs");
     if (n_pairs && !cand_start) return c->fail(SCRG_ERR_INVALID_ARG, "null candidate array");
 
     // genome and every read are packed exactly once (README.md:83 of the reference asks for this);
@@ -1178,7 +1195,7 @@ static scrg_status align_mapping_impl(scrg_ctx* c, const scrg_params* params, co
             probs[k].read_len = read_lens[r];
         }
     }
-    return run_batch(c, p, seqs, w, probs, out, resident ? c->genome_words : 0);
+    return run_batch(c, p, seqs, w, probs, out, resident ? c->genome_words : 0, resident);
 }
 
 // scrg_genome_set: stage, transfer and pack a genome once; it stays at the front of the handle's sequence
