@@ -35,7 +35,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=100000, help="pairs per GPU")
+    ap.add_argument("--pairs", type=int, default=0,
+                    help="pairs per GPU and step (default: 100000 = BASELINE configs[1]; 125000 at --gpus 8 = configs[3], 1 M pairs over 8 GPUs)")
     ap.add_argument("--read-len", type=int, default=10000)
     ap.add_argument("--profile", default="ont", help="error profile (scrooge_amd.synth.PROFILES)")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per pair (0 = library default)")
@@ -50,9 +51,12 @@ def parse():
                     help="N > 1: how CIGARs travel to rank 0 — edit streams, 1 byte per edit, written by the align kernel "
                          "itself (default; W-O <= 31) or encoded from its runs (edits-from-runs: any W/O), packed runs "
                          "(1 byte per run, restored on rank 0 inside the timed region) or scrg_run pairs")
-    ap.add_argument("--gather-root", default="rotate", choices=["rotate", "0"],
-                    help="N > 1, edit streams: the rank a step's results are gathered to — step k to rank k mod N (default: "
-                         "every GPU receives one step in N, a consumer per GPU) or always rank 0")
+    ap.add_argument("--gather-root", default="0", choices=["rotate", "0"],
+                    help="N > 1, edit streams: the rank a step's results are gathered to and decoded on — always rank 0 (default, "
+                         "SURVEY.md §8e) or step k to rank k mod N (every GPU receives and decodes one step in N)")
+    ap.add_argument("--no-decode", action="store_true",
+                    help="N > 1, edit streams: leave the gathered CIGARs as edit streams on the root (default: the root restores "
+                         "scrg_run pairs for every rank's pairs inside the timed region, scrg_decode_edit_stream)")
     ap.add_argument("--sustained-steps", type=int, default=150,
                     help="N = 1: after the timed region, time this many more pipelined steps for the 'sustained' field (0 = skip)")
     ap.add_argument("--streams", type=int, default=4, help="pipeline depth: consecutive steps rotate over this many streams/handles")
@@ -134,11 +138,11 @@ def device_pairs(torch, n, read_len, err, ratio, seed, device, slack=0.15, chunk
 
 STEP_TEXT = {
     "local": "align kernel + run compaction",
-    "edits": "align kernel writing every CIGAR as an edit stream (scrg_align_device_edits: one byte per edit, a lossless "
-             "encoding the window breaks are restored from) + compaction of the streams + RCCL gather of scores and streams "
-             "to the step's root (config.gather.root), one collective and one buffer set per pipelined step (overlaps the "
-             "next kernels); the root keeps the streams, their decoding to scrg_run (scrg_decode_edit_stream) is checked for "
-             "every rank's slot of the last step after the timed region",
+    "edits": "align kernel writing every CIGAR as an edit stream + its run count (scrg_align_device_edits: one byte per edit, a "
+             "lossless encoding the window breaks are restored from) + compaction of the streams + RCCL gather of scores, run "
+             "counts and streams to the step's root (config.gather.root), one collective and one buffer set per pipelined step "
+             "(overlaps the next kernels) + on the root, INSIDE the timed region, scrg_decode_edit_stream of every rank's slot "
+             "(one launch for all N x pairs) into one dense scrg_run array: the step ends with the CIGAR runs of all pairs on the root",
     "edits-from-runs": "align kernel (runs) + edit-stream encoding (scrg_encode_edit_stream) + RCCL gather of scores and "
                        "streams to the step's root (config.gather.root), one collective and one buffer set per pipelined step; the "
                        "root keeps the streams, their decoding is checked for every rank's slot after the timed region",
@@ -150,6 +154,8 @@ STEP_TEXT = {
 
 def main():
     args = parse()
+    if not args.pairs:
+        args.pairs = 125000 if args.gpus == 8 else 100000
     import torch
     import torch.distributed as dist
 
@@ -266,6 +272,8 @@ def main():
     total_runs = int(n_runs.sum().item())
     denses = [torch.empty(max(total_runs, 8) * 2, dtype=torch.uint8, device=device) for _ in range(n_lanes)]
     gather = None
+    decode_on = False
+    decode_args = None
     gather_format = args.gather_format
     if gather_format == "packed" and p.W - p.O > 63:
         gather_format = "runs"                       # packed runs hold counts up to 63
@@ -278,12 +286,15 @@ def main():
         from scrooge_amd.distributed import EditStreamGather
         if gather_format == "edits":
             t_len = torch.empty(n, dtype=torch.int32, device=device)
-            al.align_device_edits(n, seq, desc, runs, ed, t_len, status, **kw)
+            t_cnt = torch.empty(n, dtype=torch.int32, device=device)
+            al.align_device_edits(n, seq, desc, runs, ed, t_len, status, t_cnt, **kw)
             torch.cuda.synchronize()
             assert int(status.max().item()) == 0
+            assert torch.equal(t_cnt, n_runs), "run counts of the edit-stream kernel differ from the runs kernel's"
             stream_bytes = int(((t_len.to(torch.int64) + 3) // 4 * 4).sum().item())
             al.align_device(n, seq, desc, runs, ed, n_runs, status, **kw)
             torch.cuda.synchronize()
+            del t_cnt
         else:
             bound = int(ed.sum().item()) + n * (L >> 6) + 4 * n + 64
             tmp = torch.empty(bound, dtype=torch.uint8, device=device)
@@ -297,8 +308,15 @@ def main():
             del tmp, t_off
         del t_len
         gather = EditStreamGather(n, stream_bytes, device, dst="rotate" if args.gather_root == "rotate" else 0,
-                                  depth=max(2, n_lanes), ordered=gather_format == "edits")
+                                  depth=max(2, n_lanes), ordered=gather_format == "edits",
+                                  total_runs=total_runs if gather_format == "edits" else None)
         gather.prime()                               # (set-up: connections to every root exist before anything is timed)
+        # the root's decoder: a handle of its own (its stream is the gather's decode stream), one read length for all pairs
+        decode_on = gather_format == "edits" and not args.no_decode
+        if decode_on:
+            decoder = scrooge_amd.Aligner(local_rank)
+            decoder.params = al.params
+            decode_args = (decoder, torch.tensor([L], dtype=torch.int64, device=device), 0, dict(kw))
     elif dist_on:
         from scrooge_amd.distributed import ResultGather
         packed_gather = gather_format == "packed"    # runs travel as one byte each; rank 0 restores scrg_run pairs
@@ -338,18 +356,18 @@ def main():
                 # gathered into the step's send buffer (4-byte aligned, pair order) and one RCCL collective takes
                 # scores + streams to rank 0 over xGMI; one buffer set per pipelined step, so the gather of this step
                 # overlaps the next steps' align kernels
+                gather.finish(j)                       # buffers of step j-DEPTH are free again (gathered, and decoded on their root)
+                g = gather.buffers(j)
                 if k is not None:
                     ev[k][0].record()
-                aligners[b].align_device_edits(n, seq, desc, o["runs"], o["ed"], o["n_runs"], o["status"], **kw)
+                aligners[b].align_device_edits(n, seq, desc, o["runs"], o["ed"], o["n_runs"], o["status"], g["cnt"], **kw)
                 if k is not None:
                     ev[k][1].record()
-                gather.finish(j)                       # buffers of step j-DEPTH are free again
-                g = gather.buffers(j)
                 r4 = (o["n_runs"].to(torch.int64) + 3) & -4
                 boff = torch.cumsum(r4, 0) - r4
                 g["len"].copy_(o["n_runs"])
                 aligners[b].compact_runs(n, desc, o["runs"], (r4 >> 1).to(torch.int32), boff >> 1, g["stream"])
-                gather.start(j, o["ed"])
+                gather.start(j, o["ed"], decode=decode_args if step.decode else None)
                 return
             if k is not None:
                 ev[k][0].record()
@@ -377,6 +395,7 @@ def main():
                 aligners[b].compact_runs(n, desc, o["runs"], o["n_runs"], dense_off, denses[b])
 
     step.count = 0
+    step.decode = decode_on
     for _ in range(args.warmup):
         step()
     if gather is not None:
@@ -418,6 +437,11 @@ def main():
             # edits as the gathered edit distance; the root's own slot must be, run for run, what its kernel produced
             rl = torch.tensor([L], dtype=torch.int64, device=device)
             gather_check = True
+            # what the timed region itself produced on this root: the runs of ALL ranks' pairs of the last step, one launch
+            dec = gather.decoded(step.count - 1) if decode_on else None
+            if dec is not None and int(dec["bad"].item()) != 0:
+                print("decode on rank %d: %d pairs did not decode" % (rank, int(dec["bad"].item())), file=sys.stderr)
+                gather_check = False
             for r in range(world):
                 v = gather.results(step.count - 1, r)
                 torch.cuda.synchronize()
@@ -430,6 +454,12 @@ def main():
                 if r == rank:
                     checks.update(own_scores=bool(torch.equal(v["ed"].to(torch.int64), ed) and torch.equal(cnt_g, n_runs)),
                                   own_runs=bool(runs_g is not None and torch.equal(runs_g[: 2 * total_runs], dense[: 2 * total_runs])))
+                if dec is not None and runs_g is not None:
+                    # the slot's part of the one-launch decode == the two-pass decode of the slot alone
+                    a0 = int(dec["run_off"][r * n].item())
+                    tr = int(cnt_g.to(torch.int64).sum().item())
+                    checks["decoded_in_timed_region"] = bool(torch.equal(dec["cnt"][r * n: (r + 1) * n], cnt_g) and
+                                                             torch.equal(dec["runs"][2 * a0: 2 * (a0 + tr)], runs_g[: 2 * tr]))
                 if not all(checks.values()):
                     print("gather check on rank %d, slot of rank %d: %s (undecodable pairs: %d)" % (rank, r, checks, n_bad), file=sys.stderr)
                     gather_check = False
@@ -447,6 +477,27 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)
+    # Reference point outside the timed region (N > 1): the same steps with the results LEFT as edit streams on the root
+    # (no decoding) — what the decoding costs the job is the difference to `value`.  Never the headline.
+    streams_only = None
+    if dist_on and decode_on:
+        step.decode = False
+        gather.finish_all()
+        dist.barrier()
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        gather.finish_all()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        tso = torch.tensor([time.perf_counter() - ts], dtype=torch.float64, device=device)
+        dist.all_reduce(tso, op=dist.ReduceOp.MAX)
+        streams_only = {"value": world * n * args.steps / float(tso.item()), "unit": "pairs/s",
+                        "ms_per_step": float(tso.item()) / args.steps * 1e3,
+                        "note": "the same steps without the root's decoding (gathered CIGARs stay edit streams); measured after the timed region"}
+        step.decode = decode_on
     # reference point outside the timed region: the same step on ONE stream (no overlap between launches)
     serial = None
     if n_lanes > 1 and not dist_on and not args.stats:
@@ -601,7 +652,31 @@ def main():
                             "stream_bytes_per_pair": sbytes / n,
                             "note": "the step of the N > 1 runs without the collective: scrg_align_device_edits + compaction "
                                     "of the streams, same pipeline; measured after the timed region"}
-        del sdense, lens
+        # the receiving side of the same step: one slot's streams back to scrg_run pairs (what the root of an N-GPU job does
+        # for every rank's slot, all slots in one launch), checked against the runs kernel's output of the timed region
+        with torch.cuda.stream(streams[0]):
+            aligners[0].align_device_edits(n, seq, desc, outs[0]["runs"], outs[0]["ed"], lens[0], outs[0]["status"], **kw)
+            r4 = (lens[0].to(torch.int64) + 3) & -4
+            boff = torch.cumsum(r4, 0) - r4
+            aligners[0].compact_runs(n, desc, outs[0]["runs"], (r4 >> 1).to(torch.int32), boff >> 1, sdense[0])
+            cnt64 = n_runs.to(torch.int64)
+            doff = torch.cumsum(cnt64, 0) - cnt64
+            back = torch.zeros(total_runs * 2 + 64, dtype=torch.uint8, device=device)
+            nbad = torch.zeros(1, dtype=torch.int32, device=device)
+            rl1 = torch.tensor([L], dtype=torch.int64, device=device)
+            dev_ = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
+            aligners[0].decode_edit_stream(n, sdense[0], boff, lens[0], rl1, 0, doff, back, n_runs, nbad, **kw)
+            dev_[0].record()
+            for _ in range(5):
+                aligners[0].decode_edit_stream(n, sdense[0], boff, lens[0], rl1, 0, doff, back, n_runs, nbad, **kw)
+            dev_[1].record()
+        torch.cuda.synchronize()
+        dec_ok = int(nbad.item()) == 0 and bool(torch.equal(back[: 2 * total_runs], dense[: 2 * total_runs]))
+        assert dec_ok, "decoded edit streams differ from the runs of the timed region"
+        edit_stream_step["decode_ms_per_slot"] = dev_[0].elapsed_time(dev_[1]) / 5
+        edit_stream_step["decode_note"] = ("scrg_decode_edit_stream of this step's %d streams into the dense scrg_run array, one launch "
+                                           "alone on the GPU; all %d pairs' runs identical to the timed region's" % (n, n))
+        del sdense, lens, back
 
     pairs_total = world * n * args.steps
     value = pairs_total / dt
@@ -624,13 +699,17 @@ def main():
         "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-        "config": {"workload": "unstructured pairwise: %d x %d bp %s-error pairs per GPU, W=%d O=%d"
-                               % (n, L, args.profile, p.W, p.O),
+        "config": {"workload": "unstructured pairwise: %d x %d bp %s-error pairs per GPU and step (%s), W=%d O=%d"
+                               % (n, L, args.profile,
+                                  "BASELINE configs[3]: 1 M pairs over 8 GPUs, results gathered to and decoded on the root" if (world == 8 and n == 125000)
+                                  else ("BASELINE configs[1]" if (world == 1 and n == 100000 and L == 10000) else "%d GPU(s)" % world), p.W, p.O),
                    "pairs_per_gpu": n, "read_len": L, "text_len": text_len, "error_profile": args.profile,
                    "W": p.W, "O": p.O, "lanes_per_pair": p.lanes_per_pair, "lds_rows": p.lds_rows,
                    "sequence_layout": "lane-interleaved groups of 64 pairs (scrg_pack_planar_groups)" if groups else "contiguous per sequence",
                    "launch": geom, "step": STEP_TEXT[gather_format if dist_on else "local"],
+                   "backend": (dist.get_backend() if dist_on else None), "rccl_ranks": (dist.get_world_size() if dist_on else 1),
                    "gather": ({"format": gather_format, "root": ("step k to rank k mod N" if (edits and args.gather_root == "rotate") else "rank 0"),
+                               "decoded_to_runs_inside_timed_region": bool(decode_on),
                                "bytes_per_rank_and_step": gather.wire if edits else None,
                                "stream_bytes_per_pair": (stream_bytes / n) if stream_bytes is not None else None} if dist_on else None),
                    "pipeline": ("consecutive steps alternate between %d streams (own handle, work queue and output buffers each): "
@@ -644,6 +723,7 @@ def main():
         "serial": serial,              # the same step without overlap between launches, measured after the timed region
         "sustained": sustained,        # the same pipelined step over many more steps (fill and drain amortised), after the timed region
         "edit_stream_step": edit_stream_step,   # the N > 1 step (CIGARs as edit streams) on this one GPU, without the collective
+        "gather_without_decode": streams_only,  # N > 1: the same steps with the gathered CIGARs left as edit streams (after the timed region)
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "genasm_lane_kernel" if p.lanes_per_pair == 1 else "genasm_align_kernel<%d, false>" % p.lanes_per_pair,

@@ -224,12 +224,15 @@ scrg_status scrg_align_device(scrg_ctx *ctx, const scrg_params *params, uint64_t
  * never longer than edit distance + read_len / 64 bytes; 2 * cigar_cap >= that always fits).  The kernel does less
  * work than for runs (it visits edits, not run boundaries) and writes a quarter of the bytes.
  * scrg_compact_runs with d_n_runs[p] = (d_stream_len[p] + 3) / 4 * 2 and even d_dense_offset gathers the slices.
+ * d_n_runs may be NULL; otherwise d_n_runs[p] = the number of runs of the same alignment (what scrg_align_device
+ * reports): sent along with the streams it lets the receiver lay out the decoded runs by a prefix sum and restore them
+ * with ONE scrg_decode_edit_stream pass (no counting pass).
  * One-pair-per-lane kernels only: lanes_per_pair = 1 (the default for every W and O); SCRG_ERR_INVALID_ARG for the
  * GenASM-row mappings (use scrg_align_device + scrg_encode_edit_stream there).  d_streams 32-byte aligned. */
 scrg_status scrg_align_device_edits(scrg_ctx *ctx, const scrg_params *params, uint64_t n_pairs,
                                     const uint64_t *d_seq, const scrg_pair_desc *d_pairs,
                                     uint8_t *d_streams, int64_t *d_edit_distance,
-                                    uint32_t *d_stream_len, uint32_t *d_pair_status);
+                                    uint32_t *d_stream_len, uint32_t *d_pair_status, uint32_t *d_n_runs);
 
 /* Gathers every pair's runs from its slice into one dense array:
  * d_dense[d_dense_offset[p] + k] = d_runs[d_pairs[p].cigar_off + k]. */
@@ -261,18 +264,24 @@ scrg_status scrg_unpack_runs(scrg_ctx *ctx, uint64_t n_runs, const uint8_t *d_pa
  *   d_stream_off[p] (bytes; ~0 if the pair did not fit into stream_cap) and d_stream_len[p] say where.
  *   d_total[0] = bytes of d_stream used (the amount to transfer), d_total[1] = pairs that did not fit.
  *   stream_cap >= sum of edit distances + sum of (read_len >> 6) + 4 * n_pairs always suffices.
- * scrg_decode_edit_stream: the inverse, one thread per pair.  Read lengths are taken from
- *   d_read_len[p * read_len_stride] (stride 1: a plain array; 6: &d_pairs[0].read_len; 0: one length for all).
+ * scrg_decode_edit_stream: the inverse (one pair per lane; streams fetched by the wavefront in 64-byte chunks, runs
+ *   written in aligned 32-byte pieces).  d_stream holds stream_bytes bytes (16-byte aligned, readable up to the next
+ *   multiple of 16): a pair whose stream is not inside [0, stream_bytes) — offsets and lengths may come off a wire —
+ *   is counted as bad, never read.  Read lengths are taken from d_read_len[p * read_len_stride] (stride 1: a plain
+ *   array; 6: &d_pairs[0].read_len; 0: one length for all).
  *   With d_dense == NULL it only counts: d_n_runs[p] = runs of pair p.  Otherwise d_n_runs[p] is an input, the size
- *   of pair p's segment at d_dense + d_dense_offset[p], and the runs are written there — bit for bit the runs the
- *   align kernel produced for W/O of `params`.  *d_bad_count is incremented for every pair whose stream is not an
- *   alignment of a read of that length, or whose run count differs from d_n_runs[p]. */
+ *   of pair p's segment at d_dense + d_dense_offset[p] (d_dense 16-byte aligned), and the runs are written there —
+ *   bit for bit the runs the align kernel produced for W/O of `params`.  (scrg_align_device_edits can deliver the
+ *   run counts along with the streams, so that the receiver sizes the dense array by a prefix sum and decodes in ONE
+ *   pass.)  *d_bad_count is incremented for every pair whose stream is not an alignment of a read of that length,
+ *   or whose run count differs from d_n_runs[p]. */
 scrg_status scrg_encode_edit_stream(scrg_ctx *ctx, uint64_t n_pairs, const scrg_pair_desc *d_pairs,
                                     const scrg_run *d_runs, const uint32_t *d_n_runs,
                                     uint8_t *d_stream, uint64_t stream_cap,
                                     uint64_t *d_stream_off, uint32_t *d_stream_len, uint64_t *d_total);
 scrg_status scrg_decode_edit_stream(scrg_ctx *ctx, const scrg_params *params, uint64_t n_pairs,
-                                    const uint8_t *d_stream, const uint64_t *d_stream_off, const uint32_t *d_stream_len,
+                                    const uint8_t *d_stream, uint64_t stream_bytes,
+                                    const uint64_t *d_stream_off, const uint32_t *d_stream_len,
                                     const uint64_t *d_read_len, uint64_t read_len_stride,
                                     const uint64_t *d_dense_offset, scrg_run *d_dense, uint32_t *d_n_runs,
                                     uint32_t *d_bad_count);
@@ -285,6 +294,11 @@ scrg_status scrg_edit_stream_to_runs(const scrg_params *params, uint64_t read_le
                                      scrg_run *runs, uint64_t runs_cap, uint64_t *n_runs);
 scrg_status scrg_runs_to_edit_stream(const scrg_run *runs, uint64_t n_runs,
                                      uint8_t *stream, uint64_t stream_cap, uint64_t *n_bytes);
+/* scrg_edit_stream_to_runs through the state machine the device decoder runs in every lane (same code, compiled for the
+ * host): same arguments, same results; lets a host without a GPU — and the CPU tests — check that form too. */
+scrg_status scrg_edit_stream_to_runs_lane(const scrg_params *params, uint64_t read_len,
+                                          const uint8_t *stream, uint64_t n_bytes,
+                                          scrg_run *runs, uint64_t runs_cap, uint64_t *n_runs);
 
 /* Reference-layout 2-bit packer, mirrors the exported kernel
  * genasm_gpu::ascii_to_twobit_strings (src/genasm_gpu.cu:631-685): 4 bases per

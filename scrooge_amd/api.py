@@ -157,12 +157,13 @@ def load_library():
         "scrg_compact_runs_packed": (C.c_int32, [vp, vp, u64, vp, vp, vp, vp, vp]),
         "scrg_unpack_runs": (C.c_int32, [vp, u64, vp, vp]),
         "scrg_encode_edit_stream": (C.c_int32, [vp, u64, vp, vp, vp, vp, u64, vp, vp, vp]),
-        "scrg_decode_edit_stream": (C.c_int32, [vp, vp, u64, vp, vp, vp, vp, u64, vp, vp, vp, vp]),
+        "scrg_decode_edit_stream": (C.c_int32, [vp, vp, u64, vp, u64, vp, vp, vp, u64, vp, vp, vp, vp]),
         "scrg_edit_stream_to_runs": (C.c_int32, [C.POINTER(Params), u64, vp, u64, vp, u64, C.POINTER(u64)]),
+        "scrg_edit_stream_to_runs_lane": (C.c_int32, [C.POINTER(Params), u64, vp, u64, vp, u64, C.POINTER(u64)]),
         "scrg_runs_to_edit_stream": (C.c_int32, [vp, u64, vp, u64, C.POINTER(u64)]),
         "scrg_align_device": (C.c_int32, [vp, C.POINTER(Params), u64, vp, vp, vp, vp, vp, vp]),
         "scrg_compact_runs": (C.c_int32, [vp, u64, vp, vp, vp, vp, vp]),
-        "scrg_align_device_edits": (C.c_int32, [vp, C.POINTER(Params), u64, vp, vp, vp, vp, vp, vp]),
+        "scrg_align_device_edits": (C.c_int32, [vp, C.POINTER(Params), u64, vp, vp, vp, vp, vp, vp, vp]),
         "scrg_ascii_to_twobit": (C.c_int32, [vp, u64, vp, vp, vp, vp, vp, vp]),
         "scrg_query_launch": (C.c_int32, [vp, C.POINTER(Params), i32p, i32p, i32p, i32p]),
         "scrg_last_kernel_ms": (C.c_int32, [vp, C.POINTER(C.c_float)]),
@@ -183,24 +184,26 @@ EXPORTED_SYMBOLS = [
     "scrg_result_free", "scrg_result_pool_trim", "scrg_align_pairs", "scrg_align_mapping", "scrg_genome_set", "scrg_genome_clear",
     "scrg_align_mapping_resident", "scrg_pack_planar", "scrg_pack_planar_groups",
     "scrg_align_device", "scrg_align_device_edits", "scrg_compact_runs", "scrg_compact_runs_packed", "scrg_unpack_runs",
-    "scrg_encode_edit_stream", "scrg_decode_edit_stream", "scrg_edit_stream_to_runs", "scrg_runs_to_edit_stream", "scrg_ascii_to_twobit", "scrg_query_launch",
+    "scrg_encode_edit_stream", "scrg_decode_edit_stream", "scrg_edit_stream_to_runs", "scrg_edit_stream_to_runs_lane", "scrg_runs_to_edit_stream", "scrg_ascii_to_twobit", "scrg_query_launch",
     "scrg_last_kernel_ms", "scrg_debug_stats"]
 
 
-def edit_stream_to_cigar(stream, read_len, W=64, O=33):
+def edit_stream_to_cigar(stream, read_len, W=64, O=33, lane_form=False):
     """Host-side decoder of ONE pair's edit stream (bytes) -> the CIGAR text the aligner returns for W/O
-    (scrg_edit_stream_to_runs: no GPU involved).  Raises ScroogeError for a malformed stream."""
+    (scrg_edit_stream_to_runs: no GPU involved; lane_form=True: through the state machine the device decoder runs in
+    every lane, scrg_edit_stream_to_runs_lane).  Raises ScroogeError for a malformed stream."""
     lib = load_library()
+    fn = lib.scrg_edit_stream_to_runs_lane if lane_form else lib.scrg_edit_stream_to_runs
     p = Params()
     lib.scrg_params_default(C.byref(p))
     p.W, p.O = int(W), int(O)
     buf = (C.c_uint8 * max(1, len(stream))).from_buffer_copy(bytes(stream) or b"\0")
     n = C.c_uint64(0)
-    st = lib.scrg_edit_stream_to_runs(C.byref(p), int(read_len), buf, len(stream), None, 0, C.byref(n))
+    st = fn(C.byref(p), int(read_len), buf, len(stream), None, 0, C.byref(n))
     if st not in (SCRG_OK, SCRG_ERR_CIGAR_OVERFLOW):
         raise ScroogeError(st, "malformed edit stream")
     runs = (C.c_uint8 * (2 * max(1, n.value)))()
-    st = lib.scrg_edit_stream_to_runs(C.byref(p), int(read_len), buf, len(stream), runs, n.value, C.byref(n))
+    st = fn(C.byref(p), int(read_len), buf, len(stream), runs, n.value, C.byref(n))
     if st != SCRG_OK:
         raise ScroogeError(st, "malformed edit stream")
     return "".join("%d%s" % (runs[2 * k], chr(runs[2 * k + 1])) for k in range(n.value))
@@ -435,12 +438,13 @@ class Aligner:
                                                _ptr(seq), _ptr(pairs), _ptr(runs), _ptr(ed),
                                                _ptr(n_runs), _ptr(status)))
 
-    def align_device_edits(self, n_pairs, seq, pairs, streams_u8, ed, stream_len, status, **kw):
+    def align_device_edits(self, n_pairs, seq, pairs, streams_u8, ed, stream_len, status, n_runs=None, **kw):
         """Like align_device, but the pairs' slices receive EDIT STREAMS (one byte per edit) and stream_len their
-        lengths in bytes: the one-pair-per-lane kernels only (lanes_per_pair = 1, the default for every W/O)."""
+        lengths in bytes: the one-pair-per-lane kernels only (lanes_per_pair = 1, the default for every W/O).
+        n_runs (optional int32 tensor): the run count of every alignment, for a receiver that decodes in one pass."""
         self._check(self.lib.scrg_align_device_edits(self.h, C.byref(self._params(kw)), int(n_pairs),
                                                      _ptr(seq), _ptr(pairs), _ptr(streams_u8), _ptr(ed),
-                                                     _ptr(stream_len), _ptr(status)))
+                                                     _ptr(stream_len), _ptr(status), _ptr(n_runs)))
 
     def compact_runs(self, n_pairs, pairs, runs, n_runs, dense_off, dense):
         self._check(self.lib.scrg_compact_runs(self.h, int(n_pairs), _ptr(pairs), _ptr(runs),
@@ -466,7 +470,7 @@ class Aligner:
                            dense_off_i64, dense_u8, n_runs_i32, bad_i32, **kw):
         """Edit stream -> scrg_run pairs with the window breaks of W/O restored; dense_u8 None: count only."""
         self._check(self.lib.scrg_decode_edit_stream(self.h, C.byref(self._params(kw)), int(n_pairs), _ptr(stream_u8),
-                                                     _ptr(stream_off_i64), _ptr(stream_len_i32), _ptr(read_len_i64),
+                                                     int(stream_u8.numel()), _ptr(stream_off_i64), _ptr(stream_len_i32), _ptr(read_len_i64),
                                                      int(read_len_stride),
                                                      _ptr(dense_off_i64) if dense_off_i64 is not None else None,
                                                      _ptr(dense_u8) if dense_u8 is not None else None,

@@ -9,8 +9,7 @@
 // still in cache) writes the bytes into LDS, from where they leave as whole dwords.  2 bytes per run in, ~1 byte
 // per edit out; 0.39 ms per 100 k x 10 kb pairs.  (The one-pair-per-lane align kernel writes edit streams itself,
 // scrg_align_device_edits; this kernel serves the configurations that only produce runs.)
-// decode_edits_kernel: one thread per pair replays the windows (edit_stream.h) — the receiving side's tool, not
-// part of a rank's step.
+// (The way back, streams -> runs with the window breaks restored, is edit_stream_decode_kernel.hip.)
 #include "edit_stream.h"
 
 namespace scrg {
@@ -212,31 +211,6 @@ __global__ __launch_bounds__(256) void encode_edits_kernel(uint64_t n_pairs, con
     }
 }
 
-__global__ __launch_bounds__(64) void decode_edits_kernel(uint64_t n_pairs, uint32_t W, uint32_t O,
-                                                          const uint8_t* __restrict__ stream, const uint64_t* __restrict__ off,
-                                                          const uint32_t* __restrict__ len,
-                                                          const uint64_t* __restrict__ read_len, uint64_t read_len_stride,
-                                                          const uint64_t* __restrict__ dense_off, uint16_t* __restrict__ dense,
-                                                          uint32_t* __restrict__ n_runs, uint32_t* __restrict__ bad)
-{
-    // dense == nullptr: count only, n_runs[p] is written.  Otherwise n_runs[p] is the size of the pair's segment
-    // of `dense` (nothing is written past it) and a different count is an error.
-    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n_pairs) return;
-    const uint64_t rl = read_len[p * read_len_stride];
-    uint16_t* const d = dense ? dense + dense_off[p] : nullptr;
-    const uint64_t room = dense ? n_runs[p] : 0;
-    uint64_t k = 0;
-    uint64_t n = ~0ull;
-    if (off[p] != ~0ull)
-        n = replay_edit_stream(stream + off[p], len[p], rl, W, O, [&](uint32_t op, uint64_t t) {
-            if (k < room) d[k] = (uint16_t)((op << 8) | (uint32_t)(t & 0xffu));
-            k++;
-        });
-    if (n == ~0ull || (dense && n != room)) atomicAdd(bad, 1u);
-    if (!dense) n_runs[p] = n == ~0ull ? 0xffffffffu : (uint32_t)n;
-}
-
 hipError_t launch_encode_edits(uint64_t n_pairs, const scrg_pair_desc* d_pairs, const uint16_t* d_runs,
                                const uint32_t* d_n_runs, uint8_t* d_stream, uint64_t stream_cap, uint64_t* d_off,
                                uint32_t* d_len, uint64_t* d_total, hipStream_t s)
@@ -246,17 +220,6 @@ hipError_t launch_encode_edits(uint64_t n_pairs, const scrg_pair_desc* d_pairs, 
     const uint64_t blocks = (n_pairs + ENC_TILE - 1) / ENC_TILE;            // one workgroup per tile of 32 pairs
     hipLaunchKernelGGL(encode_edits_kernel, dim3((unsigned)blocks), dim3(256), 0, s, n_pairs, d_pairs, d_runs, d_n_runs,
                        d_stream, stream_cap, d_off, d_len, d_total);
-    return hipGetLastError();
-}
-
-hipError_t launch_decode_edits(uint64_t n_pairs, uint32_t W, uint32_t O, const uint8_t* d_stream, const uint64_t* d_off,
-                               const uint32_t* d_len, const uint64_t* d_read_len, uint64_t read_len_stride,
-                               const uint64_t* d_dense_off, uint16_t* d_dense, uint32_t* d_n_runs, uint32_t* d_bad,
-                               hipStream_t s)
-{
-    if (n_pairs == 0) return hipSuccess;
-    hipLaunchKernelGGL(decode_edits_kernel, dim3((unsigned)((n_pairs + 63) / 64)), dim3(64), 0, s, n_pairs, W, O, d_stream,
-                       d_off, d_len, d_read_len, read_len_stride, d_dense_off, d_dense, d_n_runs, d_bad);
     return hipGetLastError();
 }
 

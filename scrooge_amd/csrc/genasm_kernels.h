@@ -21,6 +21,8 @@ struct AlignArgs {
     int64_t* ed;
     uint32_t* n_runs;
     uint32_t* status;
+    uint32_t* run_count;          // edit-stream output only, may be null: the number of runs the same alignment has (what
+                                  //   scrg_align_device would report in n_runs), so that a receiver can size the decoded array
     uint32_t* counter;            // work queue head, zeroed before launch
     uint32_t* spill;              // grid * slots * SPILL_ROWS * 32 words
     uint32_t n_pairs;

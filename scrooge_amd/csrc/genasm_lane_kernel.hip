@@ -260,6 +260,7 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
                     a.ed[pair] = (int64_t)edits;
                     a.n_runs[pair] = pos;
                     a.status[pair] = pos > 2u * (uint64_t)cigar_cap ? 1u : 0u;
+                    if (a.run_count) a.run_count[pair] = (uint32_t)(nr + 1);
                 } else if (fin) {
                     const uint32_t n_runs = (uint32_t)(nr + 1);
                     while (n_runs - flushed >= 16u) write_piece();
@@ -404,6 +405,8 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
                 // pending matches are handled in line, longer runs / stretches on a side path (well under one per cent
                 // of the iterations at 10 % error).
                 uint32_t E = SCRG_ABL(a, 4) ? 0u : (D | X | Im);
+                // (the runs this window has in the other output format: one per insertion run, one per D / X / = run start)
+                nr += (int32_t)(__builtin_popcount(B) + __builtin_popcount(Im));
                 uint32_t c = ffbh_u32(E);
                 uint32_t ni = lds8[scr_b + c];
                 auto put = [&](uint32_t at, uint32_t b) { lds8[ring_b + (at & 63u)] = (uint8_t)b; };

@@ -204,6 +204,7 @@ __global__ __launch_bounds__(64) void genasm_lane_mw_kernel(AlignArgs a)
                     a.ed[pair] = (int64_t)edits;
                     a.n_runs[pair] = pos;
                     a.status[pair] = pos > 2u * (uint64_t)cigar_cap ? 1u : 0u;
+                    if (a.run_count) a.run_count[pair] = (uint32_t)(nr + 1);
                 } else if (fin) {
                     const uint32_t n_runs = (uint32_t)(nr + 1);
                     while (n_runs - flushed >= 16u) write_piece();
@@ -376,6 +377,7 @@ __global__ __launch_bounds__(64) void genasm_lane_mw_kernel(AlignArgs a)
                 Row<RW> Ev;
 #pragma unroll
                 for (int r = 0; r < RW; r++) Ev.w[r] = D.w[r] | X.w[r] | Im.w[r];
+                nr += (int32_t)(row_pop<RW>(B) + row_pop<RW>(Im));       // the runs this window has in the other output format
                 while (__any(row_any<RW>(Ev))) {
                     if (row_any<RW>(Ev)) {
                         const uint32_t c = row_clz<RW>(Ev);

@@ -480,7 +480,7 @@ scrg_status scrg_pack_planar_groups(scrg_ctx* c, const char* d_ascii, uint64_t n
 
 static scrg_status align_device_impl(scrg_ctx* c, const scrg_params* params, uint64_t n_pairs, const uint64_t* d_seq,
                                      const scrg_pair_desc* d_pairs, scrg_run* d_runs, int64_t* d_edit_distance,
-                                     uint32_t* d_n_runs, uint32_t* d_pair_status, bool edits)
+                                     uint32_t* d_n_runs, uint32_t* d_pair_status, bool edits, uint32_t* d_run_count = nullptr)
 {
     if (!c) return SCRG_ERR_INVALID_ARG;
     scrg_params p;
@@ -519,6 +519,7 @@ static scrg_status align_device_impl(scrg_ctx* c, const scrg_params* params, uin
     a.ed = d_edit_distance;
     a.n_runs = d_n_runs;
     a.status = d_pair_status;
+    a.run_count = d_run_count;
     a.counter = c->counter.as<uint32_t>();
     a.spill = c->spill.as<uint32_t>();
     a.n_pairs = (uint32_t)n_pairs;
@@ -558,11 +559,11 @@ scrg_status scrg_align_device(scrg_ctx* c, const scrg_params* params, uint64_t n
 
 scrg_status scrg_align_device_edits(scrg_ctx* c, const scrg_params* params, uint64_t n_pairs, const uint64_t* d_seq,
                                     const scrg_pair_desc* d_pairs, uint8_t* d_streams, int64_t* d_edit_distance,
-                                    uint32_t* d_stream_len, uint32_t* d_pair_status)
+                                    uint32_t* d_stream_len, uint32_t* d_pair_status, uint32_t* d_n_runs)
 {
     if (reinterpret_cast<uintptr_t>(d_streams) & 31u) return c ? c->fail(SCRG_ERR_INVALID_ARG, "d_streams needs 32-byte alignment") : SCRG_ERR_INVALID_ARG;
     return align_device_impl(c, params, n_pairs, d_seq, d_pairs, reinterpret_cast<scrg_run*>(d_streams), d_edit_distance,
-                             d_stream_len, d_pair_status, true);
+                             d_stream_len, d_pair_status, true, d_n_runs);
 }
 
 scrg_status scrg_last_kernel_ms(scrg_ctx* c, float* ms)
@@ -641,21 +642,46 @@ scrg_status scrg_encode_edit_stream(scrg_ctx* c, uint64_t n_pairs, const scrg_pa
 }
 
 scrg_status scrg_decode_edit_stream(scrg_ctx* c, const scrg_params* params, uint64_t n_pairs, const uint8_t* d_stream,
-                                    const uint64_t* d_stream_off, const uint32_t* d_stream_len, const uint64_t* d_read_len,
-                                    uint64_t read_len_stride, const uint64_t* d_dense_offset, scrg_run* d_dense,
-                                    uint32_t* d_n_runs, uint32_t* d_bad_count)
+                                    uint64_t stream_bytes, const uint64_t* d_stream_off, const uint32_t* d_stream_len,
+                                    const uint64_t* d_read_len, uint64_t read_len_stride, const uint64_t* d_dense_offset,
+                                    scrg_run* d_dense, uint32_t* d_n_runs, uint32_t* d_bad_count)
 {
     if (!c) return SCRG_ERR_INVALID_ARG;
     scrg_params p;
     if (!resolve_params(params, &p)) return c->fail(SCRG_ERR_INVALID_ARG, "bad scrg_params");
-    if (!d_bad_count || (n_pairs && (!d_stream_off || !d_stream_len || !d_read_len || !d_n_runs)))
+    if (!d_bad_count || (n_pairs && (!d_stream_off || !d_stream_len || !d_read_len || !d_n_runs)) || (stream_bytes && !d_stream))
         return c->fail(SCRG_ERR_INVALID_ARG, "null device pointer");
     if (d_dense && !d_dense_offset) return c->fail(SCRG_ERR_INVALID_ARG, "d_dense needs d_dense_offset");
+    // streams are fetched in aligned 16-byte blocks, runs leave in aligned 16-byte stores
+    if ((reinterpret_cast<uintptr_t>(d_stream) & 15u) || (reinterpret_cast<uintptr_t>(d_dense) & 15u))
+        return c->fail(SCRG_ERR_INVALID_ARG, "d_stream and d_dense need 16-byte alignment");
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, scrg::launch_decode_edits(n_pairs, (uint32_t)p.W, (uint32_t)p.O, d_stream, d_stream_off, d_stream_len,
+    HIP_TRY(c, scrg::launch_decode_edits(n_pairs, (uint32_t)p.W, (uint32_t)p.O, d_stream, stream_bytes, d_stream_off, d_stream_len,
                                          d_read_len, read_len_stride, d_dense_offset, reinterpret_cast<uint16_t*>(d_dense),
                                          d_n_runs, d_bad_count, c->stream));
     return SCRG_OK;
+}
+
+// The device decoder's per-lane state machine (edit_stream.h: decode_lane_step, the code decode_edits_kernel runs in
+// every lane) on the host, for ONE pair: same arguments and results as scrg_edit_stream_to_runs.  Exists so that the
+// state machine can be held against the plain replay without a GPU (tests/test_edit_stream.py).
+scrg_status scrg_edit_stream_to_runs_lane(const scrg_params* params, uint64_t read_len, const uint8_t* stream, uint64_t n_bytes,
+                                          scrg_run* runs, uint64_t runs_cap, uint64_t* n_runs)
+{
+    scrg_params p;
+    if (!n_runs || (n_bytes && !stream) || (runs_cap && !runs) || !resolve_params(params, &p)) return SCRG_ERR_INVALID_ARG;
+    *n_runs = 0;
+    if (read_len > 0x7fffffffull || n_bytes > 0x7fffffffull) return SCRG_ERR_INVALID_ARG;
+    scrg::DecodeLane s;
+    scrg::decode_lane_init(s, (uint32_t)p.W, (uint32_t)p.O, 0u, (uint32_t)n_bytes, (uint32_t)read_len);
+    while (s.alive)
+        scrg::decode_lane_step(s, [&]() -> uint32_t { return stream[s.pos]; }, [] {},
+                               [&](uint32_t k, uint32_t word) {
+                                   if (k < runs_cap) { runs[k].count = (uint8_t)word; runs[k].op = (char)(word >> 8); }
+                               });
+    if (!scrg::decode_lane_clean(s)) return SCRG_ERR_INVALID_ARG;
+    *n_runs = s.n;
+    return s.n > runs_cap ? SCRG_ERR_CIGAR_OVERFLOW : SCRG_OK;
 }
 
 scrg_status scrg_edit_stream_to_runs(const scrg_params* params, uint64_t read_len, const uint8_t* stream, uint64_t n_bytes,

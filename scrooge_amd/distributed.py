@@ -195,27 +195,33 @@ class ResultGather:
 class EditStreamGather:
     """Gather of a batch's device results to rank `dst` with the CIGARs as EDIT STREAMS (one byte per edit, ~1.0 KB
     for a 10 kb read at 10 % error instead of 4.3 KB of scrg_run pairs), so that what a rank produces per second fits
-    the one xGMI link it has to `dst`.
+    the one xGMI link it has to `dst`, and their DECODING back to scrg_run pairs on `dst` — what the
+    reference delivers is CIGARs on the receiving side (src/genasm_gpu.cu:955-968), so the step is not finished before
+    the runs exist there.
 
     One buffer per rank and step, ONE collective per step:
         ordered (streams in pair order at 4-byte aligned offsets — what scrg_align_device_edits + compaction gives):
-            [ int32 edit distance x n | int32 stream length x n | streams ]                          8 bytes per pair
+            [ int32 edit distance x n | int32 stream length x n | int32 run count x n | streams ]       12 bytes per pair
         not ordered (scrg_encode_edit_stream places the streams in no particular order):
             [ int32 edit distance x n | int32 stream length x n | int64 stream offset x n | streams ]   16 bytes per pair
-    `buffers(k)` hands out the views the producer writes into ("len", "stream", and "off" — a scratch tensor when the
-    offsets do not travel); `start(k, ed)` adds the scores and enqueues the gather asynchronously (it overlaps the align
-    kernels of the following steps); `finish(k)` makes the current stream wait for it before the buffers are reused.
-    `dst` keeps the streams as they arrive; `results(k, r)` gives views of rank r's slot (offsets re-derived from the
-    lengths when they did not travel) and `decode(...)` (scrg_decode_edit_stream) restores scrg_run pairs, window
-    breaks included, where a consumer wants them.  Sizes are exchanged once: the data, hence every size, is the
-    same each step in bench.py.
+    (every part starts at a multiple of 64 bytes).  `buffers(k)` hands out the views the producer writes into ("len",
+    "cnt", "stream", and "off" — a scratch tensor when the offsets do not travel); `start(k, ed)` adds the scores and
+    enqueues the gather asynchronously (it overlaps the align kernels of the following steps); `finish(k)` makes the
+    current stream wait for it — and for the decoding of what it brought — before the buffers are reused.
 
-    `dst` may be "rotate": step k is gathered to rank k mod world, so that every rank receives one step in `world`
-    (a consumer per GPU: each batch's results end up complete on one GPU, and the link into any one GPU carries a
-    step's results only every `world`-th step); every rank then holds receive buffers, and `results` / `decode` of
-    step k are valid on `root_of(k)`."""
+    Receiving side.  The slots of all ranks are ONE tensor per buffer set, so `decode_all(k, ...)` restores the runs of
+    every rank's pairs with ONE scrg_decode_edit_stream launch (world x n pairs: enough wavefronts to fill the GPU) into
+    one dense array per buffer set: run offsets are a prefix sum over the run counts that travelled with the streams,
+    so there is no counting pass and no host synchronisation.  `start(k, ed, decode=(aligner, read_len, stride))` enqueues
+    that on a stream of its own, ordered after the collective: inside whatever region the caller is timing.
+    `results(k, r)` gives views of rank r's slot, `decoded(k)` the dense runs with their offsets and counts, and
+    `decode(...)` (two passes, one slot) remains for streams that came without counts.  Sizes are exchanged once: the
+    data, hence every size, is the same each step in bench.py.
 
-    def __init__(self, n_pairs, stream_bytes, device, dst=0, group=None, depth=2, ordered=True):
+    `dst` may be "rotate": step k is gathered to rank k mod world, so that every rank receives (and decodes) one step in
+    `world`; every rank then holds receive buffers, and `results` / `decoded` of step k are valid on `root_of(k)`."""
+
+    def __init__(self, n_pairs, stream_bytes, device, dst=0, group=None, depth=2, ordered=True, total_runs=None):
         self.group, self.n = group, int(n_pairs)
         self.rotate = dst == "rotate"
         self.dst = 0 if self.rotate else int(dst)
@@ -223,25 +229,40 @@ class EditStreamGather:
         self.ordered = bool(ordered)
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
-        t = torch.tensor([int(stream_bytes)], dtype=torch.int64, device=device)
+        self.device = device
+        t = torch.tensor([int(stream_bytes), int(total_runs or 0), int(n_pairs)], dtype=torch.int64, device=device)
         sizes = [torch.zeros_like(t) for _ in range(self.world)]
         dist.all_gather(sizes, t, group=group)
-        self.totals = [int(x.item()) for x in sizes]
-        self.cap = (max(max(self.totals), 8) + 7) // 8 * 8
+        self.totals = [int(x[0].item()) for x in sizes]
+        self.run_totals = [int(x[1].item()) for x in sizes]
+        if any(int(x[2].item()) != self.n for x in sizes):
+            raise ValueError("EditStreamGather: every rank must bring the same number of pairs (pad the last shard)")
+        self.with_counts = self.ordered and total_runs is not None
+        self.cap = (max(max(self.totals), 8) + 63) // 64 * 64
         n = self.n
-        self.n8 = (n + 1) // 2 * 2                           # int32 arrays padded to a multiple of 8 bytes
-        self.head = 8 * self.n8 + (0 if self.ordered else 8 * n)      # bytes of scalars in front of the streams
+        r64 = lambda x: (x + 63) // 64 * 64
+        self.o_len = r64(4 * n)                               # byte offsets of the parts of a slot
+        self.o_cnt = self.o_off = self.o_len + r64(4 * n)
+        self.head = self.o_cnt + (r64(4 * n) if self.ordered else r64(8 * n))      # bytes of scalars in front of the streams
         self.wire = self.head + self.cap                     # bytes per rank and step on the link
         d = self.DEPTH
         self.send = [torch.zeros(self.wire, dtype=torch.uint8, device=device) for _ in range(d)]
         self.total = [torch.zeros(2, dtype=torch.int64, device=device) for _ in range(d)]
         self.off_scratch = [torch.zeros(n, dtype=torch.int64, device=device) for _ in range(d)] if self.ordered else None
+        self.recv_all = [None] * d
         self.recv = [None] * d
-        if self.rotate or self.rank == self.dst:
-            self.recv = [[torch.empty(self.wire, dtype=torch.uint8, device=device) for _ in range(self.world)]
-                         for _ in range(d)]
+        self.is_cuda = torch.device(device).type == "cuda"
+        self.holds_results = self.rotate or self.rank == self.dst
+        if self.holds_results:
+            self.recv_all = [torch.zeros(self.world * self.wire + 64, dtype=torch.uint8, device=device) for _ in range(d)]
+            self.recv = [[ra[r * self.wire: (r + 1) * self.wire] for r in range(self.world)] for ra in self.recv_all]
         self.pending = [None] * d
-        self.host_stage = dist.get_backend(group) == "gloo" and torch.device(device).type == "cuda"
+        self.host_stage = dist.get_backend(group) == "gloo" and self.is_cuda
+        # decoding on the receiving rank: one dense array, offsets, counts and an error counter per buffer set
+        self.dense = [None] * d
+        self.dec = [None] * d
+        self.dec_event = [None] * d
+        self.dec_stream = None
 
     def root_of(self, k):
         """The rank step k is gathered to."""
@@ -259,11 +280,13 @@ class EditStreamGather:
             torch.cuda.synchronize()
 
     def _views(self, buf):
-        n, n8 = self.n, self.n8
-        v = {"ed": buf[: 4 * n].view(torch.int32), "len": buf[4 * n8: 4 * n8 + 4 * n].view(torch.int32),
+        n = self.n
+        v = {"ed": buf[: 4 * n].view(torch.int32), "len": buf[self.o_len: self.o_len + 4 * n].view(torch.int32),
              "stream": buf[self.head:]}
-        if not self.ordered:
-            v["off"] = buf[8 * n8: 8 * n8 + 8 * n].view(torch.int64)
+        if self.ordered:
+            v["cnt"] = buf[self.o_cnt: self.o_cnt + 4 * n].view(torch.int32)
+        else:
+            v["off"] = buf[self.o_off: self.o_off + 8 * n].view(torch.int64)
         return v
 
     def buffers(self, k):
@@ -274,9 +297,10 @@ class EditStreamGather:
             v["off"] = self.off_scratch[b]
         return v
 
-    def start(self, k, ed):
-        """The streams and their lengths (and offsets, if they travel) of step k must already be in `buffers(k)`
-        (enqueued on the current stream)."""
+    def start(self, k, ed, decode=None):
+        """The streams, their lengths and run counts (or offsets, if they travel) of step k must already be in
+        `buffers(k)` (enqueued on the current stream).  decode = (aligner, read_len tensor, read_len_stride, params dict):
+        the root also enqueues the decoding of all slots (decode_all), ordered after the collective."""
         b = k % self.DEPTH
         dst = self.root_of(k)
         self._views(self.send[b])["ed"].copy_(ed)            # (int64 -> int32)
@@ -287,24 +311,33 @@ class EditStreamGather:
             if host is not None:
                 for r in range(self.world):
                     self.recv[b][r].copy_(host[r])
-            return
-        if os.environ.get("SCRG_BENCH_NOCOLL") == "1":        # experiment: everything but the collective
-            return
-        self.pending[b] = dist.gather(self.send[b], self.recv[b] if self.rank == dst else None, dst=dst, group=self.group,
-                                      async_op=True)
+        elif os.environ.get("SCRG_BENCH_NOCOLL") == "1":      # experiment: everything but the collective
+            pass
+        else:
+            self.pending[b] = dist.gather(self.send[b], self.recv[b] if self.rank == dst else None, dst=dst, group=self.group,
+                                          async_op=True)
+        if decode is not None and self.rank == dst:
+            self.decode_all(k, *decode)
+
+    def _wait(self, b):
+        if self.pending[b] is not None:
+            self.pending[b].wait()                            # the CURRENT stream waits for the collective
+            self.pending[b] = None
 
     def finish(self, k):
         b = k % self.DEPTH
-        if self.pending[b] is not None:
-            self.pending[b].wait()
-            self.pending[b] = None
+        self._wait(b)
+        if self.dec_event[b] is not None:                     # ... and for the decoding of what it brought
+            if self.is_cuda:
+                torch.cuda.current_stream().wait_event(self.dec_event[b])
+            self.dec_event[b] = None
 
     def finish_all(self):
         for b in range(self.DEPTH):
             self.finish(b)
 
     def results(self, k, r):
-        """Views (ed, len, off, stream) of what rank r sent for step k, on root_of(k) (after finish(k)); `off` is
+        """Views (ed, len, cnt, off, stream) of what rank r sent for step k, on root_of(k) (after finish(k)); `off` is
         re-derived from the lengths when the streams are ordered."""
         v = self._views(self.recv[k % self.DEPTH][r])
         if self.ordered:
@@ -312,10 +345,57 @@ class EditStreamGather:
             v["off"] = torch.cumsum(r4, 0) - r4
         return v
 
+    def decode_all(self, k, aligner, read_len, read_len_stride, params=None):
+        """Restores the scrg_run pairs of EVERY rank's pairs of step k on its root with one launch (needs the run
+        counts on the wire: ordered streams built with total_runs).  read_len: int64 device tensor for the world * n
+        pairs in slot order, with its stride (0: one length for all) — see scrg_decode_edit_stream.  Enqueued on the
+        gather's own decode stream, ordered after the collective of step k; `decoded(k)` gives the result."""
+        if not self.with_counts:
+            raise ValueError("decode_all needs ordered streams with run counts (total_runs=...)")
+        b = k % self.DEPTH
+        n, W = self.n, self.world
+        if self.dense[b] is None:
+            cap_runs = sum(self.run_totals)
+            self.dense[b] = torch.zeros(cap_runs * 2 + 64, dtype=torch.uint8, device=self.device)
+            self.dec[b] = {"bad": torch.zeros(1, dtype=torch.int32, device=self.device)}
+        if self.is_cuda and self.dec_stream is None:
+            self.dec_stream = torch.cuda.Stream(device=self.device)
+        cur = torch.cuda.current_stream() if self.is_cuda else None
+        ctx = torch.cuda.stream(self.dec_stream) if self.is_cuda else _NullCtx()
+        if self.is_cuda:
+            self.dec_stream.wait_stream(cur)
+        with ctx:
+            self._wait(b)                                     # the decode stream waits for the collective, nobody else
+            slots = self.recv_all[b][: W * self.wire].view(W, self.wire)
+            ln = slots[:, self.o_len: self.o_len + 4 * n].contiguous().view(torch.int32).reshape(-1)
+            cnt = slots[:, self.o_cnt: self.o_cnt + 4 * n].contiguous().view(torch.int32).reshape(-1)
+            r4 = ((ln.to(torch.int64) + 3) & -4).view(W, n)
+            off = torch.cumsum(r4, 1) - r4 + (torch.arange(W, dtype=torch.int64, device=self.device) * self.wire + self.head).view(W, 1)
+            c64 = cnt.to(torch.int64)
+            doff = torch.cumsum(c64, 0) - c64
+            d = self.dec[b]
+            d.update(len=ln, cnt=cnt, off=off.reshape(-1), run_off=doff)
+            d["bad"].zero_()
+            if self.is_cuda:
+                aligner.set_stream(self.dec_stream.cuda_stream)
+            aligner.decode_edit_stream(W * n, self.recv_all[b], d["off"], ln, read_len, read_len_stride, doff, self.dense[b],
+                                       cnt, d["bad"], **(params or {}))
+            if self.is_cuda:
+                self.dec_event[b] = torch.cuda.Event()
+                self.dec_event[b].record(self.dec_stream)
+
+    def decoded(self, k):
+        """-> dict(runs: uint8 [2 * total runs], run_off: int64 [world * n], cnt: int32 [world * n], bad: int32 [1]) of
+        step k on its root, pairs in slot order (rank 0's n pairs, rank 1's, ...).  Valid after finish(k)."""
+        b = k % self.DEPTH
+        d = dict(self.dec[b])
+        d["runs"] = self.dense[b]
+        return d
+
     def decode(self, aligner, k, r, read_len, read_len_stride, **params):
         """scrg_run bytes of rank r's pairs of step k on dst -> (dense uint8 tensor, run counts int32, run offsets
         int64, number of pairs whose stream is not an alignment of a read of that length).  `read_len`: int64 device
-        tensor, see scrg_decode_edit_stream.  Two passes: count, then decode."""
+        tensor, see scrg_decode_edit_stream.  Two passes: count, then decode (for streams that travel without counts)."""
         v = self.results(k, r)
         dev = v["len"].device
         cnt = torch.zeros(self.n, dtype=torch.int32, device=dev)
@@ -329,9 +409,17 @@ class EditStreamGather:
             return None, cnt, None, int(bad.item())
         cnt64 = cnt.to(torch.int64)
         off = torch.cumsum(cnt64, 0) - cnt64
-        dense = torch.zeros(int(cnt64.sum().item()) * 2 + 8, dtype=torch.uint8, device=dev)
+        dense = torch.zeros(int(cnt64.sum().item()) * 2 + 64, dtype=torch.uint8, device=dev)
         sync()
         aligner.decode_edit_stream(self.n, v["stream"], v["off"], v["len"], read_len, read_len_stride, off, dense,
                                    cnt, bad, **params)
         sync()
         return dense, cnt, off, int(bad.item())
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False

@@ -170,7 +170,11 @@ def _worker_edits(rank, world, port, q, ordered):
         streams = [api.cigar_to_edit_stream(c) for c in cigars]
         n = 3
         total = sum((len(s) + 3) // 4 * 4 for s in streams)
-        g = sd.EditStreamGather(n, total, torch.device("cpu"), dst=0, depth=2, ordered=ordered)
+        import re
+        n_runs = [len(re.findall(r"[=XID]", c)) for c in cigars]
+        g = sd.EditStreamGather(n, total, torch.device("cpu"), dst=0, depth=2, ordered=ordered,
+                                total_runs=sum(n_runs) if ordered else None)
+        assert g.with_counts == ordered and g.run_totals == ([8, 10] if ordered else [0, 0])
         order = [0, 1, 2] if ordered else [2, 0, 1]          # not ordered: the streams sit anywhere, offsets travel
         for k in range(3):
             g.finish(k)
@@ -179,6 +183,8 @@ def _worker_edits(rank, world, port, q, ordered):
             for i in order:
                 s = streams[i]
                 v["off"][i], v["len"][i] = at, len(s)
+                if ordered:
+                    v["cnt"][i] = n_runs[i]              # the run counts travel with ordered streams (one-pass decode on the root)
                 v["stream"][at: at + len(s)] = torch.frombuffer(bytearray(s), dtype=torch.uint8) if s else torch.zeros(0, dtype=torch.uint8)
                 at += (len(s) + 3) // 4 * 4
             ed = torch.tensor([sum(1 for b in s if b >> 6) + k for s in streams], dtype=torch.int64)
@@ -190,7 +196,8 @@ def _worker_edits(rank, world, port, q, ordered):
                 v = g.results(2, r)
                 raw = bytes(v["stream"].tolist())
                 got = [raw[o: o + l] for o, l in zip(v["off"].tolist(), v["len"].tolist())]
-                out.append((v["ed"].tolist(), got, g.totals[r], g.wire))
+                out.append((v["ed"].tolist(), got, g.totals[r], g.wire, v["cnt"].tolist() if ordered else None,
+                            (g.o_len, g.o_cnt, g.head)))
             q.put(out)
     finally:
         dist.destroy_process_group()
@@ -216,10 +223,14 @@ def test_edit_stream_gather(ordered):
     cigars = [["5=1X4=", "31=31=9=", "2I3="], ["1D30=1=1X29=11=", "", "31=1I30=9="]]
     read_len = [[10, 71, 5], [72, 0, 71]]
     for r in range(2):
-        eds, streams, total, wire = out[r]
+        eds, streams, total, wire, cnt, parts = out[r]
         assert [api.edit_stream_to_cigar(s, L) for s, L in zip(streams, read_len[r])] == cigars[r]
         assert eds == [sum(1 for b in s if b >> 6) + 2 for s in streams]
-        assert wire == (8 * 4 if ordered else 8 * 4 + 8 * 3) + 8            # scalars (int32 arrays padded to 8 bytes) + streams
+        # every part of a slot starts at a multiple of 64 bytes: edit distances, lengths, run counts (or offsets), streams
+        assert parts == (64, 128, 192) and wire == 192 + 64
+        if ordered:
+            import re
+            assert cnt == [len(re.findall(r"[=XID]", c)) for c in cigars[r]]
 
 
 def _worker_rotate(rank, world, port, q):

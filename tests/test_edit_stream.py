@@ -39,6 +39,8 @@ def round_trip(cigar, read_len, ed, W, O):
     assert s == py_encode(cigar)
     assert sum(1 for b in s if b >> 6) == ed          # one byte per edit (+ the long-match bytes, op 0)
     assert api.edit_stream_to_cigar(s, read_len, W=W, O=O) == cigar
+    # the same through the state machine the GPU decoder runs in every lane (edit_stream.h: decode_lane_step)
+    assert api.edit_stream_to_cigar(s, read_len, W=W, O=O, lane_form=True) == cigar
 
 
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "pairs_*.json"))), ids=os.path.basename)
@@ -82,6 +84,7 @@ def test_long_match_stretches():
         assert s == b"\x3f" * (p >> 6) + bytes([1 << 6 | (p & 63)])
         # W-O = 31: the decoder restores the window breaks
         want = api.edit_stream_to_cigar(s, p + 6)
+        assert api.edit_stream_to_cigar(s, p + 6, lane_form=True) == want
         runs = re.findall(r"(\d+)([=XID])", want)
         assert all(int(c) <= 31 for c, _ in runs)
         assert sum(int(c) for c, op in runs if op == "=") == p + 5 and [op for _, op in runs].count("X") == 1
@@ -91,14 +94,20 @@ def test_long_match_stretches():
     assert api.edit_stream_to_cigar(b"", 0) == ""
 
 
-def test_malformed_streams_are_rejected():
+@pytest.mark.parametrize("lane_form", [False, True])
+def test_malformed_streams_are_rejected(lane_form):
     with pytest.raises(api.ScroogeError):
-        api.edit_stream_to_cigar(bytes([1 << 6 | 5]), 3)            # 5 matches + X in a read of 3
+        api.edit_stream_to_cigar(bytes([1 << 6 | 5]), 3, lane_form=lane_form)            # 5 matches + X in a read of 3
     with pytest.raises(api.ScroogeError):
-        api.edit_stream_to_cigar(bytes([2 << 6, 2 << 6]), 1)        # two insertions, one base
+        api.edit_stream_to_cigar(bytes([2 << 6, 2 << 6]), 1, lane_form=lane_form)        # two insertions, one base
     with pytest.raises(api.ScroogeError):
-        api.edit_stream_to_cigar(bytes([0x3F]), 10)                  # 64 matches in a read of 10
-    assert api.edit_stream_to_cigar(bytes([3 << 6]), 2) == "1D2="    # a deletion uses no read base
+        api.edit_stream_to_cigar(bytes([0x3F]), 10, lane_form=lane_form)                  # 64 matches in a read of 10
+    with pytest.raises(api.ScroogeError):
+        api.edit_stream_to_cigar(bytes([0x3F, 0x3F]), 100, lane_form=lane_form)           # 128 matches in a read of 100
+    with pytest.raises(api.ScroogeError):
+        api.edit_stream_to_cigar(bytes([1 << 6]), 0, lane_form=lane_form)                 # an edit in an empty read
+    assert api.edit_stream_to_cigar(bytes([3 << 6]), 2, lane_form=lane_form) == "1D2="    # a deletion uses no read base
+    assert api.edit_stream_to_cigar(bytes([3 << 6] * 70), 2, lane_form=lane_form) == "31D31D8D2="     # deletions only: windows end on the text side
     with pytest.raises(ValueError):
         api.cigar_to_edit_stream("5M")
 
@@ -121,3 +130,41 @@ def test_c_example_runs_without_a_gpu():
     assert lines[1] == "stream 2 bytes: 68 db"            # X after 40 matches: 1 << 6 | 40; D after 27: 3 << 6 | 27
     assert lines[2] == "decoded 31=9=1X21=6=1D24=8="
     assert lines[3].startswith("W32/O17 15=") and lines[-1] == "ok"
+
+
+@pytest.mark.parametrize("W,O", [(64, 33), (64, 1), (5, 2), (2, 1), (256, 1), (128, 65)])
+def test_lane_state_machine_equals_replay_on_arbitrary_streams(W, O):
+    """Fuzz: ANY byte string is either rejected by both decoders or gives the same runs in both — non-canonical
+    streams included (op-0 bytes of any length, runs of them, edits after the read is used up)."""
+    import ctypes as C
+    lib = api.load_library()
+    rng = np.random.Generator(np.random.PCG64(7 * W + O))
+    p = api.Params()
+    lib.scrg_params_default(C.byref(p))
+    p.W, p.O = W, O
+    accepted = 0
+    for it in range(3000):
+        n = int(rng.integers(0, 40))
+        kind = it % 3
+        if kind == 0:
+            raw = rng.integers(0, 256, n, dtype=np.uint8)
+        elif kind == 1:              # mostly small match counts: many windows end inside edits
+            raw = (rng.integers(0, 4, n, dtype=np.uint8) << 6 | rng.integers(0, 3, n, dtype=np.uint8)).astype(np.uint8)
+        else:                        # long stretches: op-0 bytes in a row
+            raw = np.where(rng.random(n) < 0.6, rng.integers(0, 64, n), rng.integers(64, 256, n)).astype(np.uint8)
+        s = raw.tobytes()
+        # a read length that the stream fits exactly (most of the time), or a wrong one
+        used = sum((b & 63) + (1 if (b >> 6) in (0, 1, 2) else 0) for b in s)
+        read_len = used + (int(rng.integers(0, 50)) if it % 5 else -int(rng.integers(1, 3)))
+        if read_len < 0:
+            read_len = 0
+        buf = (C.c_uint8 * max(1, n)).from_buffer_copy(s or b"\0")
+        out = []
+        for fn in (lib.scrg_edit_stream_to_runs, lib.scrg_edit_stream_to_runs_lane):
+            cnt = C.c_uint64(0)
+            runs = (C.c_uint8 * (2 * (2 * n + read_len + 8)))()
+            st = fn(C.byref(p), read_len, buf, n, runs, 2 * n + read_len + 8, C.byref(cnt))
+            out.append((st, cnt.value, bytes(runs[: 2 * cnt.value]) if st == api.SCRG_OK else b""))
+        assert out[0] == out[1], (it, s.hex(), read_len, out)
+        accepted += out[0][0] == api.SCRG_OK
+    assert accepted > 500

@@ -522,9 +522,11 @@ def test_edit_stream_round_trip(aligner, oracle, W, O):
             ed2 = torch.empty(n, dtype=torch.int64, device=dev)
             ln2 = torch.empty(n, dtype=torch.int32, device=dev)
             st2 = torch.empty(n, dtype=torch.int32, device=dev)
-            aligner.align_device_edits(n, seq, desc, slices, ed2, ln2, st2, W=W, O=O)
+            rc2 = torch.full((n,), -1, dtype=torch.int32, device=dev)
+            aligner.align_device_edits(n, seq, desc, slices, ed2, ln2, st2, rc2, W=W, O=O)
             torch.cuda.synchronize()
             assert ed2.cpu().tolist() == eds and int(st2.max().item()) == 0 and ln2.cpu().tolist() == lh
+            assert torch.equal(rc2, nr)                # the run count of the same alignment travels with the stream
             sl = slices.cpu().numpy().tobytes()
             for k in range(n):
                 r4 = (lh[k] + 3) // 4 * 4
@@ -551,6 +553,23 @@ def test_edit_stream_round_trip(aligner, oracle, W, O):
             for k in range(n):
                 assert sl[2 * k * cap: 2 * k * cap + min(32, (lh[k] + 3) // 4 * 4)] == (want[k] + bytes(3))[: min(32, (lh[k] + 3) // 4 * 4)], k
                 assert sl[2 * k * cap + 32: 2 * (k + 1) * cap] == b"\xee" * (2 * cap - 32), k
+        # streams that are not inside the buffer (offsets and lengths may come off a wire) are counted, never read; the
+        # others still decode
+        o_bad = s_off.clone()
+        l_bad = s_len.clone()
+        o_bad[0] = stream.numel() + 4096
+        o_bad[1] = stream.numel() - 2
+        l_bad[1] = 64
+        l_bad[2] = 0x7fffffff
+        back.zero_()
+        nbad.zero_()
+        aligner.decode_edit_stream(n, stream, o_bad, l_bad, desc.view(-1)[3:], 6, off, back, nr, nbad, W=W, O=O)
+        torch.cuda.synchronize()
+        lo = int(off[3].item())
+        assert 1 <= int(nbad.item()) <= 3 and torch.equal(back[2 * lo: 2 * total], dense[2 * lo: 2 * total])
+        assert int(back[2 * total:].max().item()) == 0
+        with pytest.raises(scrooge_amd.ScroogeError):          # 16-byte alignment of the stream buffer
+            aligner.decode_edit_stream(n, stream[4:], s_off, s_len, desc.view(-1)[3:], 6, off, back, nr, nbad, W=W, O=O)
         with pytest.raises(scrooge_amd.ScroogeError):          # the one-pair-per-lane kernels only
             aligner.align_device_edits(n, seq, desc, runs, ed, nr, st, W=W, O=O, lanes_per_pair=64)
         # a stream buffer that is too small: the pairs that do not fit are counted and marked, the others are intact
