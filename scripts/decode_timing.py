@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--profile", default="ont")
     ap.add_argument("--slots", type=int, default=8)
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--busy", type=int, default=60, help="align launches enqueued in front of every timed series (clock warm-up)")
+    ap.add_argument("--probe", action="store_true", help="library built with -DSCRG_DEC_PROBE: print the kernel's cycle counters")
     ap.add_argument("--W", type=int, default=64)
     ap.add_argument("--O", type=int, default=33)
     args = ap.parse_args()
@@ -82,13 +84,15 @@ def main():
     doff_all = torch.cumsum(c64a, 0) - c64a
     dense = torch.zeros(S * total_runs * 2 + 64, dtype=torch.uint8, device=dev)
     rl = torch.tensor([L], dtype=torch.int64, device=dev)
-    nbad = torch.zeros(1, dtype=torch.int32, device=dev)
+    nbad = torch.zeros(32, dtype=torch.int32, device=dev)        # ([2..13]: counters of a -DSCRG_DEC_PROBE build)
     out_cnt = torch.empty(S * n, dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
 
     def timed(fn):
         fn()
-        torch.cuda.synchronize()
+        # the clocks of an idle GPU take milliseconds to come up: keep it busy with align launches right up to the timed launches
+        for _ in range(args.busy):
+            al.align_device(n, seq, desc, slices, ed, cnt, st, **kw)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         for _ in range(args.reps):
@@ -101,15 +105,33 @@ def main():
     for slots in sorted(set([1, S])):
         m = slots * n
         t_count = timed(lambda: al.decode_edit_stream(m, stream, off_all, len_all, rl, 0, None, None, out_cnt, nbad, **kw))
-        assert torch.equal(out_cnt[:m], cnt_all[:m]) and int(nbad.item()) == 0
+        assert torch.equal(out_cnt[:m], cnt_all[:m]) and int(nbad[0].item()) == 0
         t_dec = timed(lambda: al.decode_edit_stream(m, stream, off_all, len_all, rl, 0, doff_all, dense, cnt_all, nbad, **kw))
         torch.cuda.synchronize()
-        assert int(nbad.item()) == 0
+        assert int(nbad[0].item()) == 0
         for k in range(slots):
             assert torch.equal(dense[2 * k * total_runs: 2 * (k + 1) * total_runs], want[: 2 * total_runs]), "slot %d differs" % k
         gb = (slots * (sbytes + 2.0 * total_runs)) / 1e9
         res["slots_%d" % slots] = {"count_only_ms": t_count, "decode_ms": t_dec, "decode_ms_per_slot": t_dec / slots,
                                    "decode_M_pairs_per_s": m / t_dec / 1e3, "algorithmic_GB": gb, "GB_per_s": gb / (t_dec * 1e-3)}
+    if args.probe:
+        for store in (False, True):
+            nbad.zero_()
+            if store:
+                al.decode_edit_stream(n, stream, off_all, len_all, rl, 0, doff_all, dense, cnt_all, nbad, **kw)
+            else:
+                al.decode_edit_stream(n, stream, off_all, len_all, rl, 0, None, None, out_cnt, nbad, **kw)
+            torch.cuda.synchronize()
+            v = nbad[2:22].view(torch.int64).cpu().tolist()
+            w = (n + 63) // 64
+            first = (1 << 62) - v[7]
+            res["probe_store" if store else "probe_count"] = {
+                "waves": w, "wave_life_us": v[5] / w / 100.0, "shader_clock_ghz": v[4] / max(1, v[5]) * 0.1,
+                "last_start_us": (v[6] - first) / 100.0, "first_end_us": (((1 << 62) - v[9]) - first) / 100.0,
+                "last_end_us": (v[8] - first) / 100.0,
+                "iterations_per_wave": v[0] / w, "steps_per_wave": 4 * v[0] / w,
+                "cycles_per_step": v[1] / max(1, 4 * v[0]), "flush_cycles_per_iteration": v[2] / max(1, v[0]),
+                "input_cycles_per_iteration": v[3] / max(1, v[0]), "loop_cycles_per_wave": v[4] / w}
     print(json.dumps(res))
 
 

@@ -96,28 +96,49 @@ SCRG_HD inline uint64_t replay_edit_stream(const uint8_t* s, uint64_t n_bytes, u
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// The same replay as a STATE MACHINE, one step at a time: what decode_edits_kernel runs in every lane (one pair per
-// lane), compiled for the host too (scrg_edit_stream_to_runs_lane) so that the CPU tests can hold it against
-// replay_edit_stream() above on every golden fixture.  Differences in form, not in result:
+// The same replay as a branch-free STATE MACHINE, one step at a time: what decode_edits_kernel runs in every lane (one
+// pair per lane, 64 pairs per wavefront), compiled for the host too (scrg_edit_stream_to_runs_lane) so that the CPU
+// tests can hold this very code against replay_edit_stream() above on every golden fixture.  Differences in form, not
+// in result:
 //   * one step places the matches of the pending stream byte that fit the window, then its edit if the window is not
 //     full, then closes the window if it is — instead of one event per loop trip;
 //   * bytes with op 0 ("len + 1 matches, no edit") are accumulated into the match count of the next edit byte before
 //     anything is placed, so a match run is never continued by a later step: the only merge left is an edit joining
 //     the run of the same edit directly before it (no match, no window break in between);
 //   * runs are handed to `put(k, word)` speculatively: slot k holds run k (count | op << 8) and may be rewritten until
-//     run k + 1 starts; `n` counts the runs started.
-// `peek()` returns the stream byte at `pos` (only called while pos < end), `advance()` moves on.
+//     run k + 1 starts (both slots a step might touch are always written: put() must tolerate k = n, a free slot);
+//   * conditions are 0 / ~0 masks and every update is arithmetic on them: the 64 lanes of a wavefront are at 64
+//     different places of their streams, so a branch would be taken by some lane every time — straight-line code issues
+//     at the VALU rate (the first version of this step, with nested conditionals, ran at 24 cycles per instruction).
+// A step consumes at most one stream byte: the caller hands in the byte at `pos` and is told whether it was taken.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ uint32_t es_neg_mask(uint32_t x)              // ~0 iff (int32)x < 0
+{
+    uint32_t r;
+    asm("v_ashrrev_i32 %0, 31, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+__device__ __forceinline__ uint32_t es_sel(uint32_t a, uint32_t b, uint32_t m)   // bits of a where m is set, else b
+{
+    return __builtin_amdgcn_bitop3_b32(a, b, m, 0xE4);           // (a & m) | (b & ~m); truth table bit index = a * 4 + b * 2 + m (genasm_device.h: bitop3_table)
+}
+#else
+inline uint32_t es_neg_mask(uint32_t x) { return (uint32_t)((int32_t)x >> 31); }
+inline uint32_t es_sel(uint32_t a, uint32_t b, uint32_t m) { return (a & m) | (b & ~m); }
+#endif
+SCRG_HD inline uint32_t es_nz_mask(uint32_t x) { return es_neg_mask(0u - x); }      // ~0 iff x != 0, for x < 2^31
+SCRG_HD inline uint32_t es_min(uint32_t a, uint32_t b) { return a < b ? a : b; }
+
 struct DecodeLane {
     uint32_t L;                 // W - O: a window consumes at most L text and L read characters (genasm_cpu.cpp:309-310)
     uint32_t pos, end;          // next stream byte, end of the stream
-    uint32_t m, e;              // matches pending, the edit after them (EDIT_OP_NONE: none yet)
-    uint32_t ready;             // the pending byte is complete (an edit byte has arrived, or the stream is used up)
-    uint32_t tail;              // stream used up: the rest of the read matches
+    uint32_t m, e;              // matches pending, the edit after them (EDIT_OP_NONE: no edit byte has arrived yet)
+    uint32_t tailM;             // mask: stream used up, the rest of the read matches
     uint32_t left;              // read characters from the start of the current window to the end of the read
     uint32_t jl, ri, rj;        // window: read limit min(left, L); text / read characters it can still take
     uint32_t cur, prev_e;       // run n - 1 as a word; the edit it consists of if the next edit may join it, else 0
     uint32_t n;                 // runs started
-    uint32_t alive, bad;
+    uint32_t aliveM, bad;       // mask: the read is not finished; the stream is not an alignment of this read
 };
 
 SCRG_HD inline void decode_lane_init(DecodeLane& s, uint32_t W, uint32_t O, uint32_t pos, uint32_t end, uint32_t read_len)
@@ -125,79 +146,76 @@ SCRG_HD inline void decode_lane_init(DecodeLane& s, uint32_t W, uint32_t O, uint
     s.L = W - O;
     s.pos = pos;
     s.end = end;
-    s.m = s.e = s.ready = s.tail = 0;
+    s.m = s.e = s.tailM = 0;
     s.left = read_len;
     s.jl = read_len < s.L ? read_len : s.L;
     s.ri = s.L;
     s.rj = s.jl;
     s.cur = s.prev_e = s.n = 0;
-    s.alive = read_len != 0;
+    s.aliveM = read_len != 0 ? ~0u : 0u;
     s.bad = 0;
 }
 
 // true when the pair is finished: every byte used, nothing pending (the counterpart of replay_edit_stream's last line)
 SCRG_HD inline bool decode_lane_clean(const DecodeLane& s) { return !s.bad && s.pos == s.end && s.m == 0 && s.e == EDIT_OP_NONE; }
 
-template <typename Peek, typename Advance, typename Put>
-SCRG_HD inline void decode_lane_step(DecodeLane& s, Peek&& peek, Advance&& advance, Put&& put)
+template <typename Put>
+SCRG_HD inline uint32_t decode_lane_step(DecodeLane& s, const uint32_t bn0, Put&& put)      // -> 1 if the byte at pos was consumed
 {
-    if (!s.alive) return;
-    if (!s.ready) {
-        if (s.pos < s.end) {
-            const uint32_t b = peek();
-            advance();
-            s.pos++;
-            const uint32_t e = b >> 6;
-            s.m += (b & 63u) + (e == EDIT_OP_NONE ? 1u : 0u);
-            s.e = e;
-            s.ready = e != EDIT_OP_NONE;
-        } else {
-            // the matches after the last edit are implied by the read length (with op-0 bytes pending: they are part of them)
-            const uint32_t rest = s.left - (s.jl - s.rj);
-            if (s.m <= rest) s.m = rest;          // (else: the stream overruns the read; m stays non-zero to the end: bad)
-            s.tail = s.ready = 1;
-        }
-    }
-    if (s.ready) {
-        uint32_t t = s.m < s.ri ? s.m : s.ri;
-        t = t < s.rj ? t : s.rj;
-        if (t) {
-            s.m -= t;
-            s.ri -= t;
-            s.rj -= t;
-            s.cur = ((uint32_t)'=' << 8) | t;
-            put(s.n, s.cur);
-            s.n++;
-            s.prev_e = 0;
-        }
-        if (s.m == 0 && s.e != EDIT_OP_NONE && s.ri != 0 && s.rj != 0) {
-            if (s.e == s.prev_e) {
-                s.cur += 1;
-                put(s.n - 1, s.cur);
-            } else {
-                s.cur = (edit_char_of_code(s.e) << 8) | 1u;
-                put(s.n, s.cur);
-                s.n++;
-            }
-            s.prev_e = s.e;
-            s.ri -= s.e != EDIT_OP_I ? 1u : 0u;
-            s.rj -= s.e != EDIT_OP_D ? 1u : 0u;
-            s.e = EDIT_OP_NONE;
-            s.ready = 0;
-        }
-    }
-    if (s.ri == 0 || s.rj == 0) {
-        // the window is full (genasm_cpu.cpp:307-310): the next one starts where it stopped, its run is flushed (:400-403)
-        s.left -= s.jl - s.rj;
-        s.prev_e = 0;
-        s.jl = s.left < s.L ? s.left : s.L;
-        s.ri = s.L;
-        s.rj = s.jl;
-        if (s.left == 0) s.alive = 0;
-    } else if (s.tail && s.m == 0) {
-        s.bad = 1;                                // nothing left to place and the read is not finished: not an alignment of this read
-        s.alive = 0;
-    }
+    constexpr uint32_t EQW = (uint32_t)'=' << 8;
+    // ---- the next stream byte, if nothing is pending (an edit byte completes the pending item, an op-0 byte only adds matches)
+    const uint32_t fetchM = ~(es_nz_mask(s.e) | s.tailM) & s.aliveM;
+    const uint32_t hasM = es_neg_mask(s.pos - s.end);                // pos < end
+    const uint32_t takeM = fetchM & hasM;
+    const uint32_t e_new = bn0 >> 6;
+    s.m += ((bn0 & 63u) + ((bn0 - 64u) >> 31)) & takeM;              // len, + 1 for op 0
+    s.e = es_sel(e_new, s.e, takeM);
+    s.pos -= takeM;
+    // the stream is used up (once per pair): the matches after the last edit are implied by the read length (op-0 bytes
+    // pending are part of them; more of them than the read has left means the stream overruns the read: m then stays
+    // non-zero to the end and the pair is reported)
+    const uint32_t tail_now = fetchM & ~hasM;
+    const uint32_t rest = s.left - (s.jl - s.rj);
+    s.m = es_sel(s.m < rest ? rest : s.m, s.m, tail_now);
+    s.tailM |= tail_now;
+    const uint32_t readyM = es_nz_mask(s.e) | s.tailM;
+    // ---- the matches that fit the window: always a new run
+    const uint32_t t = es_min(es_min(s.m, s.ri), s.rj) & readyM;
+    s.m -= t;
+    s.ri -= t;
+    s.rj -= t;
+    const uint32_t tnzM = es_nz_mask(t);
+    const uint32_t wm = EQW | t;
+    put(s.n, wm);                                                    // (t == 0: a free slot, rewritten by the next run)
+    s.cur = es_sel(wm, s.cur, tnzM);
+    s.n -= tnzM;
+    s.prev_e &= ~tnzM;
+    // ---- the edit, if all its matches are placed and the window is not full
+    const uint32_t doM = es_nz_mask(es_min(es_min(s.e, s.ri), s.rj)) & ~es_nz_mask(s.m);
+    const uint32_t sameM = ~es_nz_mask(s.e ^ s.prev_e);
+    const uint32_t mergeM = doM & sameM, newM = doM & ~sameM;
+    const uint32_t opw = ((0x44495800u >> (((s.e << 3) + 24u) & 31u)) & 0xff00u) | 1u;      // 'X', 'I', 'D' for e = 1, 2, 3
+    s.cur = es_sel(s.cur + 1u, es_sel(opw, s.cur, newM), mergeM);
+    put(s.n + mergeM, s.cur);                                        // run n - 1 grows, or run n starts (or nothing changes)
+    s.n -= newM;
+    s.prev_e = es_sel(s.e, s.prev_e, doM);
+    s.ri -= s.e & doM & 1u;                                          // X and D consume a text character,
+    s.rj -= (6u >> s.e) & doM & 1u;                                  // X and I a read character
+    s.e &= ~doM;
+    // ---- the window is full (genasm_cpu.cpp:307-310): the next one starts where it stopped, its run is flushed (:400-403)
+    const uint32_t endM = ~es_nz_mask(es_min(s.ri, s.rj)) & s.aliveM;
+    s.left -= (s.jl - s.rj) & endM;
+    s.prev_e &= ~endM;
+    const uint32_t jl_new = es_min(s.left, s.L);
+    s.jl = es_sel(jl_new, s.jl, endM);
+    s.ri = es_sel(s.L, s.ri, endM);
+    s.rj = es_sel(jl_new, s.rj, endM);
+    s.aliveM &= es_nz_mask(s.left);
+    // nothing left to place and the read is not finished: not an alignment of this read
+    const uint32_t stuck = s.tailM & ~es_nz_mask(s.m) & ~endM & s.aliveM;
+    s.bad |= stuck;
+    s.aliveM &= ~stuck;
+    return takeM & 1u;
 }
 
 hipError_t launch_encode_edits(uint64_t n_pairs, const scrg_pair_desc* d_pairs, const uint16_t* d_runs,
@@ -206,6 +224,7 @@ hipError_t launch_encode_edits(uint64_t n_pairs, const scrg_pair_desc* d_pairs, 
 hipError_t launch_decode_edits(uint64_t n_pairs, uint32_t W, uint32_t O, const uint8_t* d_stream, uint64_t stream_bytes,
                                const uint64_t* d_off, const uint32_t* d_len, const uint64_t* d_read_len,
                                uint64_t read_len_stride, const uint64_t* d_dense_off, uint16_t* d_dense, uint32_t* d_n_runs,
-                               uint32_t* d_bad, hipStream_t s);
+                               uint32_t* d_bad, void* sort_ws, size_t sort_temp_bytes, hipStream_t s);
+size_t decode_sort_temp_bytes(uint64_t n_pairs);
 
 }  // namespace scrg

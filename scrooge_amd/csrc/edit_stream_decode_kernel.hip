@@ -4,29 +4,35 @@
 // D2H in stream form: what must come out is what the reference delivers, CIGARs with one run list per window
 // (src/genasm_cpu.cpp:304-305, 400-403; host side of src/genasm_gpu.cu:955-968).
 //
-// One pair per LANE, 64 pairs per wavefront, the state machine of edit_stream.h (decode_lane_step: one stream byte,
-// its matches cut at the window limits, the edit, the window end — O(edits + windows) steps per pair, no per-base work).
-// What makes it fast is the memory side:
-//   in : a lane's stream is consumed byte by byte, but it is FETCHED by the wavefront: 64-byte chunks, four lanes
-//        x 16 bytes per pair and chunk, sixteen pairs per load instruction, into a 128-byte ring per lane in LDS
-//        (every 64-byte block of the gathered buffer is read exactly once, as one request);
-//   out: runs are staged in a 32-run ring per lane in LDS, indexed by the run's position in the OUTPUT array modulo 32,
-//        and leave as aligned 32-byte pieces (two 16-byte stores); only the first and the last piece of a pair, which
-//        it shares with its neighbours in the dense array, go out run by run.
-// 13.25 KB of LDS per wavefront, 12 wavefronts per CU.  Bound: VALU issue (about 60 instructions per step, ~1300 steps
-// for a 10 kb read at 10 % error) next to 0.1 GB read + 0.43 GB written per 100 k pairs.
+// One pair per LANE, 64 pairs per wavefront, the branch-free state machine of edit_stream.h (decode_lane_step: one
+// stream byte, its matches cut at the window limits, the edit, the window end — O(edits + windows) steps per pair, no
+// per-base work, about 90 VALU instructions per step and no branch: the lanes of a wavefront are at 64 different places
+// of their streams, so every conditional would be taken by some lane every time).  Around it:
+//   in : a lane reads its own stream in aligned 16-byte blocks, two blocks ahead, all lanes at the same iterations (a
+//        block is touched a whole epoch of 16 steps after its load was issued); the bytes are consumed through a 64-bit
+//        shift register that is topped up one dword at a time.  No LDS, no cross-lane traffic; a 64-byte sector of the
+//        gathered buffer is asked for four times within ~100 steps and is served by the L2 after the first.
+//   out: runs are staged in a 64-run ring per lane in LDS, indexed by the run's position in the OUTPUT array modulo 64,
+//        and leave as aligned 64-byte pieces (four 16-byte stores per lane); only the first and the last piece of a
+//        pair, which it shares with its neighbours in the dense array, go out run by run.  Pieces are written when ONE
+//        lane's ring is three quarters full, by every lane that has a whole piece: fewer, fuller passes.
+// 9 KB of LDS per wavefront (count-only: none).  Bound: VALU issue, next to 0.1 GB read + 0.43 GB written per 100 k
+// 10 kb pairs.
+#include <hipcub/hipcub.hpp>
+
 #include "edit_stream.h"
 
 namespace scrg {
 
 namespace {
 
-constexpr uint32_t DEC_IN_RING = 128;                 // bytes of stream per lane in LDS
-constexpr uint32_t DEC_IN_STRIDE = DEC_IN_RING + 16;  // 16-byte aligned (ds_write_b128), lanes spread over the banks
-constexpr uint32_t DEC_CHUNK = 64;                    // bytes fetched per pair and refill
-constexpr uint32_t DEC_OUT_STRIDE = 68;               // 32 runs + one dword
-constexpr uint32_t DEC_WAVE_LDS = 64u * (DEC_IN_STRIDE + DEC_OUT_STRIDE);
-constexpr int DEC_STEPS_PER_CHECK = 4;                // steps between two looks at the rings (<= 2 runs and 1 byte per step)
+constexpr uint32_t DEC_RING = 64;                     // runs per lane in LDS
+constexpr uint32_t DEC_PIECE = 32;                    // runs per store pass: 64 bytes
+constexpr uint32_t DEC_OUT_STRIDE = 2u * DEC_RING + 16u;    // 16-byte aligned rows, lanes spread over the banks
+constexpr uint32_t DEC_WAVE_LDS = 64u * DEC_OUT_STRIDE;
+constexpr uint32_t DEC_FLUSH_AT = 48;                 // final runs in one lane's ring that start a store pass
+constexpr int DEC_STEPS_PER_CHECK = 4;                // steps between two looks at the buffers (<= 2 runs and 1 byte per step)
+constexpr uint32_t DEC_EPOCH = 4;                     // iterations between two block moves: 16 steps, at most 16 bytes
 
 struct DecodeArgs {
     uint64_t n_pairs;
@@ -41,6 +47,7 @@ struct DecodeArgs {
     uint16_t* dense;
     uint32_t* n_runs;
     uint32_t* bad;
+    const uint32_t* order;      // optional: thread t takes pair order[t] (pairs sorted by stream length, longest first)
 };
 
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
@@ -52,13 +59,15 @@ typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 template <bool STORE>
 __global__ __launch_bounds__(256) void decode_edits_kernel(DecodeArgs a)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t lds_all[4 * DEC_WAVE_LDS];
+    __shared__ __attribute__((aligned(16))) uint8_t lds_all[STORE ? 4 * DEC_WAVE_LDS : 16];
     const uint32_t lane = threadIdx.x & 63u;
-    uint8_t* const wave_lds = lds_all + (threadIdx.x >> 6) * DEC_WAVE_LDS;
-    uint8_t* const in_me = wave_lds + lane * DEC_IN_STRIDE;
-    uint8_t* const out_me = wave_lds + 64u * DEC_IN_STRIDE + lane * DEC_OUT_STRIDE;
-    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool valid = p < a.n_pairs;
+    uint8_t* const out_me = lds_all + (STORE ? (threadIdx.x >> 6) * DEC_WAVE_LDS + lane * DEC_OUT_STRIDE : 0u);
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = tid < a.n_pairs;
+    // Longest streams first: the pairs of a wavefront then need about the same number of steps (the wavefront runs until
+    // its last lane is done — a batch of 10 kb reads has a few pairs in ten thousand whose alignment went astray and
+    // whose stream is five times the usual length), and the long ones do not start last.
+    const uint64_t p = valid ? (a.order ? (uint64_t)a.order[tid] : tid) : 0;
 
     uint64_t off = 0, g0 = 0;
     uint32_t len = 0, rl = 0, cap = 0;
@@ -69,7 +78,7 @@ __global__ __launch_bounds__(256) void decode_edits_kernel(DecodeArgs a)
         const uint64_t rl64 = a.read_len[p * a.read_len_stride];
         // a stream that is not inside the buffer (offsets and lengths may come off a wire) or a pair marked "did not
         // fit" by the encoder is reported, never read
-        bad_input = off == ~0ull || off > a.stream_bytes || len > a.stream_bytes - off || rl64 > 0x7fffffffull;
+        bad_input = off == ~0ull || off > a.stream_bytes || len > a.stream_bytes - off || len > 0x3fffffffu || rl64 > 0x7fffffffull;
         rl = bad_input ? 0u : (uint32_t)rl64;
         if (bad_input) { off = 0; len = 0; }
         if (STORE) {
@@ -77,94 +86,154 @@ __global__ __launch_bounds__(256) void decode_edits_kernel(DecodeArgs a)
             cap = a.n_runs[p];
         }
     }
-    const uint64_t base = off & ~(uint64_t)(DEC_CHUNK - 1u);    // the lane's stream positions are relative to this block
-    const uint64_t limit16 = (a.stream_bytes + 15u) & ~15ull;   // whole 16-byte blocks of the buffer may be read
-    uint32_t loaded = 0;                                        // stream bytes in my ring: [loaded - 128, loaded), a multiple of 64
-
     DecodeLane s;
-    decode_lane_init(s, a.W, a.O, (uint32_t)(off - base), (uint32_t)(off - base) + len, rl);
-    if (!valid) s.alive = 0;
+    decode_lane_init(s, a.W, a.O, 0u, len, rl);
+    if (!valid) s.aliveM = 0;
 
-    // ---- input: the wavefront fetches the next 64-byte chunk of every lane that has room for it ----
-    auto refill = [&]() {
-        const bool want = s.alive && loaded < s.end && (int32_t)(loaded - s.pos) <= (int32_t)(DEC_IN_RING - DEC_CHUNK);
-        if (!__any(want)) return;
-#pragma unroll
-        for (uint32_t r = 0; r < 4; r++) {
-            const int q = (int)(16u * r + (lane >> 2));          // the pair (lane) this lane fetches for, and which quarter
-            const uint32_t sub = (lane & 3u) * 16u;
-            const uint64_t qbase = (uint64_t)__shfl((long long)base, q, 64);
-            const uint32_t qloaded = (uint32_t)__shfl((int)loaded, q, 64);
-            const bool qwant = __shfl((int)want, q, 64) != 0;
-            const uint64_t at = qbase + qloaded + sub;
-            if (qwant && at < limit16) {
-                const u32x4_t v = *reinterpret_cast<const u32x4_t*>(a.stream + at);
-                *reinterpret_cast<u32x4_t*>(wave_lds + (uint32_t)q * DEC_IN_STRIDE + ((qloaded + sub) & (DEC_IN_RING - 1u))) = v;
+    // ---- input: my stream, in aligned 16-byte blocks, through a 64-bit shift register ----
+    const uint64_t limit16 = (a.stream_bytes + 15u) & ~15ull;   // whole 16-byte blocks of the buffer may be read
+    const uint64_t stream_end = off + len;
+    uint64_t blk = off & ~15ull;                                 // the block in `cur`
+    auto load_block = [&](uint64_t at) -> u32x4_t {
+        u32x4_t v = {0u, 0u, 0u, 0u};
+        if (at < stream_end && at < limit16) v = *reinterpret_cast<const u32x4_t*>(a.stream + at);
+        return v;
+    };
+    // Three blocks in registers: the one being used, the next, and the one after that, which is being LOADED.  Blocks move
+    // up (and the next load is issued) only every DEC_EPOCH iterations, for all lanes at once: a block is first touched a
+    // whole epoch after its load was issued, so the wait in front of the move costs nothing — issued lane by lane as
+    // blocks run out, some lane's load would be seconds old at every look and the wavefront would wait for memory each time.
+    // (A lane uses at most 16 bytes per epoch; after the move it has at least 20 loaded bytes in front of it.)
+    u32x4_t cur = load_block(blk), nxt = load_block(blk + 16u), nx2 = load_block(blk + 32u);
+    uint32_t di = ((uint32_t)off & 15u) >> 2;                    // the dword of cur:nxt that goes into the shift register next (0..7)
+    uint64_t sr = 0;                                             // the next `have` bytes of the stream, lowest first
+    uint32_t have = 0;
+    auto advance_blocks = [&]() {
+        const bool rot = di >= 4u;
+        if (__any(rot)) {
+            if (rot) {
+                cur = nxt;
+                nxt = nx2;
+                di -= 4u;
+                blk += 16u;
+                nx2 = load_block(blk + 32u);
             }
         }
-        if (want) loaded += DEC_CHUNK;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
-    refill();
-    refill();
-    // two bytes of lookahead in registers: the byte at pos and the one after it
-    uint32_t bn0 = in_me[s.pos & (DEC_IN_RING - 1u)], bn1 = in_me[(s.pos + 1u) & (DEC_IN_RING - 1u)];
+    // one more dword for every lane that is down to four bytes or fewer (a lane uses at most four between two calls)
+    auto top_up = [&]() {
+        const uint32_t hiM = 0u - ((di >> 2) & 1u), b1M = 0u - ((di >> 1) & 1u), b0M = 0u - (di & 1u);
+        const uint32_t x = es_sel(nxt.x, cur.x, hiM), y = es_sel(nxt.y, cur.y, hiM), z = es_sel(nxt.z, cur.z, hiM), w = es_sel(nxt.w, cur.w, hiM);
+        const uint32_t d = es_sel(es_sel(w, z, b0M), es_sel(y, x, b0M), b1M);
+        const uint32_t wantM = es_neg_mask(have - 5u);          // have <= 4
+        sr |= (uint64_t)(d & wantM) << (8u * (have & 7u));
+        have += 4u & wantM;
+        di += 1u & wantM;
+    };
+    top_up();
+    {   // the stream need not start at a dword
+        const uint32_t skip = (uint32_t)off & 3u;
+        sr >>= 8u * skip;
+        have -= skip;
+    }
+    top_up();
+    advance_blocks();            // (di <= 3 from here on at every move, <= 7 in between: four top-ups per epoch)
 
-    // ---- output: run k of the pair is element g0 + k of the dense array; ring slot = that index modulo 32 ----
-    const uint32_t slot0 = (uint32_t)g0 & 31u;
-    int32_t kf = -(int32_t)((uint32_t)g0 & 15u);                // runs below kf are in memory (or not mine); g0 + kf is a multiple of 16
+    // ---- output: run k of the pair is element g0 + k of the dense array; ring slot = that index modulo 64 ----
+    const uint32_t slot0 = (uint32_t)g0 & (DEC_RING - 1u);
+    int32_t kf = -(int32_t)((uint32_t)g0 & (DEC_PIECE - 1u));    // runs below kf are in memory (or not mine); g0 + kf is a multiple of 32
     uint16_t* const dst0 = STORE ? a.dense + g0 : nullptr;
     auto put = [&](uint32_t k, uint32_t word) {
-        if (STORE) *reinterpret_cast<uint16_t*>(out_me + (((slot0 + k) & 31u) << 1)) = (uint16_t)word;
+        if (STORE) *reinterpret_cast<uint16_t*>(out_me + (((slot0 + k) & (DEC_RING - 1u)) << 1)) = (uint16_t)word;
     };
-    // the 16 runs from kf on: an aligned 32-byte piece of the output; `upto`: runs below this index exist
+    // the 32 runs from kf on: an aligned 64-byte piece of the output; `upto`: runs below this index exist
     auto write_piece = [&](uint32_t upto) {
-        const uint32_t* const src = reinterpret_cast<const uint32_t*>(out_me + (((slot0 + (uint32_t)kf) & 31u) << 1));
-        uint32_t w[8];
+        const u32x4_t* const src = reinterpret_cast<const u32x4_t*>(out_me + (((slot0 + (uint32_t)kf) & (DEC_RING - 1u)) << 1));
+        u32x4_t w[4];
 #pragma unroll
-        for (int k = 0; k < 8; k++) w[k] = src[k];
+        for (int k = 0; k < 4; k++) w[k] = src[k];
         const uint32_t lim = upto < cap ? upto : cap;
-        const bool whole = kf >= 0 && (uint32_t)kf + 16u <= lim;
+        const bool whole = kf >= 0 && (uint32_t)kf + DEC_PIECE <= lim;
         if (whole) {
-            uint4* const d = reinterpret_cast<uint4*>(dst0 + kf);
-            d[0] = make_uint4(w[0], w[1], w[2], w[3]);
-            d[1] = make_uint4(w[4], w[5], w[6], w[7]);
+            u32x4_t* const d = reinterpret_cast<u32x4_t*>(dst0 + kf);
+#pragma unroll
+            for (int k = 0; k < 4; k++) d[k] = w[k];
         }
         if (__any(!whole)) {
             if (!whole) {
 #pragma unroll
-                for (int k = 0; k < 16; k++) {
+                for (int k = 0; k < (int)DEC_PIECE; k++) {
                     const int32_t idx = kf + k;
-                    if (idx >= 0 && (uint32_t)idx < lim) dst0[idx] = (uint16_t)(w[k >> 1] >> (16 * (k & 1)));
+                    const uint32_t dw = w[k >> 3][(k >> 1) & 3];
+                    if (idx >= 0 && (uint32_t)idx < lim) dst0[idx] = (uint16_t)(dw >> (16 * (k & 1)));
                 }
             }
         }
-        kf += 16;
+        kf += (int32_t)DEC_PIECE;
     };
-    // every piece whose runs are final (run n - 1 may still grow while the pair is alive)
+    // final runs: all but run n - 1, which may still grow while the pair is alive.  A store pass starts when one lane
+    // has DEC_FLUSH_AT of them waiting and takes every lane's whole pieces along.
     auto flush_pieces = [&]() {
+        const int32_t fin = (int32_t)(s.n - (s.aliveM & 1u));
+        if (!__any(fin - kf >= (int32_t)DEC_FLUSH_AT)) return;
         for (;;) {
-            const bool need = kf + 16 <= (int32_t)(s.n - (s.alive ? 1u : 0u));
+            const bool need = kf + (int32_t)DEC_PIECE <= fin;
             if (!__any(need)) break;
             if (need) write_piece(s.n);
         }
     };
 
-    for (;;) {
+#ifdef SCRG_DEC_PROBE           // (probe build only, scripts/decode_timing.py --probe: shader cycles per part of the loop, summed over wavefronts)
+    uint64_t pc_steps = 0, pc_flush = 0, pc_input = 0, pc_iter = 0;
+    const uint64_t pc_begin = __builtin_readcyclecounter();
+    const uint64_t pr_begin = __builtin_amdgcn_s_memrealtime();
+#define SCRG_DEC_T(var) const uint64_t var = __builtin_readcyclecounter()
+#define SCRG_DEC_ACC(acc, a_, b_) acc += (b_) - (a_)
+#else
+#define SCRG_DEC_T(var)
+#define SCRG_DEC_ACC(acc, a_, b_)
+#endif
+    for (uint32_t iter = 0;; iter++) {
+        SCRG_DEC_T(t0);
 #pragma unroll
         for (int it = 0; it < DEC_STEPS_PER_CHECK; it++) {
-            decode_lane_step(s, [&]() { return bn0; }, [&]() { bn0 = bn1; }, put);
-            bn1 = in_me[(s.pos + 1u) & (DEC_IN_RING - 1u)];
+            const uint32_t took = decode_lane_step(s, (uint32_t)sr & 0xffu, put);
+            sr >>= 8u * took;
+            have -= took;
         }
+        SCRG_DEC_T(t1);
+        if ((iter & (DEC_EPOCH - 1u)) == DEC_EPOCH - 1u) advance_blocks();       // (before this iteration's stores: the wait in it covers older ones only)
         if (STORE) flush_pieces();
-        refill();
-        if (!__any(s.alive != 0)) break;
+        SCRG_DEC_T(t2);
+        top_up();
+        SCRG_DEC_T(t3);
+        SCRG_DEC_ACC(pc_steps, t0, t1);
+        SCRG_DEC_ACC(pc_flush, t1, t2);
+        SCRG_DEC_ACC(pc_input, t2, t3);
+#ifdef SCRG_DEC_PROBE
+        pc_iter++;
+#endif
+        if (!__any(s.aliveM != 0u)) break;
     }
+#ifdef SCRG_DEC_PROBE
+    if (lane == 0) {
+        unsigned long long* const probe = reinterpret_cast<unsigned long long*>(a.bad + 2);
+        const uint64_t pr_end = __builtin_amdgcn_s_memrealtime();
+        atomicAdd(probe + 0, (unsigned long long)pc_iter);
+        atomicAdd(probe + 1, (unsigned long long)pc_steps);
+        atomicAdd(probe + 2, (unsigned long long)pc_flush);
+        atomicAdd(probe + 3, (unsigned long long)pc_input);
+        atomicAdd(probe + 4, (unsigned long long)(__builtin_readcyclecounter() - pc_begin));
+        atomicAdd(probe + 5, (unsigned long long)(pr_end - pr_begin));                // 100 MHz ticks
+        atomicMax(probe + 6, (unsigned long long)pr_begin);                           // latest start
+        atomicMax(probe + 7, (unsigned long long)((1ull << 62) - pr_begin));          // earliest start
+        atomicMax(probe + 8, (unsigned long long)pr_end);                             // latest end
+        atomicMax(probe + 9, (unsigned long long)((1ull << 62) - pr_end));            // earliest end
+    }
+#endif
     const bool clean = decode_lane_clean(s) && !bad_input;
     if (STORE) {
-        // the last, partial piece
+        // what is left in the rings: whole pieces of pairs that ended since the last pass, and every pair's last, partial one
         while (__any(kf < (int32_t)s.n)) {
             if (kf < (int32_t)s.n) write_piece(s.n);
         }
@@ -175,13 +244,45 @@ __global__ __launch_bounds__(256) void decode_edits_kernel(DecodeArgs a)
     }
 }
 
+__global__ void iota_kernel(uint32_t* v, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = i;
+}
+
+// Bits of the stream length the order is made from: 16-byte granularity, lengths up to 1 MB told apart.
+constexpr int DEC_SORT_BEGIN_BIT = 4, DEC_SORT_END_BIT = 20;
+
+size_t decode_sort_temp_bytes(uint64_t n_pairs)
+{
+    size_t bytes = 0;
+    (void)hipcub::DeviceRadixSort::SortPairsDescending(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
+                                                       (uint32_t*)nullptr, (int)n_pairs, DEC_SORT_BEGIN_BIT, DEC_SORT_END_BIT, (hipStream_t)0);
+    return bytes;
+}
+
+// sort_ws: null (pairs are taken in index order) or a work area of 3 * n_pairs uint32 followed by decode_sort_temp_bytes()
+// bytes (256-byte aligned): the pairs are then taken longest stream first.
 hipError_t launch_decode_edits(uint64_t n_pairs, uint32_t W, uint32_t O, const uint8_t* d_stream, uint64_t stream_bytes,
                                const uint64_t* d_off, const uint32_t* d_len, const uint64_t* d_read_len,
                                uint64_t read_len_stride, const uint64_t* d_dense_off, uint16_t* d_dense, uint32_t* d_n_runs,
-                               uint32_t* d_bad, hipStream_t s)
+                               uint32_t* d_bad, void* sort_ws, size_t sort_temp_bytes, hipStream_t s)
 {
     if (n_pairs == 0) return hipSuccess;
-    DecodeArgs a{n_pairs, W, O, d_stream, stream_bytes, d_off, d_len, d_read_len, read_len_stride, d_dense_off, d_dense, d_n_runs, d_bad};
+    const uint32_t* order = nullptr;
+    if (sort_ws && n_pairs < 0x7fffffffull) {
+        uint32_t* const idx = static_cast<uint32_t*>(sort_ws);
+        uint32_t* const keys_out = idx + n_pairs;
+        uint32_t* const idx_out = keys_out + n_pairs;
+        void* const temp = reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(idx_out + n_pairs) + 255u) & ~(uintptr_t)255u);
+        hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, s, idx, (uint32_t)n_pairs);
+        size_t tb = sort_temp_bytes;
+        hipError_t e = hipcub::DeviceRadixSort::SortPairsDescending(temp, tb, d_len, keys_out, idx, idx_out, (int)n_pairs,
+                                                                    DEC_SORT_BEGIN_BIT, DEC_SORT_END_BIT, s);
+        if (e != hipSuccess) return e;
+        order = idx_out;
+    }
+    DecodeArgs a{n_pairs, W, O, d_stream, stream_bytes, d_off, d_len, d_read_len, read_len_stride, d_dense_off, d_dense, d_n_runs, d_bad, order};
     const dim3 grid((unsigned)((n_pairs + 255) / 256)), block(256);
     if (d_dense) hipLaunchKernelGGL(decode_edits_kernel<true>, grid, block, 0, s, a);
     else hipLaunchKernelGGL(decode_edits_kernel<false>, grid, block, 0, s, a);

@@ -127,6 +127,7 @@ struct scrg_ctx {
     DevBuf counter;     // work queue head
     DevBuf spill;       // HBM overflow rows of R
     DevBuf stats;       // profiling counters (params.reserved[1] != 0)
+    DevBuf sort_ws;     // scrg_decode_edit_stream: pair order by stream length (indices, sorted keys / indices, radix sort scratch)
     // staging used by the host-pointer entry points
     HostPinned h_ascii;
     HostPinned h_desc;   // problem descriptors (pinned: no page faults after the first call, full-rate H2D)
@@ -314,6 +315,7 @@ void scrg_ctx_destroy(scrg_ctx* c)
     c->counter.release();
     c->spill.release();
     c->stats.release();
+    c->sort_ws.release();
     c->h_ascii.release();
     c->h_desc.release();
     for (HostPinned* b : {&c->h_out, &c->h_runs, &c->h_off}) b->release();
@@ -656,9 +658,17 @@ scrg_status scrg_decode_edit_stream(scrg_ctx* c, const scrg_params* params, uint
     if ((reinterpret_cast<uintptr_t>(d_stream) & 15u) || (reinterpret_cast<uintptr_t>(d_dense) & 15u))
         return c->fail(SCRG_ERR_INVALID_ARG, "d_stream and d_dense need 16-byte alignment");
     HIP_TRY(c, hipSetDevice(c->device));
+    // batches that fill the GPU are decoded longest stream first (a wavefront's 64 pairs then finish together)
+    void* ws = nullptr;
+    size_t temp_bytes = 0;
+    if (n_pairs >= 4096 && n_pairs < 0x7fffffffull) {
+        temp_bytes = scrg::decode_sort_temp_bytes(n_pairs);
+        HIP_TRY(c, c->sort_ws.ensure(3 * n_pairs * sizeof(uint32_t) + 256 + temp_bytes));
+        ws = c->sort_ws.p;
+    }
     HIP_TRY(c, scrg::launch_decode_edits(n_pairs, (uint32_t)p.W, (uint32_t)p.O, d_stream, stream_bytes, d_stream_off, d_stream_len,
                                          d_read_len, read_len_stride, d_dense_offset, reinterpret_cast<uint16_t*>(d_dense),
-                                         d_n_runs, d_bad_count, c->stream));
+                                         d_n_runs, d_bad_count, ws, temp_bytes, c->stream));
     return SCRG_OK;
 }
 
@@ -674,11 +684,10 @@ scrg_status scrg_edit_stream_to_runs_lane(const scrg_params* params, uint64_t re
     if (read_len > 0x7fffffffull || n_bytes > 0x7fffffffull) return SCRG_ERR_INVALID_ARG;
     scrg::DecodeLane s;
     scrg::decode_lane_init(s, (uint32_t)p.W, (uint32_t)p.O, 0u, (uint32_t)n_bytes, (uint32_t)read_len);
-    while (s.alive)
-        scrg::decode_lane_step(s, [&]() -> uint32_t { return stream[s.pos]; }, [] {},
-                               [&](uint32_t k, uint32_t word) {
-                                   if (k < runs_cap) { runs[k].count = (uint8_t)word; runs[k].op = (char)(word >> 8); }
-                               });
+    while (s.aliveM)
+        (void)scrg::decode_lane_step(s, s.pos < n_bytes ? (uint32_t)stream[s.pos] : 0u, [&](uint32_t k, uint32_t word) {
+            if (k < runs_cap) { runs[k].count = (uint8_t)word; runs[k].op = (char)(word >> 8); }
+        });
     if (!scrg::decode_lane_clean(s)) return SCRG_ERR_INVALID_ARG;
     *n_runs = s.n;
     return s.n > runs_cap ? SCRG_ERR_CIGAR_OVERFLOW : SCRG_OK;

@@ -647,5 +647,11 @@ def test_bench_gather_on_rccl_single_rank(fmt):
     assert out.returncode == 0, out.stderr[-2000:]
     j = json.loads([l for l in out.stdout.splitlines() if l.startswith('{"metric"')][0])
     assert j["gather_check"] is True and j["value"] > 0 and j["config"]["gather"]["format"] == fmt
+    assert j["config"]["backend"] == "nccl" and j["config"]["rccl_ranks"] == 1 and j["config"]["gather"]["root"] == "rank 0"
+    # the contract step: CIGAR runs of every rank's pairs exist on the root when the clock stops (edit streams decoded inside
+    # the timed region); the same steps without the decoding are reported next to it, never as the headline
+    assert j["config"]["gather"]["decoded_to_runs_inside_timed_region"] == (fmt == "edits")
+    if fmt == "edits":
+        assert j["gather_without_decode"]["value"] > 0
     if fmt.startswith("edits"):
         assert 0.09 * 3000 < j["config"]["gather"]["stream_bytes_per_pair"] < 0.13 * 3000       # one byte per edit at 10 % error
