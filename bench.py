@@ -27,7 +27,6 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: HBM3E 8 TB/s
 VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9   # 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6 T int32 lane-ops/s
-VALU_INSTR_PER_ROUND = 2440                 # lane kernel, SQ_INSTS_VALU per window round (overridden by profiles/r02_pmc_sq_summary.json)
 
 
 def parse():
@@ -60,6 +59,10 @@ def parse():
     ap.add_argument("--sustained-steps", type=int, default=150,
                     help="N = 1: after the timed region, time this many more pipelined steps for the 'sustained' field (0 = skip)")
     ap.add_argument("--streams", type=int, default=4, help="pipeline depth: consecutive steps rotate over this many streams/handles")
+    ap.add_argument("--other-configs", default="auto", choices=["auto", "on", "off"],
+                    help="after the timed region, also measure BASELINE configs[0] (4 M x 150 bp), configs[2] (read mapping, 1 M reads x 4 "
+                         "candidates on a 100 Mbp chromosome) and configs[4] (40 k x 50 kb PacBio-error pairs), each with an oracle-checked sample; "
+                         "auto = only in the default single-GPU run of the headline workload")
     ap.add_argument("--no-build", action="store_true",
                     help="never rebuild the library (profiling: nothing may fork a compiler under rocprofv3)")
     ap.add_argument("--stats", action="store_true", help="profiling only: print kernel round/step counters")
@@ -134,6 +137,238 @@ def device_pairs(torch, n, read_len, err, ratio, seed, device, slack=0.15, chunk
         out[b0:b0 + b, tw * 32: tw * 32 + read_len] = lut[read[:, :read_len].long()]
         del src, u, v, emit, pos, read, p_ins, p_keep, base, delta, ins_base
     return out, tw, rw, text_len
+
+
+
+def kernel_sources_digest():
+    """sha256 of the sources the one-pair-per-lane align kernel is made of: the PMC instruction count in profiles/ is only
+    used for the roofline figure if it was measured on exactly this code."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("genasm_lane_kernel.hip", "genasm_device.h", "genasm_kernels.h"):
+        with open(os.path.join(ROOT, "scrooge_amd", "csrc", f), "rb") as fh:
+            h.update(f.encode())
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def pmc_instruction_count():
+    """-> (VALU instructions per window round, source note) from the newest profiles/r*_pmc_sq_summary.json that was
+    measured on the current kernel sources, else (None, why)."""
+    import glob
+    want = kernel_sources_digest()
+    stale = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sq_summary.json")), reverse=True):
+        try:
+            pj = json.load(open(f))
+        except Exception:
+            continue
+        if pj.get("kernel_sources_sha256") == want and pj.get("valu_instructions_per_window_round"):
+            return float(pj["valu_instructions_per_window_round"]), "SQ_INSTS_VALU / window rounds, rocprofv3 --pmc, %s (same kernel sources: sha256 %s...)" % (os.path.basename(f), want[:12])
+        stale = stale or os.path.basename(f)
+    return None, ("no PMC summary for the current kernel sources (sha256 %s...; newest file: %s): re-run scripts/collect_profiles.sh" % (want[:12], stale))
+
+
+def run_other_config(torch, scrooge_amd, device, local_rank, streams, name, n, L, profile, steps, warmup, check_pairs, seed, cores):
+    """One more BASELINE configuration of the unstructured interface, measured the same way as the headline (pairs generated
+    and packed on the GPU, lane-interleaved layout, steps = align kernel + run compaction rotating over the streams) after
+    the timed region, with the first `check_pairs` pairs of the last step compared, runs and all, with the CPU checker."""
+    from scrooge_amd import synth
+    err, ratio = synth.PROFILES[profile]
+    rows, tw, rw, text_len = device_pairs(torch, n, L, err, ratio, seed, device, chunk=max(256, min(8192, (1 << 28) // (L + 64))))
+    G = scrooge_amd.api.GROUP
+    row_words = tw + rw
+    seq = torch.zeros((n + G - 1) // G * G * row_words + scrooge_amd.api.SEQ_PAD_WORDS_GROUPS, dtype=torch.int64, device=device)
+    bad = torch.zeros(1, dtype=torch.int32, device=device)
+    als = [scrooge_amd.Aligner(local_rank) for _ in streams]
+    for a_, st_ in zip(als, streams):
+        a_.set_stream(st_.cuda_stream)
+    for st_ in streams:
+        st_.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(streams[0]):
+        als[0].pack_planar_groups(rows.view(-1), n, row_words, seq, bad)
+    sample = rows[:check_pairs].cpu().numpy() if check_pairs else None
+    torch.cuda.synchronize()
+    del rows
+    torch.cuda.empty_cache()
+    assert int(bad.item()) == 0
+    cap = (2 * L + 8 + 15) // 16 * 16
+    idx = torch.arange(n, dtype=torch.int64, device=device)
+    first = (idx // G) * row_words * G + idx % G
+    desc = torch.stack([first * 32, torch.full_like(idx, text_len), (first + tw * G) * 32, torch.full_like(idx, L),
+                        idx * cap, torch.full_like(idx, cap)], dim=1).contiguous()
+    kw = dict(text_stride_words=G, read_stride_words=G)
+    outs = [dict(runs=torch.empty(n * cap * 2, dtype=torch.uint8, device=device), ed=torch.empty(n, dtype=torch.int64, device=device),
+                 n_runs=torch.empty(n, dtype=torch.int32, device=device), status=torch.empty(n, dtype=torch.int32, device=device))
+            for _ in streams]
+    with torch.cuda.stream(streams[0]):
+        als[0].align_device(n, seq, desc, outs[0]["runs"], outs[0]["ed"], outs[0]["n_runs"], outs[0]["status"], **kw)
+    torch.cuda.synchronize()
+    assert int(outs[0]["status"].max().item()) == 0
+    total_runs = int(outs[0]["n_runs"].sum().item())
+    denses = [torch.empty(max(total_runs, 8) * 2, dtype=torch.uint8, device=device) for _ in streams]
+
+    def one(j):
+        b = j % len(streams)
+        o = outs[b]
+        with torch.cuda.stream(streams[b]):
+            als[b].align_device(n, seq, desc, o["runs"], o["ed"], o["n_runs"], o["status"], **kw)
+            c64 = o["n_runs"].to(torch.int64)
+            als[b].compact_runs(n, desc, o["runs"], o["n_runs"], torch.cumsum(c64, 0) - c64, denses[b])
+
+    for j in range(warmup):
+        one(j)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for j in range(steps):
+        one(warmup + j)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    last = (warmup + steps - 1) % len(streams)
+    res = {"workload": name, "pairs": n, "read_len": L, "error_profile": profile, "steps": steps, "value": n * steps / dt, "unit": "pairs/s",
+           "ms_per_step": dt / steps * 1e3, "runs_per_pair": total_runs / n,
+           "step": "align kernel + run compaction, steps rotate over %d streams; measured after the timed region of the headline" % len(streams)}
+    if check_pairs:
+        from oracle.pyoracle import Oracle, Reference
+        k = check_pairs
+        if Reference.available():
+            e_cpu, off_cpu, runs_cpu, ns = Reference().align_rows(sample, 0, text_len, tw * 32, L, threads=cores)
+            against = "reference genasm_cpu.cpp (oracle/_ref)"
+        else:
+            e_cpu, off_cpu, runs_cpu, _, ns = Oracle(allow_compile=False).align_rows(sample, 0, text_len, tw * 32, L, threads=cores)
+            against = "oracle/liboracle.so (restatement)"
+        o = outs[last]
+        cnt = o["n_runs"][:k].cpu().numpy().astype(np.uint64)
+        off_gpu = np.concatenate([np.zeros(1, np.uint64), np.cumsum(cnt, dtype=np.uint64)])
+        runs_gpu = denses[last][: 2 * int(off_gpu[k])].cpu().numpy().reshape(-1, 2)
+        ok = bool((o["ed"][:k].cpu().numpy() == e_cpu).all() and (off_gpu == off_cpu).all() and np.array_equal(runs_gpu, runs_cpu))
+        res["parity"] = {"checked_pairs": k, "runs_bit_exact": ok, "against": against}
+        res["cpu_pairs_per_s"] = k / (ns * 1e-9)
+        res["cpu_threads"] = cores
+        assert ok, "other_configs: GPU result differs from the CPU checker (%s)" % name
+    for a_ in als:
+        a_.close()
+    del outs, denses, seq, desc
+    torch.cuda.empty_cache()
+    return res
+
+
+def run_mapping_config(torch, scrooge_amd, device, local_rank, streams, genome_len, n_reads, steps, warmup, check_reads, seed, cores):
+    """BASELINE configs[2], the read-mapping interface through the device-pointer layer: one synthetic chromosome packed once
+    (contiguous), n_reads x 150 bp Illumina-like reads x 4 candidates each (true locus, two shifted by 1-3 bases, one random
+    locus), the text of a candidate = the genome suffix from its start (src/genasm_cpu.cpp:512-514); reads in lane-interleaved
+    groups.  Kernel + run compaction per step, like the headline; the candidates of the first `check_reads` reads are
+    compared, runs and all, with the CPU checker."""
+    G = scrooge_amd.api.GROUP
+    L, n_c = 150, 4
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    lut = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=device)
+    gcodes = torch.randint(0, 4, (genome_len,), generator=g, device=device, dtype=torch.uint8)
+    gw = (genome_len + 31) // 32
+    g_ascii = torch.zeros(gw * 32, dtype=torch.uint8, device=device)
+    g_ascii[:genome_len] = lut[gcodes.long()]
+    starts = torch.randint(0, genome_len - 400, (n_reads,), generator=g, device=device, dtype=torch.int64)
+    # reads: 0.9 % substitutions, and one deletion or one insertion in 7.5 % of the reads each (1 % errors, 90:5:5)
+    j = torch.arange(L, device=device, dtype=torch.int64).view(1, L)
+    u = torch.rand((n_reads, 3), generator=g, device=device)
+    pos = torch.randint(1, L - 1, (n_reads, 1), generator=g, device=device, dtype=torch.int64)
+    is_del = (u[:, 0:1] < 0.075)
+    is_ins = (u[:, 1:2] < 0.075) & ~is_del
+    src = j + (is_del & (j >= pos)).long() - (is_ins & (j > pos)).long()
+    codes = gcodes[(starts.view(-1, 1) + src).view(-1)].view(n_reads, L)
+    sub = torch.rand((n_reads, L), generator=g, device=device) < 0.009
+    codes = torch.where(sub, (codes + torch.randint(1, 4, (n_reads, L), generator=g, device=device, dtype=torch.uint8)) & 3, codes)
+    codes = torch.where(is_ins & (j == pos), torch.randint(0, 4, (n_reads, L), generator=g, device=device, dtype=torch.uint8), codes)
+    del src, sub
+    sh = torch.randint(1, 4, (n_reads, 2), generator=g, device=device, dtype=torch.int64)
+    cand = torch.stack([starts, (starts - sh[:, 0]).clamp_(min=0), starts + sh[:, 1],
+                        torch.randint(0, genome_len - 10, (n_reads,), generator=g, device=device, dtype=torch.int64)], dim=1)     # [n_reads, 4]
+    n = n_reads * n_c
+    rw = (L + 31) // 32
+    r_ascii = torch.zeros((n_reads, rw * 32), dtype=torch.uint8, device=device)
+    r_ascii[:, :L] = lut[codes.long()]
+    del codes
+    pair_rows = r_ascii.repeat_interleave(n_c, dim=0)               # a row per pair: the read of candidate k of read r
+    n_groups = (n + G - 1) // G
+    seq = torch.zeros(gw + n_groups * G * rw + scrooge_amd.api.SEQ_PAD_WORDS_GROUPS, dtype=torch.int64, device=device)
+    bad = torch.zeros(1, dtype=torch.int32, device=device)
+    als = [scrooge_amd.Aligner(local_rank) for _ in streams]
+    for a_, st_ in zip(als, streams):
+        a_.set_stream(st_.cuda_stream)
+        st_.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(streams[0]):
+        als[0].pack_planar(g_ascii, seq[:gw], bad)
+        als[0].pack_planar_groups(pair_rows.view(-1), n, rw, seq[gw:], bad)
+    torch.cuda.synchronize()
+    assert int(bad.item()) == 0
+    del pair_rows
+    cap = (2 * L + 8 + 15) // 16 * 16
+    idx = torch.arange(n, dtype=torch.int64, device=device)
+    first = gw + (idx // G) * rw * G + idx % G
+    cs = cand.view(-1)
+    desc = torch.stack([cs, genome_len - cs, first * 32, torch.full_like(idx, L), idx * cap, torch.full_like(idx, cap)], dim=1).contiguous()
+    kw = dict(text_stride_words=1, read_stride_words=G)
+    outs = [dict(runs=torch.empty(n * cap * 2, dtype=torch.uint8, device=device), ed=torch.empty(n, dtype=torch.int64, device=device),
+                 n_runs=torch.empty(n, dtype=torch.int32, device=device), status=torch.empty(n, dtype=torch.int32, device=device))
+            for _ in streams]
+    with torch.cuda.stream(streams[0]):
+        als[0].align_device(n, seq, desc, outs[0]["runs"], outs[0]["ed"], outs[0]["n_runs"], outs[0]["status"], **kw)
+    torch.cuda.synchronize()
+    assert int(outs[0]["status"].max().item()) == 0
+    total_runs = int(outs[0]["n_runs"].sum().item())
+    denses = [torch.empty(max(total_runs, 8) * 2, dtype=torch.uint8, device=device) for _ in streams]
+
+    def one(k_):
+        b = k_ % len(streams)
+        o = outs[b]
+        with torch.cuda.stream(streams[b]):
+            als[b].align_device(n, seq, desc, o["runs"], o["ed"], o["n_runs"], o["status"], **kw)
+            c64 = o["n_runs"].to(torch.int64)
+            als[b].compact_runs(n, desc, o["runs"], o["n_runs"], torch.cumsum(c64, 0) - c64, denses[b])
+
+    for k_ in range(warmup):
+        one(k_)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k_ in range(steps):
+        one(warmup + k_)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    last = (warmup + steps - 1) % len(streams)
+    res = {"workload": "read-mapping interface: %d Mbp chromosome, %d x 150 bp reads x 4 candidates (BASELINE configs[2])" % (genome_len // 1000000, n_reads),
+           "pairs": n, "steps": steps, "value": n * steps / dt, "unit": "pairs/s", "ms_per_step": dt / steps * 1e3,
+           "mean_edit_distance_true_locus": float(outs[last]["ed"][0::4][:100000].float().mean().item()),
+           "step": "align kernel + run compaction over the genome packed once and the reads in lane-interleaved groups, steps rotate over %d streams; "
+                   "measured after the timed region of the headline (device-pointer layer: host staging and text rendering not included)" % len(streams)}
+    if check_reads:
+        from oracle.pyoracle import Oracle, Reference
+        k = check_reads * n_c
+        TL = 400                                   # a candidate's text runs to the end of the genome; the alignment of a 150 bp read stays far inside 400
+        tpos = cand[:check_reads].reshape(-1, 1) + torch.arange(TL, device=device, dtype=torch.int64).view(1, TL)
+        trows = lut[gcodes[tpos.clamp_(max=genome_len - 1).view(-1)].long()].view(k, TL)
+        rows = torch.zeros((k, 416 + rw * 32), dtype=torch.uint8, device=device)
+        rows[:, :TL] = trows
+        rows[:, 416: 416 + rw * 32] = r_ascii[:check_reads].repeat_interleave(n_c, dim=0)
+        sample = rows.cpu().numpy()
+        if Reference.available():
+            e_cpu, off_cpu, runs_cpu, ns = Reference().align_rows(sample, 0, TL, 416, L, threads=cores)
+            against = "reference genasm_cpu.cpp (oracle/_ref), pairwise overload on 400-base text prefixes"
+        else:
+            e_cpu, off_cpu, runs_cpu, _, ns = Oracle(allow_compile=False).align_rows(sample, 0, TL, 416, L, threads=cores)
+            against = "oracle/liboracle.so (restatement) on 400-base text prefixes"
+        o = outs[last]
+        cnt = o["n_runs"][:k].cpu().numpy().astype(np.uint64)
+        off_gpu = np.concatenate([np.zeros(1, np.uint64), np.cumsum(cnt, dtype=np.uint64)])
+        runs_gpu = denses[last][: 2 * int(off_gpu[k])].cpu().numpy().reshape(-1, 2)
+        ok = bool((o["ed"][:k].cpu().numpy() == e_cpu).all() and (off_gpu == off_cpu).all() and np.array_equal(runs_gpu, runs_cpu))
+        res["parity"] = {"checked_pairs": k, "runs_bit_exact": ok, "against": against}
+        res["cpu_pairs_per_s"] = k / (ns * 1e-9)
+        res["cpu_threads"] = cores
+        assert ok, "other_configs: GPU result differs from the CPU checker (read mapping)"
+    for a_ in als:
+        a_.close()
+    return res
 
 
 STEP_TEXT = {
@@ -259,8 +494,9 @@ def main():
                  status=torch.empty(n, dtype=torch.int32, device=device)) for _ in range(n_lanes)]
     runs, ed, n_runs, status = (outs[0][k] for k in ("runs", "ed", "n_runs", "status"))
     # keep a host copy of a sample for the CPU leg before freeing the ASCII staging
-    sample_cap = min(n, 50000)
-    sample_rows = ascii_rows[:sample_cap].cpu() if (rank == 0 and world == 1 and args.cpu_seconds > 0) else None
+    # (the whole batch: the CPU leg checks every pair of it)
+    sample_cap = n
+    sample_rows = ascii_rows.cpu() if (rank == 0 and world == 1 and args.cpu_seconds > 0) else None
     del ascii_rows
     torch.cuda.empty_cache()
     gen_s = time.time() - t_gen
@@ -573,52 +809,48 @@ def main():
     if sample_rows is not None:
         from oracle.pyoracle import Oracle, Reference
         rows = sample_rows.numpy()
-        texts_all = [rows[i, :text_len].tobytes() for i in range(sample_cap)]
-        reads_all = [rows[i, tw * 32: tw * 32 + L].tobytes() for i in range(sample_cap)]
+        r_off = tw * 32                       # a row = text slot, then read slot (device_pairs)
         cores = usable_cores()
         orc = Oracle(allow_compile=False)          # (built before the GPU was initialised, or prebuilt: never compile from here)
-        cal = min(sample_cap, max(2 * cores, 16))
-        _, _, st, ns = orc.align(texts_all[:cal], reads_all[:cal], threads=cores)
+        # work counters (dc_cells, tb_steps, windows, text used) from this repo's restatement, on a small sample
+        cal = min(sample_cap, max(2 * cores, 64))
+        _, _, _, st, ns = orc.align_rows(rows[:cal], 0, text_len, r_off, L, W=p.W, O=p.O, threads=cores)
         dc_cells, tb_steps, text_used = (st["dc_cells"] / cal, st["tb_steps"] / cal, st["text_used"] / cal)
         windows = st["windows"] / cal
         rate = cal / (ns * 1e-9)
         m = int(min(sample_cap, max(cal, rate * args.cpu_seconds)))
-        use_ref = Reference.available()
+        # the CPU baseline: the reference itself (oracle/_ref, default knobs only) or the restatement, all usable cores
+        use_ref = Reference.available() and (p.W, p.O) == (64, 33)
         if use_ref:
-            e_cpu, c_cpu, ns = Reference().align(texts_all[:m], reads_all[:m], threads=cores)
+            e_cpu, off_cpu, runs_cpu, ns = Reference().align_rows(rows[:m], 0, text_len, r_off, L, threads=cores)
         else:
-            e_cpu, c_cpu, _, ns = orc.align(texts_all[:m], reads_all[:m], threads=cores)
+            e_cpu, off_cpu, runs_cpu, _, ns = orc.align_rows(rows[:m], 0, text_len, r_off, L, W=p.W, O=p.O, threads=cores)
         cpu = {"value": m / (ns * 1e-9), "unit": "pairs/s", "cores": cores,
                "kind": "reference" if use_ref else "port",
-               "sample": "first %d of the %d pairs of this workload, kernel-only time (%s), %d OpenMP threads"
-                         % (m, n, "genasm_cpu.cpp:589-591 via oracle/_ref" if use_ref else "oracle/liboracle.so", cores)}
+               "sample": "%s %d of the %d pairs of this workload, kernel-only time (%s), %d OpenMP threads"
+                         % ("all" if m == n else "the first", m, n,
+                            "genasm_cpu.cpp:589-591 via oracle/_ref" if use_ref else "oracle/liboracle.so", cores)}
         # the same checker on ONE thread (SURVEY.md §8d asks for both), about two seconds' worth of pairs
         m1 = int(min(m, max(8, cpu["value"] / max(1, cores) * 2.0)))
         if use_ref:
-            _, _, ns1 = Reference().align(texts_all[:m1], reads_all[:m1], threads=1)
+            _, _, _, ns1 = Reference().align_rows(rows[:m1], 0, text_len, r_off, L, threads=1)
         else:
-            _, _, _, ns1 = orc.align(texts_all[:m1], reads_all[:m1], threads=1)
+            _, _, _, _, ns1 = orc.align_rows(rows[:m1], 0, text_len, r_off, L, W=p.W, O=p.O, threads=1)
         cpu["single_thread"] = {"value": m1 / (ns1 * 1e-9), "unit": "pairs/s", "sample_pairs": m1}
-        # parity of the timed GPU results on the same sample
-        k = min(m, 2000)
-        cnt = n_runs[:k].cpu().tolist()
-        off = (torch.cumsum(n_runs[:k].to(torch.int64), 0) - n_runs[:k].to(torch.int64)).cpu().tolist()
-        d = dense[: 2 * (off[-1] + cnt[-1])].cpu().numpy()
-        ed_h = ed[:k].cpu().tolist()
-        ok = True
-        for i in range(k):
-            seg = d[2 * off[i]: 2 * (off[i] + cnt[i])]
-            cig = "".join("%d%s" % (seg[2 * j], chr(seg[2 * j + 1])) for j in range(cnt[i]))
-            if cig != c_cpu[i] or ed_h[i] != e_cpu[i]:
-                ok = False
-                break
-        # edit distance and run count of every pair the CPU leg aligned (CIGAR text of the first k)
+        # parity of the timed GPU results, EVERY pair the CPU leg aligned: edit distances, run offsets and the runs
+        # themselves, array against array ({count, op} byte pairs, the reference's CIGARs parsed in oracle/ref_driver.cpp)
         ed_all = ed[:m].cpu().numpy()
-        nr_all = n_runs[:m].cpu().numpy()
-        n_ops_cpu = np.array([sum(1 for ch in c if not ch.isdigit()) for c in c_cpu[:m]])
-        ok_all = bool((ed_all == np.array(e_cpu[:m])).all() and (nr_all == n_ops_cpu).all())
-        parity = {"checked_pairs": k, "bit_exact": ok, "checked_edit_distances_and_run_counts": m, "all_equal": ok_all}
-        assert ok and ok_all, "GPU result differs from the CPU checker on the bench sample"
+        cnt_gpu = n_runs[:m].cpu().numpy().astype(np.uint64)
+        off_gpu = np.concatenate([np.zeros(1, np.uint64), np.cumsum(cnt_gpu, dtype=np.uint64)])
+        runs_gpu = dense[: 2 * int(off_gpu[m])].cpu().numpy().reshape(-1, 2)
+        ok_ed = bool((ed_all == e_cpu).all())
+        ok_off = bool((off_gpu == off_cpu).all())
+        ok_runs = ok_off and bool(np.array_equal(runs_gpu, runs_cpu))
+        parity = {"checked_pairs": m, "of_pairs": n, "edit_distances_equal": ok_ed, "run_counts_equal": ok_off,
+                  "runs_bit_exact": ok_runs, "runs_compared": int(off_cpu[m]),
+                  "against": "reference genasm_cpu.cpp (oracle/_ref)" if use_ref else "oracle/liboracle.so (restatement)"}
+        assert ok_ed and ok_runs, "GPU result differs from the CPU checker on the bench batch: %s" % parity
+        del rows, runs_gpu, runs_cpu
 
     # The N > 1 step writes CIGARs as edit streams (a different, lossless output format).  For a like-for-like
     # scaling figure the same step — align kernel with edit-stream output + compaction of the streams, pipelined
@@ -678,6 +910,37 @@ def main():
                                            "alone on the GPU; all %d pairs' runs identical to the timed region's" % (n, n))
         del sdense, lens, back
 
+    # window rounds of one launch (one round = one window of each of a wavefront's 64 pairs), from the kernel's own
+    # counters: one more launch with the counters switched on, after everything that is timed
+    rounds_live = None
+    if p.lanes_per_pair == 1 and not args.ablate and os.environ.get("SCRG_BENCH_NO_STATS_LAUNCH") != "1":      # (PMC passes: only plain launches)
+        keep = al.params.reserved[1]
+        al.params.reserved[1] = 1
+        with torch.cuda.stream(streams[0]):
+            aligners[0].align_device(n, seq, desc, outs[0]["runs"], outs[0]["ed"], outs[0]["n_runs"], outs[0]["status"], **kw)
+        torch.cuda.synchronize()
+        rounds_live = aligners[0].debug_stats_lane()["rounds"]
+        al.params.reserved[1] = keep
+
+    # ---------------- the other single-GPU configurations of BASELINE.json, after everything that is timed ----------------
+    other_configs = None
+    want_other = args.other_configs == "on" or (args.other_configs == "auto" and world == 1 and not dist_on and n == 100000 and L == 10000
+                                                and args.profile == "ont" and not args.serial and not args.stats and not args.ablate and not args.lanes)
+    if want_other:
+        del outs, denses, seq, desc, runs, ed, n_runs, status, dense
+        torch.cuda.empty_cache()
+        cores_ = usable_cores()
+        chk = args.cpu_seconds > 0
+        other_configs = [
+            run_other_config(torch, scrooge_amd, device, local_rank, streams,
+                             "unstructured pairwise: 4 M x 150 bp Illumina-like pairs (BASELINE configs[0] shape at GPU scale)",
+                             4000000, 150, "illumina", 6, 2, 20000 if chk else 0, args.seed + 11, cores_),
+            run_mapping_config(torch, scrooge_amd, device, local_rank, streams, 100000000, 1000000, 6, 2, 5000 if chk else 0, args.seed + 12, cores_),
+            run_other_config(torch, scrooge_amd, device, local_rank, streams,
+                             "long-read stress: 40 k x 50 kb PacBio-error (15 %) pairs, the single-GPU share of BASELINE configs[4]",
+                             40000, 50000, "pacbio15", 6, 2, 1500 if chk else 0, args.seed + 13, cores_),
+        ]
+
     pairs_total = world * n * args.steps
     value = pairs_total / dt
     if text_used is None:
@@ -694,6 +957,40 @@ def main():
                 traffic = t.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
+    # The binding roofline is VALU issue, not HBM (~9.4 KB and ~750 k issued lane-ops per pair).  achieved =
+    # instructions per window round (SQ_INSTS_VALU / rounds, rocprofv3 --pmc, used only if it was measured on exactly this
+    # kernel source) x window rounds of a launch (the kernel's own counter, this run) x 64 lanes / the launch's duration
+    # (HIP events, this run); peak = 1024 SIMDs x 32 lanes per cycle x 2.4 GHz, i.e. every op priced as a full-rate op.
+    kernel_name = "genasm_lane_kernel<false>" if p.lanes_per_pair == 1 else "genasm_align_kernel<%d, false>" % p.lanes_per_pair
+    hbm = {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+           "algorithmic_bytes_per_pair": bytes_per_pair, "algorithmic_bytes_per_launch": launch_bytes,
+           "note": "algorithmic bytes of a launch / its duration; `traffic` = HBM bytes per launch from the PMC counters (profiles/hbm_traffic.json)"}
+    instr, instr_src = (pmc_instruction_count() if p.lanes_per_pair == 1 else (None, "PMC summary exists for the one-pair-per-lane kernel only"))
+    mix_roof = None          # what the chip sustains for THIS kernel's instruction mix (scripts/mix_roof.py from scripts/ubench/valu_rate.hip)
+    try:
+        mj = json.load(open(os.path.join(ROOT, "profiles", "r03_mix_roof.json")))
+        if mj.get("kernel_sources_sha256") == kernel_sources_digest():
+            mix_roof = {"T_lane_ops_per_s": mj["roof"]["4 waves/SIMD"]["T_lane_ops_per_s"], "at": "4 wavefronts per SIMD",
+                        "source": "profiles/r03_mix_roof.json: static opcode mix of the kernel x per-class issue rates measured on this chip"}
+    except Exception:
+        pass
+    if instr is not None and rounds_live:
+        lane_ops_launch = instr * rounds_live * 64.0
+        a_valu = lane_ops_launch / (kernel_ms * 1e-3)
+        roofline = {"bound": "valu-issue", "achieved": a_valu / 1e12, "peak": VALU_PEAK_LANE_OPS / 1e12, "unit": "T int32 lane-ops/s",
+                    "frac": a_valu / VALU_PEAK_LANE_OPS, "traffic": traffic, "kernel": kernel_name,
+                    "valu_instructions_per_window_round": instr, "instruction_count_source": instr_src,
+                    "window_rounds_per_launch": rounds_live, "issued_lane_ops_per_launch": lane_ops_launch, "kernel_ms": kernel_ms,
+                    "frac_at_step_rate": lane_ops_launch / (dt / args.steps) / VALU_PEAK_LANE_OPS if not dist_on else None,
+                    "mix_weighted_roof": mix_roof,
+                    "note": "a launch that has the GPU to itself (1.5 wavefronts per SIMD: cannot fill the issue slots); frac_at_step_rate "
+                            "divides by ms_per_step of the pipelined timed region instead (2-3 launches share the SIMDs); peak prices every op "
+                            "as full-rate at 2.4 GHz — the mix-weighted issue roof of this instruction mix is in DESIGN.md §3.1",
+                    "hbm": hbm}
+    else:
+        roofline = {"bound": "valu-issue", "achieved": None, "peak": VALU_PEAK_LANE_OPS / 1e12, "unit": "T int32 lane-ops/s", "frac": None,
+                    "traffic": traffic, "kernel": kernel_name, "window_rounds_per_launch": rounds_live,
+                    "note": "no instruction count for this build: " + str(instr_src), "hbm": hbm}
     out = {
         "metric": "aligned pairs/s (+ GCUPS) at W=64, 10kb reads; 1/2/4/8 MI355X",
         "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -722,14 +1019,10 @@ def main():
         "kernel_ms_events_in_timed_region": events_ms,   # pipelined launches: includes waiting for the previous launch's wavefronts to retire
         "serial": serial,              # the same step without overlap between launches, measured after the timed region
         "sustained": sustained,        # the same pipelined step over many more steps (fill and drain amortised), after the timed region
+        "other_configs": other_configs,   # BASELINE configs[0], [2], [4] on this GPU, measured after the timed region, each with an oracle-checked sample
         "edit_stream_step": edit_stream_step,   # the N > 1 step (CIGARs as edit streams) on this one GPU, without the collective
         "gather_without_decode": streams_only,  # N > 1: the same steps with the gathered CIGARs left as edit streams (after the timed region)
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "genasm_lane_kernel" if p.lanes_per_pair == 1 else "genasm_align_kernel<%d, false>" % p.lanes_per_pair,
-                     "algorithmic_bytes_per_pair": bytes_per_pair,
-                     "note": "path is VALU-issue-bound, not HBM-bound (SURVEY.md §8d); see 'valu'.  'achieved' divides by "
-                             "kernel_ms" + (", the duration of a launch that has the GPU to itself" if serial is not None else "")},
+        "roofline": roofline,
         "cpu_baseline": cpu,
         "parity": parity,
         "gather_check": gather_check,
@@ -745,21 +1038,17 @@ def main():
             # pairs) is measured: SQ_INSTS_VALU / rounds in profiles/ (rocprofv3 --pmc); a lane-op = one lane of one
             # wave64 VALU instruction.  Peak = 1024 SIMDs x 32 lanes/cycle x 2.4 GHz (full-rate ops; the mix here has
             # ~25 % half-rate ops and the chip runs this kernel at ~2.0 GHz).
-            instr = VALU_INSTR_PER_ROUND
-            try:
-                pj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_sq_summary.json")))
-                instr = pj.get("valu_instructions_per_window_round", instr)
-            except Exception:
-                pass
-            lane_ops = instr * windows      # per pair: one lane's share of every instruction of its windows' rounds
+            instr = roofline.get("valu_instructions_per_window_round")          # None if profiles/ has no count for this kernel source
+            lane_ops = instr * windows if instr else None   # per pair: one lane's share of every instruction of its windows' rounds
             out["valu"] = {"issued_lane_ops_per_pair": lane_ops, "valu_instructions_per_window_round": instr,
-                           "windows_per_pair": windows, "achieved": lane_ops * value / world, "peak": VALU_PEAK_LANE_OPS,
-                           "frac": lane_ops * value / world / VALU_PEAK_LANE_OPS, "unit": "int32 lane-ops/s",
+                           "windows_per_pair": windows, "achieved": (lane_ops * value / world) if lane_ops else None, "peak": VALU_PEAK_LANE_OPS,
+                           "frac": (lane_ops * value / world / VALU_PEAK_LANE_OPS) if lane_ops else None, "unit": "int32 lane-ops/s",
                            "reference_formulation_lane_ops_per_pair": ref_ops,
                            "reference_formulation_equivalent_rate": ref_ops * value / world,
                            "dc_cells_per_pair": dc_cells, "tb_steps_per_pair": tb_steps,
-                           "note": "per GPU, from the whole-step rate; 'reference_formulation_*' prices the same pairs at the 14 "
-                                   "lane-ops per R[i][d] cell of genasm_cpu.cpp:247-251 (what round 1's kernel executed)"}
+                           "note": "per GPU, from the whole-step rate (the `roofline` object is the same figure for one launch from this "
+                                   "run's own counters); 'reference_formulation_*' prices the same pairs at the 14 lane-ops per R[i][d] cell of "
+                                   "genasm_cpu.cpp:247-251 (what round 1's kernel executed)"}
         else:
             out["valu"] = {"algorithmic_lane_ops_per_pair": ref_ops, "dc_cells_per_pair": dc_cells,
                            "tb_steps_per_pair": tb_steps,

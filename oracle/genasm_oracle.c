@@ -296,3 +296,98 @@ int go_align_batch_ascii(size_t n_pairs,
         *kernel_ns = t1 - t0;
     return status;
 }
+
+/* The same batch for inputs that sit in ONE array of fixed-size rows (the staging layout of bench.py: a text slot and a
+ * read slot per row) and results as arrays: edit distances, run offsets and the runs themselves as {count, op} byte pairs
+ * (the layout of the reference's CigarEntry_t, src/util.hpp:43-46) — a full-size batch is compared array against array,
+ * with no per-pair objects on the caller's side.  runs_cap counts runs; GO_ERR_CAPACITY if they do not fit. */
+int go_align_batch_rows(size_t n_pairs, const char *rows, uint64_t row_stride,
+                        uint64_t text_off, uint64_t text_len, uint64_t read_off, uint64_t read_len,
+                        int W, int O, int threads,
+                        long long *edit_distances, uint64_t *run_offsets /* n_pairs + 1 */,
+                        uint8_t *runs_out, uint64_t runs_cap,
+                        go_stats *total_stats, long long *kernel_ns)
+{
+    if (W < 2 || W > GO_MAXW || O < 0 || O >= W)
+        return GO_ERR_PARAMS;
+    if (threads < 1)
+        threads = 1;
+    const size_t cap1 = 2 * read_len + 8;
+    uint8_t *tc = (uint8_t *)malloc((n_pairs ? n_pairs : 1) * (text_len + 1));
+    uint8_t *rc_ = (uint8_t *)malloc((n_pairs ? n_pairs : 1) * (read_len + 1));
+    go_run *rr = (go_run *)malloc((n_pairs ? n_pairs : 1) * cap1 * sizeof(go_run));
+    size_t *nr = (size_t *)calloc(n_pairs ? n_pairs : 1, sizeof(*nr));
+    int status = (tc && rc_ && rr && nr) ? GO_OK : GO_ERR_CAPACITY;
+    if (status == GO_OK) {
+        int first_err = GO_OK;
+        #pragma omp parallel for num_threads(threads) schedule(static)
+        for (long long p = 0; p < (long long)n_pairs; p++) {
+            int e = encode_bases(rows + (size_t)p * row_stride + text_off, text_len, tc + (size_t)p * (text_len + 1));
+            if (e == GO_OK)
+                e = encode_bases(rows + (size_t)p * row_stride + read_off, read_len, rc_ + (size_t)p * (read_len + 1));
+            if (e != GO_OK) {
+                #pragma omp critical
+                if (first_err == GO_OK) first_err = e;
+            }
+        }
+        status = first_err;
+    }
+    go_stats sum;
+    memset(&sum, 0, sizeof(sum));
+    long long t0 = now_ns();
+    if (status == GO_OK) {
+        int first_err = GO_OK;
+        #pragma omp parallel num_threads(threads)
+        {
+            go_stats local;
+            memset(&local, 0, sizeof(local));
+            #pragma omp for schedule(dynamic)
+            for (long long p = 0; p < (long long)n_pairs; p++) {
+                int e = go_align_codes(tc + (size_t)p * (text_len + 1), text_len, rc_ + (size_t)p * (read_len + 1), read_len, W, O,
+                                       rr + (size_t)p * cap1, cap1, &nr[p], &edit_distances[p], &local);
+                if (e != GO_OK) {
+                    #pragma omp critical
+                    if (first_err == GO_OK) first_err = e;
+                }
+            }
+            #pragma omp critical
+            {
+                sum.windows += local.windows;
+                sum.dc_cells += local.dc_cells;
+                sum.tb_steps += local.tb_steps;
+                sum.runs += local.runs;
+                sum.text_used += local.text_used;
+            }
+        }
+        status = first_err;
+    }
+    long long t1 = now_ns();
+    if (status == GO_OK) {
+        uint64_t acc = 0;
+        for (size_t p = 0; p < n_pairs; p++) {
+            run_offsets[p] = acc;
+            acc += nr[p];
+        }
+        run_offsets[n_pairs] = acc;
+        if (acc > runs_cap)
+            status = GO_ERR_CAPACITY;
+    }
+    if (status == GO_OK) {
+        #pragma omp parallel for num_threads(threads) schedule(static)
+        for (long long p = 0; p < (long long)n_pairs; p++) {
+            uint8_t *o = runs_out + 2 * run_offsets[p];
+            const go_run *r = rr + (size_t)p * cap1;
+            for (size_t k = 0; k < nr[p]; k++) {
+                o[2 * k] = (uint8_t)r[k].count;
+                o[2 * k + 1] = (uint8_t)r[k].op;
+            }
+        }
+    }
+    free(tc); free(rc_); free(rr); free(nr);
+    if (total_stats)
+        *total_stats = sum;
+    if (kernel_ns)
+        *kernel_ns = t1 - t0;
+    return status;
+}
+

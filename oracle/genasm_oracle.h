@@ -75,6 +75,15 @@ int go_align_batch_ascii(size_t n_pairs,
                          char *const *cigars, long long *edit_distances,
                          go_stats *total_stats, long long *kernel_ns);
 
+/* The same for inputs in one array of fixed-size rows (text slot + read slot per row) with results as arrays: run
+ * offsets [n_pairs + 1] and the runs as {count, op} byte pairs.  runs_cap counts runs. */
+int go_align_batch_rows(size_t n_pairs, const char *rows, uint64_t row_stride,
+                        uint64_t text_off, uint64_t text_len, uint64_t read_off, uint64_t read_len,
+                        int W, int O, int threads,
+                        long long *edit_distances, uint64_t *run_offsets,
+                        uint8_t *runs_out, uint64_t runs_cap,
+                        go_stats *total_stats, long long *kernel_ns);
+
 #ifdef __cplusplus
 }
 #endif

@@ -83,6 +83,31 @@ def _marshal(texts, reads):
     return n, tp, tl, rp, rl, bufs, cp, eds
 
 
+def _align_rows(fn, rows, text_off, text_len, read_off, read_len, threads, knobs, with_stats):
+    import numpy as np
+    rows = np.ascontiguousarray(rows, dtype=np.uint8)
+    n, stride = rows.shape
+    assert text_off + text_len <= stride and read_off + read_len <= stride
+    eds = np.zeros(n, dtype=np.int64)
+    off = np.zeros(n + 1, dtype=np.uint64)
+    cap = n * (2 * int(read_len) + 8)
+    runs = np.empty(2 * max(cap, 1), dtype=np.uint8)          # (pages are touched only as far as runs are written)
+    st = GoStats()
+    ns = C.c_longlong(0)
+    vp = C.c_void_p
+    args = [C.c_size_t(n), vp(rows.ctypes.data), C.c_uint64(stride), C.c_uint64(text_off), C.c_uint64(text_len),
+            C.c_uint64(read_off), C.c_uint64(read_len)] + [C.c_int(k) for k in knobs] + \
+           [C.c_int(int(threads)), vp(eds.ctypes.data), vp(off.ctypes.data), vp(runs.ctypes.data), C.c_uint64(cap)] + \
+           ([C.byref(st)] if with_stats else []) + [C.byref(ns)]
+    fn.restype = C.c_int
+    fn.argtypes = None
+    rc = fn(*args)
+    if rc != 0:
+        raise RuntimeError("checker status %d" % rc)
+    total = int(off[n])
+    return eds, off, runs[: 2 * total].reshape(-1, 2), st.as_dict(), ns.value
+
+
 class Oracle:
     def __init__(self, allow_compile=True):
         self.lib = C.CDLL(build(allow_compile=allow_compile))
@@ -92,6 +117,12 @@ class Oracle:
             C.POINTER(C.c_char_p), C.POINTER(C.c_uint64), C.c_int, C.c_int, C.c_int,
             C.POINTER(C.c_char_p), C.POINTER(C.c_longlong), C.POINTER(GoStats),
             C.POINTER(C.c_longlong)]
+
+    def align_rows(self, rows, text_off, text_len, read_off, read_len, W=64, O=33, threads=1):
+        """A whole batch held in one 2-D uint8 array (a text slot and a read slot per row), results as arrays:
+        -> (edit distances int64 [n], run offsets uint64 [n + 1], runs uint8 [total, 2] = (count, op), stats dict, kernel_ns)"""
+        import numpy as np
+        return _align_rows(self.lib.go_align_batch_rows, rows, text_off, text_len, read_off, read_len, threads, (int(W), int(O)), True)
 
     def align(self, texts, reads, W=64, O=33, threads=1):
         """-> (edit_distances, cigars, stats dict, kernel_ns)"""
@@ -133,6 +164,11 @@ class Reference:
             C.c_char_p, C.c_uint64, C.c_size_t, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64),
             C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int,
             C.POINTER(C.c_char_p), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
+
+    def align_rows(self, rows, text_off, text_len, read_off, read_len, threads=1):
+        """Like Oracle.align_rows, through the reference itself -> (edit distances, run offsets, runs, kernel_ns)"""
+        e, off, runs, _, ns = _align_rows(self.lib.ref_align_rows, rows, text_off, text_len, read_off, read_len, threads, (), False)
+        return e, off, runs, ns
 
     def align(self, texts, reads, threads=1):
         """-> (edit_distances, cigars, kernel_ns)"""

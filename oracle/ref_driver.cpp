@@ -53,6 +53,65 @@ int ref_align_pairs(size_t n_pairs,
     return 0;
 }
 
+/* The same call for inputs that sit in ONE array of fixed-size rows (bench.py's staging layout: a text slot and a read
+ * slot per row), with the reference's CIGAR strings turned into arrays here: run offsets [n_pairs + 1] and the runs as
+ * {count, op} byte pairs (CigarEntry_t, src/util.hpp:43-46), so that a full-size batch is compared array against array.
+ * Returns 2 if a CIGAR does not parse or has a count above 255, 3 if runs_cap (in runs) is too small. */
+int ref_align_rows(size_t n_pairs, const char *rows, uint64_t row_stride,
+                   uint64_t text_off, uint64_t text_len, uint64_t read_off, uint64_t read_len,
+                   int threads,
+                   long long *edit_distances, uint64_t *run_offsets, uint8_t *runs_out, uint64_t runs_cap,
+                   long long *kernel_ns)
+{
+    genasm_cpu::enabled_algorithm_log = false;
+    std::vector<std::string> t, q;
+    t.reserve(2 * n_pairs);
+    q.reserve(2 * n_pairs);
+    for (size_t p = 0; p < n_pairs; p++) {
+        t.emplace_back(rows + p * row_stride + text_off, text_len);
+        q.emplace_back(rows + p * row_stride + read_off, read_len);
+        t.emplace_back();               // (the dummy pair that defeats the reference's double increment, see above)
+        q.emplace_back();
+    }
+    long long ns = 0;
+    std::vector<Alignment_t> res = genasm_cpu::align_all(t, q, threads, &ns);
+    if (res.size() != n_pairs)
+        return 1;
+    uint64_t acc = 0;
+    for (size_t p = 0; p < n_pairs; p++) {
+        run_offsets[p] = acc;
+        for (char c : res[p].cigar)
+            if (c < '0' || c > '9') acc++;
+        edit_distances[p] = res[p].edit_distance;
+    }
+    run_offsets[n_pairs] = acc;
+    if (acc > runs_cap)
+        return 3;
+    int bad = 0;
+    #pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(static) reduction(|:bad)
+    for (long long p = 0; p < (long long)n_pairs; p++) {
+        uint8_t *o = runs_out + 2 * run_offsets[p];
+        unsigned cnt = 0;
+        bool digits = false;
+        for (char c : res[p].cigar) {
+            if (c >= '0' && c <= '9') {
+                cnt = cnt * 10 + (unsigned)(c - '0');
+                digits = true;
+            } else {
+                if (!digits || cnt == 0 || cnt > 255 || (c != '=' && c != 'X' && c != 'I' && c != 'D')) bad = 1;
+                *o++ = (uint8_t)cnt;
+                *o++ = (uint8_t)c;
+                cnt = 0;
+                digits = false;
+            }
+        }
+        if (digits) bad = 1;
+    }
+    if (kernel_ns)
+        *kernel_ns = ns;
+    return bad ? 2 : 0;
+}
+
 /* Read-mapping overload (src/genasm_cpu.cpp:495-555): candidate k of read r
  * aligns the read against the genome suffix starting at cand_starts[...]. */
 int ref_align_mapping(const char *genome, uint64_t genome_len,

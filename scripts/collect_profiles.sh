@@ -7,7 +7,7 @@
 # The library AND the oracle (the CPU leg of the default bench command) are built first, the library is pinned with
 # SCRG_LIB, and bench.py --no-build loads both without ever forking a compiler (oracle/pyoracle.py: allow_compile=False);
 # every profiler run has its own time limit.
-tag=${1:-r02}
+tag=${1:-r03}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 python3 -c "import sys; sys.path.insert(0, '$root'); import scrooge_amd; scrooge_amd.build_library(); from oracle.pyoracle import build; build()" || exit 1
 export SCRG_LIB=$root/scrooge_amd/libscrooge_amd.so
@@ -22,6 +22,10 @@ mkdir -p $root/gpurun_out/prof_${tag}_serial
 mkdir -p $root/gpurun_out/prof_${tag}_gather
 (cd /tmp && export TMPDIR=/tmp && export SCRG_BENCH_FORCE_GATHER=1 && timeout 300 rocprofv3 --kernel-trace --stats -d $root/gpurun_out/prof_${tag}_gather -o prof --output-format csv -- \
     python3 $root/bench.py --no-build --cpu-seconds 0 > $root/gpurun_out/prof_${tag}_gather/bench.json 2> $root/gpurun_out/prof_${tag}_gather/bench.err)
+# the receiving side: scrg_decode_edit_stream, one slot alone and eight slots in one launch
+mkdir -p $root/gpurun_out/prof_${tag}_decode
+(cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $root/gpurun_out/prof_${tag}_decode -o prof --output-format csv -- \
+    python3 $root/scripts/decode_timing.py > $root/gpurun_out/prof_${tag}_decode/decode_timing.json 2> $root/gpurun_out/prof_${tag}_decode/err.txt)
 cd $root
 # window rounds per launch (kernel counters, not under the profiler)
 python3 bench.py --no-build --stats --cpu-seconds 0 --steps 2 2> gpurun_out/prof_$tag/stats.txt > /dev/null

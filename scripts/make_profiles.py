@@ -4,7 +4,9 @@ import ast, csv, glob, json, os, sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r03"
+sys.path.insert(0, root)
+import bench as _bench
 go = os.path.join(root, "gpurun_out")
 pr = os.path.join(root, "profiles")
 
@@ -51,8 +53,19 @@ kernel_stats(os.path.join(go, "prof_%s_serial" % tag), os.path.join(pr, "%s_kern
 bg = bench_line(os.path.join(go, "prof_%s_gather" % tag, "bench.json"))
 kernel_stats(os.path.join(go, "prof_%s_gather" % tag), os.path.join(pr, "%s_kernel_stats_gather_edits.csv" % rnd),
              "`SCRG_BENCH_FORCE_GATHER=1 python bench.py --cpu-seconds 0`: the N > 1 step on one GPU (one-rank RCCL group) — "
-             "genasm_lane_kernel<true> writes edit streams, compaction, one gather per step; bench line of the same run: "
+             "genasm_lane_kernel<true> writes edit streams + run counts, compaction, one gather per step, decode_edits_kernel<true> restores the runs "
+             "of the gathered slot inside the timed region; bench line of the same run: "
              "value %.4g pairs/s, gather_check %s" % ((bg["value"], bg["gather_check"]) if bg else (0, None)))
+
+try:
+    dt_ = json.loads(open(os.path.join(go, "prof_%s_decode" % tag, "decode_timing.json")).readline())
+    kernel_stats(os.path.join(go, "prof_%s_decode" % tag), os.path.join(pr, "%s_kernel_stats_decode.csv" % rnd),
+                 "`python scripts/decode_timing.py`: scrg_decode_edit_stream on the bench workload (100k x 10kb), count-only (<false>) and decode into the dense "
+                 "run array (<true>), one slot alone and 8 slots in one launch, 11 launches each (the 60 align launches in front of every series "
+                 "only keep the GPU busy); the script's own HIP-event figures: one slot %.3f ms, 8 slots %.3f ms (%.3f ms per slot, %.0f M pairs/s)"
+                 % (dt_["slots_1"]["decode_ms"], dt_["slots_8"]["decode_ms"], dt_["slots_8"]["decode_ms_per_slot"], dt_["slots_8"]["decode_M_pairs_per_s"]))
+except Exception as e:
+    print("no decode profile:", e)
 
 # rounds per launch from the --stats pass
 rounds = None
@@ -71,6 +84,7 @@ if rounds:
     out["valu_instructions_per_window_round"] = sq["SQ_INSTS_VALU"] / rounds
     out["salu_instructions_per_window_round"] = sq["SQ_INSTS_SALU"] / rounds
     out["lds_instructions_per_window_round"] = sq["SQ_INSTS_LDS"] / rounds
+out["kernel_sources_sha256"] = _bench.kernel_sources_digest()      # bench.py uses the count only for exactly this kernel source
 out["effective_clock_ghz_profiled"] = None
 out["note"] = ("per launch of genasm_lane_kernel (100k x 10kb ONT pairs, one stream, lane-interleaved layout), rocprofv3 --pmc, "
                "averages over the 3 launches of `bench.py --serial --steps 2 --warmup 0`; a window round = one window of each of "
@@ -87,8 +101,8 @@ wr_size = h["WRITE_SIZE"] * 1024.0
 alg = None
 if bs or b:
     j = bs or b
-    alg = j["roofline"]["algorithmic_bytes_per_pair"] * j["config"]["pairs_per_gpu"]
-t = {"pairs": 100000, "read_len": 10000, "profile": "ont", "kernel": "genasm_lane_kernel", "round": 2,
+    alg = j["roofline"]["hbm"]["algorithmic_bytes_per_pair"] * j["config"]["pairs_per_gpu"]
+t = {"pairs": 100000, "read_len": 10000, "profile": "ont", "kernel": "genasm_lane_kernel", "round": int(rnd[1:]) if rnd[1:].isdigit() else rnd,
      "layout": "lane-interleaved groups of 64 pairs",
      "method": "rocprofv3 --pmc, one pass per counter set (scripts/pmc_run.sh): FETCH_SIZE | WRITE_SIZE | TCC_EA0_RDREQ{,_32B} | "
                "TCC_EA0_WRREQ{,_64B} | TCC_HIT,MISS,REQ,READ; averages over the 3 align launches of `bench.py --serial --steps 2 --warmup 0 --cpu-seconds 0`",
@@ -97,7 +111,11 @@ t = {"pairs": 100000, "read_len": 10000, "profile": "ont", "kernel": "genasm_lan
                     "WRITE_SIZE (KB) x1024 = %.0f MB; WRREQ sizes (64-B and 32-B requests) = %.0f MB." % (rd_fetch / 1e6, rd / 1e6, wr_size / 1e6, wr / 1e6),
      "algorithmic_bytes_per_launch": alg,
      "l2_hit_rate": h["TCC_HIT"] / max(1.0, h["TCC_HIT"] + h["TCC_MISS"]),
-     "note": "reads = the packed sequences once (+ descriptors); writes above 2 B/run: CIGAR pieces leave the CU as 32-byte stores, and a 64-byte "
-             "request is issued when both halves of a 64-byte block are in L2 together, otherwise each half goes out on its own"}
+     "note": "reads = the packed sequences once (+ descriptors).  Writes: the payload is 2 B per run (428 MB) + 16 B of scalars per pair; the "
+             "counters tally REQUEST sizes, and a 32-byte CIGAR piece that leaves the L2 alone goes out as a 64-byte request with half of its bytes "
+             "masked (two thirds of the requests are 64-byte ones although hardly any two pieces of a 64-byte block are in the L2 together: a lane "
+             "writes them ~10 window rounds apart).  13.4 M pieces -> 14.4 M requests, 772 MB tallied for 428 MB of payload = 1.80x.  The same "
+             "runs written in 64-byte pieces (decode_edits_kernel, profiles/r03_decode_traffic.json) tally 1.23x.  Not worth 64 more bytes of LDS per "
+             "lane in the align kernel (16 -> 12 wavefronts per CU): HBM is at 4 % of its roofline"}
 json.dump(t, open(os.path.join(pr, "hbm_traffic.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in t.items() if k != "raw"}, indent=1))

@@ -8,6 +8,7 @@ bargs=$1; shift
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 python3 -c "import sys; sys.path.insert(0, '$root'); import scrooge_amd; scrooge_amd.build_library()" || exit 1
 export SCRG_LIB=$root/scrooge_amd/libscrooge_amd.so
+export SCRG_BENCH_NO_STATS_LAUNCH=1      # (the counters launch of bench.py runs extra timing code: keep it out of the averages)
 cd /tmp && export TMPDIR=/tmp
 mkdir -p $root/gpurun_out/pmc_${tag}
 i=0

@@ -167,7 +167,7 @@ int main() {
         {"v_mov_b32", k_mov}, {"v_cmp_lt_i32", k_cmp}, {"v_lshlrev_b64", k_lshl64}, {"v_addc_co_u32 vop3", k_addc}, {"v_addc pair (64b add)", k_addc_pair},
         {"v_lshl_add_u64", k_lshladd64}, {"v_cmp -> sgpr pair", k_cmp64}, {"v_add_co_u32 vcc", k_addco}, {"v_xor_b32 dependent", k_and_dep}};
     uint32_t* out; uint64_t* cyc;
-    for (int wps : {2}) {            // waves per SIMD
+    for (int wps : {1, 2, 4}) {      // waves per SIMD
         int blocks = cus * 4 * wps;
         hipMalloc(&out, (size_t)blocks * 64 * 4); hipMalloc(&cyc, (size_t)blocks * 8);
         hipMemset(out, 0, (size_t)blocks * 64 * 4);
@@ -183,9 +183,10 @@ int main() {
             std::vector<uint64_t> h(blocks); hipMemcpy(h.data(), cyc, blocks * 8, hipMemcpyDeviceToHost);
             double avg = 0; for (auto v : h) avg += v; avg /= blocks;
             double insts = (double)ITER * OPS_PER_ITER;
-            // s_memtime counts at a fixed 100 MHz-ish clock on some parts; report both
-            printf("%-22s wall %.3f ms -> %.2f cyc/inst/SIMD @2.4GHz | memtime ticks/inst/wave %.3f\n", e.name, ms,
-                   ms * 1e-3 * 2.4e9 / (insts * wps), avg / insts);
+            // shader cycles counted by the wavefronts themselves (s_memtime); the clock = those cycles / the wall time of the launch.
+            // cycles per instruction per SIMD = a wavefront's cycles / (its instructions x the wavefronts sharing its SIMD)
+            printf("%-22s wall %.3f ms  clock %.2f GHz  %.2f cyc/inst/SIMD  (%.2f cyc/inst/wave)\n", e.name, ms,
+                   avg / (ms * 1e6), avg / (insts * wps), avg / insts);
         }
         hipFree(out); hipFree(cyc);
     }
