@@ -67,10 +67,16 @@ typedef struct scrg_params {
                                 layout of scrg_pack_planar_groups() (see there).  Only lanes_per_pair = 1
                                 accepts a stride other than 1                                        */
     int32_t read_stride_words; /* the same for the reads                                             */
+    int32_t outputs;         /* host entry points: what the result holds — SCRG_OUT_ALL (0, default): runs and text;
+                                SCRG_OUT_TEXT: the CIGAR text only (runs stays empty, run_offset all zero);
+                                SCRG_OUT_RUNS: the runs only (cigar_text stays empty, cigar_offset all zero).
+                                What is not asked for does not cross PCIe                                   */
     int32_t reserved[2];     /* [0]: experiment switches, 0 unless profiling (see scrg_debug_stats: unknown bits are
                                 rejected with SCRG_ERR_INVALID_ARG, so an uninitialised struct cannot silently
                                 change results); [1]: non-zero = collect the kernel's profiling counters    */
 } scrg_params;
+
+enum { SCRG_OUT_ALL = 0, SCRG_OUT_TEXT = 1, SCRG_OUT_RUNS = 2 };
 
 void scrg_params_default(scrg_params *p);
 /* Fills in every 0 ("default") field for the given W/O and validates; the values a launch will use. */
@@ -121,8 +127,9 @@ typedef struct scrg_result {
     scrg_run *runs;           /* all runs, pair after pair                               */
     uint64_t *cigar_offset;   /* [n_pairs+1] into cigar_text (each CIGAR NUL-terminated) */
     char     *cigar_text;     /* "%d%c" rendering, as genasm_cpu.cpp:387-403             */
-    int64_t   kernel_ns;      /* align kernel only (reference: core_algorithm_ns)        */
-    int64_t   pack_ns;        /* H2D + ASCII->2-bit                                      */
+    int64_t   kernel_ns;      /* align kernel only (reference: core_algorithm_ns): the sum over
+                                 the launches of the call's chunks, which overlap         */
+    int64_t   pack_ns;        /* host threads: ASCII -> 2 bits per base into pinned memory */
     int64_t   total_ns;       /* whole call                                              */
 } scrg_result;
 
@@ -152,19 +159,45 @@ scrg_status scrg_align_mapping(scrg_ctx *ctx, const scrg_params *params,
                                const uint64_t *cand_offsets, const uint64_t *cand_start,
                                scrg_result **out);
 
-/* Many read batches against one reference: scrg_genome_set() stages, transfers and packs the genome ONCE and
+/* Many read batches against one reference: scrg_genome_set() packs the genome ONCE (host threads), transfers it and
  * keeps it in the handle's HBM; scrg_align_mapping_resident() then aligns batches against it without touching
- * the genome again (scrg_align_mapping re-stages it on every call, as the reference re-converts it,
- * genasm_cpu.cpp:508).  cand_reverse may be NULL (all forward) or hold one 0/1 per candidate (1 = align the
- * reverse complement of the read, as scrg_align_mapping_stranded in scrooge_amd_io.h).  The genome stays
- * resident until another one is set, scrg_genome_clear() is called, or scrg_align_pairs / scrg_align_mapping
- * reuse the handle's sequence array (scrg_align_mapping_resident then fails with SCRG_ERR_INVALID_ARG). */
+ * the genome again (scrg_align_mapping stages its genome on every call, as the reference re-converts it,
+ * genasm_cpu.cpp:508 — and leaves it resident afterwards).  cand_reverse may be NULL (all forward) or hold one 0/1 per
+ * candidate (1 = align the reverse complement of the read, as scrg_align_mapping_stranded in scrooge_amd_io.h).  The
+ * genome stays resident until another one is set or scrg_genome_clear() is called; pairwise calls on the same handle do
+ * not disturb it. */
 scrg_status scrg_genome_set(scrg_ctx *ctx, const char *genome, uint64_t genome_len);
 void        scrg_genome_clear(scrg_ctx *ctx);
 scrg_status scrg_align_mapping_resident(scrg_ctx *ctx, const scrg_params *params,
                                         uint64_t n_reads, const char *const *reads, const uint64_t *read_lens,
                                         const uint64_t *cand_offsets, const uint64_t *cand_start,
                                         const uint8_t *cand_reverse, scrg_result **out);
+
+/* Several GPUs, one call, one process (the reference is single-GPU: GPU_ID 0, src/genasm_gpu.cu:67).  The batch is cut
+ * into chunks in issue order (longest read first) and chunk k goes to devices[k mod n_devices]; every device has its own
+ * host thread, streams and buffers, brings its chunks' results back itself (no inter-GPU traffic) and the result is
+ * assembled in caller order exactly as by the single-device calls.  A device may be listed more than once (more chunks
+ * in flight on it).  No handle: per-device state is created on first use and kept for later calls —
+ * scrg_multi_release() frees it.  The mapping call stages the genome on every listed device.  Errors: status code and
+ * scrg_multi_last_error() (per thread). */
+scrg_status scrg_align_pairs_multi(const int32_t *devices, int32_t n_devices, const scrg_params *params, uint64_t n_pairs,
+                                   const char *const *texts, const uint64_t *text_lens,
+                                   const char *const *queries, const uint64_t *query_lens,
+                                   scrg_result **out);
+scrg_status scrg_align_mapping_multi(const int32_t *devices, int32_t n_devices, const scrg_params *params,
+                                     const char *genome, uint64_t genome_len,
+                                     uint64_t n_reads, const char *const *reads, const uint64_t *read_lens,
+                                     const uint64_t *cand_offsets, const uint64_t *cand_start,
+                                     const uint8_t *cand_reverse, scrg_result **out);
+/* How a host call with these sequence lengths is cut up (no GPU involved): issue_order[k] = caller index of the k-th
+ * pair issued (longest read first, stable — src/tests.cu:375-377; NULL to skip), chunk_first[0 .. *n_chunks] = issue index of
+ * every chunk's first pair (chunk_cap entries available; NULL to skip).  Chunk k is processed by devices[k mod n_devices];
+ * chunks are whole groups of 64 pairs except the last.  text_lens may be NULL. */
+scrg_status scrg_host_plan(const scrg_params *params, int32_t n_devices, uint64_t n_pairs, const uint64_t *text_lens,
+                           const uint64_t *read_lens, uint32_t *issue_order, uint64_t *chunk_first, uint64_t chunk_cap,
+                           uint64_t *n_chunks);
+void        scrg_multi_release(void);
+const char *scrg_multi_last_error(void);
 
 /* ---------------------------------------------------------------------------
  * Device-pointer entry points (inputs/outputs already resident in HBM; this is

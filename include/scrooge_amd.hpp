@@ -70,7 +70,8 @@ typedef struct CigarEntry {
 
 namespace scrooge_amd {
 
-// One lazily created handle per (thread, device); released at thread exit.
+// One GPU, explicitly: a handle per (thread, device), for callers that place work themselves or keep a genome resident.
+// (The free functions below, the reference's surface, use every visible GPU.)
 class Handle {
 public:
     explicit Handle(int device = 0)
@@ -78,6 +79,7 @@ public:
         scrg_status s = scrg_ctx_create(device, &ctx_);
         if (s != SCRG_OK) throw std::runtime_error(std::string("scrooge_amd: ") + scrg_status_string(s));
         scrg_params_default(&params_);
+        params_.outputs = SCRG_OUT_TEXT;      // Alignment_t carries the CIGAR as text: the runs need not cross PCIe
     }
     ~Handle() { scrg_ctx_destroy(ctx_); }
     Handle(const Handle&) = delete;
@@ -192,6 +194,44 @@ inline Handle& default_handle()
     return h;
 }
 
+namespace detail {
+// the free functions (the reference's surface) use EVERY visible GPU: scrg_align_pairs_multi / scrg_align_mapping_multi
+inline std::vector<int32_t> all_devices()
+{
+    const int n = scrg_device_count();
+    if (n <= 0) throw std::runtime_error(std::string("scrooge_amd: ") + scrg_status_string(SCRG_ERR_NO_DEVICE));
+    std::vector<int32_t> d((size_t)n);
+    for (int k = 0; k < n; k++) d[(size_t)k] = k;
+    return d;
+}
+inline std::vector<Alignment_t> collect_multi(scrg_status s, scrg_result* r, long long* ns)
+{
+    if (s != SCRG_OK && s != SCRG_ERR_CIGAR_OVERFLOW) {
+        const std::string msg = std::string("scrooge_amd: ") + scrg_status_string(s) + " (" + scrg_multi_last_error() + ")";
+        scrg_result_free(r);
+        throw std::runtime_error(msg);
+    }
+    std::vector<Alignment_t> out;
+    out.reserve(r->n_pairs);
+    for (uint64_t i = 0; i < r->n_pairs; i++) {
+        const char* b = r->cigar_text + r->cigar_offset[i];
+        out.push_back(Alignment_t{std::string(b, r->cigar_offset[i + 1] - r->cigar_offset[i] - 1), (long long)r->edit_distance[i]});
+    }
+    if (ns) *ns = (long long)r->kernel_ns;
+    const bool overflowed = (s == SCRG_ERR_CIGAR_OVERFLOW);
+    scrg_result_free(r);
+    if (overflowed) throw std::runtime_error("scrooge_amd: a pair overflowed its CIGAR slice");
+    return out;
+}
+inline scrg_params text_params()
+{
+    scrg_params p;
+    scrg_params_default(&p);
+    p.outputs = SCRG_OUT_TEXT;             // Alignment_t carries the CIGAR as text: the runs need not cross PCIe
+    return p;
+}
+}  // namespace detail
+
 // The reference exports an assignable `extern bool enabled_algorithm_log` per namespace (src/genasm_gpu.hpp:6,
 // src/genasm_cpu.hpp:5) and its callers write `genasm_gpu::enabled_algorithm_log = verbose;`
 // (src/library_example.cu:91-92, src/tests.cu:791-792).  The switch itself lives inside the shared library
@@ -210,30 +250,63 @@ struct LogSwitch {
 };
 inline LogSwitch enabled_algorithm_log;
 
-// src/genasm_gpu.hpp:7
+// src/genasm_gpu.hpp:7 — on every visible GPU
 inline std::vector<Alignment_t> align_all(Genome_t& reference, std::vector<Read_t>& reads,
                                           long long* core_algorithm_ns = nullptr)
 {
-    return default_handle().align_all(reference, reads, core_algorithm_ns);
+    const size_t nr = reads.size();
+    std::vector<const char*> rp(nr);
+    std::vector<uint64_t> rl(nr), off(nr + 1, 0), starts;
+    for (size_t r = 0; r < nr; r++) {
+        rp[r] = reads[r].content.data();
+        rl[r] = reads[r].content.size();
+        for (const CandidateLocation_t& loc : reads[r].locations) {
+            if (loc.start_in_reference < 0)
+                throw std::invalid_argument("scrooge_amd::align_all: negative start_in_reference");
+            starts.push_back((uint64_t)loc.start_in_reference);
+        }
+        off[r + 1] = starts.size();
+    }
+    const std::vector<int32_t> dev = detail::all_devices();
+    const scrg_params p = detail::text_params();
+    scrg_result* res = nullptr;
+    const scrg_status s = scrg_align_mapping_multi(dev.data(), (int32_t)dev.size(), &p, reference.content.data(), reference.content.size(), nr,
+                                                   rp.data(), rl.data(), off.data(), starts.data(), nullptr, &res);
+    return detail::collect_multi(s, res, core_algorithm_ns);
 }
 
-// src/genasm_gpu.hpp:8
+// src/genasm_gpu.hpp:8 — on every visible GPU
 inline std::vector<Alignment_t> align_all(std::vector<std::string>& texts, std::vector<std::string>& queries,
                                           long long* core_algorithm_ns = nullptr)
 {
-    return default_handle().align_all(texts, queries, core_algorithm_ns);
+    if (texts.size() != queries.size())   // reference: assert, genasm_cpu.cpp:559
+        throw std::invalid_argument("scrooge_amd::align_all: texts and queries differ in size");
+    const size_t n = texts.size();
+    std::vector<const char*> tp(n), qp(n);
+    std::vector<uint64_t> tl(n), ql(n);
+    for (size_t i = 0; i < n; i++) {
+        tp[i] = texts[i].data();
+        tl[i] = texts[i].size();
+        qp[i] = queries[i].data();
+        ql[i] = queries[i].size();
+    }
+    const std::vector<int32_t> dev = detail::all_devices();
+    const scrg_params p = detail::text_params();
+    scrg_result* res = nullptr;
+    const scrg_status s = scrg_align_pairs_multi(dev.data(), (int32_t)dev.size(), &p, n, tp.data(), tl.data(), qp.data(), ql.data(), &res);
+    return detail::collect_multi(s, res, core_algorithm_ns);
 }
 
 // Same argument list as the CPU overloads (src/genasm_cpu.hpp:6-7); `threads` is accepted and ignored.
 inline std::vector<Alignment_t> align_all(Genome_t& reference, std::vector<Read_t>& reads, int /*threads*/,
                                           long long* core_algorithm_ns)
 {
-    return default_handle().align_all(reference, reads, core_algorithm_ns);
+    return align_all(reference, reads, core_algorithm_ns);
 }
 inline std::vector<Alignment_t> align_all(std::vector<std::string>& texts, std::vector<std::string>& queries,
                                           int /*threads*/, long long* core_algorithm_ns = nullptr)
 {
-    return default_handle().align_all(texts, queries, core_algorithm_ns);
+    return align_all(texts, queries, core_algorithm_ns);
 }
 
 }  // namespace scrooge_amd

@@ -33,7 +33,7 @@ class Params(C.Structure):
     _fields_ = [("W", C.c_int32), ("O", C.c_int32), ("lanes_per_pair", C.c_int32),
                 ("lds_rows", C.c_int32), ("waves_per_cu", C.c_int32),
                 ("sort_by_length", C.c_int32), ("text_stride_words", C.c_int32), ("read_stride_words", C.c_int32),
-                ("reserved", C.c_int32 * 2)]
+                ("outputs", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 class PairDesc(C.Structure):
@@ -149,6 +149,13 @@ def load_library():
         "scrg_align_mapping": (C.c_int32, [vp, C.POINTER(Params), C.c_char_p, u64, u64,
                                            C.POINTER(C.c_char_p), C.POINTER(u64), C.POINTER(u64),
                                            C.POINTER(u64), C.POINTER(C.POINTER(Result))]),
+        "scrg_align_pairs_multi": (C.c_int32, [i32p, C.c_int32, C.POINTER(Params), u64, C.POINTER(C.c_char_p), C.POINTER(u64),
+                                               C.POINTER(C.c_char_p), C.POINTER(u64), C.POINTER(C.POINTER(Result))]),
+        "scrg_align_mapping_multi": (C.c_int32, [i32p, C.c_int32, C.POINTER(Params), C.c_char_p, u64, u64, C.POINTER(C.c_char_p),
+                                                 C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), vp, C.POINTER(C.POINTER(Result))]),
+        "scrg_host_plan": (C.c_int32, [C.POINTER(Params), C.c_int32, u64, vp, vp, vp, vp, u64, C.POINTER(u64)]),
+        "scrg_multi_release": (None, []),
+        "scrg_multi_last_error": (C.c_char_p, []),
         "scrg_genome_set": (C.c_int32, [vp, C.c_char_p, u64]),
         "scrg_genome_clear": (None, [vp]),
         "scrg_align_mapping_resident": (C.c_int32, [vp, vp, u64, vp, vp, vp, vp, vp, vp]),
@@ -181,7 +188,8 @@ EXPORTED_SYMBOLS = [
     "scrg_params_default", "scrg_params_resolve", "scrg_ctx_create", "scrg_ctx_destroy", "scrg_ctx_set_stream",
     "scrg_ctx_use_own_stream", "scrg_stream_create", "scrg_stream_destroy",
     "scrg_last_error", "scrg_status_string", "scrg_set_log", "scrg_get_log", "scrg_device_count",
-    "scrg_result_free", "scrg_result_pool_trim", "scrg_align_pairs", "scrg_align_mapping", "scrg_genome_set", "scrg_genome_clear",
+    "scrg_result_free", "scrg_result_pool_trim", "scrg_align_pairs", "scrg_align_mapping", "scrg_align_pairs_multi", "scrg_align_mapping_multi",
+    "scrg_host_plan", "scrg_multi_release", "scrg_multi_last_error", "scrg_genome_set", "scrg_genome_clear",
     "scrg_align_mapping_resident", "scrg_pack_planar", "scrg_pack_planar_groups",
     "scrg_align_device", "scrg_align_device_edits", "scrg_compact_runs", "scrg_compact_runs_packed", "scrg_unpack_runs",
     "scrg_encode_edit_stream", "scrg_decode_edit_stream", "scrg_edit_stream_to_runs", "scrg_edit_stream_to_runs_lane", "scrg_runs_to_edit_stream", "scrg_ascii_to_twobit", "scrg_query_launch",
@@ -375,6 +383,44 @@ class Aligner:
         st = self.lib.scrg_align_pairs(self.h, C.byref(self._params(kw)), n, tp, tl, qp, ql,
                                        C.byref(res))
         self._check(st, allow=(SCRG_ERR_CIGAR_OVERFLOW,))
+        return self._finish(res, st, arrays, strict)
+
+    def align_pairs_multi(self, devices, texts, queries, arrays=False, strict=True, **kw):
+        """scrg_align_pairs_multi: the same call spread over several GPUs (a device may be listed more than once)."""
+        texts, queries = _bytes_list(texts), _bytes_list(queries)
+        n = len(texts)
+        tp = (C.c_char_p * max(n, 1))(*texts)
+        qp = (C.c_char_p * max(n, 1))(*queries)
+        tl = (C.c_uint64 * max(n, 1))(*[len(t) for t in texts])
+        ql = (C.c_uint64 * max(n, 1))(*[len(q) for q in queries])
+        dv = (C.c_int32 * len(devices))(*devices)
+        res = C.POINTER(Result)()
+        st = self.lib.scrg_align_pairs_multi(dv, len(devices), C.byref(self._params(kw)), n, tp, tl, qp, ql, C.byref(res))
+        if st not in (SCRG_OK, SCRG_ERR_CIGAR_OVERFLOW):
+            raise ScroogeError(st, (self.lib.scrg_multi_last_error() or b"").decode())
+        return self._finish(res, st, arrays, strict)
+
+    def align_mapping_multi(self, devices, genome, reads, candidates, reverse=None, arrays=False, strict=True, **kw):
+        """scrg_align_mapping_multi: read mapping spread over several GPUs; reverse: optional list (per read) of 0/1 lists."""
+        genome = genome.encode() if isinstance(genome, str) else bytes(genome)
+        reads = _bytes_list(reads)
+        nr = len(reads)
+        offs, starts, rev = [0], [], []
+        for k, c in enumerate(candidates):
+            starts.extend(int(x) for x in c)
+            rev.extend(int(x) for x in (reverse[k] if reverse is not None else [0] * len(c)))
+            offs.append(len(starts))
+        rp = (C.c_char_p * max(nr, 1))(*reads)
+        rl = (C.c_uint64 * max(nr, 1))(*[len(r) for r in reads])
+        co = (C.c_uint64 * (nr + 1))(*offs)
+        cs = (C.c_uint64 * max(len(starts), 1))(*starts)
+        cr = (C.c_uint8 * max(len(rev), 1))(*rev)
+        dv = (C.c_int32 * len(devices))(*devices)
+        res = C.POINTER(Result)()
+        st = self.lib.scrg_align_mapping_multi(dv, len(devices), C.byref(self._params(kw)), genome, len(genome), nr, rp, rl, co, cs,
+                                               C.cast(cr, C.c_void_p) if reverse is not None else None, C.byref(res))
+        if st not in (SCRG_OK, SCRG_ERR_CIGAR_OVERFLOW):
+            raise ScroogeError(st, (self.lib.scrg_multi_last_error() or b"").decode())
         return self._finish(res, st, arrays, strict)
 
     # -- genasm_gpu::align_all(genome, reads)  (src/genasm_gpu.cu:890-980) ----------

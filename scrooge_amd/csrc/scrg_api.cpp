@@ -23,6 +23,7 @@
 
 #include "genasm_kernels.h"
 #include "edit_stream.h"
+#include "scrg_internal.h"
 #include "../../include/scrooge_amd_io.h"
 
 namespace {
@@ -33,85 +34,10 @@ std::atomic<int> g_live_ctx{0};          // handles alive: the result pool is em
 // on each of at most 1024 CUs): leave room for that, or the counter could wrap and hand out low indices a second time
 constexpr uint64_t kMaxPairsPerLaunch = 0xffffffffull - 64ull * 32ull * 1024ull;
 
-struct DevBuf {
-    void* p = nullptr;
-    size_t cap = 0;
-    hipError_t ensure(size_t bytes)
-    {
-        if (bytes <= cap) return hipSuccess;
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-        size_t want = bytes + bytes / 8 + 256;
-        hipError_t e = hipMalloc(&p, want);
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            e = hipMalloc(&p, bytes);
-            want = bytes;
-        }
-        if (e == hipSuccess) cap = want;
-        return e;
-    }
-    void release()
-    {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-    }
-    template <typename T> T* as() const { return static_cast<T*>(p); }
-};
-
-struct HostPinned {
-    void* p = nullptr;
-    size_t cap = 0;
-    hipError_t ensure(size_t bytes)
-    {
-        if (bytes <= cap) return hipSuccess;
-        if (p) (void)hipHostFree(p);
-        p = nullptr;
-        cap = 0;
-        hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
-        if (e == hipSuccess) cap = bytes;
-        return e;
-    }
-    void release()
-    {
-        if (p) (void)hipHostFree(p);
-        p = nullptr;
-        cap = 0;
-    }
-};
-
-int64_t now_ns()
-{
-    return std::chrono::duration_cast<std::chrono::nanoseconds>(
-               std::chrono::steady_clock::now().time_since_epoch()).count();
-}
-
-// (heavy = true: every index is a block of work — a few of them are worth the threads)
-template <typename F> void parallel_for(uint64_t n, F f, bool heavy = false)
-{
-    unsigned hw = std::thread::hardware_concurrency();
-    unsigned nt = hw ? std::min(hw, 16u) : 4u;
-    if (heavy) nt = (unsigned)std::min<uint64_t>(nt, n);
-    if (n < (heavy ? 2u : 64u) || nt <= 1) {
-        for (uint64_t i = 0; i < n; i++) f(i);
-        return;
-    }
-    std::atomic<uint64_t> next{0};
-    const uint64_t chunk = std::max<uint64_t>(1, n / (nt * 16));
-    std::vector<std::thread> th;
-    for (unsigned k = 0; k < nt; k++)
-        th.emplace_back([&]() {
-            for (;;) {
-                uint64_t b = next.fetch_add(chunk);
-                if (b >= n) break;
-                uint64_t e = std::min(n, b + chunk);
-                for (uint64_t i = b; i < e; i++) f(i);
-            }
-        });
-    for (auto& t : th) t.join();
-}
+using scrg_int::DevBuf;
+using scrg_int::HostPinned;
+using scrg_int::now_ns;
+using scrg_int::parallel_for;
 
 }  // namespace
 
@@ -128,15 +54,7 @@ struct scrg_ctx {
     DevBuf spill;       // HBM overflow rows of R
     DevBuf stats;       // profiling counters (params.reserved[1] != 0)
     DevBuf sort_ws;     // scrg_decode_edit_stream: pair order by stream length (indices, sorted keys / indices, radix sort scratch)
-    // staging used by the host-pointer entry points
-    HostPinned h_ascii;
-    HostPinned h_desc;   // problem descriptors (pinned: no page faults after the first call, full-rate H2D)
-    HostPinned h_out, h_runs, h_off;   // pinned landing zones: per-pair scalars, dense runs, dense offsets (full-rate D2H / H2D;
-                                       // results are copied out to the caller's arrays in parallel)
-    // a genome kept resident by scrg_genome_set(): the first `genome_words` words of d_seq hold it, packed
-    uint64_t genome_len = 0, genome_words = 0;
-    bool genome_resident = false;
-    DevBuf d_ascii, d_seq, d_pairs, d_runs, d_ed, d_nruns, d_status, d_bad, d_dense_off, d_dense;
+    void* host_state = nullptr;   // the pipelined host-pointer path's buffers, streams and resident genome (scrg_host.cpp), made on first use
 
     scrg_status fail(scrg_status s, const char* what, hipError_t e = hipSuccess)
     {
@@ -171,70 +89,7 @@ template <typename F> static scrg_status guarded(scrg_ctx* c, F&& f)
     }
 }
 
-// Result arrays are recycled: a batch of millions of pairs returns hundreds of MB, and freshly mapped pages cost
-// more (first-touch faults) than filling them.  scrg_result_free() parks the big arrays here, the next call of
-// similar size takes them back.  At most 12 blocks / 2 GB are kept; everything else goes to malloc/free.
-namespace {
-struct ResultPool {
-    struct Block { void* p; size_t cap; };
-    std::mutex mu;
-    std::vector<Block> blocks;
-    size_t held = 0;
-    static constexpr size_t kMinPooled = 1u << 20, kMaxHeld = 2ull << 30, kMaxBlocks = 12;
-
-    void* get(size_t bytes, bool zero)
-    {
-        void* p = nullptr;
-        size_t cap = 0;
-        if (bytes >= kMinPooled) {
-            std::lock_guard<std::mutex> g(mu);
-            size_t best = blocks.size();
-            for (size_t i = 0; i < blocks.size(); i++)
-                if (blocks[i].cap >= bytes && blocks[i].cap <= 2 * bytes + (64u << 20) &&
-                    (best == blocks.size() || blocks[i].cap < blocks[best].cap))
-                    best = i;
-            if (best != blocks.size()) {
-                p = blocks[best].p;
-                cap = blocks[best].cap;
-                held -= cap;
-                blocks.erase(blocks.begin() + (long)best);
-            }
-        }
-        if (!p) {
-            cap = bytes >= kMinPooled ? bytes + bytes / 8 : bytes;
-            p = malloc(cap + sizeof(size_t) * 2);
-            if (!p) return nullptr;
-            static_cast<size_t*>(p)[0] = cap;
-        }
-        void* user = static_cast<char*>(p) + sizeof(size_t) * 2;
-        if (zero) memset(user, 0, bytes);
-        return user;
-    }
-    void put(void* user)
-    {
-        if (!user) return;
-        void* p = static_cast<char*>(user) - sizeof(size_t) * 2;
-        const size_t cap = static_cast<size_t*>(p)[0];
-        if (cap >= kMinPooled) {
-            std::lock_guard<std::mutex> g(mu);
-            if (blocks.size() < kMaxBlocks && held + cap <= kMaxHeld) {
-                blocks.push_back({p, cap});
-                held += cap;
-                return;
-            }
-        }
-        free(p);
-    }
-    void trim()
-    {
-        std::lock_guard<std::mutex> g(mu);
-        for (Block& b : blocks) free(b.p);
-        blocks.clear();
-        held = 0;
-    }
-};
-ResultPool g_pool;
-}  // namespace
+using scrg_int::g_pool;
 
 extern "C" {
 
@@ -316,12 +171,9 @@ void scrg_ctx_destroy(scrg_ctx* c)
     c->spill.release();
     c->stats.release();
     c->sort_ws.release();
-    c->h_ascii.release();
-    c->h_desc.release();
-    for (HostPinned* b : {&c->h_out, &c->h_runs, &c->h_off}) b->release();
-    for (DevBuf* b : {&c->d_ascii, &c->d_seq, &c->d_pairs, &c->d_runs, &c->d_ed, &c->d_nruns, &c->d_status,
-                      &c->d_bad, &c->d_dense_off, &c->d_dense})
-        b->release();
+    if (c->host_state) scrg_host::state_free(c->host_state);
+    c->host_state = nullptr;
+    (void)hipSetDevice(c->device);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -376,11 +228,13 @@ static bool resolve_params(const scrg_params* in, scrg_params* p)
         p->sort_by_length = in->sort_by_length;
         p->text_stride_words = in->text_stride_words;
         p->read_stride_words = in->read_stride_words;
+        p->outputs = in->outputs;
         p->reserved[0] = in->reserved[0];      // ablation switches and profiling counters travel with the parameters
         p->reserved[1] = in->reserved[1];
     }
     // experiment switches: only those that leave the results intact, unless this is an ablation build (genasm_kernels.h)
     if (p->reserved[0] & ~scrg::SCRG_ALLOWED_SWITCHES) return false;
+    if (p->outputs < SCRG_OUT_ALL || p->outputs > SCRG_OUT_RUNS) return false;
     if (p->text_stride_words == 0) p->text_stride_words = 1;
     if (p->read_stride_words == 0) p->read_stride_words = 1;
     if (p->text_stride_words < 1 || p->read_stride_words < 1) return false;
@@ -764,512 +618,158 @@ void scrg_result_free(scrg_result* r)
     free(r);
 }
 
+}  // extern "C"
+
+// ---------------------------------------------------------------------------
+// host-pointer entry points: thin argument checks in front of the pipeline of scrg_host.cpp
+// ---------------------------------------------------------------------------
 namespace {
 
-struct SeqRef {
-    const char* p;
-    uint64_t len;
-    uint64_t word_off;   // first planar word of this sequence
-    bool revcomp = false;   // stage the reverse complement (reverse-strand candidates)
-};
+thread_local std::string g_multi_error;
+std::mutex g_multi_mu;
+std::vector<std::pair<int, void*>> g_multi_states;       // (device, state), in the order they were first asked for
+std::vector<char> g_multi_busy;
 
-inline char complement_base(char c)
+void* ctx_state(scrg_ctx* c)
 {
-    switch (c) {
-    case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A';
-    case 'a': return 't'; case 'c': return 'g'; case 'g': return 'c'; case 't': return 'a';
-    default: return c;   // left as is: the pack kernel reports it as a bad base
-    }
+    if (!c->host_state) c->host_state = scrg_host::state_create(c->device);
+    return c->host_state;
 }
 
-struct Problem {         // one (text, read) problem in caller order
-    uint64_t text_off, text_len, read_off, read_len;   // base offsets into the planar array
-};
-
-// Shared tail of both host entry points: sequences are described by `seqs`
-// (each packed once, 32-base aligned), problems by `probs`.
-// `resident_words` leading words of d_seq are already packed on the device (a genome kept by scrg_genome_set):
-// they are neither staged nor transferred nor packed again; `seqs` then describes the words after them only.
-scrg_status run_batch(scrg_ctx* c, const scrg_params& p, std::vector<SeqRef>& seqs, uint64_t total_words,
-                      const std::vector<Problem>& probs, scrg_result** out, uint64_t resident_words = 0, bool resident = false)
+// checks and the pair -> read table shared by the mapping entry points
+scrg_status mapping_batch(uint64_t n_reads, const char* const* reads, const uint64_t* read_lens, const uint64_t* cand_offsets,
+                          const uint64_t* cand_start, const uint8_t* cand_reverse, scrg_host::Batch* b, std::vector<uint32_t>* pair_read,
+                          std::string* err)
 {
-    const int64_t t_begin = now_ns();
-    const uint64_t n = probs.size();
-    HIP_TRY(c, hipSetDevice(c->device));
-    const bool host_timing = getenv("SCRG_HOST_TIMING") != nullptr;
-    int64_t t_mark = t_begin;
-    auto mark = [&](const char* what) {
-        if (!host_timing) return;
-        const int64_t t = now_ns();
-        fprintf(stderr, "[scrooge_amd host] %-28s %8.3f ms\n", what, (double)(t - t_mark) / 1e6);
-        t_mark = t;
-    };
-
-    scrg_result* r = static_cast<scrg_result*>(calloc(1, sizeof(scrg_result)));
-    if (!r) return c->fail(SCRG_ERR_OOM, "result header");
-    r->n_pairs = n;
-    auto bail = [&](scrg_status s) {
-        scrg_result_free(r);
-        return s;
-    };
-    // (every element of these four is written below; only the terminating entries need the zero)
-    r->edit_distance = static_cast<int64_t*>(g_pool.get((n + 1) * sizeof(int64_t), n < 4096));
-    r->pair_status = static_cast<uint32_t*>(g_pool.get((n + 1) * sizeof(uint32_t), n < 4096));
-    r->run_offset = static_cast<uint64_t*>(g_pool.get((n + 1) * sizeof(uint64_t), n < 4096));
-    r->cigar_offset = static_cast<uint64_t*>(g_pool.get((n + 1) * sizeof(uint64_t), n < 4096));
-    if (r->edit_distance) r->edit_distance[n] = 0;
-    if (r->pair_status) r->pair_status[n] = 0;
-    if (r->run_offset) r->run_offset[0] = r->run_offset[n] = 0;
-    if (r->cigar_offset) r->cigar_offset[0] = r->cigar_offset[n] = 0;
-    if (!r->edit_distance || !r->pair_status || !r->run_offset || !r->cigar_offset)
-        return bail(c->fail(SCRG_ERR_OOM, "result arrays"));
-
-    // ---- stage ASCII (32 bytes per planar word, zero padded), H2D, pack ----
-    const uint64_t seq_words = total_words + SCRG_SEQ_PAD_WORDS;
-    const uint64_t new_words = total_words - resident_words;       // words to stage, transfer and pack in this call
-    const size_t ascii_bytes = (size_t)new_words * 32;
-    if (ascii_bytes) {
-        hipError_t e = c->h_ascii.ensure(ascii_bytes);
-        if (e != hipSuccess) return bail(c->fail(SCRG_ERR_OOM, "pinned staging buffer", e));
-        char* h = static_cast<char*>(c->h_ascii.p);
-        // sequences of up to 4 MB are copied whole, one per index; longer ones (a chromosome) are cut into pieces of
-        // 4 MB so that all threads share them
-        struct Piece { uint64_t seq, from, to; };
-        const uint64_t PIECE = 4u << 20;
-        auto copy_piece = [&](const Piece& pc) {
-            const SeqRef& q = seqs[pc.seq];
-            char* dst = h + (q.word_off - resident_words) * 32;
-            const uint64_t data_to = std::min(pc.to, q.len);
-            if (pc.from < data_to) {
-                if (!q.revcomp) memcpy(dst + pc.from, q.p + pc.from, data_to - pc.from);
-                else
-                    for (uint64_t k = pc.from; k < data_to; k++) dst[k] = complement_base(q.p[q.len - 1 - k]);
-            }
-            if (pc.to > std::max(pc.from, q.len)) memset(dst + std::max(pc.from, q.len), 0, pc.to - std::max(pc.from, q.len));
-        };
-        std::vector<Piece> pieces;                      // of the long sequences only
-        for (uint64_t s = 0; s < seqs.size(); s++) {
-            const uint64_t span = ((seqs[s].len + 31) / 32) * 32;
-            if (span > PIECE)
-                for (uint64_t a = 0; a < span; a += PIECE) pieces.push_back({s, a, std::min(span, a + PIECE)});
-        }
-        parallel_for(pieces.size(), [&](uint64_t i) { copy_piece(pieces[i]); }, true);
-        parallel_for(seqs.size(), [&](uint64_t s) {
-            const uint64_t span = ((seqs[s].len + 31) / 32) * 32;
-            if (span <= PIECE && span) copy_piece(Piece{s, 0, span});
-        });
+    if ((n_reads && (!reads || !read_lens)) || !cand_offsets) { *err = "null input array"; return SCRG_ERR_INVALID_ARG; }
+    const uint64_t n_pairs = cand_offsets[n_reads];
+    if (n_pairs > kMaxPairsPerLaunch || n_reads > 0xfffffff0ull) { *err = "too many pairs"; return SCRG_ERR_INVALID_ARG; }
+    if (n_pairs && !cand_start) { *err = "null candidate array"; return SCRG_ERR_INVALID_ARG; }
+    for (uint64_t r = 0; r < n_reads; r++) {
+        if (read_lens[r] && !reads[r]) { *err = "null read pointer"; return SCRG_ERR_INVALID_ARG; }
+        if (read_lens[r] > 0x7fffffffull) { *err = "read longer than 2^31-1"; return SCRG_ERR_INVALID_ARG; }
+        if (cand_offsets[r + 1] < cand_offsets[r]) { *err = "cand_offsets not monotone"; return SCRG_ERR_INVALID_ARG; }
     }
-    hipError_t e;
-    if (resident_words && (size_t)seq_words * 8 > c->d_seq.cap) {
-        // the sequence array has to grow: keep the resident genome (device-to-device) instead of packing it again
-        DevBuf bigger;
-        if ((e = bigger.ensure((size_t)seq_words * 8)) != hipSuccess) return bail(c->fail(SCRG_ERR_OOM, "device sequence buffer", e));
-        if ((e = hipMemcpyAsync(bigger.p, c->d_seq.p, resident_words * 8, hipMemcpyDeviceToDevice, c->stream)) != hipSuccess ||
-            (e = hipStreamSynchronize(c->stream)) != hipSuccess) {
-            bigger.release();
-            return bail(c->fail(SCRG_ERR_HIP, "moving the resident genome", e));
-        }
-        c->d_seq.release();
-        c->d_seq = bigger;
-    }
-    if (!resident) c->genome_resident = false;     // d_seq is about to be overwritten from word 0
-    if ((e = c->d_ascii.ensure(ascii_bytes + 32)) != hipSuccess || (e = c->d_seq.ensure(seq_words * 8)) != hipSuccess ||
-        (e = c->d_bad.ensure(4)) != hipSuccess)
-        return bail(c->fail(SCRG_ERR_OOM, "device sequence buffers", e));
-    mark("result arrays + staging copy");
-    const int64_t t_pack0 = now_ns();
-    if ((e = hipMemsetAsync(c->d_bad.p, 0, 4, c->stream)) != hipSuccess ||
-        (e = hipMemsetAsync(c->d_seq.as<uint64_t>() + total_words, 0, SCRG_SEQ_PAD_WORDS * 8, c->stream)) != hipSuccess)
-        return bail(c->fail(SCRG_ERR_HIP, "memset", e));
-    if (ascii_bytes) {
-        if ((e = hipMemcpyAsync(c->d_ascii.p, c->h_ascii.p, ascii_bytes, hipMemcpyHostToDevice, c->stream)) != hipSuccess)
-            return bail(c->fail(SCRG_ERR_HIP, "H2D ascii", e));
-        scrg_status s = scrg_pack_planar(c, c->d_ascii.as<char>(), new_words, c->d_seq.as<uint64_t>() + resident_words,
-                                         c->d_bad.as<uint32_t>());
-        if (s != SCRG_OK) return bail(s);
-    }
-    uint32_t bad = 0;
-    if ((e = hipMemcpyAsync(&bad, c->d_bad.p, 4, hipMemcpyDeviceToHost, c->stream)) != hipSuccess ||
-        (e = hipStreamSynchronize(c->stream)) != hipSuccess)
-        return bail(c->fail(SCRG_ERR_HIP, "pack", e));
-    r->pack_ns = now_ns() - t_pack0;
-    mark("H2D + pack kernel");
-    if (bad) return bail(c->fail(SCRG_ERR_BAD_BASE, "input contains characters other than ACGTacgt"));
-
-    // ---- problem descriptors, longest read first (src/tests.cu:375-377) ----
-    std::vector<uint32_t> order(n);
-    std::atomic<int> unsorted{0};
-    {
-        // identity, and at the same time: is the batch already in issue order?  (read sets of one length, or sorted
-        // ones, need no sort: 4 M comparisons instead of 90 M)
-        const uint64_t BLK = 1u << 16, nb = (n + BLK - 1) / BLK;
-        parallel_for(nb, [&](uint64_t b) {
-            bool ok = true;
-            for (uint64_t k = b * BLK; k < std::min(n, (b + 1) * BLK); k++) {
-                order[k] = (uint32_t)k;
-                if (k && probs[k - 1].read_len < probs[k].read_len) ok = false;
-            }
-            if (!ok) unsorted.store(1, std::memory_order_relaxed);
-        }, true);
-    }
-    if (p.sort_by_length) {
-        const bool sorted = unsorted.load() == 0;
-        if (!sorted)
-            std::stable_sort(order.begin(), order.end(),
-                             [&](uint32_t x, uint32_t y) { return probs[x].read_len > probs[y].read_len; });
-    }
-    mark("  order");
-    if (hipError_t eh = c->h_desc.ensure(std::max<uint64_t>(n, 1) * sizeof(scrg_pair_desc)); eh != hipSuccess)
-        return bail(c->fail(SCRG_ERR_OOM, "pinned descriptor buffer", eh));
-    scrg_pair_desc* const desc = static_cast<scrg_pair_desc*>(c->h_desc.p);
-    // slices: same bound as the reference's GPU list sizing (2*read_len, genasm_gpu.cu:906-911), whole 32-byte
-    // pieces; offsets by a two-level prefix sum (blocks of 64 k pairs in parallel)
-    uint64_t arena = 0;
-    {
-        const uint64_t BLK = 1u << 16, nb = (n + BLK - 1) / BLK;
-        std::vector<uint64_t> block_sum(nb + 1, 0);
-        parallel_for(nb, [&](uint64_t b) {
-            uint64_t acc = 0;
-            for (uint64_t k = b * BLK; k < std::min(n, (b + 1) * BLK); k++) {
-                const Problem& q = probs[order[k]];
-                scrg_pair_desc& d = desc[k];
-                d.text_off = q.text_off;
-                d.text_len = q.text_len;
-                d.read_off = q.read_off;
-                d.read_len = q.read_len;
-                d.cigar_cap = (2 * q.read_len + 8 + 15) & ~(uint64_t)15;
-                d.cigar_off = acc;
-                acc += d.cigar_cap;
-            }
-            block_sum[b + 1] = acc;
-        }, true);
-        for (uint64_t b = 0; b < nb; b++) block_sum[b + 1] += block_sum[b];
-        arena = block_sum[nb];
-        parallel_for(nb, [&](uint64_t b) {
-            if (block_sum[b])
-                for (uint64_t k = b * BLK; k < std::min(n, (b + 1) * BLK); k++) desc[k].cigar_off += block_sum[b];
-        }, true);
-    }
-    mark("  build descriptors");
-    if (n == 0) {
-        r->runs = static_cast<scrg_run*>(g_pool.get(sizeof(scrg_run), true));
-        r->cigar_text = static_cast<char*>(g_pool.get(1, true));
-        r->total_ns = now_ns() - t_begin;
-        *out = r;
-        return SCRG_OK;
-    }
-    if ((e = c->d_pairs.ensure(n * sizeof(scrg_pair_desc))) != hipSuccess ||
-        (e = c->d_runs.ensure(arena * sizeof(scrg_run))) != hipSuccess || (e = c->d_ed.ensure(n * 8)) != hipSuccess ||
-        (e = c->d_nruns.ensure(n * 4)) != hipSuccess || (e = c->d_status.ensure(n * 4)) != hipSuccess ||
-        (e = c->d_dense_off.ensure(n * 8)) != hipSuccess)
-        return bail(c->fail(SCRG_ERR_OOM, "device result buffers", e));
-    if ((e = hipMemcpyAsync(c->d_pairs.p, desc, n * sizeof(scrg_pair_desc), hipMemcpyHostToDevice, c->stream)) !=
-        hipSuccess)
-        return bail(c->fail(SCRG_ERR_HIP, "H2D descriptors", e));
-
-    mark("descriptors (sort, build, H2D)");
-    // ---- the timed region of the reference: kernel + sync (genasm_gpu.cu:939-944) ----
-    scrg_params pd = p;                   // this path packs contiguously, whatever the caller's device-layout strides say
-    pd.text_stride_words = pd.read_stride_words = 1;
-    scrg_status s = scrg_align_device(c, &pd, n, c->d_seq.as<uint64_t>(), c->d_pairs.as<scrg_pair_desc>(),
-                                      c->d_runs.as<scrg_run>(), c->d_ed.as<int64_t>(), c->d_nruns.as<uint32_t>(),
-                                      c->d_status.as<uint32_t>());
-    if (s != SCRG_OK) return bail(s);
-    float ms = 0.f;
-    s = scrg_last_kernel_ms(c, &ms);
-    if (s != SCRG_OK) return bail(s);
-    r->kernel_ns = (int64_t)((double)ms * 1e6);
-    if (g_log.load() && ms > 0.f)   // the reference's log line, genasm_gpu.cu:949-951
-        fprintf(stderr, "core algorithm ran at %lld aligns/second\n", (long long)((double)n * 1000.0 / ms));
-
-    mark("align kernel");
-    // ---- read back: per-pair scalars, then the compacted runs ----
-    // (pinned landing zone: a D2H into pageable memory runs at a fraction of the link rate)
-    if ((e = c->h_out.ensure(n * 16)) != hipSuccess) return bail(c->fail(SCRG_ERR_OOM, "pinned result buffer", e));
-    int64_t* const ed = static_cast<int64_t*>(c->h_out.p);
-    uint32_t* const nr = reinterpret_cast<uint32_t*>(ed + n);
-    uint32_t* const st = nr + n;
-    if ((e = hipMemcpyAsync(ed, c->d_ed.p, n * 8, hipMemcpyDeviceToHost, c->stream)) != hipSuccess ||
-        (e = hipMemcpyAsync(nr, c->d_nruns.p, n * 4, hipMemcpyDeviceToHost, c->stream)) != hipSuccess ||
-        (e = hipMemcpyAsync(st, c->d_status.p, n * 4, hipMemcpyDeviceToHost, c->stream)) != hipSuccess ||
-        (e = hipStreamSynchronize(c->stream)) != hipSuccess)
-        return bail(c->fail(SCRG_ERR_HIP, "D2H scalars", e));
-    mark("  D2H scalars");
-
-    // dense layout in caller order
-    if ((e = c->h_off.ensure(n * 8)) != hipSuccess) return bail(c->fail(SCRG_ERR_OOM, "pinned offset buffer", e));
-    uint64_t* const dense_off_sorted = static_cast<uint64_t*>(c->h_off.p);
-    {
-        // run_offset[i] = exclusive prefix sum of the (capped) run counts in caller order: counts are scattered into
-        // run_offset itself, then a two-level scan (blocks of 64 k in parallel)
-        parallel_for(n, [&](uint64_t k) {
-            r->run_offset[order[k]] = std::min<uint64_t>(nr[k], desc[k].cigar_cap);
-        });
-        const uint64_t BLK = 1u << 16, nb = (n + BLK - 1) / BLK;
-        std::vector<uint64_t> block_sum(nb + 1, 0);
-        parallel_for(nb, [&](uint64_t b) {
-            uint64_t acc = 0;
-            for (uint64_t i = b * BLK; i < std::min(n, (b + 1) * BLK); i++) {
-                const uint64_t cnt = r->run_offset[i];
-                r->run_offset[i] = acc;
-                acc += cnt;
-            }
-            block_sum[b + 1] = acc;
-        }, true);
-        for (uint64_t b = 0; b < nb; b++) block_sum[b + 1] += block_sum[b];
-        parallel_for(nb, [&](uint64_t b) {
-            if (block_sum[b])
-                for (uint64_t i = b * BLK; i < std::min(n, (b + 1) * BLK); i++) r->run_offset[i] += block_sum[b];
-        }, true);
-        r->run_offset[n] = block_sum[nb];
-        parallel_for(n, [&](uint64_t k) { dense_off_sorted[k] = r->run_offset[order[k]]; });
-    }
-    const uint64_t total_runs = r->run_offset[n];
-    mark("  dense offsets");
-    r->runs = static_cast<scrg_run*>(g_pool.get((total_runs + 1) * sizeof(scrg_run), false));
-    if (!r->runs) return bail(c->fail(SCRG_ERR_OOM, "runs"));
-    if (total_runs) {
-        if ((e = c->d_dense.ensure(total_runs * sizeof(scrg_run))) != hipSuccess)
-            return bail(c->fail(SCRG_ERR_OOM, "dense runs", e));
-        if ((e = hipMemcpyAsync(c->d_dense_off.p, dense_off_sorted, n * 8, hipMemcpyHostToDevice, c->stream)) !=
-            hipSuccess)
-            return bail(c->fail(SCRG_ERR_HIP, "H2D offsets", e));
-        s = scrg_compact_runs(c, n, c->d_pairs.as<scrg_pair_desc>(), c->d_runs.as<scrg_run>(), c->d_nruns.as<uint32_t>(),
-                              c->d_dense_off.as<uint64_t>(), c->d_dense.as<scrg_run>());
-        if (s != SCRG_OK) return bail(s);
-        if ((e = c->h_runs.ensure(total_runs * sizeof(scrg_run))) != hipSuccess)
-            return bail(c->fail(SCRG_ERR_OOM, "pinned run buffer", e));
-        if ((e = hipMemcpyAsync(c->h_runs.p, c->d_dense.p, total_runs * sizeof(scrg_run), hipMemcpyDeviceToHost, c->stream)) !=
-                hipSuccess ||
-            (e = hipStreamSynchronize(c->stream)) != hipSuccess)
-            return bail(c->fail(SCRG_ERR_HIP, "D2H runs", e));
-        mark("  compaction + D2H runs");
-        const uint64_t bytes = total_runs * sizeof(scrg_run), CH = 1u << 20;
-        parallel_for((bytes + CH - 1) / CH, [&](uint64_t i) {
-            memcpy(reinterpret_cast<char*>(r->runs) + i * CH, static_cast<const char*>(c->h_runs.p) + i * CH,
-                   std::min<uint64_t>(CH, bytes - i * CH));
-        }, true);
-    }
-
-    mark("  copy runs out");
-    std::atomic<int> any_overflow{0};
-    parallel_for(n, [&](uint64_t k) {
-        r->edit_distance[order[k]] = ed[k];
-        r->pair_status[order[k]] = st[k] ? (uint32_t)SCRG_ERR_CIGAR_OVERFLOW : (uint32_t)SCRG_OK;
-        if (st[k]) any_overflow.store(1, std::memory_order_relaxed);
+    pair_read->resize(n_pairs);
+    parallel_for(n_reads, [&](uint64_t r) {
+        for (uint64_t k = cand_offsets[r]; k < cand_offsets[r + 1]; k++) (*pair_read)[k] = (uint32_t)r;
     });
-    const scrg_status worst = any_overflow.load() ? SCRG_ERR_CIGAR_OVERFLOW : SCRG_OK;
+    b->n_pairs = n_pairs;
+    b->mapping = true;
+    b->reads = reads;
+    b->read_lens = read_lens;
+    b->cand_start = cand_start;
+    b->cand_reverse = cand_reverse;
+    b->pair_read = pair_read->data();
+    b->n_reads = n_reads;
+    return SCRG_OK;
+}
 
-    // ---- "%d%c" text, as genasm_cpu.cpp:387-403 ----
-    {
-        // (decimal digits of a count: from a table — the low bytes of `word` are the digits, `len` of them)
-        struct DigitLut {
-            uint32_t word[256];
-            uint8_t len[256];
-            DigitLut()
-            {
-                for (unsigned v = 0; v < 256; v++) {
-                    char d[4];
-                    const int l = snprintf(d, sizeof d, "%u", v);
-                    uint32_t w = 0;
-                    for (int k = 0; k < l; k++) w |= (uint32_t)(uint8_t)d[k] << (8 * k);
-                    word[v] = w;
-                    len[v] = (uint8_t)l;
-                }
-            }
-        };
-        static const DigitLut dig;
-        uint64_t acc = 0;
-        {
-            // length of every pair's text and its offset within its block in one pass over the runs, then the block sums
-            const uint64_t BLK = 1u << 13, nb = (n + BLK - 1) / BLK;
-            std::vector<uint64_t> block_sum(nb + 1, 0);
-            parallel_for(nb, [&](uint64_t b) {
-                uint64_t a = 0;
-                for (uint64_t i = b * BLK; i < std::min(n, (b + 1) * BLK); i++) {
-                    uint64_t chars = 0;
-                    for (uint64_t k = r->run_offset[i]; k < r->run_offset[i + 1]; k++) chars += dig.len[r->runs[k].count] + 1u;
-                    r->cigar_offset[i] = a;
-                    a += chars + 1;
-                }
-                block_sum[b + 1] = a;
-            }, true);
-            for (uint64_t b = 0; b < nb; b++) block_sum[b + 1] += block_sum[b];
-            parallel_for(nb, [&](uint64_t b) {
-                if (block_sum[b])
-                    for (uint64_t i = b * BLK; i < std::min(n, (b + 1) * BLK); i++) r->cigar_offset[i] += block_sum[b];
-            }, true);
-            acc = block_sum[nb];
-        }
-        r->cigar_offset[n] = acc;
-        mark("  text sizes");
-        r->cigar_text = static_cast<char*>(g_pool.get(acc + 1, false));
-        if (!r->cigar_text) return bail(c->fail(SCRG_ERR_OOM, "cigar text"));
-        parallel_for(n, [&](uint64_t i) {
-            char* w = r->cigar_text + r->cigar_offset[i];
-            const uint64_t k0 = r->run_offset[i], k1 = r->run_offset[i + 1];
-            // every run but the last: one 4-byte store (digits + op; the one or two bytes too many land where the next
-            // run of the same pair is written afterwards); the last run byte by byte — the next pair may be another thread's
-            for (uint64_t k = k0; k + 1 < k1; k++) {
-                const unsigned cnt = r->runs[k].count, l = dig.len[cnt];
-                const uint32_t v = dig.word[cnt] | ((uint32_t)(uint8_t)r->runs[k].op << (8 * l));
-                memcpy(w, &v, 4);
-                w += l + 1;
-            }
-            if (k1 > k0) {
-                const unsigned cnt = r->runs[k1 - 1].count, l = dig.len[cnt];
-                for (unsigned q = 0; q < l; q++) *w++ = (char)(dig.word[cnt] >> (8 * q));
-                *w++ = r->runs[k1 - 1].op;
-            }
-            *w = '\0';
-        });
+scrg_status pairs_batch(uint64_t n_pairs, const char* const* texts, const uint64_t* text_lens, const char* const* queries,
+                        const uint64_t* query_lens, scrg_host::Batch* b, std::string* err)
+{
+    if (n_pairs && (!texts || !text_lens || !queries || !query_lens)) { *err = "null input array"; return SCRG_ERR_INVALID_ARG; }
+    if (n_pairs > kMaxPairsPerLaunch) { *err = "too many pairs"; return SCRG_ERR_INVALID_ARG; }
+    for (uint64_t i = 0; i < n_pairs; i++) {
+        if ((text_lens[i] && !texts[i]) || (query_lens[i] && !queries[i])) { *err = "null sequence pointer"; return SCRG_ERR_INVALID_ARG; }
+        if (query_lens[i] > 0x7fffffffull) { *err = "read longer than 2^31-1"; return SCRG_ERR_INVALID_ARG; }
     }
-    mark("CIGAR text");
-    r->total_ns = now_ns() - t_begin;
-    *out = r;
-    if (worst != SCRG_OK) c->fail(worst, "at least one pair overflowed its CIGAR slice (see pair_status)");
-    return worst;
+    b->n_pairs = n_pairs;
+    b->mapping = false;
+    b->texts = texts;
+    b->text_lens = text_lens;
+    b->reads = queries;
+    b->read_lens = query_lens;
+    return SCRG_OK;
+}
+
+scrg_status ctx_align(scrg_ctx* c, const scrg_params* params, scrg_host::Batch& b, scrg_result** out)
+{
+    scrg_params p;
+    if (!resolve_params(params, &p)) return c->fail(SCRG_ERR_INVALID_ARG, "bad scrg_params");
+    void* st = ctx_state(c);
+    if (!st) return c->fail(SCRG_ERR_NO_DEVICE, "no usable HIP device for the host path");
+    std::string err;
+    const scrg_status s = scrg_host::align(&st, 1, p, b, out, &err);
+    if (s != SCRG_OK) c->fail(s, err.c_str());
+    return s;
+}
+
+// the states of a multi-device call: one per listed device (a device listed twice gets two), kept for later calls
+scrg_status multi_states(const int32_t* devices, int32_t n_devices, std::vector<void*>* st, std::vector<size_t>* taken)
+{
+    std::lock_guard<std::mutex> g(g_multi_mu);
+    for (int32_t d = 0; d < n_devices; d++) {
+        size_t found = g_multi_states.size();
+        for (size_t k = 0; k < g_multi_states.size(); k++)
+            if (g_multi_states[k].first == devices[d] && !g_multi_busy[k]) { found = k; break; }
+        if (found == g_multi_states.size()) {
+            void* s = scrg_host::state_create(devices[d]);
+            if (!s) {
+                for (size_t k : *taken) g_multi_busy[k] = 0;
+                return SCRG_ERR_NO_DEVICE;
+            }
+            g_multi_states.emplace_back(devices[d], s);
+            g_multi_busy.push_back(0);
+        }
+        g_multi_busy[found] = 1;
+        taken->push_back(found);
+        st->push_back(g_multi_states[found].second);
+    }
+    return SCRG_OK;
+}
+
+void multi_done(const std::vector<size_t>& taken)
+{
+    std::lock_guard<std::mutex> g(g_multi_mu);
+    for (size_t k : taken) g_multi_busy[k] = 0;
+}
+
+scrg_status multi_align(const int32_t* devices, int32_t n_devices, const scrg_params* params, scrg_host::Batch& b, scrg_result** out)
+{
+    scrg_params p;
+    if (!resolve_params(params, &p)) { g_multi_error = "bad scrg_params"; return SCRG_ERR_INVALID_ARG; }
+    std::vector<void*> st;
+    std::vector<size_t> taken;
+    scrg_status s = multi_states(devices, n_devices, &st, &taken);
+    if (s != SCRG_OK) { g_multi_error = "no usable HIP device"; return s; }
+    std::string err;
+    s = scrg_host::align(st.data(), (int)st.size(), p, b, out, &err);
+    multi_done(taken);
+    g_multi_error = s == SCRG_OK ? "" : err;
+    return s;
+}
+
+template <typename F> scrg_status multi_guarded(F&& f)
+{
+    try {
+        return f();
+    } catch (const std::bad_alloc&) {
+        g_multi_error = "host allocation failed";
+        return SCRG_ERR_OOM;
+    } catch (...) {
+        g_multi_error = "unexpected exception";
+        return SCRG_ERR_INVALID_ARG;
+    }
 }
 
 }  // namespace
 
-static scrg_status align_pairs_impl(scrg_ctx* c, const scrg_params* params, uint64_t n_pairs, const char* const* texts,
-                             const uint64_t* text_lens, const char* const* queries, const uint64_t* query_lens,
-                             scrg_result** out)
-{
-    if (!c || !out) return SCRG_ERR_INVALID_ARG;
-    *out = nullptr;
-    if (n_pairs && (!texts || !text_lens || !queries || !query_lens))
-        return c->fail(SCRG_ERR_INVALID_ARG, "null input array");
-    scrg_params p;
-    if (!resolve_params(params, &p)) return c->fail(SCRG_ERR_INVALID_ARG, "bad scrg_params");
-    if (n_pairs > kMaxPairsPerLaunch) return c->fail(SCRG_ERR_INVALID_ARG, "too many pairs");
-
-    std::vector<SeqRef> seqs(2 * n_pairs);
-    std::vector<Problem> probs(n_pairs);
-    uint64_t w = 0;
-    for (uint64_t i = 0; i < n_pairs; i++) {
-        if ((text_lens[i] && !texts[i]) || (query_lens[i] && !queries[i]))
-            return c->fail(SCRG_ERR_INVALID_ARG, "null sequence pointer");
-        if (query_lens[i] > 0x7fffffffull) return c->fail(SCRG_ERR_INVALID_ARG, "read longer than 2^31-1");
-        seqs[2 * i] = {texts[i], text_lens[i], w, false};
-        probs[i].text_off = w * 32;
-        probs[i].text_len = text_lens[i];
-        w += (text_lens[i] + 31) / 32;
-        seqs[2 * i + 1] = {queries[i], query_lens[i], w, false};
-        probs[i].read_off = w * 32;
-        probs[i].read_len = query_lens[i];
-        w += (query_lens[i] + 31) / 32;
-    }
-    return run_batch(c, p, seqs, w, probs, out);
-}
+extern "C" {
 
 scrg_status scrg_align_pairs(scrg_ctx* c, const scrg_params* params, uint64_t n_pairs, const char* const* texts,
                              const uint64_t* text_lens, const char* const* queries, const uint64_t* query_lens,
                              scrg_result** out)
 {
-    return guarded(c, [&] { return align_pairs_impl(c, params, n_pairs, texts, text_lens, queries, query_lens, out); });
-}
-
-static scrg_status align_mapping_impl(scrg_ctx* c, const scrg_params* params, const char* genome,
-                                        uint64_t genome_len, uint64_t n_reads, const char* const* reads,
-                                        const uint64_t* read_lens, const uint64_t* cand_offsets,
-                                        const uint64_t* cand_start, const uint8_t* cand_reverse, scrg_result** out,
-                                        bool resident = false)
-{
     if (!c || !out) return SCRG_ERR_INVALID_ARG;
     *out = nullptr;
-    if (resident) {                          // the genome scrg_genome_set() left packed at the front of d_seq
-        if (!c->genome_resident) return c->fail(SCRG_ERR_INVALID_ARG, "no resident genome: call scrg_genome_set first");
-        genome = nullptr;
-        genome_len = c->genome_len;
-    }
-    if ((!resident && genome_len && !genome) || (n_reads && (!reads || !read_lens)) || !cand_offsets)
-        return c->fail(SCRG_ERR_INVALID_ARG, "null input array");
-    scrg_params p;
-    if (!resolve_params(params, &p)) return c->fail(SCRG_ERR_INVALID_ARG, "bad scrg_params");
-    const uint64_t n_pairs = cand_offsets[n_reads];
-    if (n_pairs > kMaxPairsPerLaunch) return c->fail(SCRG_ERR_INVALID_ARG, "too many pairs");
-    if (n_pairs && !cand_start) return c->fail(SCRG_ERR_INVALID_ARG, "null candidate array");
-
-    // genome and every read are packed exactly once (README.md:83 of the reference asks for this);
-    // a read with reverse-strand candidates is additionally staged reverse-complemented, once
-    std::vector<SeqRef> seqs;
-    seqs.reserve(1 + n_reads);
-    std::vector<Problem> probs(n_pairs);
-    uint64_t w = 0;
-    if (!resident) seqs.push_back({genome, genome_len, 0, false});
-    w += (genome_len + 31) / 32;
-    for (uint64_t r = 0; r < n_reads; r++) {
-        if (read_lens[r] && !reads[r]) return c->fail(SCRG_ERR_INVALID_ARG, "null read pointer");
-        if (read_lens[r] > 0x7fffffffull) return c->fail(SCRG_ERR_INVALID_ARG, "read longer than 2^31-1");
-        if (cand_offsets[r + 1] < cand_offsets[r]) return c->fail(SCRG_ERR_INVALID_ARG, "cand_offsets not monotone");
-        bool any_fwd = false, any_rev = false;
-        for (uint64_t k = cand_offsets[r]; k < cand_offsets[r + 1]; k++) {
-            if (cand_reverse && cand_reverse[k]) any_rev = true;
-            else any_fwd = true;
-        }
-        const uint64_t words = (read_lens[r] + 31) / 32;
-        uint64_t fwd_off = 0, rev_off = 0;
-        if (any_fwd || !any_rev) {
-            seqs.push_back({reads[r], read_lens[r], w, false});
-            fwd_off = w * 32;
-            w += words;
-        }
-        if (any_rev) {
-            seqs.push_back({reads[r], read_lens[r], w, true});
-            rev_off = w * 32;
-            w += words;
-        }
-        for (uint64_t k = cand_offsets[r]; k < cand_offsets[r + 1]; k++) {
-            if (cand_start[k] > genome_len) return c->fail(SCRG_ERR_INVALID_ARG, "candidate past end of genome");
-            // text = genome suffix from start_in_reference (genasm_cpu.cpp:512-514)
-            probs[k].text_off = cand_start[k];
-            probs[k].text_len = genome_len - cand_start[k];
-            probs[k].read_off = (cand_reverse && cand_reverse[k]) ? rev_off : fwd_off;
-            probs[k].read_len = read_lens[r];
-        }
-    }
-    return run_batch(c, p, seqs, w, probs, out, resident ? c->genome_words : 0, resident);
-}
-
-// scrg_genome_set: stage, transfer and pack a genome once; it stays at the front of the handle's sequence
-// array until another genome is set, scrg_genome_clear() is called or a call that brings its own sequences
-// (scrg_align_pairs, scrg_align_mapping) reuses the array.
-static scrg_status genome_set_impl(scrg_ctx* c, const char* genome, uint64_t genome_len)
-{
-    if (!c || (genome_len && !genome)) return SCRG_ERR_INVALID_ARG;
-    HIP_TRY(c, hipSetDevice(c->device));
-    c->genome_resident = false;
-    const uint64_t words = (genome_len + 31) / 32;
-    const size_t bytes = (size_t)words * 32;
-    hipError_t e;
-    if ((e = c->h_ascii.ensure(bytes + 32)) != hipSuccess) return c->fail(SCRG_ERR_OOM, "pinned staging buffer", e);
-    char* const h = static_cast<char*>(c->h_ascii.p);
-    const uint64_t PIECE = 4u << 20;
-    parallel_for((bytes + PIECE - 1) / PIECE, [&](uint64_t i) {
-        const uint64_t a = i * PIECE, b = std::min<uint64_t>(bytes, a + PIECE), d = std::min(b, genome_len);
-        if (a < d) memcpy(h + a, genome + a, d - a);
-        if (b > std::max(a, genome_len)) memset(h + std::max(a, genome_len), 0, b - std::max(a, genome_len));
-    }, true);
-    if ((e = c->d_ascii.ensure(bytes + 32)) != hipSuccess || (e = c->d_seq.ensure((words + SCRG_SEQ_PAD_WORDS) * 8)) != hipSuccess ||
-        (e = c->d_bad.ensure(4)) != hipSuccess)
-        return c->fail(SCRG_ERR_OOM, "device sequence buffers", e);
-    HIP_TRY(c, hipMemsetAsync(c->d_bad.p, 0, 4, c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->d_seq.as<uint64_t>() + words, 0, SCRG_SEQ_PAD_WORDS * 8, c->stream));
-    if (bytes) {
-        HIP_TRY(c, hipMemcpyAsync(c->d_ascii.p, h, bytes, hipMemcpyHostToDevice, c->stream));
-        scrg_status s = scrg_pack_planar(c, c->d_ascii.as<char>(), words, c->d_seq.as<uint64_t>(), c->d_bad.as<uint32_t>());
-        if (s != SCRG_OK) return s;
-    }
-    uint32_t bad = 0;
-    HIP_TRY(c, hipMemcpyAsync(&bad, c->d_bad.p, 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (bad) return c->fail(SCRG_ERR_BAD_BASE, "genome contains characters other than ACGTacgt");
-    c->genome_len = genome_len;
-    c->genome_words = words;
-    c->genome_resident = true;
-    return SCRG_OK;
+    return guarded(c, [&] {
+        scrg_host::Batch b;
+        std::string err;
+        scrg_status s = pairs_batch(n_pairs, texts, text_lens, queries, query_lens, &b, &err);
+        if (s != SCRG_OK) return c->fail(s, err.c_str());
+        return ctx_align(c, params, b, out);
+    });
 }
 
 scrg_status scrg_align_mapping_stranded(scrg_ctx* c, const scrg_params* params, const char* genome,
@@ -1277,29 +777,19 @@ scrg_status scrg_align_mapping_stranded(scrg_ctx* c, const scrg_params* params, 
                                         const uint64_t* read_lens, const uint64_t* cand_offsets,
                                         const uint64_t* cand_start, const uint8_t* cand_reverse, scrg_result** out)
 {
+    if (!c || !out) return SCRG_ERR_INVALID_ARG;
+    *out = nullptr;
     return guarded(c, [&] {
-        return align_mapping_impl(c, params, genome, genome_len, n_reads, reads, read_lens, cand_offsets, cand_start,
-                                  cand_reverse, out);
-    });
-}
-
-scrg_status scrg_genome_set(scrg_ctx* c, const char* genome, uint64_t genome_len)
-{
-    return guarded(c, [&] { return genome_set_impl(c, genome, genome_len); });
-}
-
-void scrg_genome_clear(scrg_ctx* c)
-{
-    if (c) c->genome_resident = false;
-}
-
-scrg_status scrg_align_mapping_resident(scrg_ctx* c, const scrg_params* params, uint64_t n_reads, const char* const* reads,
-                                        const uint64_t* read_lens, const uint64_t* cand_offsets, const uint64_t* cand_start,
-                                        const uint8_t* cand_reverse, scrg_result** out)
-{
-    return guarded(c, [&] {
-        return align_mapping_impl(c, params, nullptr, 0, n_reads, reads, read_lens, cand_offsets, cand_start, cand_reverse,
-                                  out, true);
+        if (genome_len && !genome) return c->fail(SCRG_ERR_INVALID_ARG, "null input array");
+        scrg_host::Batch b;
+        std::vector<uint32_t> pair_read;
+        std::string err;
+        scrg_status s = mapping_batch(n_reads, reads, read_lens, cand_offsets, cand_start, cand_reverse, &b, &pair_read, &err);
+        if (s != SCRG_OK) return c->fail(s, err.c_str());
+        static const char empty_genome[1] = {0};
+        b.genome = genome ? genome : empty_genome;          // (the genome is staged by this call, as the reference re-converts it, genasm_cpu.cpp:508)
+        b.genome_len = genome_len;
+        return ctx_align(c, params, b, out);
     });
 }
 
@@ -1310,5 +800,111 @@ scrg_status scrg_align_mapping(scrg_ctx* c, const scrg_params* params, const cha
     return scrg_align_mapping_stranded(c, params, genome, genome_len, n_reads, reads, read_lens, cand_offsets,
                                        cand_start, nullptr, out);
 }
+
+// scrg_genome_set: pack (host threads) and transfer a genome once; it stays at the front of the handle's sequence
+// array until another genome is set or scrg_genome_clear() is called.
+scrg_status scrg_genome_set(scrg_ctx* c, const char* genome, uint64_t genome_len)
+{
+    if (!c || (genome_len && !genome)) return SCRG_ERR_INVALID_ARG;
+    return guarded(c, [&] {
+        void* st = ctx_state(c);
+        if (!st) return c->fail(SCRG_ERR_NO_DEVICE, "no usable HIP device for the host path");
+        std::string err;
+        static const char empty_genome[1] = {0};
+        const scrg_status s = scrg_host::genome_set(st, genome ? genome : empty_genome, genome_len, &err);
+        if (s != SCRG_OK) c->fail(s, err.c_str());
+        return s;
+    });
+}
+
+void scrg_genome_clear(scrg_ctx* c)
+{
+    if (c && c->host_state) scrg_host::genome_clear(c->host_state);
+}
+
+scrg_status scrg_align_mapping_resident(scrg_ctx* c, const scrg_params* params, uint64_t n_reads, const char* const* reads,
+                                        const uint64_t* read_lens, const uint64_t* cand_offsets, const uint64_t* cand_start,
+                                        const uint8_t* cand_reverse, scrg_result** out)
+{
+    if (!c || !out) return SCRG_ERR_INVALID_ARG;
+    *out = nullptr;
+    return guarded(c, [&] {
+        if (!c->host_state || !scrg_host::genome_resident(c->host_state, nullptr))
+            return c->fail(SCRG_ERR_INVALID_ARG, "no resident genome: call scrg_genome_set first");
+        scrg_host::Batch b;
+        std::vector<uint32_t> pair_read;
+        std::string err;
+        scrg_status s = mapping_batch(n_reads, reads, read_lens, cand_offsets, cand_start, cand_reverse, &b, &pair_read, &err);
+        if (s != SCRG_OK) return c->fail(s, err.c_str());
+        b.genome = nullptr;                                  // the resident one
+        return ctx_align(c, params, b, out);
+    });
+}
+
+scrg_status scrg_align_pairs_multi(const int32_t* devices, int32_t n_devices, const scrg_params* params, uint64_t n_pairs,
+                                   const char* const* texts, const uint64_t* text_lens, const char* const* queries,
+                                   const uint64_t* query_lens, scrg_result** out)
+{
+    if (!out || !devices || n_devices < 1 || n_devices > 64) return SCRG_ERR_INVALID_ARG;
+    *out = nullptr;
+    return multi_guarded([&] {
+        scrg_host::Batch b;
+        std::string err;
+        scrg_status s = pairs_batch(n_pairs, texts, text_lens, queries, query_lens, &b, &err);
+        if (s != SCRG_OK) { g_multi_error = err; return s; }
+        return multi_align(devices, n_devices, params, b, out);
+    });
+}
+
+scrg_status scrg_align_mapping_multi(const int32_t* devices, int32_t n_devices, const scrg_params* params, const char* genome,
+                                     uint64_t genome_len, uint64_t n_reads, const char* const* reads, const uint64_t* read_lens,
+                                     const uint64_t* cand_offsets, const uint64_t* cand_start, const uint8_t* cand_reverse,
+                                     scrg_result** out)
+{
+    if (!out || !devices || n_devices < 1 || n_devices > 64 || (genome_len && !genome)) return SCRG_ERR_INVALID_ARG;
+    *out = nullptr;
+    return multi_guarded([&] {
+        scrg_host::Batch b;
+        std::vector<uint32_t> pair_read;
+        std::string err;
+        scrg_status s = mapping_batch(n_reads, reads, read_lens, cand_offsets, cand_start, cand_reverse, &b, &pair_read, &err);
+        if (s != SCRG_OK) { g_multi_error = err; return s; }
+        static const char empty_genome[1] = {0};
+        b.genome = genome ? genome : empty_genome;
+        b.genome_len = genome_len;
+        return multi_align(devices, n_devices, params, b, out);
+    });
+}
+
+scrg_status scrg_host_plan(const scrg_params* params, int32_t n_devices, uint64_t n_pairs, const uint64_t* text_lens,
+                           const uint64_t* read_lens, uint32_t* issue_order, uint64_t* chunk_first, uint64_t chunk_cap, uint64_t* n_chunks)
+{
+    if (n_devices < 1 || !n_chunks || (n_pairs && !read_lens)) return SCRG_ERR_INVALID_ARG;
+    return multi_guarded([&] {
+        scrg_params p;
+        if (!resolve_params(params, &p)) return (scrg_status)SCRG_ERR_INVALID_ARG;
+        scrg_host::Batch b;
+        std::vector<uint64_t> zeros;
+        b.n_pairs = n_pairs;
+        b.mapping = false;
+        b.read_lens = read_lens;
+        if (!text_lens) {
+            zeros.assign(n_pairs, 0);
+            text_lens = zeros.data();
+        }
+        b.text_lens = text_lens;
+        return scrg_host::plan(p, n_devices, b, issue_order, chunk_first, chunk_cap, n_chunks);
+    });
+}
+
+void scrg_multi_release(void)
+{
+    std::lock_guard<std::mutex> g(g_multi_mu);
+    for (auto& ds : g_multi_states) scrg_host::state_free(ds.second);
+    g_multi_states.clear();
+    g_multi_busy.clear();
+}
+
+const char* scrg_multi_last_error(void) { return g_multi_error.c_str(); }
 
 }  // extern "C"

@@ -1,0 +1,1037 @@
+// scrg_host.cpp — the host-pointer entry points as a PIPELINE over chunks, streams and GPUs.
+//
+// What the reference does around its kernel (src/genasm_gpu.cu:890-1065: convert and concatenate the sequences, size the
+// CIGAR storage, launch, walk the lists into strings) happens here per CHUNK of a few thousand pairs, four chunks in
+// flight per GPU, so that the PCIe transfers, the kernels and the host's own work overlap:
+//
+//   host   pack the chunk's sequences to 2 bits per base (AVX2: 32 bases per load, two movemasks) straight into pinned
+//          memory, in the lane-interleaved layout the align kernel reads best — a quarter of the bytes of ASCII cross PCIe
+//   H2D    packed sequences + 8..16 bytes per pair; the 48-byte problem descriptors are built on the device
+//   GPU    genasm_lane_kernel, per-pair text lengths, offsets by prefix sum, run compaction, "%d%c" rendering of the text
+//   D2H    dense runs, text, offsets, scores of the chunk into pinned staging; two sizes come back first
+//   host   the chunk's results are copied to their place in the result arrays (threads), offsets get their base
+//
+// A batch is cut in issue order (longest read first, src/tests.cu:375-377); chunk k goes to device k mod N, so several
+// GPUs share one call (scrg_align_pairs_multi: two host threads, four streams and four buffer sets per device).
+// Results are assembled in issue order as chunks finish and put into caller order at the end (nothing to do when the
+// batch already was in issue order).  No CPU fallback anywhere: without a device every entry point fails.
+#include <hip/hip_runtime.h>
+#include <immintrin.h>
+
+#include <condition_variable>
+#include <cstdio>
+#include <numeric>
+#include <shared_mutex>
+
+#include "genasm_kernels.h"
+#include "host_path.h"
+#include "scrg_internal.h"
+
+namespace {
+
+using scrg_int::DevBuf;
+using scrg_int::g_pool;
+using scrg_int::HostPinned;
+using scrg_int::now_ns;
+using scrg_int::parallel_for;
+
+constexpr int NSLOT = 4;                                 // chunks in flight per device (HIP has 4 hardware queues per process and device)
+constexpr size_t LAG2 = 2;                                // a chunk's sizes are looked at this many chunks after it was launched
+constexpr uint64_t GROUP = 64;
+constexpr uint64_t SEQ_PAD = 2 * GROUP + 2;              // SCRG_SEQ_PAD_WORDS_STRIDED(64)
+
+// ---------------------------------------------------------------------------------------------------------------
+// ASCII -> planar 2-bit on the host.  One uint64 per 32 bases: bit k of the low dword = bit 0 of base k's code, bit k of
+// the high dword = bit 1 (A0 C1 G2 T3, src/genasm_cpu.cpp:87-90; lower case too, :462-493).  (c >> 1) & 3 gives
+// A0 C1 T2 G3; code = x ^ (x >> 1).  Returns the word; *bad gets a bit for every byte that is not one of ACGTacgt.
+// ---------------------------------------------------------------------------------------------------------------
+__attribute__((target("avx2"))) inline uint64_t pack32_avx2(const char* p, uint32_t* bad)
+{
+    const __m256i x = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(p));
+    const uint32_t b1 = (uint32_t)_mm256_movemask_epi8(_mm256_slli_epi16(x, 6));      // bit 1 of every byte
+    const uint32_t b2 = (uint32_t)_mm256_movemask_epi8(_mm256_slli_epi16(x, 5));      // bit 2
+    const __m256i u = _mm256_and_si256(x, _mm256_set1_epi8((char)0xDF));
+    const __m256i ok = _mm256_or_si256(_mm256_or_si256(_mm256_cmpeq_epi8(u, _mm256_set1_epi8('A')), _mm256_cmpeq_epi8(u, _mm256_set1_epi8('C'))),
+                                       _mm256_or_si256(_mm256_cmpeq_epi8(u, _mm256_set1_epi8('G')), _mm256_cmpeq_epi8(u, _mm256_set1_epi8('T'))));
+    *bad = ~(uint32_t)_mm256_movemask_epi8(ok);
+    return ((uint64_t)b2 << 32) | (uint64_t)(b1 ^ b2);
+}
+
+inline uint64_t pack32_scalar(const char* p, uint32_t* bad)
+{
+    uint32_t lo = 0, hi = 0, bd = 0;
+    for (unsigned k = 0; k < 32; k++) {
+        const unsigned c = (unsigned char)p[k], u = c & 0xDFu;
+        const unsigned x0 = (c >> 1) & 1u, x1 = (c >> 2) & 1u;
+        lo |= (x0 ^ x1) << k;
+        hi |= x1 << k;
+        bd |= (u == 'A' || u == 'C' || u == 'G' || u == 'T' ? 0u : 1u) << k;
+    }
+    *bad = bd;
+    return ((uint64_t)hi << 32) | lo;
+}
+
+const bool g_have_avx2 = __builtin_cpu_supports("avx2");
+
+inline char complement_base(char c)
+{
+    switch (c) {
+    case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A';
+    case 'a': return 't'; case 'c': return 'g'; case 'g': return 'c'; case 't': return 'a';
+    default: return c;   // left as is: counted as a bad base
+    }
+}
+
+// words [w_from, words) of one sequence at dst[w * stride] (zero beyond the sequence); returns true if a bad base was seen
+bool pack_sequence(const char* src, uint64_t len, bool revcomp, uint64_t* dst, uint64_t stride, uint64_t words, uint64_t w_from = 0)
+{
+    bool bad_any = false;
+    const uint64_t full = len / 32;
+    uint32_t bad = 0;
+    if (!revcomp) {
+        if (g_have_avx2)
+            for (uint64_t w = w_from; w < full; w++) { dst[w * stride] = pack32_avx2(src + 32 * w, &bad); bad_any |= bad != 0; }
+        else
+            for (uint64_t w = w_from; w < full; w++) { dst[w * stride] = pack32_scalar(src + 32 * w, &bad); bad_any |= bad != 0; }
+    }
+    char tmp[32];
+    for (uint64_t w = revcomp ? w_from : std::max(full, w_from); 32 * w < len; w++) {
+        const uint64_t n = std::min<uint64_t>(32, len - 32 * w);
+        if (revcomp) for (uint64_t k = 0; k < n; k++) tmp[k] = complement_base(src[len - 1 - (32 * w + k)]);
+        else memcpy(tmp, src + 32 * w, n);
+        if (n < 32) memset(tmp + n, 'A', 32 - n);
+        uint64_t v = g_have_avx2 ? pack32_avx2(tmp, &bad) : pack32_scalar(tmp, &bad);
+        if (n < 32) {                        // padding encodes as A = 0 anyway; keep only the real bases' error bits
+            bad &= (1u << n) - 1u;
+        }
+        dst[w * stride] = v;
+        bad_any |= bad != 0;
+    }
+    for (uint64_t w = std::max((len + 31) / 32, w_from); w < words; w++) dst[w * stride] = 0;
+    return bad_any;
+}
+
+// Eight forward rows of one group of the lane-interleaved layout at once (dst[w * 64 + l], l = 0..7 consecutive lanes):
+// the whole words all eight have are packed word by word across the rows, so that every store completes a 64-byte line
+// (row by row, consecutive stores of a row are 512 bytes apart); the rest of each row follows row by row.
+__attribute__((target("avx2"))) bool pack_rows8_avx2(const char* const* src, const uint64_t* len, uint64_t* dst, uint64_t words)
+{
+    uint64_t common = ~0ull;
+    for (int l = 0; l < 8; l++) common = std::min(common, len[l] / 32);
+    uint32_t bad_acc = 0, bad = 0;
+    for (uint64_t w = 0; w < common; w++) {
+        uint64_t* const line = dst + w * GROUP;
+        for (int l = 0; l < 8; l++) {
+            line[l] = pack32_avx2(src[l] + 32 * w, &bad);
+            bad_acc |= bad;
+        }
+    }
+    bool bad_any = bad_acc != 0;
+    for (int l = 0; l < 8; l++) bad_any |= pack_sequence(src[l], len[l], false, dst + l, GROUP, words, common);
+    return bad_any;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// per-device state
+// ---------------------------------------------------------------------------------------------------------------
+struct Slot {
+    hipStream_t stream = nullptr;
+    scrg_ctx* ctx = nullptr;                 // a handle of the device-pointer layer bound to `stream`
+    hipEvent_t ev_tot = nullptr, ev_done = nullptr;
+    HostPinned h_seq, h_meta, h_out, h_tot;
+    DevBuf d_meta, d_desc, d_slices, d_ed, d_nruns, d_status, d_cnt64, d_len64, d_runoff, d_textoff, d_tot, d_dense, d_text, d_temp;
+    // the chunk in flight
+    uint64_t n = 0, first = 0;               // pairs, first issue index
+    uint64_t tot_runs = 0, tot_text = 0;
+    int64_t t_pack_ns = 0;
+};
+
+struct DeviceState {
+    int device = 0, n_cus = 0;
+    DevBuf d_seq;                            // [ genome | slot 0 | slot 1 | slot 2 ]
+    uint64_t genome_words = 0, genome_len = 0;
+    bool genome_ok = false;                  // d_seq starts with a packed genome
+    uint64_t slot_words = 0;
+    Slot slot[NSLOT];
+    std::mutex mu;                           // one call at a time per device state
+    std::string err;
+};
+
+#define HTRY(ds, call)                                                                                   \
+    do {                                                                                                 \
+        hipError_t e__ = (call);                                                                         \
+        if (e__ != hipSuccess) {                                                                         \
+            (ds)->err = std::string(#call) + ": " + hipGetErrorString(e__);                              \
+            (void)hipGetLastError();                                                                     \
+            return e__ == hipErrorOutOfMemory ? SCRG_ERR_OOM : SCRG_ERR_HIP;                             \
+        }                                                                                                \
+    } while (0)
+
+// the sequence array: genome first (so that a candidate's text offset is its start_in_reference), then one region per slot
+scrg_status ensure_seq(DeviceState* ds, uint64_t genome_words, uint64_t slot_words)
+{
+    const uint64_t gpad = genome_words ? genome_words + SCRG_SEQ_PAD_WORDS : 0;
+    const uint64_t need_slot = std::max(slot_words, ds->slot_words);
+    const uint64_t have_g = ds->genome_words ? ds->genome_words + SCRG_SEQ_PAD_WORDS : 0;
+    if (gpad == have_g && need_slot == ds->slot_words && ds->d_seq.p) return SCRG_OK;
+    HTRY(ds, hipSetDevice(ds->device));
+    HTRY(ds, hipDeviceSynchronize());
+    DevBuf bigger;
+    const uint64_t grow_slot = need_slot > ds->slot_words ? need_slot + need_slot / 4 : need_slot;
+    HTRY(ds, bigger.ensure((gpad + NSLOT * grow_slot + 8) * sizeof(uint64_t)));
+    if (ds->genome_ok && gpad == have_g && gpad)         // keep a resident genome
+        HTRY(ds, hipMemcpy(bigger.p, ds->d_seq.p, gpad * sizeof(uint64_t), hipMemcpyDeviceToDevice));
+    else
+        ds->genome_ok = false;
+    ds->d_seq.release();
+    ds->d_seq = bigger;
+    ds->genome_words = genome_words;
+    ds->slot_words = grow_slot;
+    return SCRG_OK;
+}
+
+scrg_status pack_genome(DeviceState* ds, const char* genome, uint64_t genome_len)
+{
+    const uint64_t words = (genome_len + 31) / 32;
+    ds->genome_ok = false;
+    scrg_status s = ensure_seq(ds, words, ds->slot_words);
+    if (s != SCRG_OK) return s;
+    Slot& sl = ds->slot[0];
+    HTRY(ds, hipSetDevice(ds->device));
+    HTRY(ds, sl.h_seq.ensure((words + SCRG_SEQ_PAD_WORDS) * sizeof(uint64_t)));
+    uint64_t* const h = static_cast<uint64_t*>(sl.h_seq.p);
+    const uint64_t PIECE = 1u << 15;                    // words per work item: 1 Mbase
+    std::atomic<int> bad{0};
+    parallel_for((words + PIECE - 1) / PIECE, [&](uint64_t i) {
+        const uint64_t w0 = i * PIECE, w1 = std::min(words, w0 + PIECE);
+        const uint64_t b0 = 32 * w0, b1 = std::min(genome_len, 32 * w1);
+        if (pack_sequence(genome + b0, b1 - b0, false, h + w0, 1, w1 - w0)) bad.store(1, std::memory_order_relaxed);
+    }, true);
+    for (uint64_t w = words; w < words + SCRG_SEQ_PAD_WORDS; w++) h[w] = 0;
+    if (bad.load()) {
+        ds->err = "genome contains characters other than ACGTacgt";
+        return SCRG_ERR_BAD_BASE;
+    }
+    HTRY(ds, hipMemcpyAsync(ds->d_seq.p, h, (words + SCRG_SEQ_PAD_WORDS) * sizeof(uint64_t), hipMemcpyHostToDevice, sl.stream));
+    HTRY(ds, hipStreamSynchronize(sl.stream));
+    ds->genome_len = genome_len;
+    ds->genome_ok = true;
+    return SCRG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// a call
+// ---------------------------------------------------------------------------------------------------------------
+struct Grow {                          // a result array that is appended to chunk by chunk
+    char* p = nullptr;
+    size_t cap = 0;
+};
+
+struct Call {
+    const scrg_host::Batch* b = nullptr;
+    scrg_params p;
+    uint64_t n = 0;
+    std::vector<uint32_t> order;       // issue index -> caller index
+    bool identity = true;
+    std::vector<uint64_t> chunk_first; // issue index of every chunk's first pair, + n at the end
+    int want_runs = 1, want_text = 1;
+
+    // results in issue order
+    std::shared_mutex grow_mu;
+    Grow runs, text;
+    uint64_t* iss_run_off = nullptr;   // [n + 1]
+    uint64_t* iss_text_off = nullptr;  // [n + 1]
+    int64_t* iss_ed = nullptr;
+    uint32_t* iss_status = nullptr;
+    // chunk totals, published in any order; bases are prefix sums over them
+    std::mutex tot_mu;
+    std::condition_variable tot_cv;
+    std::vector<uint64_t> c_runs, c_text;
+    std::vector<char> c_known;
+    // status
+    std::atomic<int> status{SCRG_OK};
+    std::atomic<int> any_overflow{0};
+    std::mutex err_mu;
+    std::string err;
+    std::atomic<int64_t> kernel_ns{0}, pack_ns{0};
+    unsigned threads_per_worker = 16;
+
+    void fail(scrg_status s, const std::string& what)
+    {
+        int expect = SCRG_OK;
+        if (status.compare_exchange_strong(expect, s)) {
+            std::lock_guard<std::mutex> g(err_mu);
+            err = what;
+        }
+        tot_cv.notify_all();
+    }
+    bool failed() const { return status.load() != SCRG_OK; }
+};
+
+inline uint64_t read_of(const Call& c, uint64_t p) { return c.b->mapping ? c.b->pair_read[p] : p; }
+
+// `hint`: what the whole call is expected to need (from the first chunk that arrives: bytes per pair x pairs + 8 %)
+bool grow_to(Call& c, Grow& g, size_t used, size_t need, size_t hint)
+{
+    if (need <= g.cap) return true;
+    std::unique_lock<std::shared_mutex> lk(c.grow_mu);
+    if (need <= g.cap) return true;
+    const size_t cap = std::max(std::max(need + need / 8, g.cap + g.cap / 2), hint);
+    char* np = static_cast<char*>(g_pool.get(cap, false));
+    if (!np) return false;
+    if (g.p && used) {
+        const size_t CH = 1u << 22;
+        parallel_for((used + CH - 1) / CH, [&](uint64_t i) { memcpy(np + i * CH, g.p + i * CH, std::min(CH, used - i * CH)); }, true);
+    }
+    g_pool.put(g.p);
+    g.p = np;
+    g.cap = cap;
+    return true;
+}
+
+// stage 1: pack the chunk, send it, align it, lay its results out (sizes come back through ev_tot)
+scrg_status stage1(DeviceState* ds, Slot& sl, Call& c, uint64_t chunk)
+{
+    const scrg_host::Batch& b = *c.b;
+    const uint64_t first = c.chunk_first[chunk], n = c.chunk_first[chunk + 1] - first;
+    sl.first = first;
+    sl.n = n;
+    const int64_t t0 = now_ns();
+    HTRY(ds, hipSetDevice(ds->device));
+
+    // ---- layout of the chunk's sequences: read rows (mapping: one row per run of pairs with the same read and strand), text rows
+    std::vector<uint32_t> row(b.mapping ? n : 0);
+    std::vector<uint64_t> row_pair;                  // a pair that owns each row (its read is the row's content)
+    uint64_t max_read = 0, max_text = 0;
+    {
+        // (blocks of 16 k pairs in parallel: flags "a new row starts here", block counts, then the row numbers)
+        const uint64_t BLK = 1u << 14, nb = (n + BLK - 1) / BLK;
+        std::vector<uint64_t> blk_rows(nb + 1, 0), blk_mr(nb, 0), blk_mt(nb, 0);
+        auto starts_row = [&](uint64_t i) -> bool {
+            if (i == 0) return true;
+            const uint64_t p = c.order[first + i], q = c.order[first + i - 1];
+            return !(b.pair_read[q] == b.pair_read[p] && (b.cand_reverse && b.cand_reverse[q]) == (b.cand_reverse && b.cand_reverse[p]));
+        };
+        parallel_for(nb, [&](uint64_t k) {
+            uint64_t cnt = 0, mr = 0, mt = 0;
+            for (uint64_t i = k * BLK; i < std::min(n, (k + 1) * BLK); i++) {
+                const uint64_t p = c.order[first + i];
+                if (b.mapping) {
+                    cnt += starts_row(i) ? 1 : 0;
+                    mr = std::max<uint64_t>(mr, b.read_lens[b.pair_read[p]]);
+                } else {
+                    mr = std::max<uint64_t>(mr, b.read_lens[p]);
+                    mt = std::max<uint64_t>(mt, b.text_lens[p]);
+                }
+            }
+            blk_rows[k + 1] = cnt;
+            blk_mr[k] = mr;
+            blk_mt[k] = mt;
+        }, true, c.threads_per_worker);
+        for (uint64_t k = 0; k < nb; k++) {
+            blk_rows[k + 1] += blk_rows[k];
+            max_read = std::max(max_read, blk_mr[k]);
+            max_text = std::max(max_text, blk_mt[k]);
+        }
+        if (b.mapping) {
+            row_pair.resize(blk_rows[nb]);
+            parallel_for(nb, [&](uint64_t k) {
+                uint64_t r = blk_rows[k];
+                for (uint64_t i = k * BLK; i < std::min(n, (k + 1) * BLK); i++) {
+                    if (starts_row(i)) row_pair[r++] = c.order[first + i];
+                    row[i] = (uint32_t)(r - 1);
+                }
+            }, true, c.threads_per_worker);
+        }
+    }
+    const uint64_t n_rows = b.mapping ? row_pair.size() : n;
+    const uint64_t rw = std::max<uint64_t>(1, (max_read + 31) / 32), tw = b.mapping ? 0 : std::max<uint64_t>(1, (max_text + 31) / 32);
+    const uint64_t r_groups = (n_rows + GROUP - 1) / GROUP, t_groups = b.mapping ? 0 : (n + GROUP - 1) / GROUP;
+    const uint64_t read_words = r_groups * GROUP * rw, text_words = t_groups * GROUP * tw;
+    const uint64_t seq_words = read_words + text_words + SEQ_PAD;
+    if (seq_words > ds->slot_words) {
+        ds->err = "internal: chunk larger than its slot";
+        return SCRG_ERR_INVALID_ARG;
+    }
+    HTRY(ds, sl.h_seq.ensure(seq_words * sizeof(uint64_t)));
+    uint64_t* const h = static_cast<uint64_t*>(sl.h_seq.p);
+
+    // ---- pack: one work item per group of 64 rows (the group's block of the interleaved layout is written by one thread;
+    // the GenASM-row kernels, lanes_per_pair >= 4, read contiguous rows instead)
+    const bool linear = c.p.lanes_per_pair != 1;
+    const uint64_t rstride = linear ? 1 : GROUP;
+    std::atomic<int> bad{0};
+    parallel_for(r_groups + t_groups, [&](uint64_t g) {
+        const bool is_text = g >= r_groups;
+        const uint64_t gi = is_text ? g - r_groups : g, W = is_text ? tw : rw;
+        uint64_t* const blockp = h + (is_text ? read_words : 0) + gi * GROUP * W;
+        const uint64_t rows_here = std::min<uint64_t>(GROUP, (is_text ? n : n_rows) - gi * GROUP);
+        bool bd = false;
+        // the rows of this group: source, length, strand
+        const char* rsrc[GROUP];
+        uint64_t rlen[GROUP];
+        bool rrev[GROUP];
+        for (uint64_t l = 0; l < GROUP; l++) {
+            rsrc[l] = nullptr;
+            rlen[l] = 0;
+            rrev[l] = false;
+            if (l >= rows_here) continue;
+            const uint64_t r = gi * GROUP + l;
+            if (is_text) {
+                const uint64_t p = c.order[first + r];
+                rsrc[l] = b.texts[p];
+                rlen[l] = b.text_lens[p];
+            } else if (b.mapping) {
+                const uint64_t p = row_pair[r], rd = b.pair_read[p];
+                rsrc[l] = b.reads[rd];
+                rlen[l] = b.read_lens[rd];
+                rrev[l] = b.cand_reverse && b.cand_reverse[p];
+            } else {
+                const uint64_t p = c.order[first + r];
+                rsrc[l] = b.reads[p];
+                rlen[l] = b.read_lens[p];
+            }
+        }
+        for (uint64_t l0 = 0; l0 < GROUP; l0 += 8) {
+            bool plain = !linear && g_have_avx2;
+            for (uint64_t l = l0; l < l0 + 8; l++) plain = plain && !rrev[l] && (rlen[l] == 0 || rsrc[l] != nullptr);
+            if (plain) {
+                static const char none[1] = {0};
+                const char* s8[8];
+                for (int k = 0; k < 8; k++) s8[k] = rsrc[l0 + k] ? rsrc[l0 + k] : none;
+                bd |= pack_rows8_avx2(s8, rlen + l0, blockp + l0, W);
+            } else {
+                for (uint64_t l = l0; l < l0 + 8; l++)
+                    bd |= pack_sequence(rsrc[l] ? rsrc[l] : "", rlen[l], rrev[l], linear ? blockp + l * W : blockp + l, rstride, W);
+            }
+        }
+        if (bd) bad.store(1, std::memory_order_relaxed);
+    }, true, c.threads_per_worker);
+    for (uint64_t w = read_words + text_words; w < seq_words; w++) h[w] = 0;
+    if (bad.load()) {
+        ds->err = "input contains characters other than ACGTacgt";
+        return SCRG_ERR_BAD_BASE;
+    }
+
+    // ---- per-pair scalars: read length (+ text length | start in the genome and read row)
+    const size_t meta_bytes = n * (b.mapping ? 16 : 8) + 64;
+    HTRY(ds, sl.h_meta.ensure(meta_bytes));
+    uint32_t* const m_rl = static_cast<uint32_t*>(sl.h_meta.p);
+    uint32_t* const m_tl = m_rl + n;                          // pairwise: text length | mapping: read row
+    uint64_t* const m_st = reinterpret_cast<uint64_t*>(static_cast<char*>(sl.h_meta.p) + ((8 * n + 15) & ~(size_t)15));
+    parallel_for(n, [&](uint64_t i) {
+        const uint64_t p = c.order[first + i];
+        if (b.mapping) {
+            m_rl[i] = (uint32_t)b.read_lens[b.pair_read[p]];
+            m_tl[i] = row[i];
+            m_st[i] = b.cand_start[p];
+        } else {
+            m_rl[i] = (uint32_t)b.read_lens[p];
+            m_tl[i] = (uint32_t)std::min<uint64_t>(b.text_lens[p], 0xffffffffull);
+        }
+    }, false, c.threads_per_worker);
+    sl.t_pack_ns = now_ns() - t0;
+
+    // ---- device side
+    const uint64_t cap = (2 * max_read + 8 + 15) & ~(uint64_t)15;         // runs per slice (src/genasm_gpu.cu:906-911: 2 * read_len)
+    const uint64_t slot_index = (uint64_t)(&sl - ds->slot);
+    const uint64_t gpad = ds->genome_words ? ds->genome_words + SCRG_SEQ_PAD_WORDS : 0;
+    const uint64_t base_word = gpad + slot_index * ds->slot_words;
+    uint64_t* const d_seq = ds->d_seq.as<uint64_t>();
+    HTRY(ds, sl.d_meta.ensure(meta_bytes));
+    HTRY(ds, sl.d_desc.ensure(n * sizeof(scrg_pair_desc)));
+    HTRY(ds, sl.d_slices.ensure(n * cap * sizeof(scrg_run)));
+    HTRY(ds, sl.d_ed.ensure(n * 8));
+    HTRY(ds, sl.d_nruns.ensure(n * 4));
+    HTRY(ds, sl.d_status.ensure(n * 4));
+    HTRY(ds, sl.d_cnt64.ensure(n * 8));
+    HTRY(ds, sl.d_len64.ensure(n * 8));
+    HTRY(ds, sl.d_runoff.ensure(n * 8));
+    HTRY(ds, sl.d_textoff.ensure(n * 8));
+    HTRY(ds, sl.d_tot.ensure(16));
+    const size_t temp_bytes = scrg::host_scan_temp_bytes(n);
+    HTRY(ds, sl.d_temp.ensure(temp_bytes + 256));
+    HTRY(ds, sl.h_tot.ensure(16));
+    HTRY(ds, hipMemcpyAsync(d_seq + base_word, h, seq_words * sizeof(uint64_t), hipMemcpyHostToDevice, sl.stream));
+    HTRY(ds, hipMemcpyAsync(sl.d_meta.p, sl.h_meta.p, meta_bytes, hipMemcpyHostToDevice, sl.stream));
+    scrg::HostDescArgs da{};
+    da.n = n;
+    da.desc = sl.d_desc.as<scrg_pair_desc>();
+    da.read_len = sl.d_meta.as<uint32_t>();
+    da.text_len = b.mapping ? nullptr : sl.d_meta.as<uint32_t>() + n;
+    da.row = b.mapping ? sl.d_meta.as<uint32_t>() + n : nullptr;
+    da.start = b.mapping ? reinterpret_cast<const uint64_t*>(sl.d_meta.as<char>() + ((8 * n + 15) & ~(size_t)15)) : nullptr;
+    da.genome_len = ds->genome_len;
+    da.read_base = base_word;
+    da.read_words = rw;
+    da.text_base = base_word + read_words;
+    da.text_words = tw;
+    da.cap = cap;
+    da.linear = linear ? 1u : 0u;
+    HTRY(ds, scrg::launch_build_desc(da, sl.stream));
+    scrg_params pp = c.p;
+    pp.read_stride_words = (int32_t)rstride;
+    pp.text_stride_words = b.mapping ? 1 : (int32_t)rstride;
+    scrg_status s = scrg_align_device(sl.ctx, &pp, n, d_seq, sl.d_desc.as<scrg_pair_desc>(), sl.d_slices.as<scrg_run>(), sl.d_ed.as<int64_t>(),
+                                      sl.d_nruns.as<uint32_t>(), sl.d_status.as<uint32_t>());
+    if (s != SCRG_OK) {
+        ds->err = scrg_last_error(sl.ctx);
+        return s;
+    }
+    HTRY(ds, scrg::launch_result_layout(n, sl.d_desc.as<scrg_pair_desc>(), sl.d_slices.as<uint16_t>(), sl.d_nruns.as<uint32_t>(),
+                                        sl.d_cnt64.as<uint64_t>(), sl.d_len64.as<uint64_t>(), sl.d_runoff.as<uint64_t>(),
+                                        sl.d_textoff.as<uint64_t>(), sl.d_tot.as<uint64_t>(), sl.d_temp.p, temp_bytes, c.want_text, ds->n_cus,
+                                        sl.stream));
+    HTRY(ds, hipMemcpyAsync(sl.h_tot.p, sl.d_tot.p, 16, hipMemcpyDeviceToHost, sl.stream));
+    HTRY(ds, hipEventRecord(sl.ev_tot, sl.stream));
+    return SCRG_OK;
+}
+
+// stage 2: the sizes are known — compact the runs, render the text, bring everything back
+scrg_status stage2(DeviceState* ds, Slot& sl, Call& c, uint64_t chunk)
+{
+    HTRY(ds, hipSetDevice(ds->device));
+    HTRY(ds, hipEventSynchronize(sl.ev_tot));
+    const uint64_t* const tot = static_cast<const uint64_t*>(sl.h_tot.p);
+    sl.tot_runs = tot[0];
+    sl.tot_text = tot[1];
+    {
+        std::lock_guard<std::mutex> g(c.tot_mu);
+        c.c_runs[chunk] = sl.tot_runs;
+        c.c_text[chunk] = sl.tot_text;
+        c.c_known[chunk] = 1;
+    }
+    c.tot_cv.notify_all();
+    float ms = 0.f;
+    if (scrg_last_kernel_ms(sl.ctx, &ms) == SCRG_OK) c.kernel_ns.fetch_add((int64_t)((double)ms * 1e6));
+    c.pack_ns.fetch_add(sl.t_pack_ns);
+    const uint64_t n = sl.n;
+    // staging: [ed 8n | status 4n (+pad) | run_off 8n | text_off 8n | runs 2R | text T]
+    const size_t o_ed = 0, o_st = 8 * n, o_ro = (o_st + 4 * n + 15) & ~(size_t)15, o_to = o_ro + 8 * n, o_runs = o_to + 8 * n;
+    const size_t o_text = (o_runs + 2 * sl.tot_runs + 15) & ~(size_t)15, total = o_text + sl.tot_text + 16;
+    HTRY(ds, sl.h_out.ensure(total));
+    char* const h = static_cast<char*>(sl.h_out.p);
+    HTRY(ds, sl.d_dense.ensure(2 * sl.tot_runs + 64));
+    if (c.want_text) HTRY(ds, sl.d_text.ensure(sl.tot_text + 64));
+    scrg_status s = scrg_compact_runs(sl.ctx, n, sl.d_desc.as<scrg_pair_desc>(), sl.d_slices.as<scrg_run>(), sl.d_nruns.as<uint32_t>(),
+                                      sl.d_runoff.as<uint64_t>(), sl.d_dense.as<scrg_run>());
+    if (s != SCRG_OK) {
+        ds->err = scrg_last_error(sl.ctx);
+        return s;
+    }
+    if (c.want_text)
+        HTRY(ds, scrg::launch_render_text(n, sl.d_dense.as<uint16_t>(), sl.d_runoff.as<uint64_t>(), sl.d_cnt64.as<uint64_t>(),
+                                          sl.d_textoff.as<uint64_t>(), sl.d_text.as<uint8_t>(), ds->n_cus, sl.stream));
+    HTRY(ds, hipMemcpyAsync(h + o_ed, sl.d_ed.p, 8 * n, hipMemcpyDeviceToHost, sl.stream));
+    HTRY(ds, hipMemcpyAsync(h + o_st, sl.d_status.p, 4 * n, hipMemcpyDeviceToHost, sl.stream));
+    HTRY(ds, hipMemcpyAsync(h + o_ro, sl.d_runoff.p, 8 * n, hipMemcpyDeviceToHost, sl.stream));
+    if (c.want_text) HTRY(ds, hipMemcpyAsync(h + o_to, sl.d_textoff.p, 8 * n, hipMemcpyDeviceToHost, sl.stream));
+    if (c.want_runs && sl.tot_runs) HTRY(ds, hipMemcpyAsync(h + o_runs, sl.d_dense.p, 2 * sl.tot_runs, hipMemcpyDeviceToHost, sl.stream));
+    if (c.want_text && sl.tot_text) HTRY(ds, hipMemcpyAsync(h + o_text, sl.d_text.p, sl.tot_text, hipMemcpyDeviceToHost, sl.stream));
+    HTRY(ds, hipEventRecord(sl.ev_done, sl.stream));
+    return SCRG_OK;
+}
+
+// stage 3: the chunk's results go to their place in the (issue order) result arrays
+scrg_status stage3(DeviceState* ds, Slot& sl, Call& c, uint64_t chunk)
+{
+    HTRY(ds, hipSetDevice(ds->device));
+    HTRY(ds, hipEventSynchronize(sl.ev_done));
+    // bases: everything the chunks before this one produced
+    uint64_t base_runs = 0, base_text = 0;
+    {
+        std::unique_lock<std::mutex> lk(c.tot_mu);
+        c.tot_cv.wait(lk, [&] {
+            if (c.failed()) return true;
+            for (uint64_t k = 0; k < chunk; k++)
+                if (!c.c_known[k]) return false;
+            return true;
+        });
+        if (c.failed()) return (scrg_status)c.status.load();
+        for (uint64_t k = 0; k < chunk; k++) {
+            base_runs += c.c_runs[k];
+            base_text += c.c_text[k];
+        }
+    }
+    const uint64_t n = sl.n, first = sl.first;
+    const size_t o_st = 8 * n, o_ro = (o_st + 4 * n + 15) & ~(size_t)15, o_to = o_ro + 8 * n, o_runs = o_to + 8 * n;
+    const size_t o_text = (o_runs + 2 * sl.tot_runs + 15) & ~(size_t)15;
+    const char* const h = static_cast<const char*>(sl.h_out.p);
+    const double per_pair_scale = 1.08 * (double)c.n / (double)std::max<uint64_t>(1, n);
+    if (c.want_runs && !grow_to(c, c.runs, 2 * base_runs, 2 * (base_runs + sl.tot_runs) + 2, (size_t)(2.0 * (double)sl.tot_runs * per_pair_scale) + 4096))
+        return SCRG_ERR_OOM;
+    if (c.want_text && !grow_to(c, c.text, base_text, base_text + sl.tot_text + 1, (size_t)((double)sl.tot_text * per_pair_scale) + 4096))
+        return SCRG_ERR_OOM;
+    {
+        std::shared_lock<std::shared_mutex> lk(c.grow_mu);
+        const size_t CH = 1u << 21;
+        const size_t rb = c.want_runs ? 2 * sl.tot_runs : 0, tb = c.want_text ? sl.tot_text : 0;
+        const uint64_t n_r = (rb + CH - 1) / CH, n_t = (tb + CH - 1) / CH;
+        parallel_for(n_r + n_t, [&](uint64_t i) {
+            if (i < n_r) memcpy(c.runs.p + 2 * base_runs + i * CH, h + o_runs + i * CH, std::min(CH, rb - i * CH));
+            else memcpy(c.text.p + base_text + (i - n_r) * CH, h + o_text + (i - n_r) * CH, std::min(CH, tb - (i - n_r) * CH));
+        }, true, c.threads_per_worker);
+    }
+    const int64_t* const ed = reinterpret_cast<const int64_t*>(h);
+    const uint32_t* const st = reinterpret_cast<const uint32_t*>(h + o_st);
+    const uint64_t* const ro = reinterpret_cast<const uint64_t*>(h + o_ro);
+    const uint64_t* const to = reinterpret_cast<const uint64_t*>(h + o_to);
+    std::atomic<int> ovf{0};
+    parallel_for(n, [&](uint64_t i) {
+        c.iss_ed[first + i] = ed[i];
+        c.iss_status[first + i] = st[i] ? (uint32_t)SCRG_ERR_CIGAR_OVERFLOW : (uint32_t)SCRG_OK;
+        if (st[i]) ovf.store(1, std::memory_order_relaxed);
+        c.iss_run_off[first + i] = base_runs + ro[i];
+        c.iss_text_off[first + i] = c.want_text ? base_text + to[i] : 0;
+    }, false, c.threads_per_worker);
+    if (ovf.load()) c.any_overflow.store(1);
+    return SCRG_OK;
+}
+
+// One device: a LAUNCH thread packs chunk i, sends it and starts its kernels, then looks at the sizes of chunk i - LAG2 and
+// starts its compaction, rendering and read-back; a COLLECT thread puts finished chunks into the result arrays.  A slot
+// is reused NSLOT chunks later, once its previous chunk has been collected.
+// (The align kernel of a chunk of 10 kb reads takes ~2 ms however small the chunk is — ~330 dependent window rounds —,
+// hence the two chunks between a launch and the look at its sizes: the launch thread should not wait for it.)
+void worker(DeviceState* ds, Call* c, int dev_index, int n_dev)
+{
+    std::vector<uint64_t> mine;
+    const uint64_t n_chunks = c->chunk_first.size() - 1;
+    for (uint64_t k = dev_index; k < n_chunks; k += n_dev) mine.push_back(k);
+    const size_t m = mine.size();
+    const bool timing = getenv("SCRG_HOST_TIMING") != nullptr;
+    const int64_t tw0 = now_ns();
+
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t ready = 0;            // chunks (local index) whose read-back has been enqueued: the collector may wait for them
+    size_t collected = 0;        // chunks the collector is done with
+    bool stop = false;
+
+    std::thread collector([&] {
+        for (size_t i = 0; i < m; i++) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return ready > i || stop; });
+                if (ready <= i) return;
+            }
+            const int64_t ta = now_ns();
+            scrg_status s = c->failed() ? (scrg_status)c->status.load() : stage3(ds, ds->slot[i % NSLOT], *c, mine[i]);
+            if (s != SCRG_OK) c->fail(s, ds->err.empty() ? std::string(scrg_status_string(s)) : ds->err);
+            if (timing)
+                fprintf(stderr, "[scrooge_amd host] dev %d chunk %zu collected at %.3f ms: stage3 %.3f ms\n", dev_index, i, (now_ns() - tw0) / 1e6,
+                        (now_ns() - ta) / 1e6);
+            {
+                std::lock_guard<std::mutex> g(mu);
+                collected = i + 1;
+            }
+            cv.notify_all();
+        }
+    });
+
+    for (size_t i = 0; i < m + LAG2; i++) {
+        if (c->failed()) break;
+        scrg_status s = SCRG_OK;
+        const int64_t ta = now_ns();
+        if (i < m) {
+            if (i >= (size_t)NSLOT) {               // the slot's previous chunk must have been collected
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return collected + NSLOT > i || c->failed(); });
+                if (c->failed()) break;
+            }
+            s = stage1(ds, ds->slot[i % NSLOT], *c, mine[i]);
+        }
+        const int64_t tb = now_ns();
+        if (s == SCRG_OK && i >= LAG2 && i - LAG2 < m) {
+            s = stage2(ds, ds->slot[(i - LAG2) % NSLOT], *c, mine[i - LAG2]);
+            if (s == SCRG_OK) {
+                {
+                    std::lock_guard<std::mutex> g(mu);
+                    ready = i - LAG2 + 1;
+                }
+                cv.notify_all();
+            }
+        }
+        if (timing)
+            fprintf(stderr, "[scrooge_amd host] dev %d step %zu at %.3f ms: stage1 %.3f (pack %.3f) stage2 %.3f ms\n", dev_index, i,
+                    (ta - tw0) / 1e6, (tb - ta) / 1e6, i < m ? ds->slot[i % NSLOT].t_pack_ns / 1e6 : 0.0, (now_ns() - tb) / 1e6);
+        if (s != SCRG_OK) {
+            c->fail(s, ds->err.empty() ? std::string(scrg_status_string(s)) : ds->err);
+            break;
+        }
+    }
+    {
+        std::lock_guard<std::mutex> g(mu);
+        stop = true;
+    }
+    cv.notify_all();
+    collector.join();
+    (void)hipSetDevice(ds->device);
+    for (Slot& sl : ds->slot) (void)hipStreamSynchronize(sl.stream);        // nothing of this call is in flight when it returns
+}
+
+// The plan of a call: the issue order (longest read first, src/tests.cu:375-377; stable, so a batch that is sorted already
+// keeps its order) and the chunks it is cut into.  Chunk k is processed by device state k mod n_states.
+void make_plan(Call& c, const scrg_params& resolved, int n_states, bool* sorted_issue_out)
+{
+    const scrg_host::Batch& b = *c.b;
+    const uint64_t n = c.n;
+    c.order.resize(n);
+    std::atomic<int> unsorted{0};
+    {
+        const uint64_t BLK = 1u << 16, nb = (n + BLK - 1) / BLK;
+        parallel_for(nb, [&](uint64_t blk) {
+            bool ok = true;
+            for (uint64_t k = blk * BLK; k < std::min(n, (blk + 1) * BLK); k++) {
+                c.order[k] = (uint32_t)k;
+                if (k && b.read_lens[read_of(c, k - 1)] < b.read_lens[read_of(c, k)]) ok = false;
+            }
+            if (!ok) unsorted.store(1, std::memory_order_relaxed);
+        }, true);
+    }
+    c.identity = true;
+    if (resolved.sort_by_length && unsorted.load()) {
+        std::stable_sort(c.order.begin(), c.order.end(),
+                         [&](uint32_t x, uint32_t y) { return b.read_lens[read_of(c, x)] > b.read_lens[read_of(c, y)]; });
+        c.identity = false;
+    }
+    // chunks in issue order: whole groups of 64 pairs.  A chunk's align kernel takes ~2 ms for 10 kb reads however few
+    // pairs it has, and only NSLOT of them run side by side: a small batch is cut into NSLOT chunks per device, a large one
+    // into chunks of at most 32 MB of packed sequence or 256 k pairs.  In sorted issue order the first pair of a chunk has
+    // its longest read.
+    const bool sorted_issue = resolved.sort_by_length || !unsorted.load();
+    const uint64_t max_words = 4u << 20, want_chunks = (uint64_t)n_states * NSLOT;
+    const uint64_t target = std::min<uint64_t>(1u << 18, std::max<uint64_t>(512, (n / want_chunks + GROUP - 1) / GROUP * GROUP));
+    c.chunk_first.clear();
+    c.chunk_first.push_back(0);
+    uint64_t k = 0;
+    while (k < n) {
+        uint64_t e;
+        if (sorted_issue && b.mapping) {
+            const uint64_t w = std::max<uint64_t>(1, (b.read_lens[read_of(c, c.order[k])] + 31) / 32);
+            e = k + std::max<uint64_t>(GROUP, std::min(target, max_words / w / GROUP * GROUP));
+        } else {
+            uint64_t words = 0;
+            e = k;
+            while (e < n) {
+                const uint64_t p = c.order[e];
+                const uint64_t w = (b.read_lens[read_of(c, p)] + 31) / 32 + (b.mapping ? 0 : (b.text_lens[p] + 31) / 32);
+                if (e > k && (e - k) % GROUP == 0 && (e - k >= target || words + w > max_words)) break;
+                words += w;
+                e++;
+            }
+        }
+        e = std::min(e, n);
+        c.chunk_first.push_back(e);
+        k = e;
+    }
+    if (sorted_issue_out) *sorted_issue_out = sorted_issue;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+// interface (scrg_internal.h)
+// ---------------------------------------------------------------------------------------------------------------
+namespace scrg_host {
+
+// The issue order and the chunk boundaries a call with these lengths would use (no GPU involved): what the CPU tests check.
+scrg_status plan(const scrg_params& resolved, int n_states, const Batch& b, uint32_t* order_out, uint64_t* chunk_first_out,
+                 uint64_t chunk_cap, uint64_t* n_chunks_out)
+{
+    if (n_states < 1 || !n_chunks_out) return SCRG_ERR_INVALID_ARG;
+    Call c;
+    c.b = &b;
+    c.p = resolved;
+    c.n = b.n_pairs;
+    make_plan(c, resolved, n_states, nullptr);
+    const uint64_t nc = c.chunk_first.size() - 1;
+    *n_chunks_out = nc;
+    if (order_out) memcpy(order_out, c.order.data(), c.n * sizeof(uint32_t));
+    if (chunk_first_out) {
+        if (chunk_cap < nc + 1) return SCRG_ERR_CIGAR_OVERFLOW;
+        memcpy(chunk_first_out, c.chunk_first.data(), (nc + 1) * sizeof(uint64_t));
+    }
+    return SCRG_OK;
+}
+
+void* state_create(int device)
+{
+    int nd = 0;
+    if (hipGetDeviceCount(&nd) != hipSuccess || device < 0 || device >= nd) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    if (hipSetDevice(device) != hipSuccess) return nullptr;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return nullptr;
+    DeviceState* ds = new (std::nothrow) DeviceState();
+    if (!ds) return nullptr;
+    ds->device = device;
+    ds->n_cus = prop.multiProcessorCount;
+    // three streams of different priorities: HIP maps them to different hardware queues, so the kernels of consecutive
+    // chunks share the GPU instead of queueing behind each other
+    const int prio[NSLOT] = {0, -1, 1, 0};
+    for (int k = 0; k < NSLOT; k++) {
+        Slot& sl = ds->slot[k];
+        if (hipStreamCreateWithPriority(&sl.stream, hipStreamNonBlocking, prio[k]) != hipSuccess || hipEventCreateWithFlags(&sl.ev_tot, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming) != hipSuccess || scrg_ctx_create(device, &sl.ctx) != SCRG_OK ||
+            scrg_ctx_set_stream(sl.ctx, sl.stream) != SCRG_OK) {
+            state_free(ds);
+            return nullptr;
+        }
+    }
+    return ds;
+}
+
+void state_free(void* state)
+{
+    DeviceState* ds = static_cast<DeviceState*>(state);
+    if (!ds) return;
+    (void)hipSetDevice(ds->device);
+    (void)hipDeviceSynchronize();
+    for (Slot& sl : ds->slot) {
+        if (sl.ctx) scrg_ctx_destroy(sl.ctx);
+        if (sl.ev_tot) (void)hipEventDestroy(sl.ev_tot);
+        if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
+        if (sl.stream) (void)hipStreamDestroy(sl.stream);
+        for (HostPinned* hp : {&sl.h_seq, &sl.h_meta, &sl.h_out, &sl.h_tot}) hp->release();
+        for (DevBuf* db : {&sl.d_meta, &sl.d_desc, &sl.d_slices, &sl.d_ed, &sl.d_nruns, &sl.d_status, &sl.d_cnt64, &sl.d_len64, &sl.d_runoff,
+                           &sl.d_textoff, &sl.d_tot, &sl.d_dense, &sl.d_text, &sl.d_temp})
+            db->release();
+    }
+    ds->d_seq.release();
+    delete ds;
+}
+
+scrg_status genome_set(void* state, const char* genome, uint64_t genome_len, std::string* err)
+{
+    DeviceState* ds = static_cast<DeviceState*>(state);
+    if (!ds) return SCRG_ERR_NO_DEVICE;
+    std::lock_guard<std::mutex> g(ds->mu);
+    ds->err.clear();
+    scrg_status s = pack_genome(ds, genome, genome_len);
+    if (s != SCRG_OK && err) *err = ds->err;
+    return s;
+}
+
+void genome_clear(void* state)
+{
+    DeviceState* ds = static_cast<DeviceState*>(state);
+    if (!ds) return;
+    std::lock_guard<std::mutex> g(ds->mu);
+    ds->genome_ok = false;
+}
+
+bool genome_resident(void* state, uint64_t* genome_len)
+{
+    DeviceState* ds = static_cast<DeviceState*>(state);
+    if (!ds || !ds->genome_ok) return false;
+    if (genome_len) *genome_len = ds->genome_len;
+    return true;
+}
+
+scrg_status align(void* const* states, int n_states, const scrg_params& resolved, const Batch& b, scrg_result** out, std::string* err)
+{
+    const int64_t t_begin = now_ns();
+    auto set_err = [&](const std::string& e) { if (err) *err = e; };
+    if (!out || n_states < 1 || !states) return SCRG_ERR_INVALID_ARG;
+    *out = nullptr;
+    for (int d = 0; d < n_states; d++)
+        if (!states[d]) return SCRG_ERR_NO_DEVICE;
+    const uint64_t n = b.n_pairs;
+
+    scrg_result* r = static_cast<scrg_result*>(calloc(1, sizeof(scrg_result)));
+    if (!r) return SCRG_ERR_OOM;
+    r->n_pairs = n;
+    Call c;
+    c.b = &b;
+    c.p = resolved;
+    c.n = n;
+    c.want_runs = resolved.outputs != SCRG_OUT_TEXT;
+    c.want_text = resolved.outputs != SCRG_OUT_RUNS;
+    {
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        c.threads_per_worker = std::max(1u, std::min(16u, hw / (unsigned)n_states));
+    }
+    auto bail = [&](scrg_status s, const std::string& e) {
+        set_err(e);
+        g_pool.put(c.runs.p);
+        g_pool.put(c.text.p);
+        g_pool.put(c.iss_run_off);
+        g_pool.put(c.iss_text_off);
+        g_pool.put(c.iss_ed);
+        g_pool.put(c.iss_status);
+        scrg_result_free(r);
+        return s;
+    };
+
+    bool sorted_issue = false;
+    make_plan(c, resolved, n_states, &sorted_issue);
+    const uint64_t n_chunks = c.chunk_first.size() - 1;
+    c.c_runs.assign(n_chunks, 0);
+    c.c_text.assign(n_chunks, 0);
+    c.c_known.assign(n_chunks, 0);
+
+    // ---- result arrays in issue order
+    c.iss_ed = static_cast<int64_t*>(g_pool.get((n + 1) * 8, n < 4096));
+    c.iss_status = static_cast<uint32_t*>(g_pool.get((n + 1) * 4, n < 4096));
+    c.iss_run_off = static_cast<uint64_t*>(g_pool.get((n + 1) * 8, n < 4096));
+    c.iss_text_off = static_cast<uint64_t*>(g_pool.get((n + 1) * 8, n < 4096));
+    if (!c.iss_ed || !c.iss_status || !c.iss_run_off || !c.iss_text_off) return bail(SCRG_ERR_OOM, "result arrays");
+
+    // ---- device side: lock the states, size their sequence arrays (the largest chunk decides), genome
+    std::vector<DeviceState*> ds(n_states);
+    for (int d = 0; d < n_states; d++) ds[d] = static_cast<DeviceState*>(states[d]);
+    std::vector<std::unique_lock<std::mutex>> locks;
+    {
+        std::vector<DeviceState*> uniq(ds.begin(), ds.end());
+        std::sort(uniq.begin(), uniq.end());
+        uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+        if (uniq.size() != ds.size()) return bail(SCRG_ERR_INVALID_ARG, "a device state may be used once per call");
+        for (DeviceState* u : uniq) locks.emplace_back(u->mu);
+    }
+    uint64_t slot_words = 0;
+    {
+        std::vector<uint64_t> cw(n_chunks, 0);
+        parallel_for(n_chunks, [&](uint64_t k) {
+            // upper bound of the chunk's padded layout: rows x the chunk's longest read / text
+            uint64_t mr = 0, mt = 0;
+            const uint64_t a = c.chunk_first[k], e = c.chunk_first[k + 1];
+            if (sorted_issue && b.mapping) mr = b.read_lens[read_of(c, c.order[a])];
+            else
+                for (uint64_t i = a; i < e; i++) {
+                    const uint64_t p = c.order[i];
+                    mr = std::max<uint64_t>(mr, b.read_lens[read_of(c, p)]);
+                    if (!b.mapping) mt = std::max<uint64_t>(mt, b.text_lens[p]);
+                }
+            const uint64_t rows = (e - a + GROUP - 1) / GROUP * GROUP;
+            cw[k] = rows * std::max<uint64_t>(1, (mr + 31) / 32) + (b.mapping ? 0 : rows * std::max<uint64_t>(1, (mt + 31) / 32)) + SEQ_PAD;
+        }, true);
+        for (uint64_t w : cw) slot_words = std::max(slot_words, w);
+    }
+    for (int d = 0; d < n_states; d++) {
+        ds[d]->err.clear();
+        scrg_status s = SCRG_OK;
+        if (b.mapping && b.genome) s = pack_genome(ds[d], b.genome, b.genome_len);
+        else if (b.mapping && !ds[d]->genome_ok) {
+            ds[d]->err = "no resident genome: call scrg_genome_set first";
+            s = SCRG_ERR_INVALID_ARG;
+        }
+        if (s == SCRG_OK) s = ensure_seq(ds[d], ds[d]->genome_words, slot_words);
+        if (s != SCRG_OK) return bail(s, ds[d]->err);
+    }
+    if (b.mapping) {
+        const uint64_t glen = ds[0]->genome_len;
+        std::atomic<int> past{0};
+        parallel_for(n, [&](uint64_t p) { if (b.cand_start[p] > glen) past.store(1, std::memory_order_relaxed); });
+        if (past.load()) return bail(SCRG_ERR_INVALID_ARG, "candidate past end of genome");
+    }
+
+    const int64_t t_setup = now_ns();
+    // ---- run: one worker per device
+    if (n) {
+        if (n_states == 1) worker(ds[0], &c, 0, 1);
+        else {
+            std::vector<std::thread> th;
+            for (int d = 0; d < n_states; d++) th.emplace_back(worker, ds[d], &c, d, n_states);
+            for (auto& t : th) t.join();
+        }
+    }
+    if (c.failed()) return bail((scrg_status)c.status.load(), c.err);
+    if (getenv("SCRG_HOST_TIMING"))
+        fprintf(stderr, "[scrooge_amd host] %llu pairs, %llu chunks, %d device state(s): set-up %.3f ms, pipeline %.3f ms\n", (unsigned long long)n,
+                (unsigned long long)n_chunks, n_states, (t_setup - t_begin) / 1e6, (now_ns() - t_setup) / 1e6);
+
+    uint64_t total_runs = 0, total_text = 0;
+    for (uint64_t k = 0; k < n_chunks; k++) {
+        total_runs += c.c_runs[k];
+        total_text += c.c_text[k];
+    }
+    c.iss_run_off[n] = total_runs;
+    c.iss_text_off[n] = total_text;
+    if (!c.runs.p) c.runs.p = static_cast<char*>(g_pool.get(16, true));
+    if (!c.text.p) c.text.p = static_cast<char*>(g_pool.get(16, true));
+
+    // ---- caller order
+    if (c.identity) {
+        r->edit_distance = c.iss_ed;
+        r->pair_status = c.iss_status;
+        r->run_offset = c.iss_run_off;
+        r->cigar_offset = c.iss_text_off;
+        r->runs = reinterpret_cast<scrg_run*>(c.runs.p);
+        r->cigar_text = c.text.p;
+        r->edit_distance[n] = 0;
+        r->pair_status[n] = 0;
+        c.iss_ed = nullptr; c.iss_status = nullptr; c.iss_run_off = nullptr; c.iss_text_off = nullptr;
+        c.runs.p = nullptr; c.text.p = nullptr;
+    } else {
+        r->edit_distance = static_cast<int64_t*>(g_pool.get((n + 1) * 8, false));
+        r->pair_status = static_cast<uint32_t*>(g_pool.get((n + 1) * 4, false));
+        r->run_offset = static_cast<uint64_t*>(g_pool.get((n + 1) * 8, false));
+        r->cigar_offset = static_cast<uint64_t*>(g_pool.get((n + 1) * 8, false));
+        r->runs = static_cast<scrg_run*>(g_pool.get(2 * total_runs + 16, false));
+        r->cigar_text = static_cast<char*>(g_pool.get(total_text + 16, false));
+        if (!r->edit_distance || !r->pair_status || !r->run_offset || !r->cigar_offset || !r->runs || !r->cigar_text)
+            return bail(SCRG_ERR_OOM, "result arrays");
+        // per-pair sizes into caller order, prefix sums (two levels, blocks of 64 k pairs in parallel), then the gather
+        parallel_for(n, [&](uint64_t k) {
+            const uint64_t p = c.order[k];
+            r->run_offset[p] = c.iss_run_off[k + 1] - c.iss_run_off[k];
+            r->cigar_offset[p] = c.iss_text_off[k + 1] - c.iss_text_off[k];
+            r->edit_distance[p] = c.iss_ed[k];
+            r->pair_status[p] = c.iss_status[k];
+        });
+        const uint64_t BLK = 1u << 16, nb = (n + BLK - 1) / BLK;
+        std::vector<uint64_t> bs_r(nb + 1, 0), bs_t(nb + 1, 0);
+        parallel_for(nb, [&](uint64_t blk) {
+            uint64_t ar = 0, at = 0;
+            for (uint64_t i = blk * BLK; i < std::min(n, (blk + 1) * BLK); i++) {
+                const uint64_t cr = r->run_offset[i], ct = r->cigar_offset[i];
+                r->run_offset[i] = ar;
+                r->cigar_offset[i] = at;
+                ar += cr;
+                at += ct;
+            }
+            bs_r[blk + 1] = ar;
+            bs_t[blk + 1] = at;
+        }, true);
+        for (uint64_t blk = 0; blk < nb; blk++) { bs_r[blk + 1] += bs_r[blk]; bs_t[blk + 1] += bs_t[blk]; }
+        parallel_for(nb, [&](uint64_t blk) {
+            for (uint64_t i = blk * BLK; i < std::min(n, (blk + 1) * BLK); i++) {
+                r->run_offset[i] += bs_r[blk];
+                r->cigar_offset[i] += bs_t[blk];
+            }
+        }, true);
+        r->run_offset[n] = total_runs;
+        r->cigar_offset[n] = total_text;
+        r->edit_distance[n] = 0;
+        r->pair_status[n] = 0;
+        parallel_for(n, [&](uint64_t k) {
+            const uint64_t p = c.order[k];
+            if (c.want_runs)
+                memcpy(reinterpret_cast<char*>(r->runs) + 2 * r->run_offset[p], c.runs.p + 2 * c.iss_run_off[k], 2 * (c.iss_run_off[k + 1] - c.iss_run_off[k]));
+            if (c.want_text)
+                memcpy(r->cigar_text + r->cigar_offset[p], c.text.p + c.iss_text_off[k], c.iss_text_off[k + 1] - c.iss_text_off[k]);
+        });
+        g_pool.put(c.runs.p); g_pool.put(c.text.p);
+        g_pool.put(c.iss_ed); g_pool.put(c.iss_status); g_pool.put(c.iss_run_off); g_pool.put(c.iss_text_off);
+        c.runs.p = c.text.p = nullptr;
+        c.iss_ed = nullptr; c.iss_status = nullptr; c.iss_run_off = nullptr; c.iss_text_off = nullptr;
+    }
+    if (!c.want_runs) memset(r->run_offset, 0, (n + 1) * sizeof(uint64_t));
+    if (!c.want_text) memset(r->cigar_offset, 0, (n + 1) * sizeof(uint64_t));
+    r->kernel_ns = c.kernel_ns.load();
+    if (scrg_get_log() && r->kernel_ns > 0)   // the reference's log line, src/genasm_gpu.cu:949-951 (kernel time: the sum over the chunks' launches)
+        fprintf(stderr, "core algorithm ran at %lld aligns/second\n", (long long)((double)n * 1e9 / (double)r->kernel_ns));
+    r->pack_ns = c.pack_ns.load();
+    r->total_ns = now_ns() - t_begin;
+    *out = r;
+    if (c.any_overflow.load()) {
+        set_err("at least one pair overflowed its CIGAR slice (see pair_status)");
+        return SCRG_ERR_CIGAR_OVERFLOW;
+    }
+    return SCRG_OK;
+}
+
+}  // namespace scrg_host

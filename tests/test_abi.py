@@ -63,7 +63,7 @@ def test_struct_layouts():
     import ctypes as C
     assert C.sizeof(api.Run) == 2        # CigarEntry_t, src/util.hpp:43-46
     assert C.sizeof(api.PairDesc) == 48
-    assert C.sizeof(api.Params) == 40    # 10 x int32 (scrooge_amd.h: scrg_params)
+    assert C.sizeof(api.Params) == 44    # 11 x int32 (scrooge_amd.h: scrg_params)
 
 
 def test_status_strings(lib):

@@ -4,6 +4,8 @@ edit distance and CIGAR text must be identical."""
 import numpy as np
 import pytest
 
+import scrooge_amd
+
 from scrooge_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -259,7 +261,13 @@ def test_resident_genome(aligner, golden_mapping, oracle):
         eds, cigars, _, _ = oracle.align(texts, qs, threads=8)
         _check(aligner.align_mapping(None, reads, cands), eds, cigars, "resident, large batch")
         _check(aligner.align_mapping(None, gm["reads"], gm["candidates"]), gm["ed"], gm["cigar"], "resident, again")
-        aligner.align_pairs(["ACGT"], ["ACGT"])                 # reuses the sequence array: the genome is gone
+        # a pairwise call in between leaves the genome where it is (it sits in front of the chunks' sequence regions)
+        assert aligner.align_pairs(["ACGT"], ["ACGT"]) == [("4=", 0)]
+        big_t, big_q = synth.make_pairs(300, 4000, "ont", seed=31)          # large enough to make the sequence array grow
+        eds2, cig2, _, _ = oracle.align(big_t, big_q, threads=8)
+        _check(aligner.align_pairs(big_t, big_q), eds2, cig2, "pairs between resident batches")
+        _check(aligner.align_mapping(None, gm["reads"], gm["candidates"]), gm["ed"], gm["cigar"], "resident, after pairwise calls")
+        aligner.clear_genome()
         with pytest.raises(scrooge_amd.ScroogeError):
             aligner.align_mapping(None, gm["reads"], gm["candidates"])
     finally:
@@ -304,3 +312,61 @@ def test_dense_run_patterns(aligner, oracle):
         _check(aligner.align_pairs(T, Q, lanes_per_pair=g), eds, cigars, "dense runs g=%d" % g)
     e32, c32, _, _ = oracle.align(T, Q, W=32, O=17, threads=8)
     _check(aligner.align_pairs(T, Q, W=32, O=17), e32, c32, "dense runs W=32")
+
+
+def test_multi_device_entry_points(aligner, golden_pairs, golden_mapping, oracle):
+    """scrg_align_pairs_multi / scrg_align_mapping_multi (one call, several GPUs, one host thread pair per device): the one
+    GPU of the test box listed four times — four device states, sixteen streams, chunks dealt round-robin — must give
+    the results of the single-device call, in caller order: goldens, ragged batches against the oracle, reverse strand."""
+    g = golden_pairs
+    T = [c["text"] for c in g["cases"]]
+    Q = [c["read"] for c in g["cases"]]
+    for devs in ([0], [0, 0, 0, 0]):
+        _check(aligner.align_pairs_multi(devs, T, Q), [c["ed"] for c in g["cases"]], [c["cigar"] for c in g["cases"]], "golden pairs %s" % devs)
+        gm = golden_mapping
+        _check(aligner.align_mapping_multi(devs, gm["genome"], gm["reads"], gm["candidates"]), gm["ed"], gm["cigar"], "golden mapping %s" % devs)
+    # a ragged batch in no particular order: 5000 pairs of 0..3 kb -> many chunks on each state, results permuted back
+    rng = np.random.Generator(np.random.PCG64(77))
+    T, Q = [], []
+    for L in rng.integers(0, 3000, 5000):
+        t, q = synth.make_pair(int(L), 0.1, (23, 31, 46), rng, 0.15) if L else (np.zeros(3, np.uint8), np.zeros(0, np.uint8))
+        T.append(synth.BASES[t].tobytes())
+        Q.append(synth.BASES[q].tobytes())
+    eds, cigars, _, _ = oracle.align(T, Q, threads=8)
+    _check(aligner.align_pairs_multi([0, 0, 0, 0], T, Q), eds, cigars, "ragged, four states")
+    _check(aligner.align_pairs_multi([0, 0], T, Q, sort_by_length=0), eds, cigars, "ragged, unsorted issue order")
+    _check(aligner.align_pairs(T, Q), eds, cigars, "ragged, one handle")
+    # reverse-strand candidates through the multi entry point
+    genome = synth.random_seq(30000, rng)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    reads, cands, revs, texts, qs = [], [], [], [], []
+    for k in range(300):
+        s0 = int(rng.integers(0, 29000))
+        r = genome[s0:s0 + int(rng.integers(40, 400))]
+        rev = k % 3 == 0
+        reads.append(r.translate(comp)[::-1] if rev else r)
+        cands.append([s0, max(0, s0 - 2)])
+        revs.append([1 if rev else 0] * 2)
+        for st in cands[-1]:
+            texts.append(genome[st:st + 600])
+            qs.append(r)
+    eds, cigars, _, _ = oracle.align(texts, qs, threads=8)
+    _check(aligner.align_mapping_multi([0, 0, 0], genome, reads, cands, reverse=revs), eds, cigars, "stranded mapping, three states")
+    with pytest.raises(scrooge_amd.ScroogeError):
+        aligner.align_pairs_multi([0, 99], T[:10], Q[:10])          # no such device: an error, not a smaller job
+
+
+def test_output_selection(aligner, oracle):
+    """scrg_params.outputs: text only / runs only leave the other array empty (it never crosses PCIe); the part that is
+    asked for is identical to the full result."""
+    T, Q = synth.make_pairs(700, 1500, "ont", seed=12)
+    Q[3] = b""
+    full = aligner.align_pairs(T, Q, arrays=True)
+    text = aligner.align_pairs(T, Q, arrays=True, outputs=1)
+    runs = aligner.align_pairs(T, Q, arrays=True, outputs=2)
+    assert (text["edit_distance"] == full["edit_distance"]).all() and text["cigar_text"] == full["cigar_text"]
+    assert (text["cigar_offset"] == full["cigar_offset"]).all() and text["runs"].shape[0] == 0 and int(text["run_offset"].max()) == 0
+    assert (runs["edit_distance"] == full["edit_distance"]).all() and (runs["runs"] == full["runs"]).all()
+    assert (runs["run_offset"] == full["run_offset"]).all() and int(runs["cigar_offset"].max()) == 0
+    with pytest.raises(scrooge_amd.ScroogeError):
+        aligner.align_pairs(T[:4], Q[:4], outputs=3)

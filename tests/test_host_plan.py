@@ -1,0 +1,61 @@
+"""How a host call is cut up (scrg_host_plan: no GPU involved): the issue order is what the reference's callers do for load
+balance — longest read first (src/tests.cu:375-377), stable —, chunks are whole groups of 64 pairs that tile the issue
+order, and chunk k belongs to device k mod N: the in-process counterpart of scrooge_amd.distributed.shard_plan."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from scrooge_amd import api
+
+
+def plan(read_lens, text_lens=None, n_devices=1, sort=1):
+    lib = api.load_library()
+    n = len(read_lens)
+    rl = (C.c_uint64 * max(n, 1))(*read_lens)
+    tl = (C.c_uint64 * max(n, 1))(*(text_lens if text_lens is not None else [0] * n))
+    order = (C.c_uint32 * max(n, 1))()
+    chunks = (C.c_uint64 * (n // 64 + 8))()
+    nc = C.c_uint64(0)
+    p = api.Params()
+    lib.scrg_params_default(C.byref(p))
+    p.sort_by_length = sort
+    st = lib.scrg_host_plan(C.byref(p), n_devices, n, tl, rl, order, chunks, n // 64 + 8, C.byref(nc))
+    assert st == api.SCRG_OK
+    return list(order[:n]), list(chunks[: nc.value + 1])
+
+
+@pytest.mark.parametrize("n_devices", [1, 2, 8])
+def test_issue_order_and_chunks(n_devices):
+    rng = np.random.Generator(np.random.PCG64(n_devices))
+    lens = rng.integers(0, 12000, 7001).tolist()
+    order, chunks = plan(lens, [int(1.15 * x) for x in lens], n_devices)
+    assert sorted(order) == list(range(len(lens)))                                  # a permutation
+    got = [lens[i] for i in order]
+    assert got == sorted(lens, reverse=True)                                        # longest read first
+    for a, b in zip(order, order[1:]):                                              # stable: ties keep the caller's order
+        if lens[a] == lens[b]:
+            assert a < b
+    assert chunks[0] == 0 and chunks[-1] == len(lens) and all(x < y for x, y in zip(chunks, chunks[1:]))
+    assert all((y - x) % 64 == 0 for x, y in zip(chunks[:-2], chunks[1:-1]))        # whole groups of 64, except the last chunk
+    # enough chunks for every device and stream, none beyond 32 MB of packed sequence
+    assert len(chunks) - 1 >= min(4 * n_devices, (len(lens) + 511) // 512)
+    for x, y in zip(chunks, chunks[1:]):
+        words = sum((lens[i] + 31) // 32 + (int(1.15 * lens[i]) + 31) // 32 for i in order[x:y])
+        assert words <= (4 << 20) + 2 * 64 * 800
+    # every device gets about the same number of bases: chunk k goes to device k mod N, longest reads dealt first
+    per_dev = [0] * n_devices
+    for k, (x, y) in enumerate(zip(chunks, chunks[1:])):
+        per_dev[k % n_devices] += sum(lens[i] for i in order[x:y])
+    if len(chunks) - 1 >= 4 * n_devices:
+        assert max(per_dev) < 1.6 * (sum(per_dev) / n_devices)
+
+
+def test_sorted_batches_keep_their_order():
+    lens = [5000] * 1000 + [150] * 3000
+    order, chunks = plan(lens)
+    assert order == list(range(4000))                       # already longest first: results need no permutation
+    order, _ = plan(list(reversed(lens)), sort=0)
+    assert order == list(range(4000))                       # sort_by_length = 0: issue order = caller order
+    order, chunks = plan([])
+    assert order == [] and chunks == [0]
