@@ -138,6 +138,31 @@ static inline go_bv256 bv256_clrbit(go_bv256 v, unsigned b)
 #undef GO_BV_MAXW
 #undef GO_NAME
 
+/* Test hook over the 4-word vector above (tests/test_row_ops.py pins it to the known answers of the reference's
+ * bitvector tests, src/bitvector_test.cu:22-132).  op: 0 shl(a, s)  1 or  2 and  3 clrbit(a, s)  4 pattern-mask style
+ * insertion of the 32 bits `b[0]` at bit s (src/bitvector.hpp insert_bits: or into place); returns bit_is_zero(a, s). */
+int go_bv256_op(int op, const uint64_t a[4], const uint64_t b[4], unsigned s, uint64_t out[4])
+{
+    go_bv256 x, y, r;
+    memcpy(x.w, a, sizeof x.w);
+    memcpy(y.w, b, sizeof y.w);
+    r = x;
+    switch (op) {
+    case 0: r = s >= 256u ? bv256_fill(0) : bv256_shl(x, s); break;
+    case 1: r = bv256_or(x, y); break;
+    case 2: r = bv256_and(x, y); break;
+    case 3: r = bv256_clrbit(x, s); break;
+    case 4: {
+        go_bv256 piece = { { y.w[0] & 0xffffffffull, 0, 0, 0 } };
+        r = bv256_or(x, bv256_shl(piece, s));
+        break;
+    }
+    default: return -1;
+    }
+    memcpy(out, r.w, sizeof r.w);
+    return (int)((x.w[(s % 256u) / 64u] >> (s % 64u)) & 1u) == 0;
+}
+
 int go_align_codes(const uint8_t *text, size_t text_len,
                    const uint8_t *read, size_t read_len,
                    int W, int O,

@@ -75,6 +75,9 @@ int go_align_batch_ascii(size_t n_pairs,
                          char *const *cigars, long long *edit_distances,
                          go_stats *total_stats, long long *kernel_ns);
 
+/* Test hook over the 256-bit vector type (see genasm_oracle.c). */
+int go_bv256_op(int op, const uint64_t a[4], const uint64_t b[4], unsigned s, uint64_t out[4]);
+
 /* The same for inputs in one array of fixed-size rows (text slot + read slot per row) with results as arrays: run
  * offsets [n_pairs + 1] and the runs as {count, op} byte pairs.  runs_cap counts runs. */
 int go_align_batch_rows(size_t n_pairs, const char *rows, uint64_t row_stride,

@@ -24,7 +24,7 @@ class GoStats(C.Structure):
 def _digest():
     import hashlib
     h = hashlib.sha256()
-    for f in ("genasm_oracle.c", "genasm_oracle_core.inc", "genasm_oracle.h", "Makefile", "ref_driver.cpp"):
+    for f in ("genasm_oracle.c", "genasm_oracle_core.inc", "genasm_oracle.h", "Makefile", "ref_driver.cpp", "ref_score_driver.cpp"):
         with open(os.path.join(HERE, f), "rb") as fh:
             h.update(f.encode())
             h.update(fh.read())

@@ -19,28 +19,10 @@
 
 #include "genasm_kernels.h"
 #include "genasm_device.h"
+#include "row_ops.h"
 
 namespace scrg {
 
-template <int NW> struct BV {
-    uint64_t w[NW];     // w[0]: characters 0..63 (character j at bit 63-j), w[1]: 64..127, ...
-};
-
-template <int NW> __device__ __forceinline__ BV<NW> bv_fill(uint64_t x)
-{
-    BV<NW> r;
-#pragma unroll
-    for (int i = 0; i < NW; i++) r.w[i] = x;
-    return r;
-}
-template <int NW> __device__ __forceinline__ BV<NW> bv_shl1(const BV<NW>& v)
-{
-    BV<NW> r;
-#pragma unroll
-    for (int i = 0; i < NW - 1; i++) r.w[i] = (v.w[i] << 1) | (v.w[i + 1] >> 63);
-    r.w[NW - 1] = v.w[NW - 1] << 1;
-    return r;
-}
 template <int NW> __device__ __forceinline__ BV<NW> bv_dpp_from_next(const BV<NW>& v)
 {
     BV<NW> r;

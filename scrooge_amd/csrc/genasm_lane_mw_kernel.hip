@@ -20,107 +20,13 @@
 
 #include "genasm_kernels.h"
 #include "genasm_device.h"
+#include "row_ops.h"
 
 namespace scrg {
 
 namespace {
 
 constexpr uint32_t MW_RING_BYTES = 68;             // 32 runs + one dword per lane (bank skew)
-constexpr uint64_t TOP = 0x8000000000000000ull;
-
-__device__ __forceinline__ uint32_t clz64_mw(uint64_t v) { return v ? (uint32_t)__builtin_clzll(v) : 64u; }
-
-// An RW-word row, word 0 the most significant; column / pattern row c <-> bit 63 - c % 64 of word c / 64.
-template <int RW> struct Row {
-    uint64_t w[RW];
-};
-template <int RW> __device__ __forceinline__ Row<RW> row_zero()
-{
-    Row<RW> r;
-#pragma unroll
-    for (int k = 0; k < RW; k++) r.w[k] = 0;
-    return r;
-}
-template <int RW> __device__ __forceinline__ Row<RW> row_shl(const Row<RW>& a, uint32_t s)       // towards word 0, s < 64 RW
-{
-    Row<RW> r;
-    const uint32_t ws = s >> 6, b = s & 63u;
-#pragma unroll
-    for (int k = 0; k < RW; k++) {
-        uint64_t hi = 0, lo = 0;
-#pragma unroll
-        for (int q = 0; q < RW; q++) {
-            if ((uint32_t)q == (uint32_t)k + ws) hi = a.w[q];
-            if ((uint32_t)q == (uint32_t)k + ws + 1u) lo = a.w[q];
-        }
-        r.w[k] = b ? ((hi << b) | (lo >> (64u - b))) : hi;
-    }
-    return r;
-}
-template <int RW> __device__ __forceinline__ Row<RW> row_shl1_in(const Row<RW>& a, uint64_t in)   // << 1, `in` enters at the bottom
-{
-    Row<RW> r;
-#pragma unroll
-    for (int k = 0; k < RW; k++) r.w[k] = (a.w[k] << 1) | (k + 1 < RW ? a.w[k + 1] >> 63 : in);
-    return r;
-}
-template <int RW> __device__ __forceinline__ Row<RW> row_shr1(const Row<RW>& a)
-{
-    Row<RW> r;
-#pragma unroll
-    for (int k = 0; k < RW; k++) r.w[k] = (a.w[k] >> 1) | (k ? a.w[k - 1] << 63 : 0ull);
-    return r;
-}
-template <int RW> __device__ __forceinline__ uint32_t row_clz(const Row<RW>& a)
-{
-    uint32_t n = 0;
-    bool done = false;
-#pragma unroll
-    for (int k = 0; k < RW; k++) {
-        const uint32_t c = clz64_mw(a.w[k]);
-        if (!done) n += c;
-        done = done || a.w[k] != 0;
-    }
-    return n;
-}
-template <int RW> __device__ __forceinline__ Row<RW> row_bit(uint32_t c)
-{
-    Row<RW> r;
-#pragma unroll
-    for (int k = 0; k < RW; k++) r.w[k] = (c >> 6) == (uint32_t)k ? TOP >> (c & 63u) : 0ull;
-    return r;
-}
-template <int RW> __device__ __forceinline__ bool row_test(const Row<RW>& a, uint32_t c)
-{
-    uint64_t v = 0;
-#pragma unroll
-    for (int k = 0; k < RW; k++) v |= (c >> 6) == (uint32_t)k ? a.w[k] : 0ull;
-    return ((v >> (63u - (c & 63u))) & 1ull) != 0;
-}
-template <int RW> __device__ __forceinline__ Row<RW> row_top(uint32_t t)       // the top t bits set
-{
-    Row<RW> r;
-#pragma unroll
-    for (int k = 0; k < RW; k++) {
-        const uint32_t lo = 64u * (uint32_t)k;
-        r.w[k] = t >= lo + 64u ? ~0ull : (t <= lo ? 0ull : ~(~0ull >> (t - lo)));
-    }
-    return r;
-}
-template <int RW> __device__ __forceinline__ bool row_any(const Row<RW>& a)
-{
-    uint64_t v = 0;
-#pragma unroll
-    for (int k = 0; k < RW; k++) v |= a.w[k];
-    return v != 0;
-}
-template <int RW> __device__ __forceinline__ uint32_t row_pop(const Row<RW>& a)
-{
-    uint32_t n = 0;
-#pragma unroll
-    for (int k = 0; k < RW; k++) n += (uint32_t)__popcll(a.w[k]);
-    return n;
-}
 
 }  // namespace
 

@@ -57,6 +57,104 @@ def test_config3_read_mapping_candidates(aligner, oracle):
     _same(alns, eds, cigars)
 
 
+def _mapping_workload(n_reads, G, seed):
+    """BASELINE configs[2]: one synthetic chromosome of G bases, n_reads x 150 bp reads with ~1 % errors (0.9 % substitutions,
+    one deletion or one insertion in 7.5 % of the reads each), 4 candidates per read: the true locus, two loci shifted by
+    1-3 bases, one random locus."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    L = 150
+    gcodes = rng.integers(0, 4, G, dtype=np.uint8)
+    starts = rng.integers(0, G - 400, n_reads)
+    codes = np.empty((n_reads, L), np.uint8)
+    j = np.arange(L)[None, :]
+    for lo in range(0, n_reads, 125000):                  # in pieces: bounded temporaries
+        hi = min(n_reads, lo + 125000)
+        m = hi - lo
+        pos = rng.integers(1, L - 1, (m, 1))
+        u = rng.random((m, 2))
+        is_del = u[:, 0:1] < 0.075
+        is_ins = (u[:, 1:2] < 0.075) & ~is_del
+        src = j + (is_del & (j >= pos)) - (is_ins & (j > pos))
+        c = gcodes[starts[lo:hi, None] + src]
+        sub = rng.random((m, L)) < 0.009
+        c = np.where(sub, (c + rng.integers(1, 4, (m, L), dtype=np.uint8)) & 3, c)
+        c = np.where(is_ins & (j == pos), rng.integers(0, 4, (m, L), dtype=np.uint8), c)
+        codes[lo:hi] = c
+    cand = np.stack([starts, np.maximum(0, starts - rng.integers(1, 4, n_reads)), starts + rng.integers(1, 4, n_reads),
+                     rng.integers(0, G - 10, n_reads)], axis=1)
+    return gcodes, codes, cand
+
+
+def test_config3_full_size_host_api(aligner, oracle):
+    """BASELINE configs[2] AT FULL SIZE through the host entry point the reference's mapping overload binds to
+    (scrg_align_mapping = genasm_gpu::align_all(genome, reads, candidates), src/genasm_gpu.cu:1067-1200): a 100 Mbp
+    chromosome, 1 M x 150 bp reads x 4 candidates = 4 M pairs in one call.  The first 12.5 k reads (50 k pairs) are
+    compared with the oracle, CIGAR for CIGAR; every one of the 4 M results is held to the size-independent properties
+    (the read is consumed exactly, the text is not overrun, the edit distance is the number of non-match columns, the
+    rendered text has one letter per run) and, where the alignment has no gaps, to the Hamming distance of the two
+    sequences; the same call against the resident genome returns the same arrays."""
+    G, n_reads, L, n_c = 100_000_000, 1_000_000, 150, 4
+    gcodes, codes, cand = _mapping_workload(n_reads, G, seed=2024)
+    genome = synth.BASES[gcodes].tobytes()
+    ascii_reads = synth.BASES[codes]
+    reads = [ascii_reads[r].tobytes() for r in range(n_reads)]
+    cands = cand.tolist()
+    res = aligner.align_mapping(genome, reads, cands, arrays=True)
+    n = n_reads * n_c
+    assert res["edit_distance"].shape == (n,) and not res["status"].any()
+
+    # -- oracle, CIGAR for CIGAR, on the first 50 k pairs
+    k = 12500
+    texts, qs = [], []
+    for r in range(k):
+        for s in cands[r]:
+            texts.append(genome[s:s + 400])               # enough of the suffix for a 150 bp read
+            qs.append(reads[r])
+    eds, cigars, _, _ = oracle.align(texts, qs, threads=16)
+    off = res["cigar_offset"]
+    bad = [i for i in range(n_c * k) if int(res["edit_distance"][i]) != eds[i]
+           or res["cigar_text"][int(off[i]):int(off[i + 1]) - 1].decode() != cigars[i]]
+    assert not bad, "%d of %d differ from the oracle, first %d" % (len(bad), n_c * k, bad[0])
+
+    # -- every pair: properties on the run arrays
+    ro = res["run_offset"].astype(np.int64)
+    assert (np.diff(ro) > 0).all()                        # no empty alignment: every read has 150 bases
+    cnt = res["runs"][:, 0].astype(np.int64)
+    op = res["runs"][:, 1]
+    assert np.isin(op, np.frombuffer(b"=XID", np.uint8)).all() and (cnt > 0).all()
+    is_m, is_x, is_i, is_d = (op == ord(c) for c in "=XID")
+    seg = ro[:-1]
+    read_used = np.add.reduceat(np.where(is_d, 0, cnt), seg)
+    text_used = np.add.reduceat(np.where(is_i, 0, cnt), seg)
+    edits = np.add.reduceat(np.where(is_m, 0, cnt), seg)
+    assert (read_used == L).all()
+    assert (text_used <= G - cand.reshape(-1)).all()
+    assert (edits == res["edit_distance"]).all()
+    text = np.frombuffer(res["cigar_text"], np.uint8)
+    assert int(np.isin(text, np.frombuffer(b"=XID", np.uint8)).sum()) == int(ro[-1]) and int((text == 0).sum()) == n
+    assert (text[res["cigar_offset"][1:].astype(np.int64) - 1] == 0).all()
+    # gap-free alignments walk the diagonal: their edit distance is the Hamming distance of read and text
+    gaps = np.add.reduceat((is_i | is_d).astype(np.int64), seg)
+    flat = np.nonzero(gaps == 0)[0]
+    assert len(flat) > 0.8 * n_reads                      # the true loci of the 85 % of reads without an insertion or deletion
+    for lo in range(0, len(flat), 500000):
+        f = flat[lo:lo + 500000]
+        t = gcodes[cand.reshape(-1)[f, None] + np.arange(L)[None, :]]
+        assert ((t != codes[f // n_c]).sum(axis=1) == res["edit_distance"][f]).all()
+    ed = res["edit_distance"].reshape(n_reads, n_c)
+    assert ed[:, 0].mean() < 3 and ed[:, 3].mean() > 50   # true locus vs random locus
+
+    # -- the same batch against the genome kept on the device (scrg_genome_set + scrg_align_mapping_resident)
+    aligner.set_genome(genome)
+    try:
+        res2 = aligner.align_mapping(None, reads, cands, arrays=True)
+    finally:
+        aligner.clear_genome()
+    for key in ("edit_distance", "status", "run_offset", "runs", "cigar_offset"):
+        assert np.array_equal(res[key], res2[key]), key
+    assert res["cigar_text"] == res2["cigar_text"]
+
+
 def test_config5_long_noisy_reads(aligner, oracle):
     """BASELINE configs[4] in miniature: 50 kb PacBio-error reads at 15 % (multi-window traceback
     over ~1650 windows per pair, frequent window distances above the LDS rows)."""
