@@ -364,7 +364,9 @@ scrg_status scrg_last_kernel_ms(scrg_ctx *ctx, float *ms);
  * params.reserved[0] holds experiment switches; scrg_params_resolve() and every entry point REJECT any bit other
  * than the ones that leave the results intact:
  *   lanes_per_pair = 1: 1 turns the wavefront priority rotation off, 64 / 128 launch workgroups of one / two
- *     wavefronts instead of four;  lanes_per_pair = 8: 32 turns the diagonal-major path off.
+ *     wavefronts instead of four, 256 selects the kernel that keeps the window table in HBM where the one that
+ *     keeps it in registers would serve (32 <= W-O <= 63, W <= 128);  lanes_per_pair = 8: 32 turns the
+ *     diagonal-major path off.
  * (Ablation switches — skip the table, a traceback pass, the stores; results wrong by design — exist only in a
  * library built with -DSCRG_ABLATE for profiling, scripts/ab.sh; the shipped library has no such code path.) */
 scrg_status scrg_debug_stats(scrg_ctx *ctx, uint64_t out[12]);

@@ -41,10 +41,11 @@ struct AlignArgs {
 // table, the runs, the walk, the stores — results are wrong by design) are compiled in only with -DSCRG_ABLATE
 // (scripts/ab.sh build ablate -DSCRG_ABLATE; bench.py --ablate): the shipped library has no code path that produces
 // wrong results on request, and scrg_params_resolve() rejects any other bit.
-constexpr int32_t SCRG_SAFE_SWITCHES = 1 | 32 | 64 | 128;
+constexpr int32_t SCRG_SWITCH_MW_TABLE = 256;     // 32 <= W-O <= 63, W <= 128: genasm_lane_mw_kernel (table in HBM) instead of genasm_lane_wide_kernel
+constexpr int32_t SCRG_SAFE_SWITCHES = 1 | 32 | 64 | 128 | SCRG_SWITCH_MW_TABLE;
 #ifdef SCRG_ABLATE
 #define SCRG_ABL(args, bit) (((args).debug & (bit)) != 0)
-constexpr int32_t SCRG_ALLOWED_SWITCHES = 0xff;
+constexpr int32_t SCRG_ALLOWED_SWITCHES = 0x1ff;
 #else
 #define SCRG_ABL(args, bit) false
 constexpr int32_t SCRG_ALLOWED_SWITCHES = SCRG_SAFE_SWITCHES;
@@ -70,6 +71,11 @@ SCRG_HD inline unsigned lane_mw_len_bytes(int tb_limit) { return (((unsigned)tb_
 SCRG_HD inline unsigned lane_mw_lds_bytes(int tb_limit) { return 64u * (68u + lane_mw_len_bytes(tb_limit)); }
 SCRG_HD inline size_t lane_mw_table_bytes(int tb_limit) { return (size_t)tb_limit * 2u * ((unsigned)tb_limit / 64u + 1u) * 64u * 8u; }
 hipError_t launch_align_lane_mw(const AlignArgs& a, int grid, size_t lds_bytes, hipStream_t s, bool edits = false);
+// genasm_lane_wide_kernel (one pair per lane, W <= 128, 32 <= W-O <= 63): the table in registers, built in two halves.
+// LDS per wavefront and lane: CIGAR ring, 32 insertion-run lengths, the window's Eq words for the four bases and "no match".
+SCRG_HD inline bool lane_wide_serves(int W, int tb_limit) { return W <= 128 && tb_limit >= 32 && tb_limit <= 63; }
+SCRG_HD inline unsigned lane_wide_lds_bytes(int W) { return 64u * (68u + 36u + (W <= 64 ? 40u : 80u)); }
+hipError_t launch_align_lane_wide(const AlignArgs& a, int grid, size_t lds_bytes, hipStream_t s, bool edits = false);
 
 SCRG_HD inline unsigned stored_row_dwords(int W, int tb_limit)
 {

@@ -260,6 +260,9 @@ static bool resolve_params(const scrg_params* in, scrg_params* p)
         // consumes at most W-O <= 31 characters, genasm_lane_mw_kernel.hip (64-bit rows, table in HBM) beyond
         if (p->lanes_per_pair == 0) p->lanes_per_pair = 1;
         if (p->lds_rows == 0) p->lds_rows = 12;
+        // 32 <= W-O <= 63: genasm_lane_wide_kernel.hip, whose table takes 128 registers: two wavefronts per SIMD
+        if (p->lanes_per_pair == 1 && p->waves_per_cu == 0 && scrg::lane_wide_serves(p->W, tbl) && !(p->reserved[0] & scrg::SCRG_SWITCH_MW_TABLE))
+            p->waves_per_cu = 8;
     }
     // 11 and 12 wavefronts per CU align equally fast (the kernel is issue-bound); 11 leaves VGPRs and LDS on
     // every CU for kernels of other streams (RCCL's gather in bench.py --gpus N).  The LDS footprint caps it.
@@ -279,6 +282,8 @@ static bool resolve_params(const scrg_params* in, scrg_params* p)
 
 static size_t lds_bytes_for(const scrg_params& p)
 {
+    if (p.lanes_per_pair == 1 && scrg::lane_wide_serves(p.W, p.W - p.O) && !(p.reserved[0] & scrg::SCRG_SWITCH_MW_TABLE))
+        return scrg::lane_wide_lds_bytes(p.W);       // genasm_lane_wide_kernel
     if (p.lanes_per_pair == 1 && (p.W > 64 || p.W - p.O > 31))
         return scrg::lane_mw_lds_bytes(p.W - p.O);   // genasm_lane_mw_kernel: CIGAR ring + insertion-run lengths (the table is in HBM)
     if (p.lanes_per_pair == 1) return 64 * (68 + 36 + 32 + 8);  // per lane: CIGAR staging ring (32 runs + 1 dword), insertion-run lengths of a window, Eq table (+ the "no match" word)
@@ -361,7 +366,8 @@ static scrg_status align_device_impl(scrg_ctx* c, const scrg_params* params, uin
     HIP_TRY(c, c->counter.ensure(sizeof(uint32_t)));
     const size_t spill_rows = p.W > 64 ? (size_t)p.W + 1 : scrg::SPILL_ROWS;
     const size_t spill_row_dw = scrg::stored_row_dwords(p.W, p.W - p.O);
-    const bool lane_mw = p.lanes_per_pair == 1 && (p.W > 64 || p.W - p.O > 31);      // rows of more than 32 bits: genasm_lane_mw_kernel
+    const bool lane_wide = p.lanes_per_pair == 1 && scrg::lane_wide_serves(p.W, p.W - p.O) && !(p.reserved[0] & scrg::SCRG_SWITCH_MW_TABLE);
+    const bool lane_mw = !lane_wide && p.lanes_per_pair == 1 && (p.W > 64 || p.W - p.O > 31);      // rows of more than 32 bits: genasm_lane_mw_kernel
     if (lane_mw)                         // its window tables: one slab of HBM per wavefront
         HIP_TRY(c, c->spill.ensure((size_t)n_waves * scrg::lane_mw_table_bytes(p.W - p.O)));
     else if (p.lanes_per_pair != 1)      // (genasm_lane_kernel keeps its table in registers: nothing spills)
@@ -393,7 +399,9 @@ static scrg_status align_device_impl(scrg_ctx* c, const scrg_params* params, uin
     }
 
     HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));
-    if (lane_mw)
+    if (lane_wide)
+        HIP_TRY(c, scrg::launch_align_lane_wide(a, n_waves, (size_t)lds, c->stream, edits));
+    else if (lane_mw)
         HIP_TRY(c, scrg::launch_align_lane_mw(a, n_waves, (size_t)lds, c->stream, edits));
     else if (p.W > 64)
         HIP_TRY(c, scrg::launch_align_multiword(p.lanes_per_pair, a, n_waves, (size_t)lds, c->stream));

@@ -379,3 +379,157 @@ int lane_align_codes_mw(const uint8_t *text, size_t text_len, const uint8_t *rea
     *n_runs = out.n; *edit_distance = total;
     return out.overflow ? GO_ERR_CAPACITY : GO_OK;
 }
+
+/* ------------------------------------------------------------------------------------------------------------
+ * 32 <= W-O <= 63, W <= 128 (genasm_lane_band_kernel.hip): the traceback rows are one 64-bit word, too many bits for
+ * a table in registers — but a walk that starts at (0, 0) stays near the diagonal.  Column i keeps the 32 rows
+ * lo_i .. lo_i + 31, lo_i = clamp(i - 16, 0, 32), of both words (a table of 2 (W-O) dwords, as many registers as
+ * the 31-column kernel's); the walk records, per column, whether it was above the band on entry or ran off its lower
+ * end inside an insertion run.  A lane for which that happened in a column it was alive in has the window redone on
+ * the full rows (lane_tb_full below = the multi-word walk with one word).  Rows >= jlim all carry the stop mark: a
+ * live walk never gets past row jlim, and a finished lane reads "stop" wherever the band has moved to.
+ * ---------------------------------------------------------------------------------------------------------- */
+#define BAND_UP 16
+static unsigned band_lo(int i) { int lo = i - BAND_UP; return (unsigned)(lo < 0 ? 0 : (lo > 32 ? 32 : lo)); }
+static uint32_t band_ext(uint64_t w, int i) { return (uint32_t)(w >> (32u - band_lo(i))); }
+
+typedef struct { uint64_t nDm, Xm, nIm; unsigned j; uint8_t ilen[64]; } walk_out;
+
+/* full rows: what genasm_lane_mw_kernel's first pass does with RW = 1 */
+static void lane_walk_full(const uint64_t *V1, const uint64_t *V0, int TBL, unsigned jlim, walk_out *o)
+{
+    const uint64_t stop = 0x8000000000000000ull >> jlim;
+    unsigned j = 0;
+    uint64_t nDm = 0, Xm = 0, nIm = 0;
+    for (int i = 0; i < TBL; i++) {
+        const uint64_t nv1 = ~(V1[i] | stop), v0 = V0[i] | stop;
+        const uint64_t x = (nv1 | ~v0 | stop) << j;
+        const unsigned ni = (unsigned)lp_clz64(x);
+        o->ilen[i] = (uint8_t)ni;
+        nIm = (nIm << 1) | (x >> 63);
+        j += ni;
+        const uint64_t nt1 = nv1 << j, t0 = v0 << j;
+        nDm = (nDm << 1) | (nt1 >> 63);
+        Xm = (Xm << 1) | (t0 >> 63);
+        j += (unsigned)(nt1 >> 63);
+    }
+    o->nDm = nDm; o->Xm = Xm; o->nIm = nIm; o->j = j;
+}
+
+/* the band: returns 1 when the lane left it in a column it was alive in */
+static int lane_walk_band(const uint64_t *V1, const uint64_t *V0, int TBL, unsigned jlim, walk_out *o)
+{
+    const uint64_t S = ~0ull >> jlim;                         /* rows >= jlim */
+    uint32_t j = 0;
+    uint64_t nDm = 0, Xm = 0, nIm = 0, Fm = 0;
+    for (int i = 0; i < TBL; i++) {
+        const uint32_t sb = band_ext(S, i);
+        const uint32_t nv1 = ~(band_ext(V1[i], i) | sb), v0 = band_ext(V0[i], i) | sb;     /* (what the table holds) */
+        const uint32_t jr = j - band_lo(i);                   /* negative: above the band, > 31: below it */
+        /* a 64-bit shift (v_lshlrev_b64 takes the count modulo 64) of the word in the upper half: a row outside the
+         * band shifts everything out, and so does an insertion run that reaches the band's lower end */
+        const uint32_t x = (uint32_t)((((uint64_t)(nv1 | ~v0 | sb) << 32) << (jr & 63u)) >> 32);
+        const uint32_t ni = lp_ffbh32(x);                     /* 0xffffffff: outside the band */
+        o->ilen[i] = (uint8_t)ni;
+        Fm = (Fm << 1) | (ni >> 31);
+#ifdef BAND_DEBUG
+        if (ni >> 31) fprintf(stderr, "col %d j %u lo %u jr %d jlim %u TBL %d\n", i, j, band_lo(i), (int)jr, jlim, TBL);
+#endif
+        nIm = (nIm << 1) | (x >> 31);
+        j += ni;
+        const uint32_t sh = (j - band_lo(i)) & 31u;
+        const uint32_t nt1 = nv1 << sh, t0 = v0 << sh;
+        nDm = (nDm << 1) | (nt1 >> 31);
+        Xm = (Xm << 1) | (t0 >> 31);
+        j += nt1 >> 31;
+    }
+    o->nDm = nDm; o->Xm = Xm; o->nIm = nIm; o->j = j;
+    const unsigned nsh = 64u - (unsigned)TBL;
+    const uint64_t Draw = ~(nDm << nsh), Xraw = Xm << nsh;
+    const unsigned ti = (unsigned)lp_clz64((Draw & Xraw) | (0x8000000000000000ull >> TBL));
+    const uint64_t alive_in = ti >= 63 ? ~0ull : ~(~0ull >> (ti + 1));      /* columns 0 .. ti: the lane entered them alive */
+    /* what a finished lane reads once the band has moved past its row is arbitrary: its row is jlim (the stop mark is
+     * the only place that reads "deletion and substitution"), and an insertion run can only start in a column it entered alive */
+    if (ti < (unsigned)TBL) o->j = jlim;
+    o->nIm |= ~(alive_in >> nsh);
+    return ((Fm << nsh) & alive_in) != 0;
+}
+
+typedef struct lane_stats_band { uint64_t windows, columns, tb_columns, escapes; } lane_stats_band;
+
+int lane_align_codes_band(const uint8_t *text, size_t text_len, const uint8_t *read, size_t read_len, int W, int O,
+                          go_run *runs, size_t cap, size_t *n_runs, long long *edit_distance, lane_stats_band *ls)
+{
+    const int NW = (W + 63) / 64, TBL = W - O;
+    if (W < 2 || W > 128 || O < 1 || TBL < 32 || TBL > 63) return GO_ERR_PARAMS;
+    run_sink out = { runs, cap, 0, 0 };
+    size_t tpos = 0, rpos = 0; long long total = 0;
+    uint64_t V1[64], V0[64];
+    while (rpos < read_len) {
+        const int n = (int)(text_len - tpos < (size_t)W ? text_len - tpos : (size_t)W);
+        const int m = (int)(read_len - rpos < (size_t)W ? read_len - rpos : (size_t)W);
+        const unsigned jlim = (unsigned)(m < TBL ? m : TBL);
+        uint64_t Rlo[2] = {0}, Rhi[2] = {0}, valid[2] = {0};
+        for (int k = 0; k < 64 * NW; k++) {
+            const uint8_t qc = k < m ? read[rpos + k] : (uint8_t)((k * 7 + 3) & 3);
+            Rlo[k / 64] |= (uint64_t)(qc & 1) << (63 - k % 64);
+            Rhi[k / 64] |= (uint64_t)(qc >> 1) << (63 - k % 64);
+            if (k < m) valid[k / 64] |= 1ull << (63 - k % 64);
+        }
+        uint64_t Pv[2], Mv[2] = {0};
+        for (int w = 0; w < NW; w++) Pv[w] = valid[w];
+        for (int i = 64 * NW - 1; i >= 0; i--) {
+            const uint8_t tc = i < n ? text[tpos + i] : (uint8_t)((i * 5 + 1) & 3);
+            const uint64_t sl = 0ull - (uint64_t)(tc & 1), sh = 0ull - (uint64_t)(tc >> 1);
+            uint64_t Eq[2], Xv[2], Xh[2], Ph[2], Mh[2], Pvn[2], Mvn[2];
+            unsigned carry = 0;
+            for (int w = NW - 1; w >= 0; w--) {
+                Eq[w] = (i < n ? ~((Rlo[w] ^ sl) | (Rhi[w] ^ sh)) : 0ull) | ~valid[w];
+                Xv[w] = Eq[w] | Mv[w];
+                const uint64_t t = Eq[w] & Pv[w];
+                const unsigned __int128 s = (unsigned __int128)t + Pv[w] + carry;
+                carry = (unsigned)(s >> 64);
+                Xh[w] = (((uint64_t)s) ^ Pv[w]) | Eq[w];
+                Ph[w] = Mv[w] | ~(Xh[w] | Pv[w]);
+                Mh[w] = Pv[w] & Xh[w];
+            }
+            for (int w = 0; w < NW; w++) {
+                const uint64_t ph1 = (Ph[w] << 1) | (w + 1 < NW ? Ph[w + 1] >> 63 : 0);
+                const uint64_t mh1 = (Mh[w] << 1) | (w + 1 < NW ? Mh[w + 1] >> 63 : 0);
+                Pvn[w] = mh1 | ~(Xv[w] | ph1);
+                Mvn[w] = ph1 & Xv[w];
+            }
+            if (i < TBL) { V1[i] = Pvn[0] | Ph[0]; V0[i] = Pvn[0] | ~(Ph[0] | Xh[0]); }
+            for (int w = 0; w < NW; w++) { Pv[w] = Pvn[w]; Mv[w] = Mvn[w]; }
+            ls->columns++;
+        }
+        walk_out wo;
+        if (lane_walk_band(V1, V0, TBL, jlim, &wo)) {
+            ls->escapes++;
+            lane_walk_full(V1, V0, TBL, jlim, &wo);
+        }
+        ls->tb_columns += (uint64_t)TBL;
+        /* pass 2 on one-word masks (as lane_align_codes_mw with RW = 1) */
+        const unsigned nsh = 64u - (unsigned)TBL;
+        const uint64_t Draw = ~(wo.nDm << nsh), Xraw = wo.Xm << nsh, Im = ~wo.nIm << nsh;
+        const unsigned ti = (unsigned)lp_clz64((Draw & Xraw) | (0x8000000000000000ull >> TBL));
+        const uint64_t A = ti ? ~(~0ull >> ti) : 0ull;        /* (ti <= 63) */
+        const uint64_t D = Draw & A, X = Xraw & A;
+        const uint64_t B = ((D ^ (D >> 1)) | (X ^ (X >> 1)) | Im | 0x8000000000000000ull) & A;
+        total += (long long)(wo.j - ti + 2u * (unsigned)__builtin_popcountll(D) + (unsigned)__builtin_popcountll(X));
+        uint64_t E = B | Im;
+        while (E) {
+            const unsigned c = (unsigned)lp_clz64(E);
+            const uint64_t bit = 0x8000000000000000ull >> c;
+            if (Im & bit) sink_push(&out, 'I', wo.ilen[c]);
+            E &= ~bit;
+            unsigned nx = (unsigned)lp_clz64(E);
+            if (nx > ti) nx = ti;
+            if (B & bit) sink_push(&out, (D & bit) ? 'D' : ((X & bit) ? 'X' : '='), nx - c);
+        }
+        ls->windows++;
+        tpos += ti; rpos += wo.j;
+    }
+    *n_runs = out.n; *edit_distance = total;
+    return out.overflow ? GO_ERR_CAPACITY : GO_OK;
+}

@@ -90,13 +90,13 @@ def test_product_does_not_reference_oracle():
 
 
 def test_unknown_experiment_switches_are_rejected(lib):
-    """scrg_params.reserved[0]: only the switches that leave the results intact pass (1, 32, 64, 128); the ablation
+    """scrg_params.reserved[0]: only the switches that leave the results intact pass (1, 32, 64, 128, 256); the ablation
     switches of the profiling build (2, 4, 8, 16: skip the table / the runs / the walk / the stores) and anything an
     uninitialised struct might hold are SCRG_ERR_INVALID_ARG in the shipped library."""
     import ctypes as C
     p, out = api.Params(), api.Params()
     for flags, ok in ((0, True), (1, True), (32, True), (64 | 1, True), (128, True), (2, False), (4, False), (8, False),
-                      (16, False), (0x7fffffff, False), (-1, False), (256, False)):
+                      (16, False), (0x7fffffff, False), (-1, False), (256, True), (512, False)):
         lib.scrg_params_default(C.byref(p))
         p.reserved[0] = flags
         assert (lib.scrg_params_resolve(C.byref(p), C.byref(out)) == api.SCRG_OK) == ok, flags

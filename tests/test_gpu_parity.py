@@ -183,6 +183,44 @@ def test_windows_over_64_vs_oracle(aligner, oracle, w, o, g):
            "W=%d O=%d g=%d spill" % (w, o, g))
 
 
+@pytest.mark.parametrize("w,o", [(64, 2), (64, 1), (64, 16), (64, 32), (63, 20), (40, 5), (33, 1), (128, 65), (96, 49), (80, 41),
+                                 (112, 57), (128, 96), (100, 40), (65, 2), (127, 64)])
+def test_table_in_two_halves(aligner, oracle, w, o):
+    """32 <= W-O <= 63, W <= 128 (the reference's small-overlap and W > 64 sweep points, scripts/profile.py:88-100,
+    180-185): genasm_lane_wide_kernel builds the window's table in two halves of 32 columns in registers.  Runs that
+    cross from the first half into the second are one run (long matches on low-error reads, long gaps), walks that end
+    in the first half never enter the second, texts that end inside a window take the short-window variant.  The
+    kernel it replaces for these W/O (table in HBM, reserved[0] = 256) gives the same results."""
+    t, q = synth.make_pairs(150, 2000, "ont", seed=w * 13 + o)
+    a, b = synth.make_pairs(40, 2500, "pacbio15", seed=w + o + 1)
+    c, d = synth.make_pairs(300, 300, "illumina", seed=w + o + 2)       # long match runs across the halves
+    t, q = t + a + c, q + b + d
+    rng = np.random.Generator(np.random.PCG64(w * 5 + o))
+    for _ in range(100):                       # unrelated sequences, ragged and empty inputs
+        t.append(synth.random_seq(int(rng.integers(0, 500)), rng))
+        q.append(synth.random_seq(int(rng.integers(0, 500)), rng))
+    for _ in range(40):                        # low-complexity sequences: long insertion / deletion runs, many ties
+        t.append(bytes(rng.choice(np.frombuffer(b"AC", np.uint8), int(rng.integers(1, 400)))))
+        q.append(bytes(rng.choice(np.frombuffer(b"AC", np.uint8), int(rng.integers(1, 400)))))
+    for _ in range(40):                        # one long gap
+        s = synth.random_seq(int(rng.integers(200, 700)), rng)
+        cut, gap = int(rng.integers(10, 150)), int(rng.integers(10, 60))
+        t += [s, s[:cut] + s[cut + gap:]]
+        q += [s[:cut] + s[cut + gap:], s]
+    t += [b"", b"ACGT", b"A" * 300, b"A" * 10, b"ACGT" * 100]
+    q += [b"ACGT", b"", b"A" * 10, b"A" * 300, b"TGCA" * 100]
+    eds, cigars, _, _ = oracle.align(t, q, W=w, O=o, threads=8)
+    _check(aligner.align_pairs(t, q, W=w, O=o), eds, cigars, "W=%d O=%d" % (w, o))
+    p = aligner.make_params(W=w, O=o)
+    p.reserved[0] = 256
+    keep = aligner.params
+    aligner.params = p
+    try:
+        _check(aligner.align_pairs(t, q), eds, cigars, "W=%d O=%d, table in HBM" % (w, o))
+    finally:
+        aligner.params = keep
+
+
 def test_windows_over_64_limits(aligner):
     import scrooge_amd
     with pytest.raises(scrooge_amd.ScroogeError):

@@ -96,3 +96,30 @@ def test_lane_multiword_form_matches_oracle(proto, W, O):
         want = _run(proto.go_align_codes, t, q, (C.c_int(W), C.c_int(O)), (None,))
         assert got == want
     assert ls.windows > 300
+
+
+class LSB(C.Structure):
+    _fields_ = [("windows", C.c_uint64), ("columns", C.c_uint64), ("tb_columns", C.c_uint64), ("escapes", C.c_uint64)]
+
+
+@pytest.mark.parametrize("W,O", [(64, 2), (64, 32), (64, 16), (64, 1), (63, 20), (40, 5), (33, 1), (128, 65), (96, 49), (80, 41),
+                                 (112, 57), (128, 96), (100, 40), (65, 2)])
+def test_lane_band_form_matches_oracle(proto, W, O):
+    """32 <= W-O <= 63 (genasm_lane_band_kernel.hip): the table keeps 32 rows around the diagonal per column; a walk
+    that leaves the band in a column it is alive in has the window redone on the full rows.  Related sequences stay
+    inside (no escapes on the sequencing-error profiles), unrelated and low-complexity ones do not."""
+    T, Q = _cases(W * 100 + O + 11)
+    rng = np.random.Generator(np.random.PCG64(W + O))
+    for _ in range(30):                       # long gaps: the walk crosses the band's edges
+        a = synth.random_seq(int(rng.integers(200, 600)), rng)
+        cut, gap = int(rng.integers(10, 150)), int(rng.integers(10, 60))
+        T += [a, a[:cut] + a[cut + gap:]]
+        Q += [a[:cut] + a[cut + gap:], a]
+    ls, related = LSB(), LSB()
+    for k, (t, q) in enumerate(zip(T, Q)):
+        st = related if k < 62 else ls        # the first 62 cases of _cases(): ont / pacbio15 / illumina pairs
+        got = _run(proto.lane_align_codes_band, t, q, (C.c_int(W), C.c_int(O)), (C.byref(st),))
+        want = _run(proto.go_align_codes, t, q, (C.c_int(W), C.c_int(O)), (None,))
+        assert got == want, k
+    assert related.windows > 300 and ls.escapes > 0
+    assert related.escapes <= related.windows // 200, (related.escapes, related.windows)
