@@ -4,7 +4,8 @@ configuration with the reference's column names where a knob has an equivalent h
     python scripts/sweep.py out.csv [pairs] [read_len]
 
 W and O are runtime parameters here (the reference recompiles per configuration, profile.py:131-142);
-supported range 2 <= W <= 256, 1 <= O < W (W-O > 31 and W > 64: multi-word rows, the table in HBM).  "threadblocks/sm" = persistent wavefronts per CU,
+supported range 2 <= W <= 256, 1 <= O < W (one pair per lane: W-O <= 31 genasm_lane_kernel, 32 <= W-O <= 63 and W <= 128
+genasm_lane_wide_kernel — table in registers, built in two halves —, beyond that genasm_lane_mw_kernel, table in HBM).  "threadblocks/sm" = persistent wavefronts per CU,
 "used smem per threadblock (B)" = LDS bytes per wavefront; SENE/DENT/ET are always on (they do not
 change results)."""
 import csv, sys
@@ -37,9 +38,9 @@ name = torch.cuda.get_device_name(0)
 configs = [(64, 33, 0, 0, 0)]                                                                    # library defaults (one pair per lane, 16 waves/CU)
 configs += [(W, min(W // 2 + 1, W - 1), 0, 0, 0) for W in (16, 24, 32, 40, 48, 56)]        # W sweep, O = W/2+1 (profile.py:78): lane kernel
 configs += [(64, O, 0, 0, 0) for O in (36, 40, 48, 56, 60)]                                    # O sweep at W=64 (profile.py:88-100): lane kernel
-configs += [(64, O, 0, 0, 0) for O in (2, 16, 32)]                                              # small overlaps (W-O > 31): genasm_lane_mw_kernel (64-bit rows, table in HBM)
+configs += [(64, O, 0, 0, 0) for O in (2, 16, 32)]                                              # small overlaps (W-O > 31): genasm_lane_wide_kernel (64-bit rows, table in registers in two halves)
 configs += [(64, O, 8, 13, 3) for O in (2, 16, 32)]                                             # the same on the GenASM-row kernel (G=8, WIDE storage)
-configs += [(W, W // 2 + 1, 0, 0, 0) for W in (80, 96, 112, 128, 160, 192, 224, 256)]         # W sweep past one word (profile.py:180-185): genasm_lane_mw_kernel
+configs += [(W, W // 2 + 1, 0, 0, 0) for W in (80, 96, 112, 128, 160, 192, 224, 256)]         # W sweep past one word (profile.py:180-185): genasm_lane_wide_kernel up to W=128, genasm_lane_mw_kernel beyond
 configs += [(128, 20, 0, 0, 0), (256, 1, 0, 0, 0)]                                               # rows of two and four words
 configs += [(W, W // 2 + 1, 32, 0, 0) for W in (96, 128, 192, 256)]                              # the same on the GenASM-row kernel with multi-word entries
 configs += [(128, 65, 64, 0, 0), (256, 129, 64, 0, 0), (256, 129, 32, 20, 0)]

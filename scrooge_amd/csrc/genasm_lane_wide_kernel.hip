@@ -33,6 +33,9 @@ namespace scrg {
 
 namespace {
 
+#ifndef WD_BLOCKS_PER_CU
+#define WD_BLOCKS_PER_CU 2
+#endif
 constexpr int WD_HALF = 32;                      // columns per half
 constexpr uint32_t WD_RING_BYTES = 68;           // 32 runs + one dword: lanes land on distinct LDS banks
 constexpr uint32_t WD_SCRATCH_BYTES = 36;        // insertion-run length of each column of a half, one byte each (+ bank skew)
@@ -207,7 +210,7 @@ __device__ __forceinline__ void wd_sweep(WdState<NW>& st, const WdWindow<NW>& w,
 // Workgroups are four independent wavefronts (as genasm_lane_kernel); two workgroups per CU: the table's 128 registers
 // leave room for two wavefronts per SIMD.
 template <int NW, bool EDITS>
-__global__ __launch_bounds__(256, 2) void genasm_lane_wide_kernel(AlignArgs a)
+__global__ __launch_bounds__(256, WD_BLOCKS_PER_CU) void genasm_lane_wide_kernel(AlignArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     char* const lds_b = reinterpret_cast<char*>(lds);
@@ -390,11 +393,28 @@ __global__ __launch_bounds__(256, 2) void genasm_lane_wide_kernel(AlignArgs a)
 #pragma unroll
             for (int q = 0; q < 2 * NW; q++) { win.tl[q] ^= swl; win.th[q] ^= swh; }
         }
-        const bool short_n = __any(has_pair && n != 64u * NW);
+        // short_n: some lane's text ends inside the columns 0..63; short_pro (W > 64): ... inside the columns 64 .. the
+        // first column of the prologue sweep
+        const bool short_n = __any(has_pair && n < 64u);
+        const bool short_pro = NW == 2 && __any(has_pair && n != ((W + 15u) & ~15u));
         uint64_t tab[WD_HALF][2];
         if constexpr (NW == 2) {
-            if (short_n) wd_sweep<NW, true, 127, 64, -1>(st0, win, tab, eq_b, nomatch_b);
-            else wd_sweep<NW, false, 127, 64, -1>(st0, win, tab, eq_b, nomatch_b);
+            // columns 64 .. W-1, common to both halves.  (A column past the end of the text leaves the boundary vectors as
+            // they are — Eq = "no match" gives Xh = ~valid, Ph = Mh = 0 — so the sweep starts at the first column a
+            // window of W characters can have, rounded up to 16.)
+            if (W <= 80u) {
+                if (short_pro) wd_sweep<NW, true, 79, 64, -1>(st0, win, tab, eq_b, nomatch_b);
+                else wd_sweep<NW, false, 79, 64, -1>(st0, win, tab, eq_b, nomatch_b);
+            } else if (W <= 96u) {
+                if (short_pro) wd_sweep<NW, true, 95, 64, -1>(st0, win, tab, eq_b, nomatch_b);
+                else wd_sweep<NW, false, 95, 64, -1>(st0, win, tab, eq_b, nomatch_b);
+            } else if (W <= 112u) {
+                if (short_pro) wd_sweep<NW, true, 111, 64, -1>(st0, win, tab, eq_b, nomatch_b);
+                else wd_sweep<NW, false, 111, 64, -1>(st0, win, tab, eq_b, nomatch_b);
+            } else {
+                if (short_pro) wd_sweep<NW, true, 127, 64, -1>(st0, win, tab, eq_b, nomatch_b);
+                else wd_sweep<NW, false, 127, 64, -1>(st0, win, tab, eq_b, nomatch_b);
+            }
         }
 
         // ---------------- the two halves: table, walk, runs ----------------
@@ -459,34 +479,77 @@ __global__ __launch_bounds__(256, 2) void genasm_lane_wide_kernel(AlignArgs a)
 
             if constexpr (EDITS) {
                 // pass 2, edit stream (genasm_lane_kernel<true>): the columns that hold an edit
+                // Only columns with an edit are visited: an insertion run (before the column's step), then a deletion or
+                // substitution.  mbase + c = matches pending when column c is reached; an insertion at c leaves none at c
+                // (mbase = -c), a deletion/substitution none at c + 1.  Every byte goes to the slot after the last
+                // committed one; only committing moves on.  Three insertions and 127 pending matches are handled in line,
+                // longer runs / stretches on a side path.  (A lane that has no event left has c = 0xffffffff and takes its
+                // mask bits with a field width of 0: a half has a column 31.)
                 uint32_t E = D | X | Im;
                 nr += (int32_t)(__builtin_popcount(B) + __builtin_popcount(Im));
-                auto emit = [&](uint32_t b) {
-                    lds8[ring_b + (pos & 63u)] = (uint8_t)b;
-                    pos++;
-                    if (pos - flushed >= 32u) write_piece();
-                };
-                while (__any(E != 0u)) {
-                    if (E != 0u) {
-                        const uint32_t c = wd_ffbh(E);
-                        const uint32_t bit = 0x80000000u >> c;
-                        E &= ~bit;
-                        uint32_t t = mbase + c;
-                        if (Im & bit) {
-                            const uint32_t ni = lds8[scr_b + c];
-                            for (uint32_t q = t >> 6; q; q--) emit(0x3Fu);
-                            emit(0x80u | (t & 63u));
-                            for (uint32_t q = 1; q < ni; q++) emit(0x80u);
-                            t = 0;
-                            mbase = 0u - c;
-                        }
-                        if ((D | X) & bit) {
-                            for (uint32_t q = t >> 6; q; q--) emit(0x3Fu);
-                            emit(((X & bit) ? 0x40u : 0xC0u) | (t & 63u));
-                            mbase = ~c;
+                uint32_t c = wd_ffbh(E);
+                uint32_t ni = lds8[scr_b + (c & 31u)];
+                const uint32_t DX = D | X;
+                auto put = [&](uint32_t at, uint32_t b) { lds8[ring_b + (at & 63u)] = (uint8_t)b; };
+                auto event = [&]() {
+                    const uint32_t sh = 31u - c;
+                    const uint32_t bit = 0x80000000u >> (c & 31u);
+                    const uint32_t lv = ~c >> 31;
+                    uint32_t iB = __builtin_amdgcn_ubfe(Im, sh, lv), dx = __builtin_amdgcn_ubfe(DX, sh, lv);
+                    const uint32_t xB = __builtin_amdgcn_ubfe(X, sh, lv);
+                    const uint32_t t = mbase + c;
+                    E = bitop3<WT_ANDN>(E, bit, bit);
+                    const uint32_t nx = wd_ffbh(E);
+                    const uint32_t step = 0xC0u - 0x80u * xB;                  // 'D' 3 << 6, 'X' 1 << 6
+                    const uint32_t live = iB | dx;                             // (0 only for a lane that is done)
+                    uint32_t k64 = (t >> 6) * live;                            // bytes 0x3F owed before the edit byte
+                    const bool side = max(ni * iB, 2u * k64) > 3u;             // more than 3 insertions or 127 matches pending
+                    if (__any(side)) {
+                        if (side) {
+                            auto emit = [&](uint32_t b) {
+                                put(pos, b);
+                                pos++;
+                                if (pos - flushed >= 32u) write_piece();
+                            };
+                            uint32_t tt = t;
+                            if (iB) {
+                                for (uint32_t q = tt >> 6; q; q--) emit(0x3Fu);
+                                emit(0x80u | (tt & 63u));
+                                for (uint32_t q = 1; q < ni; q++) emit(0x80u);
+                                tt = 0;
+                                mbase = 0u - c;
+                            }
+                            if (dx) {
+                                for (uint32_t q = tt >> 6; q; q--) emit(0x3Fu);
+                                emit(step | (tt & 63u));
+                                mbase = ~c;
+                            }
+                            iB = dx = k64 = 0;
                         }
                     }
+                    // in line: one byte 0x3F (64..127 matches pending), up to three insertions, the step
+                    put(pos, 0x3Fu);
+                    pos += k64;
+                    put(pos, 0x80u | (t & 63u));
+                    put(pos + 1u, 0x80u);
+                    put(pos + 2u, 0x80u);
+                    pos += iB ? (ni > 3u ? 3u : ni) : 0u;
+                    put(pos, step | ((iB ? 0u : t) & 63u));
+                    pos += dx;
+                    mbase = dx ? ~c : (iB ? 0u - c : mbase);
+                    ni = lds8[scr_b + (nx & 31u)];
+                    c = nx;
+                };
+                uint32_t trips = 0;
+                while (__any(E != 0u)) {
+                    event();
+                    event();
+                    if (++trips == 2u) {                       // <= 4 x 5 new bytes between checks + 4 speculative ones: the 64-byte ring cannot wrap
+                        trips = 0;
+                        flush_pieces();
+                    }
                 }
+                flush_pieces();
                 mbase += ti;
             } else {
                 // pass 2, runs (genasm_lane_kernel<false>)
@@ -529,7 +592,6 @@ __global__ __launch_bounds__(256, 2) void genasm_lane_wide_kernel(AlignArgs a)
                 flush_pieces();
             }
         }
-        if constexpr (EDITS) flush_pieces();
         read_idx += j;
         st_rounds++;
     }
