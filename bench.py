@@ -169,7 +169,7 @@ def pmc_instruction_count():
     return None, ("no PMC summary for the current kernel sources (sha256 %s...; newest file: %s): re-run scripts/collect_profiles.sh" % (want[:12], stale))
 
 
-def run_other_config(torch, scrooge_amd, device, local_rank, streams, name, n, L, profile, steps, warmup, check_pairs, seed, cores):
+def run_other_config(torch, scrooge_amd, device, local_rank, streams, name, n, L, profile, steps, warmup, check_pairs, seed, cores, W=64, O=33):
     """One more BASELINE configuration of the unstructured interface, measured the same way as the headline (pairs generated
     and packed on the GPU, lane-interleaved layout, steps = align kernel + run compaction rotating over the streams) after
     the timed region, with the first `check_pairs` pairs of the last step compared, runs and all, with the CPU checker."""
@@ -197,7 +197,7 @@ def run_other_config(torch, scrooge_amd, device, local_rank, streams, name, n, L
     first = (idx // G) * row_words * G + idx % G
     desc = torch.stack([first * 32, torch.full_like(idx, text_len), (first + tw * G) * 32, torch.full_like(idx, L),
                         idx * cap, torch.full_like(idx, cap)], dim=1).contiguous()
-    kw = dict(text_stride_words=G, read_stride_words=G)
+    kw = dict(text_stride_words=G, read_stride_words=G, W=W, O=O)
     outs = [dict(runs=torch.empty(n * cap * 2, dtype=torch.uint8, device=device), ed=torch.empty(n, dtype=torch.int64, device=device),
                  n_runs=torch.empty(n, dtype=torch.int32, device=device), status=torch.empty(n, dtype=torch.int32, device=device))
             for _ in streams]
@@ -225,17 +225,17 @@ def run_other_config(torch, scrooge_amd, device, local_rank, streams, name, n, L
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     last = (warmup + steps - 1) % len(streams)
-    res = {"workload": name, "pairs": n, "read_len": L, "error_profile": profile, "steps": steps, "value": n * steps / dt, "unit": "pairs/s",
+    res = {"workload": name, "pairs": n, "read_len": L, "error_profile": profile, "W": W, "O": O, "steps": steps, "value": n * steps / dt, "unit": "pairs/s",
            "ms_per_step": dt / steps * 1e3, "runs_per_pair": total_runs / n,
            "step": "align kernel + run compaction, steps rotate over %d streams; measured after the timed region of the headline" % len(streams)}
     if check_pairs:
         from oracle.pyoracle import Oracle, Reference
         k = check_pairs
-        if Reference.available():
-            e_cpu, off_cpu, runs_cpu, ns = Reference().align_rows(sample, 0, text_len, tw * 32, L, threads=cores)
-            against = "reference genasm_cpu.cpp (oracle/_ref)"
+        if Reference.available(W, O):
+            e_cpu, off_cpu, runs_cpu, ns = Reference(W, O).align_rows(sample, 0, text_len, tw * 32, L, threads=cores)
+            against = "reference genasm_cpu.cpp (oracle/_ref%s)" % ("" if (W, O) == (64, 33) else ", built with -DCLI_W=%d -DCLI_O=%d" % (W, O))
         else:
-            e_cpu, off_cpu, runs_cpu, _, ns = Oracle(allow_compile=False).align_rows(sample, 0, text_len, tw * 32, L, threads=cores)
+            e_cpu, off_cpu, runs_cpu, _, ns = Oracle(allow_compile=False).align_rows(sample, 0, text_len, tw * 32, L, W=W, O=O, threads=cores)
             against = "oracle/liboracle.so (restatement)"
         o = outs[last]
         cnt = o["n_runs"][:k].cpu().numpy().astype(np.uint64)
@@ -939,6 +939,14 @@ def main():
             run_other_config(torch, scrooge_amd, device, local_rank, streams,
                              "long-read stress: 40 k x 50 kb PacBio-error (15 %) pairs, the single-GPU share of BASELINE configs[4]",
                              40000, 50000, "pacbio15", 6, 2, 1500 if chk else 0, args.seed + 13, cores_),
+            # two points of the reference's knob sweeps (scripts/profile.py:88-100 small overlaps, :180-185 W > 64) on the headline
+            # workload: 32 <= W-O <= 63 runs on genasm_lane_wide_kernel (table in registers, built in two halves)
+            run_other_config(torch, scrooge_amd, device, local_rank, streams,
+                             "knob sweep point W=64 O=2: 100 k x 10 kb ONT-error pairs", 100000, 10000, "ont", 10, 2, 2000 if chk else 0,
+                             args.seed + 14, cores_, W=64, O=2),
+            run_other_config(torch, scrooge_amd, device, local_rank, streams,
+                             "knob sweep point W=128 O=65: 100 k x 10 kb ONT-error pairs", 100000, 10000, "ont", 10, 2, 2000 if chk else 0,
+                             args.seed + 15, cores_, W=128, O=65),
         ]
 
     pairs_total = world * n * args.steps

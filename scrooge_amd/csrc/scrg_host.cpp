@@ -36,7 +36,7 @@ using scrg_int::now_ns;
 using scrg_int::parallel_for;
 
 constexpr int NSLOT = 4;                                 // chunks in flight per device (HIP has 4 hardware queues per process and device)
-constexpr size_t LAG2 = 2;                                // a chunk's sizes are looked at this many chunks after it was launched
+constexpr size_t LAG2_DEFAULT = 2;                        // a chunk's sizes are looked at this many chunks after it was launched
 constexpr uint64_t GROUP = 64;
 constexpr uint64_t SEQ_PAD = 2 * GROUP + 2;              // SCRG_SEQ_PAD_WORDS_STRIDED(64)
 
@@ -600,6 +600,9 @@ void worker(DeviceState* ds, Call* c, int dev_index, int n_dev)
     for (uint64_t k = dev_index; k < n_chunks; k += n_dev) mine.push_back(k);
     const size_t m = mine.size();
     const bool timing = getenv("SCRG_HOST_TIMING") != nullptr;
+    // a call whose chunks all have a slot launches every one of them before it waits for the first (a chunk's kernel takes
+    // ~2 ms for 10 kb reads however small the chunk); a longer call keeps one slot of slack between launch and collection
+    const size_t LAG2 = m <= (size_t)NSLOT ? (size_t)NSLOT - 1 : LAG2_DEFAULT;
     const int64_t tw0 = now_ns();
 
     std::mutex mu;
