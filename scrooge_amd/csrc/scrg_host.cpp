@@ -35,7 +35,11 @@ using scrg_int::HostPinned;
 using scrg_int::now_ns;
 using scrg_int::parallel_for;
 
-constexpr int NSLOT = 4;                                 // chunks in flight per device (HIP has 4 hardware queues per process and device)
+constexpr int NSLOT = 4;                                 // chunks in flight per device (HIP has 4 hardware queues per process and device) ...
+constexpr int MAXSLOT = 8;                               // ... and twice as many for short reads: their kernels take ~0.2 ms per chunk, what limits such a call is
+                                                         // how soon a slot comes back (pack, H2D, kernels, look at the sizes, compaction, text, D2H, collection)
+constexpr uint64_t SHORT_READS = 1000;                   // longest read of a call that uses MAXSLOT slots
+constexpr size_t NCOLLECT = 2;                            // collect threads per device
 constexpr size_t LAG2_DEFAULT = 2;                        // a chunk's sizes are looked at this many chunks after it was launched
 constexpr uint64_t GROUP = 64;
 constexpr uint64_t SEQ_PAD = 2 * GROUP + 2;              // SCRG_SEQ_PAD_WORDS_STRIDED(64)
@@ -139,7 +143,7 @@ struct Slot {
     scrg_ctx* ctx = nullptr;                 // a handle of the device-pointer layer bound to `stream`
     hipEvent_t ev_tot = nullptr, ev_done = nullptr;
     HostPinned h_seq, h_meta, h_out, h_tot;
-    DevBuf d_meta, d_desc, d_slices, d_ed, d_nruns, d_status, d_cnt64, d_len64, d_runoff, d_textoff, d_tot, d_dense, d_text, d_temp;
+    DevBuf d_meta, d_desc, d_slices, d_ed, d_nruns, d_cnt64, d_len64, d_tot, d_dense, d_temp;     // d_ed: the per-pair results (PerPairLayout), d_dense: runs, then text
     // the chunk in flight
     uint64_t n = 0, first = 0;               // pairs, first issue index
     uint64_t tot_runs = 0, tot_text = 0;
@@ -152,7 +156,7 @@ struct DeviceState {
     uint64_t genome_words = 0, genome_len = 0;
     bool genome_ok = false;                  // d_seq starts with a packed genome
     uint64_t slot_words = 0;
-    Slot slot[NSLOT];
+    Slot slot[MAXSLOT];
     std::mutex mu;                           // one call at a time per device state
     std::string err;
 };
@@ -178,7 +182,7 @@ scrg_status ensure_seq(DeviceState* ds, uint64_t genome_words, uint64_t slot_wor
     HTRY(ds, hipDeviceSynchronize());
     DevBuf bigger;
     const uint64_t grow_slot = need_slot > ds->slot_words ? need_slot + need_slot / 4 : need_slot;
-    HTRY(ds, bigger.ensure((gpad + NSLOT * grow_slot + 8) * sizeof(uint64_t)));
+    HTRY(ds, bigger.ensure((gpad + MAXSLOT * grow_slot + 8) * sizeof(uint64_t)));
     if (ds->genome_ok && gpad == have_g && gpad)         // keep a resident genome
         HTRY(ds, hipMemcpy(bigger.p, ds->d_seq.p, gpad * sizeof(uint64_t), hipMemcpyDeviceToDevice));
     else
@@ -222,9 +226,17 @@ scrg_status pack_genome(DeviceState* ds, const char* genome, uint64_t genome_len
 // ---------------------------------------------------------------------------------------------------------------
 // a call
 // ---------------------------------------------------------------------------------------------------------------
-struct Grow {                          // a result array that is appended to chunk by chunk
+// A chunk's per-pair results, on the device and in the host staging area: [ed 8n | status 4n (+pad) | run_off 8n | text_off 8n]
+struct PerPairLayout {
+    size_t o_st, o_ro, o_to, bytes;
+    explicit PerPairLayout(uint64_t n) : o_st(8 * n), o_ro((8 * n + 4 * n + 15) & ~(size_t)15), o_to(o_ro + 8 * n), bytes(o_ro + 16 * n) {}
+    size_t host_runs() const { return (bytes + 256 + 4095) & ~(size_t)4095; }      // staging area: where the runs (then the text) start
+};
+
+struct Grow {                          // a result array that the chunks' collectors fill, each chunk at its own offset
     char* p = nullptr;
     size_t cap = 0;
+    std::atomic<size_t> hi{0};         // end of the highest region that has been written (chunks may be collected out of order)
 };
 
 struct Call {
@@ -255,6 +267,7 @@ struct Call {
     std::string err;
     std::atomic<int64_t> kernel_ns{0}, pack_ns{0};
     unsigned threads_per_worker = 16;
+    int n_slots = NSLOT;               // slots a device uses for this call (make_plan)
 
     void fail(scrg_status s, const std::string& what)
     {
@@ -270,15 +283,20 @@ struct Call {
 
 inline uint64_t read_of(const Call& c, uint64_t p) { return c.b->mapping ? c.b->pair_read[p] : p; }
 
-// `hint`: what the whole call is expected to need (from the first chunk that arrives: bytes per pair x pairs + 8 %)
-bool grow_to(Call& c, Grow& g, size_t used, size_t need, size_t hint)
+// `hint`: what the whole call is expected to need (from the first chunk that arrives: bytes per pair x pairs + 8 %).
+// Writers hold grow_mu shared while they copy and raise g.hi first; a regrow (exclusive) moves everything below g.hi.
+bool grow_to(Call& c, Grow& g, size_t need, size_t hint)
 {
-    if (need <= g.cap) return true;
+    {
+        std::shared_lock<std::shared_mutex> lk(c.grow_mu);
+        if (need <= g.cap) return true;
+    }
     std::unique_lock<std::shared_mutex> lk(c.grow_mu);
     if (need <= g.cap) return true;
     const size_t cap = std::max(std::max(need + need / 8, g.cap + g.cap / 2), hint);
     char* np = static_cast<char*>(g_pool.get(cap, false));
     if (!np) return false;
+    const size_t used = std::min(g.hi.load(), g.cap);
     if (g.p && used) {
         const size_t CH = 1u << 22;
         parallel_for((used + CH - 1) / CH, [&](uint64_t i) { memcpy(np + i * CH, g.p + i * CH, std::min(CH, used - i * CH)); }, true);
@@ -441,13 +459,18 @@ scrg_status stage1(DeviceState* ds, Slot& sl, Call& c, uint64_t chunk)
     HTRY(ds, sl.d_meta.ensure(meta_bytes));
     HTRY(ds, sl.d_desc.ensure(n * sizeof(scrg_pair_desc)));
     HTRY(ds, sl.d_slices.ensure(n * cap * sizeof(scrg_run)));
-    HTRY(ds, sl.d_ed.ensure(n * 8));
+    // the four per-pair result arrays sit back to back in one buffer, in the layout of the host staging area: ONE read-back
+    // (a read-back of 1-2 MB runs at ~12 GB/s; six of them per chunk were 0.85 ms of 1.3 ms per 250 k mapping pairs)
+    const PerPairLayout lay(n);
+    HTRY(ds, sl.d_ed.ensure(lay.bytes + 256));
+    char* const d_pp = sl.d_ed.as<char>();
+    int64_t* const d_ed = reinterpret_cast<int64_t*>(d_pp);
+    uint32_t* const d_status = reinterpret_cast<uint32_t*>(d_pp + lay.o_st);
+    uint64_t* const d_runoff = reinterpret_cast<uint64_t*>(d_pp + lay.o_ro);
+    uint64_t* const d_textoff = reinterpret_cast<uint64_t*>(d_pp + lay.o_to);
     HTRY(ds, sl.d_nruns.ensure(n * 4));
-    HTRY(ds, sl.d_status.ensure(n * 4));
     HTRY(ds, sl.d_cnt64.ensure(n * 8));
     HTRY(ds, sl.d_len64.ensure(n * 8));
-    HTRY(ds, sl.d_runoff.ensure(n * 8));
-    HTRY(ds, sl.d_textoff.ensure(n * 8));
     HTRY(ds, sl.d_tot.ensure(16));
     const size_t temp_bytes = scrg::host_scan_temp_bytes(n);
     HTRY(ds, sl.d_temp.ensure(temp_bytes + 256));
@@ -472,15 +495,15 @@ scrg_status stage1(DeviceState* ds, Slot& sl, Call& c, uint64_t chunk)
     scrg_params pp = c.p;
     pp.read_stride_words = (int32_t)rstride;
     pp.text_stride_words = b.mapping ? 1 : (int32_t)rstride;
-    scrg_status s = scrg_align_device(sl.ctx, &pp, n, d_seq, sl.d_desc.as<scrg_pair_desc>(), sl.d_slices.as<scrg_run>(), sl.d_ed.as<int64_t>(),
-                                      sl.d_nruns.as<uint32_t>(), sl.d_status.as<uint32_t>());
+    scrg_status s = scrg_align_device(sl.ctx, &pp, n, d_seq, sl.d_desc.as<scrg_pair_desc>(), sl.d_slices.as<scrg_run>(), d_ed,
+                                      sl.d_nruns.as<uint32_t>(), d_status);
     if (s != SCRG_OK) {
         ds->err = scrg_last_error(sl.ctx);
         return s;
     }
     HTRY(ds, scrg::launch_result_layout(n, sl.d_desc.as<scrg_pair_desc>(), sl.d_slices.as<uint16_t>(), sl.d_nruns.as<uint32_t>(),
-                                        sl.d_cnt64.as<uint64_t>(), sl.d_len64.as<uint64_t>(), sl.d_runoff.as<uint64_t>(),
-                                        sl.d_textoff.as<uint64_t>(), sl.d_tot.as<uint64_t>(), sl.d_temp.p, temp_bytes, c.want_text, ds->n_cus,
+                                        sl.d_cnt64.as<uint64_t>(), sl.d_len64.as<uint64_t>(), d_runoff,
+                                        d_textoff, sl.d_tot.as<uint64_t>(), sl.d_temp.p, temp_bytes, c.want_text, ds->n_cus,
                                         sl.stream));
     HTRY(ds, hipMemcpyAsync(sl.h_tot.p, sl.d_tot.p, 16, hipMemcpyDeviceToHost, sl.stream));
     HTRY(ds, hipEventRecord(sl.ev_tot, sl.stream));
@@ -506,28 +529,35 @@ scrg_status stage2(DeviceState* ds, Slot& sl, Call& c, uint64_t chunk)
     if (scrg_last_kernel_ms(sl.ctx, &ms) == SCRG_OK) c.kernel_ns.fetch_add((int64_t)((double)ms * 1e6));
     c.pack_ns.fetch_add(sl.t_pack_ns);
     const uint64_t n = sl.n;
-    // staging: [ed 8n | status 4n (+pad) | run_off 8n | text_off 8n | runs 2R | text T]
-    const size_t o_ed = 0, o_st = 8 * n, o_ro = (o_st + 4 * n + 15) & ~(size_t)15, o_to = o_ro + 8 * n, o_runs = o_to + 8 * n;
-    const size_t o_text = (o_runs + 2 * sl.tot_runs + 15) & ~(size_t)15, total = o_text + sl.tot_text + 16;
+    // staging: [ed 8n | status 4n (+pad) | run_off 8n | text_off 8n | runs 2R (+pad) | text T]; on the device the per-pair
+    // arrays are one buffer in this layout and runs + text another: two read-backs per chunk
+    const PerPairLayout lay(n);
+    const size_t o_runs = lay.host_runs(), text_rel = (2 * sl.tot_runs + 15) & ~(size_t)15;
+    const size_t o_text = o_runs + text_rel, total = o_text + sl.tot_text + 512;
     HTRY(ds, sl.h_out.ensure(total));
     char* const h = static_cast<char*>(sl.h_out.p);
-    HTRY(ds, sl.d_dense.ensure(2 * sl.tot_runs + 64));
-    if (c.want_text) HTRY(ds, sl.d_text.ensure(sl.tot_text + 64));
+    HTRY(ds, sl.d_dense.ensure(text_rel + (c.want_text ? sl.tot_text : 0) + 512));
+    char* const d_pp = sl.d_ed.as<char>();
+    uint64_t* const d_runoff = reinterpret_cast<uint64_t*>(d_pp + lay.o_ro);
+    uint64_t* const d_textoff = reinterpret_cast<uint64_t*>(d_pp + lay.o_to);
+    uint8_t* const d_text = sl.d_dense.as<uint8_t>() + text_rel;
     scrg_status s = scrg_compact_runs(sl.ctx, n, sl.d_desc.as<scrg_pair_desc>(), sl.d_slices.as<scrg_run>(), sl.d_nruns.as<uint32_t>(),
-                                      sl.d_runoff.as<uint64_t>(), sl.d_dense.as<scrg_run>());
+                                      d_runoff, sl.d_dense.as<scrg_run>());
     if (s != SCRG_OK) {
         ds->err = scrg_last_error(sl.ctx);
         return s;
     }
     if (c.want_text)
-        HTRY(ds, scrg::launch_render_text(n, sl.d_dense.as<uint16_t>(), sl.d_runoff.as<uint64_t>(), sl.d_cnt64.as<uint64_t>(),
-                                          sl.d_textoff.as<uint64_t>(), sl.d_text.as<uint8_t>(), ds->n_cus, sl.stream));
-    HTRY(ds, hipMemcpyAsync(h + o_ed, sl.d_ed.p, 8 * n, hipMemcpyDeviceToHost, sl.stream));
-    HTRY(ds, hipMemcpyAsync(h + o_st, sl.d_status.p, 4 * n, hipMemcpyDeviceToHost, sl.stream));
-    HTRY(ds, hipMemcpyAsync(h + o_ro, sl.d_runoff.p, 8 * n, hipMemcpyDeviceToHost, sl.stream));
-    if (c.want_text) HTRY(ds, hipMemcpyAsync(h + o_to, sl.d_textoff.p, 8 * n, hipMemcpyDeviceToHost, sl.stream));
-    if (c.want_runs && sl.tot_runs) HTRY(ds, hipMemcpyAsync(h + o_runs, sl.d_dense.p, 2 * sl.tot_runs, hipMemcpyDeviceToHost, sl.stream));
-    if (c.want_text && sl.tot_text) HTRY(ds, hipMemcpyAsync(h + o_text, sl.d_text.p, sl.tot_text, hipMemcpyDeviceToHost, sl.stream));
+        HTRY(ds, scrg::launch_render_text(n, sl.d_dense.as<uint16_t>(), d_runoff, sl.d_cnt64.as<uint64_t>(), d_textoff, d_text, ds->n_cus, sl.stream));
+    // (whole multiples of 256 bytes to page-aligned host addresses: the buffers have the slack)
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    HTRY(ds, hipMemcpyAsync(h, d_pp, up(c.want_text ? lay.bytes : lay.o_to), hipMemcpyDeviceToHost, sl.stream));
+    if (c.want_runs && c.want_text && sl.tot_runs + sl.tot_text)
+        HTRY(ds, hipMemcpyAsync(h + o_runs, sl.d_dense.p, up(text_rel + sl.tot_text), hipMemcpyDeviceToHost, sl.stream));
+    else if (c.want_runs && sl.tot_runs)
+        HTRY(ds, hipMemcpyAsync(h + o_runs, sl.d_dense.p, up(2 * sl.tot_runs), hipMemcpyDeviceToHost, sl.stream));
+    else if (c.want_text && sl.tot_text)
+        HTRY(ds, hipMemcpyAsync(h + o_text, d_text, up(sl.tot_text), hipMemcpyDeviceToHost, sl.stream));
     HTRY(ds, hipEventRecord(sl.ev_done, sl.stream));
     return SCRG_OK;
 }
@@ -554,17 +584,24 @@ scrg_status stage3(DeviceState* ds, Slot& sl, Call& c, uint64_t chunk)
         }
     }
     const uint64_t n = sl.n, first = sl.first;
-    const size_t o_st = 8 * n, o_ro = (o_st + 4 * n + 15) & ~(size_t)15, o_to = o_ro + 8 * n, o_runs = o_to + 8 * n;
-    const size_t o_text = (o_runs + 2 * sl.tot_runs + 15) & ~(size_t)15;
+    const PerPairLayout lay(n);
+    const size_t o_st = lay.o_st, o_ro = lay.o_ro, o_to = lay.o_to, o_runs = lay.host_runs();
+    const size_t o_text = o_runs + ((2 * sl.tot_runs + 15) & ~(size_t)15);
     const char* const h = static_cast<const char*>(sl.h_out.p);
     const double per_pair_scale = 1.08 * (double)c.n / (double)std::max<uint64_t>(1, n);
-    if (c.want_runs && !grow_to(c, c.runs, 2 * base_runs, 2 * (base_runs + sl.tot_runs) + 2, (size_t)(2.0 * (double)sl.tot_runs * per_pair_scale) + 4096))
+    if (c.want_runs && !grow_to(c, c.runs, 2 * (base_runs + sl.tot_runs) + 2, (size_t)(2.0 * (double)sl.tot_runs * per_pair_scale) + 4096))
         return SCRG_ERR_OOM;
-    if (c.want_text && !grow_to(c, c.text, base_text, base_text + sl.tot_text + 1, (size_t)((double)sl.tot_text * per_pair_scale) + 4096))
+    if (c.want_text && !grow_to(c, c.text, base_text + sl.tot_text + 1, (size_t)((double)sl.tot_text * per_pair_scale) + 4096))
         return SCRG_ERR_OOM;
     {
         std::shared_lock<std::shared_mutex> lk(c.grow_mu);
-        const size_t CH = 1u << 21;
+        auto raise = [](std::atomic<size_t>& hi, size_t v) {
+            size_t cur = hi.load();
+            while (cur < v && !hi.compare_exchange_weak(cur, v)) {}
+        };
+        if (c.want_runs) raise(c.runs.hi, 2 * (base_runs + sl.tot_runs));
+        if (c.want_text) raise(c.text.hi, base_text + sl.tot_text);
+        const size_t CH = 1u << 19;
         const size_t rb = c.want_runs ? 2 * sl.tot_runs : 0, tb = c.want_text ? sl.tot_text : 0;
         const uint64_t n_r = (rb + CH - 1) / CH, n_t = (tb + CH - 1) / CH;
         parallel_for(n_r + n_t, [&](uint64_t i) {
@@ -588,11 +625,13 @@ scrg_status stage3(DeviceState* ds, Slot& sl, Call& c, uint64_t chunk)
     return SCRG_OK;
 }
 
-// One device: a LAUNCH thread packs chunk i, sends it and starts its kernels, then looks at the sizes of chunk i - LAG2 and
-// starts its compaction, rendering and read-back; a COLLECT thread puts finished chunks into the result arrays.  A slot
-// is reused NSLOT chunks later, once its previous chunk has been collected.
-// (The align kernel of a chunk of 10 kb reads takes ~2 ms however small the chunk is — ~330 dependent window rounds —,
-// hence the two chunks between a launch and the look at its sizes: the launch thread should not wait for it.)
+// One device: a LAUNCH thread packs chunk i, sends it and starts its kernels; the sizes of an earlier chunk are looked at
+// as soon as they have arrived (without waiting, unless the chunk is LAG2 launches behind) and its compaction, rendering
+// and read-back are started; two COLLECT threads put finished chunks into the result arrays.  A slot is reused n_slots
+// chunks later, once its previous chunk has been collected.  n_slots is 4 for long reads — the align kernel of a chunk of
+// 10 kb reads takes ~2 ms however small the chunk is (~330 dependent window rounds), and HIP has four hardware queues —
+// and 8 for short ones, where a chunk's kernels take ~0.5 ms and what limits the call is how soon a slot comes back
+// (1 M x 4 mapping pairs: 21 ms with four slots, 16 ms with eight; the read-back alone is 11.5 ms at PCIe rate).
 void worker(DeviceState* ds, Call* c, int dev_index, int n_dev)
 {
     std::vector<uint64_t> mine;
@@ -602,73 +641,92 @@ void worker(DeviceState* ds, Call* c, int dev_index, int n_dev)
     const bool timing = getenv("SCRG_HOST_TIMING") != nullptr;
     // a call whose chunks all have a slot launches every one of them before it waits for the first (a chunk's kernel takes
     // ~2 ms for 10 kb reads however small the chunk); a longer call keeps one slot of slack between launch and collection
-    const size_t LAG2 = m <= (size_t)NSLOT ? (size_t)NSLOT - 1 : LAG2_DEFAULT;
+    const size_t NS = (size_t)c->n_slots;
+    const size_t LAG2 = m <= NS ? NS - 1 : (NS > (size_t)NSLOT ? NS - 2 : LAG2_DEFAULT);      // launches a chunk's stage 2 may be behind
     const int64_t tw0 = now_ns();
 
     std::mutex mu;
     std::condition_variable cv;
     size_t ready = 0;            // chunks (local index) whose read-back has been enqueued: the collector may wait for them
-    size_t collected = 0;        // chunks the collector is done with
     bool stop = false;
 
-    std::thread collector([&] {
-        for (size_t i = 0; i < m; i++) {
+    // COLLECT threads: chunk i (local index) is taken by collector i mod NCOLLECT — a chunk's place in the result arrays
+    // depends only on the totals of the chunks before it, which are known before it is read back
+    std::vector<char> done(m, 0);
+    auto collect = [&](size_t which) {
+        for (size_t i = which; i < m; i += NCOLLECT) {
             {
                 std::unique_lock<std::mutex> lk(mu);
                 cv.wait(lk, [&] { return ready > i || stop; });
                 if (ready <= i) return;
             }
             const int64_t ta = now_ns();
-            scrg_status s = c->failed() ? (scrg_status)c->status.load() : stage3(ds, ds->slot[i % NSLOT], *c, mine[i]);
+            scrg_status s = c->failed() ? (scrg_status)c->status.load() : stage3(ds, ds->slot[i % NS], *c, mine[i]);
             if (s != SCRG_OK) c->fail(s, ds->err.empty() ? std::string(scrg_status_string(s)) : ds->err);
             if (timing)
                 fprintf(stderr, "[scrooge_amd host] dev %d chunk %zu collected at %.3f ms: stage3 %.3f ms\n", dev_index, i, (now_ns() - tw0) / 1e6,
                         (now_ns() - ta) / 1e6);
             {
                 std::lock_guard<std::mutex> g(mu);
-                collected = i + 1;
+                done[i] = 1;
             }
             cv.notify_all();
         }
-    });
+    };
+    std::thread collectors[NCOLLECT];
+    for (size_t k = 0; k < NCOLLECT; k++) collectors[k] = std::thread(collect, k);
 
-    for (size_t i = 0; i < m + LAG2; i++) {
-        if (c->failed()) break;
-        scrg_status s = SCRG_OK;
-        const int64_t ta = now_ns();
-        if (i < m) {
-            if (i >= (size_t)NSLOT) {               // the slot's previous chunk must have been collected
-                std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return collected + NSLOT > i || c->failed(); });
-                if (c->failed()) break;
-            }
-            s = stage1(ds, ds->slot[i % NSLOT], *c, mine[i]);
-        }
+    // LAUNCH thread.  A chunk's sizes are looked at (stage 2) as soon as they have arrived — asked for without waiting after
+    // every launch — and waited for only when the chunk is LAG chunks behind the launches or nothing is left to launch.
+    size_t next2 = 0;
+    bool ok = true;
+    auto do_stage2 = [&](size_t k) -> bool {
         const int64_t tb = now_ns();
-        if (s == SCRG_OK && i >= LAG2 && i - LAG2 < m) {
-            s = stage2(ds, ds->slot[(i - LAG2) % NSLOT], *c, mine[i - LAG2]);
-            if (s == SCRG_OK) {
-                {
-                    std::lock_guard<std::mutex> g(mu);
-                    ready = i - LAG2 + 1;
-                }
-                cv.notify_all();
-            }
+        scrg_status s = stage2(ds, ds->slot[k % NS], *c, mine[k]);
+        if (s != SCRG_OK) {
+            c->fail(s, ds->err.empty() ? std::string(scrg_status_string(s)) : ds->err);
+            return false;
         }
+        {
+            std::lock_guard<std::mutex> g(mu);
+            ready = k + 1;
+        }
+        cv.notify_all();
+        if (timing) fprintf(stderr, "[scrooge_amd host] dev %d chunk %zu stage2 at %.3f ms: %.3f ms\n", dev_index, k, (tb - tw0) / 1e6, (now_ns() - tb) / 1e6);
+        return true;
+    };
+    for (size_t i = 0; i < m && ok; i++) {
+        if (c->failed()) break;
+        const int64_t ta = now_ns();
+        if (i >= NS) {               // the slot's previous chunk must have been collected (its stage 2 is behind us: LAG < NS)
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return done[i - NS] || c->failed(); });
+            if (c->failed()) break;
+        }
+        scrg_status s = stage1(ds, ds->slot[i % NS], *c, mine[i]);
         if (timing)
-            fprintf(stderr, "[scrooge_amd host] dev %d step %zu at %.3f ms: stage1 %.3f (pack %.3f) stage2 %.3f ms\n", dev_index, i,
-                    (ta - tw0) / 1e6, (tb - ta) / 1e6, i < m ? ds->slot[i % NSLOT].t_pack_ns / 1e6 : 0.0, (now_ns() - tb) / 1e6);
+            fprintf(stderr, "[scrooge_amd host] dev %d chunk %zu stage1 at %.3f ms: %.3f ms (pack %.3f)\n", dev_index, i, (ta - tw0) / 1e6,
+                    (now_ns() - ta) / 1e6, ds->slot[i % NS].t_pack_ns / 1e6);
         if (s != SCRG_OK) {
             c->fail(s, ds->err.empty() ? std::string(scrg_status_string(s)) : ds->err);
             break;
         }
+        while (ok && next2 <= i) {
+            const bool must = i + 1 - next2 > LAG2;
+            if (!must && hipEventQuery(ds->slot[next2 % NS].ev_tot) != hipSuccess) {
+                (void)hipGetLastError();
+                break;
+            }
+            ok = do_stage2(next2++);
+        }
     }
+    while (ok && !c->failed() && next2 < m) ok = do_stage2(next2++);
     {
         std::lock_guard<std::mutex> g(mu);
         stop = true;
     }
     cv.notify_all();
-    collector.join();
+    for (auto& t : collectors) t.join();
     (void)hipSetDevice(ds->device);
     for (Slot& sl : ds->slot) (void)hipStreamSynchronize(sl.stream);        // nothing of this call is in flight when it returns
 }
@@ -680,18 +738,22 @@ void make_plan(Call& c, const scrg_params& resolved, int n_states, bool* sorted_
     const scrg_host::Batch& b = *c.b;
     const uint64_t n = c.n;
     c.order.resize(n);
-    std::atomic<int> unsorted{0};
+    std::atomic<int> unsorted{0}, long_reads{0};
     {
         const uint64_t BLK = 1u << 16, nb = (n + BLK - 1) / BLK;
         parallel_for(nb, [&](uint64_t blk) {
-            bool ok = true;
+            bool ok = true, lng = false;
             for (uint64_t k = blk * BLK; k < std::min(n, (blk + 1) * BLK); k++) {
                 c.order[k] = (uint32_t)k;
-                if (k && b.read_lens[read_of(c, k - 1)] < b.read_lens[read_of(c, k)]) ok = false;
+                const uint64_t len = b.read_lens[read_of(c, k)];
+                if (k && b.read_lens[read_of(c, k - 1)] < len) ok = false;
+                if (len > SHORT_READS) lng = true;
             }
             if (!ok) unsorted.store(1, std::memory_order_relaxed);
+            if (lng) long_reads.store(1, std::memory_order_relaxed);
         }, true);
     }
+    c.n_slots = long_reads.load() ? NSLOT : MAXSLOT;
     c.identity = true;
     if (resolved.sort_by_length && unsorted.load()) {
         std::stable_sort(c.order.begin(), c.order.end(),
@@ -703,7 +765,7 @@ void make_plan(Call& c, const scrg_params& resolved, int n_states, bool* sorted_
     // into chunks of at most 32 MB of packed sequence or 256 k pairs.  In sorted issue order the first pair of a chunk has
     // its longest read.
     const bool sorted_issue = resolved.sort_by_length || !unsorted.load();
-    const uint64_t max_words = 4u << 20, want_chunks = (uint64_t)n_states * NSLOT;
+    const uint64_t max_words = 4u << 20, want_chunks = (uint64_t)n_states * c.n_slots;
     const uint64_t target = std::min<uint64_t>(1u << 18, std::max<uint64_t>(512, (n / want_chunks + GROUP - 1) / GROUP * GROUP));
     c.chunk_first.clear();
     c.chunk_first.push_back(0);
@@ -774,8 +836,8 @@ void* state_create(int device)
     ds->n_cus = prop.multiProcessorCount;
     // three streams of different priorities: HIP maps them to different hardware queues, so the kernels of consecutive
     // chunks share the GPU instead of queueing behind each other
-    const int prio[NSLOT] = {0, -1, 1, 0};
-    for (int k = 0; k < NSLOT; k++) {
+    const int prio[MAXSLOT] = {0, -1, 1, 0, 0, -1, 1, 0};
+    for (int k = 0; k < MAXSLOT; k++) {
         Slot& sl = ds->slot[k];
         if (hipStreamCreateWithPriority(&sl.stream, hipStreamNonBlocking, prio[k]) != hipSuccess || hipEventCreateWithFlags(&sl.ev_tot, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming) != hipSuccess || scrg_ctx_create(device, &sl.ctx) != SCRG_OK ||
@@ -799,8 +861,7 @@ void state_free(void* state)
         if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
         if (sl.stream) (void)hipStreamDestroy(sl.stream);
         for (HostPinned* hp : {&sl.h_seq, &sl.h_meta, &sl.h_out, &sl.h_tot}) hp->release();
-        for (DevBuf* db : {&sl.d_meta, &sl.d_desc, &sl.d_slices, &sl.d_ed, &sl.d_nruns, &sl.d_status, &sl.d_cnt64, &sl.d_len64, &sl.d_runoff,
-                           &sl.d_textoff, &sl.d_tot, &sl.d_dense, &sl.d_text, &sl.d_temp})
+        for (DevBuf* db : {&sl.d_meta, &sl.d_desc, &sl.d_slices, &sl.d_ed, &sl.d_nruns, &sl.d_cnt64, &sl.d_len64, &sl.d_tot, &sl.d_dense, &sl.d_temp})
             db->release();
     }
     ds->d_seq.release();
