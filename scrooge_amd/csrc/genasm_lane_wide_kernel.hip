@@ -21,7 +21,7 @@
 // still in the staging ring (the last committed run never leaves before the next one is committed).
 //
 // tests/proto/lane_proto.c (lane_align_codes_mw, RW = 1) restates the arithmetic; tests/test_gpu_parity.py holds the
-// kernel against the oracle and the reference-built fixtures at W/O = 64/2, 64/16, 64/32, 128/65, 96/49, ...
+// kernel against the CPU checker and the reference-built fixtures at W/O = 64/2, 64/16, 64/32, 128/65, 96/49, ...
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>

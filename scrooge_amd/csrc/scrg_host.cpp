@@ -293,7 +293,16 @@ bool grow_to(Call& c, Grow& g, size_t need, size_t hint)
     }
     std::unique_lock<std::shared_mutex> lk(c.grow_mu);
     if (need <= g.cap) return true;
-    const size_t cap = std::max(std::max(need + need / 8, g.cap + g.cap / 2), hint);
+    // sizes in classes (steps of 2^(1/4)): which chunk arrives first, and with it the hint, differs from call to call, and
+    // the pool hands a block back only to a request it fits (a fresh block of 100 MB costs ~10 ms of page faults)
+    size_t cap = std::max(std::max(need + need / 8, g.cap + g.cap / 2), hint);
+    if (cap > (1u << 20)) {
+        size_t cls = (size_t)1 << 20;
+        while (cls < cap) cls <<= 1;                       // 2^k >= cap
+        const size_t q = cls / 8;                          // candidates: 5/8, 6/8, 7/8, 8/8 of 2^k
+        for (size_t m8 = 5; m8 <= 8; m8++)
+            if (q * m8 >= cap) { cap = q * m8; break; }
+    }
     char* np = static_cast<char*>(g_pool.get(cap, false));
     if (!np) return false;
     const size_t used = std::min(g.hi.load(), g.cap);
@@ -1090,6 +1099,8 @@ scrg_status align(void* const* states, int n_states, const scrg_params& resolved
         fprintf(stderr, "core algorithm ran at %lld aligns/second\n", (long long)((double)n * 1e9 / (double)r->kernel_ns));
     r->pack_ns = c.pack_ns.load();
     r->total_ns = now_ns() - t_begin;
+    if (getenv("SCRG_HOST_TIMING"))
+        fprintf(stderr, "[scrooge_amd host] total %.3f ms (results in %s order)\n", r->total_ns / 1e6, c.identity ? "issue = caller" : "caller (permuted)");
     *out = r;
     if (c.any_overflow.load()) {
         set_err("at least one pair overflowed its CIGAR slice (see pair_status)");

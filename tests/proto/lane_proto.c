@@ -432,9 +432,6 @@ static int lane_walk_band(const uint64_t *V1, const uint64_t *V0, int TBL, unsig
         const uint32_t ni = lp_ffbh32(x);                     /* 0xffffffff: outside the band */
         o->ilen[i] = (uint8_t)ni;
         Fm = (Fm << 1) | (ni >> 31);
-#ifdef BAND_DEBUG
-        if (ni >> 31) fprintf(stderr, "col %d j %u lo %u jr %d jlim %u TBL %d\n", i, j, band_lo(i), (int)jr, jlim, TBL);
-#endif
         nIm = (nIm << 1) | (x >> 31);
         j += ni;
         const uint32_t sh = (j - band_lo(i)) & 31u;

@@ -105,9 +105,13 @@ class LSB(C.Structure):
 @pytest.mark.parametrize("W,O", [(64, 2), (64, 32), (64, 16), (64, 1), (63, 20), (40, 5), (33, 1), (128, 65), (96, 49), (80, 41),
                                  (112, 57), (128, 96), (100, 40), (65, 2)])
 def test_lane_band_form_matches_oracle(proto, W, O):
-    """32 <= W-O <= 63 (genasm_lane_band_kernel.hip): the table keeps 32 rows around the diagonal per column; a walk
-    that leaves the band in a column it is alive in has the window redone on the full rows.  Related sequences stay
-    inside (no escapes on the sequencing-error profiles), unrelated and low-complexity ones do not."""
+    """32 <= W-O <= 63, a design that was prototyped and NOT adopted: the table keeps 32 rows around the diagonal per
+    column, and a walk that leaves the band in a column it is alive in has the window redone on the full rows.  The form is
+    exact (checked here), but at W-O close to W — the reference's O = 2 sweep point — the traceback reaches the end of the
+    window, where the insertion-first rule parks the insertions the window is forced to make (j - i up to +26, down to
+    -12 on ONT-error reads): several per cent of the windows leave any band of 32 rows, i.e. most rounds of a wavefront
+    of 64 pairs would take the slow path.  genasm_lane_wide_kernel.hip keeps full rows and builds the table in two
+    halves instead (lane_align_codes_mw with one-word rows is its restatement)."""
     T, Q = _cases(W * 100 + O + 11)
     rng = np.random.Generator(np.random.PCG64(W + O))
     for _ in range(30):                       # long gaps: the walk crosses the band's edges
@@ -122,4 +126,7 @@ def test_lane_band_form_matches_oracle(proto, W, O):
         want = _run(proto.go_align_codes, t, q, (C.c_int(W), C.c_int(O)), (None,))
         assert got == want, k
     assert related.windows > 300 and ls.escapes > 0
-    assert related.escapes <= related.windows // 200, (related.escapes, related.windows)
+    if W - O <= W // 2:                       # the traceback stays away from the window's end: the band holds related reads
+        assert related.escapes <= related.windows // 200, (related.escapes, related.windows)
+    elif (W, O) in ((64, 2), (64, 1)):        # ... and here it does not
+        assert related.escapes > related.windows // 300, (related.escapes, related.windows)
