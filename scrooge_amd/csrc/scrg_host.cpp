@@ -419,6 +419,11 @@ scrg_status stage1(DeviceState* ds, Slot& sl, Call& c, uint64_t chunk)
                 rlen[l] = b.read_lens[p];
             }
         }
+        // short rows (reads of a mapper: a million separate strings) are cache misses, not bandwidth: ask for all of the
+        // group's lines before the first one is needed
+        if (W <= 16)
+            for (uint64_t l = 0; l < rows_here; l++)
+                for (uint64_t o = 0; o < rlen[l]; o += 64) __builtin_prefetch(rsrc[l] + o, 0, 0);
         for (uint64_t l0 = 0; l0 < GROUP; l0 += 8) {
             bool plain = !linear && g_have_avx2;
             for (uint64_t l = l0; l < l0 + 8; l++) plain = plain && !rrev[l] && (rlen[l] == 0 || rsrc[l] != nullptr);
