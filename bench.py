@@ -3,10 +3,13 @@
 
 One "step" = one pass of the align kernel over one batch of synthetic
 PBSIM2-shaped pairs that is already packed and resident in HBM, followed by
-the run compaction and (N > 1) the RCCL gather of edit distances + CIGAR runs
-to rank 0.  Workload at N=1 = BASELINE.json configs[1]: 100k x 10 kb ONT-error
-pairs, W=64, O=33.  N > 1 is weak scaling (every rank aligns its own 100k
-pairs; no data-path collective other than the result gather).
+the run compaction and (N > 1) the RCCL gather of edit distances + CIGARs
+to rank 0, which decodes them to runs inside the timed region.  Workload at
+N=1 = BASELINE.json configs[1]: 100k x 10 kb ONT-error pairs, W=64, O=33.
+N > 1 is weak scaling: a step is N x --pairs pairs (125k per GPU at N = 8 =
+configs[3], 1 M pairs over 8 GPUs), sharded with no data-path collective other
+than the result gather; rank 0, which also decodes every rank's CIGARs, aligns
+a smaller share of the step (--root-share).
 
     python bench.py --gpus 1 --steps 5 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
@@ -53,6 +56,11 @@ def parse():
     ap.add_argument("--gather-root", default="0", choices=["rotate", "0"],
                     help="N > 1, edit streams: the rank a step's results are gathered to and decoded on — always rank 0 (default, "
                          "SURVEY.md §8e) or step k to rank k mod N (every GPU receives and decodes one step in N)")
+    ap.add_argument("--root-share", default="auto",
+                    help="N > 1 with --gather-root 0 and the decode on: what rank 0 aligns itself, as a fraction of an equal share "
+                         "(T / N pairs of the step's T = N x --pairs); the other ranks split the rest.  Rank 0 also decodes all N "
+                         "slots (~0.2 of the align work per pair), so an equal split makes it the slowest rank.  'auto' = "
+                         "max(0, 1 - 0.2 (N - 1)): 0.8 at N = 2, 0.4 at N = 4, 0 at N = 8 (a pure collector); 'equal' = 1")
     ap.add_argument("--no-decode", action="store_true",
                     help="N > 1, edit streams: leave the gathered CIGARs as edit streams on the root (default: the root restores "
                          "scrg_run pairs for every rank's pairs inside the timed region, scrg_decode_edit_stream)")
@@ -460,6 +468,21 @@ def main():
     # ---------------- synthetic batch, generated and packed on the GPU ----------------
     n = args.pairs
     L = args.read_len
+    # Unequal shards (--root-share): every rank's buffers hold n pairs, n_real of them are real (the rest are empty reads,
+    # which the kernel retires at once and the gather carries as empty streams); rank 0 has n0, the others n.
+    nominal = n
+    share_on = (world > 1 and args.gather_root == "0" and args.gather_format == "edits" and not args.no_decode
+                and args.root_share != "equal" and not args.lanes)
+    n0 = n
+    if share_on:
+        frac = max(0.0, 1.0 - 0.2 * (world - 1)) if args.root_share == "auto" else min(1.0, max(0.0, float(args.root_share)))
+        total_pairs = world * nominal
+        n0 = int(total_pairs / world * frac) // 64 * 64
+        n = (-(-(total_pairs - n0) // (world - 1)) + 63) // 64 * 64
+        if n0 >= n:
+            share_on, n0, n = False, nominal, nominal
+    n_real = n0 if (share_on and rank == 0) else n
+    pairs_per_step_all = (n0 + (world - 1) * n) if share_on else world * n
     err, ratio = synth.PROFILES[args.profile]
     t_gen = time.time()
     ascii_rows, tw, rw, text_len = device_pairs(torch, n, L, err, ratio, args.seed + 1000 * rank, device)
@@ -487,6 +510,15 @@ def main():
                             idx * cap, torch.full_like(idx, cap)], dim=1).contiguous()
     torch.cuda.synchronize()
     assert int(bad.item()) == 0
+    desc_full = desc
+    if n_real < n:
+        desc = desc.clone()
+        desc[n_real:, 1] = 0                                  # text_len
+        desc[n_real:, 3] = 0                                  # read_len
+    # read lengths of all N x n pairs in slot order, for the root's decoder (one length for all unless shards are unequal)
+    if share_on:
+        rl_all = torch.full((world * n,), L, dtype=torch.int64, device=device)
+        rl_all[n0:n] = 0
     # result buffers, one set per pipeline lane (scrg_run = 2 bytes)
     outs = [dict(runs=torch.empty(n * cap * 2, dtype=torch.uint8, device=device),
                  ed=torch.empty(n, dtype=torch.int64, device=device),
@@ -550,9 +582,11 @@ def main():
         # the root's decoder: a handle of its own (its stream is the gather's decode stream), one read length for all pairs
         decode_on = gather_format == "edits" and not args.no_decode
         if decode_on:
-            decoder = scrooge_amd.Aligner(local_rank)
-            decoder.params = al.params
-            decode_args = (decoder, torch.tensor([L], dtype=torch.int64, device=device), 0, dict(kw))
+            # (one handle per buffer set of the gather: the decode launches of consecutive steps run side by side)
+            decoders = [scrooge_amd.Aligner(local_rank) for _ in range(max(2, n_lanes))]
+            for d_ in decoders:
+                d_.params = al.params
+            decode_args = (decoders, rl_all, 1, dict(kw)) if share_on else (decoders, torch.tensor([L], dtype=torch.int64, device=device), 0, dict(kw))
     elif dist_on:
         from scrooge_amd.distributed import ResultGather
         packed_gather = gather_format == "packed"    # runs travel as one byte each; rank 0 restores scrg_run pairs
@@ -681,7 +715,10 @@ def main():
             for r in range(world):
                 v = gather.results(step.count - 1, r)
                 torch.cuda.synchronize()
-                runs_g, cnt_g, off_g, n_bad = gather.decode(aligners[last], step.count - 1, r, rl, 0, **kw)
+                if share_on:
+                    runs_g, cnt_g, off_g, n_bad = gather.decode(aligners[last], step.count - 1, r, rl_all[r * n: (r + 1) * n], 1, **kw)
+                else:
+                    runs_g, cnt_g, off_g, n_bad = gather.decode(aligners[last], step.count - 1, r, rl, 0, **kw)
                 torch.cuda.synchronize()
                 is_edit = (v["stream"][: gather.totals[r]] >= 64).to(torch.int64)
                 csum = torch.cat([torch.zeros(1, dtype=torch.int64, device=device), torch.cumsum(is_edit, 0)])
@@ -730,7 +767,7 @@ def main():
         torch.cuda.synchronize()
         tso = torch.tensor([time.perf_counter() - ts], dtype=torch.float64, device=device)
         dist.all_reduce(tso, op=dist.ReduceOp.MAX)
-        streams_only = {"value": world * n * args.steps / float(tso.item()), "unit": "pairs/s",
+        streams_only = {"value": pairs_per_step_all * args.steps / float(tso.item()), "unit": "pairs/s",
                         "ms_per_step": float(tso.item()) / args.steps * 1e3,
                         "note": "the same steps without the root's decoding (gathered CIGARs stay edit streams); measured after the timed region"}
         step.decode = decode_on
@@ -917,10 +954,21 @@ def main():
         keep = al.params.reserved[1]
         al.params.reserved[1] = 1
         with torch.cuda.stream(streams[0]):
-            aligners[0].align_device(n, seq, desc, outs[0]["runs"], outs[0]["ed"], outs[0]["n_runs"], outs[0]["status"], **kw)
+            aligners[0].align_device(n, seq, desc_full, outs[0]["runs"], outs[0]["ed"], outs[0]["n_runs"], outs[0]["status"], **kw)
         torch.cuda.synchronize()
         rounds_live = aligners[0].debug_stats_lane()["rounds"]
         al.params.reserved[1] = keep
+        if n_real < n:
+            # rank 0 aligns fewer pairs than it has buffers for: the roofline figures below are those of a full launch
+            # (n pairs), taken here, after everything that is timed
+            a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            with torch.cuda.stream(streams[0]):
+                a_.record()
+                aligners[0].align_device(n, seq, desc_full, outs[0]["runs"], outs[0]["ed"], outs[0]["n_runs"], outs[0]["status"], **kw)
+                b_.record()
+            torch.cuda.synchronize()
+            kernel_ms = a_.elapsed_time(b_)
+            runs_per_pair = float(outs[0]["n_runs"].to(torch.int64).sum().item()) / n
 
     # ---------------- the other single-GPU configurations of BASELINE.json, after everything that is timed ----------------
     other_configs = None
@@ -949,7 +997,7 @@ def main():
                              args.seed + 15, cores_, W=128, O=65),
         ]
 
-    pairs_total = world * n * args.steps
+    pairs_total = pairs_per_step_all * args.steps
     value = pairs_total / dt
     if text_used is None:
         text_used = L * 1.015
@@ -1005,10 +1053,14 @@ def main():
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": "unstructured pairwise: %d x %d bp %s-error pairs per GPU and step (%s), W=%d O=%d"
-                               % (n, L, args.profile,
-                                  "BASELINE configs[3]: 1 M pairs over 8 GPUs, results gathered to and decoded on the root" if (world == 8 and n == 125000)
+                               % (nominal, L, args.profile,
+                                  "BASELINE configs[3]: 1 M pairs over 8 GPUs, results gathered to and decoded on the root" if (world == 8 and nominal == 125000)
                                   else ("BASELINE configs[1]" if (world == 1 and n == 100000 and L == 10000) else "%d GPU(s)" % world), p.W, p.O),
-                   "pairs_per_gpu": n, "read_len": L, "text_len": text_len, "error_profile": args.profile,
+                   "pairs_per_gpu": nominal, "pairs_per_step_all_gpus": pairs_per_step_all,
+                   "shards": ({"rank_0": n0, "other_ranks": n, "root_share": args.root_share,
+                               "note": "rank 0 also decodes every rank's CIGARs (~0.2 of the align work per pair): it aligns a smaller share, "
+                                       "the other ranks split the rest of the step's %d pairs" % (world * nominal)} if share_on else "equal"),
+                   "read_len": L, "text_len": text_len, "error_profile": args.profile,
                    "W": p.W, "O": p.O, "lanes_per_pair": p.lanes_per_pair, "lds_rows": p.lds_rows,
                    "sequence_layout": "lane-interleaved groups of 64 pairs (scrg_pack_planar_groups)" if groups else "contiguous per sequence",
                    "launch": geom, "step": STEP_TEXT[gather_format if dist_on else "local"],

@@ -61,6 +61,9 @@ __global__ __launch_bounds__(256) void decode_edits_kernel(DecodeArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint8_t lds_all[STORE ? 4 * DEC_WAVE_LDS : 16];
     const uint32_t lane = threadIdx.x & 63u;
+    // On the root of an N > 1 job this kernel shares the SIMDs with the aligner's wavefronts, and its own run time is set by
+    // its longest lanes: it goes first.  (The align kernel rotates its priorities 0..3; 3 here is at least a tie.)
+    __builtin_amdgcn_s_setprio(3);
     uint8_t* const out_me = lds_all + (STORE ? (threadIdx.x >> 6) * DEC_WAVE_LDS + lane * DEC_OUT_STRIDE : 0u);
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = tid < a.n_pairs;

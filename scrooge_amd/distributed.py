@@ -262,7 +262,7 @@ class EditStreamGather:
         self.dense = [None] * d
         self.dec = [None] * d
         self.dec_event = [None] * d
-        self.dec_stream = None
+        self.dec_streams = {}                 # one decode stream per buffer set: the decodes of consecutive steps overlap
 
     def root_of(self, k):
         """The rank step k is gathered to."""
@@ -354,16 +354,28 @@ class EditStreamGather:
             raise ValueError("decode_all needs ordered streams with run counts (total_runs=...)")
         b = k % self.DEPTH
         n, W = self.n, self.world
+        # measurement aid (scripts/root_load_probe.sh): a one-rank group decodes its slot `sim` times in the one launch, i.e.
+        # does per step what the root of a `sim`-rank job does (the same stream bytes are read, `sim` dense copies written)
+        sim = int(os.environ.get("SCRG_GATHER_SIMULATE_SENDERS", "1")) if W == 1 else 1
         if self.dense[b] is None:
-            cap_runs = sum(self.run_totals)
+            cap_runs = sum(self.run_totals) * sim
             self.dense[b] = torch.zeros(cap_runs * 2 + 64, dtype=torch.uint8, device=self.device)
             self.dec[b] = {"bad": torch.zeros(1, dtype=torch.int32, device=self.device)}
-        if self.is_cuda and self.dec_stream is None:
-            self.dec_stream = torch.cuda.Stream(device=self.device)
+        # `aligner` may be a list of handles, one per buffer set: a decode launch is bound by its longest streams (a lane
+        # replays its stream sequentially), so the launches of consecutive steps run side by side, each on the stream and
+        # with the handle (sort workspace) of its buffer set
+        if isinstance(aligner, (list, tuple)):
+            sb = b % len(aligner)
+            aligner = aligner[sb]
+        else:
+            sb = 0
+        if self.is_cuda and sb not in self.dec_streams:
+            self.dec_streams[sb] = torch.cuda.Stream(device=self.device)
+        dec_stream = self.dec_streams.get(sb)
         cur = torch.cuda.current_stream() if self.is_cuda else None
-        ctx = torch.cuda.stream(self.dec_stream) if self.is_cuda else _NullCtx()
+        ctx = torch.cuda.stream(dec_stream) if self.is_cuda else _NullCtx()
         if self.is_cuda:
-            self.dec_stream.wait_stream(cur)
+            dec_stream.wait_stream(cur)
         with ctx:
             self._wait(b)                                     # the decode stream waits for the collective, nobody else
             slots = self.recv_all[b][: W * self.wire].view(W, self.wire)
@@ -371,18 +383,21 @@ class EditStreamGather:
             cnt = slots[:, self.o_cnt: self.o_cnt + 4 * n].contiguous().view(torch.int32).reshape(-1)
             r4 = ((ln.to(torch.int64) + 3) & -4).view(W, n)
             off = torch.cumsum(r4, 1) - r4 + (torch.arange(W, dtype=torch.int64, device=self.device) * self.wire + self.head).view(W, 1)
+            off = off.reshape(-1)
+            if sim > 1:
+                ln, cnt, off = ln.repeat(sim), cnt.repeat(sim), off.repeat(sim)
             c64 = cnt.to(torch.int64)
             doff = torch.cumsum(c64, 0) - c64
             d = self.dec[b]
-            d.update(len=ln, cnt=cnt, off=off.reshape(-1), run_off=doff)
+            d.update(len=ln, cnt=cnt, off=off, run_off=doff)
             d["bad"].zero_()
             if self.is_cuda:
-                aligner.set_stream(self.dec_stream.cuda_stream)
-            aligner.decode_edit_stream(W * n, self.recv_all[b], d["off"], ln, read_len, read_len_stride, doff, self.dense[b],
+                aligner.set_stream(dec_stream.cuda_stream)
+            aligner.decode_edit_stream(W * n * sim, self.recv_all[b], d["off"], ln, read_len, read_len_stride, doff, self.dense[b],
                                        cnt, d["bad"], **(params or {}))
             if self.is_cuda:
                 self.dec_event[b] = torch.cuda.Event()
-                self.dec_event[b].record(self.dec_stream)
+                self.dec_event[b].record(dec_stream)
 
     def decoded(self, k):
         """-> dict(runs: uint8 [2 * total runs], run_off: int64 [world * n], cnt: int32 [world * n], bad: int32 [1]) of

@@ -320,18 +320,20 @@ def test_two_handles_on_two_streams_overlap(oracle):
         a.close()
 
 
-@pytest.mark.parametrize("gather_root", ["rotate", "0"])
-def test_bench_two_ranks_dry_run(gather_root):
+@pytest.mark.parametrize("gather_root,root_share", [("rotate", "auto"), ("0", "auto"), ("0", "equal"), ("0", "0"), ("0", "0.3")])
+def test_bench_two_ranks_dry_run(gather_root, root_share):
     """bench.py's multi-rank control flow (two pipeline lanes, double-buffered gather, barriers, rank 0
     printing) with two processes on this one GPU: gloo through the host instead of RCCL (SCRG_BENCH_DRYRUN),
-    so only the logic is checked, not the speed."""
+    so only the logic is checked, not the speed.  With the root fixed, rank 0 aligns a smaller share of the step's pairs
+    (--root-share: 0.8 of an equal share at N = 2 by default; 0 = a root that only collects and decodes, what 'auto'
+    gives at N = 8): its buffers are padded with empty reads, every slot still decodes to its own kernel's runs."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, SCRG_BENCH_DRYRUN="1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
-                          "--gpus", "2", "--steps", "5", "--warmup", "1", "--pairs", "6000", "--read-len", "2000",
-                          "--gather-root", gather_root],
+                          "--gpus", "2", "--steps", "5", "--warmup", "1", "--pairs", "6400", "--read-len", "2000",
+                          "--gather-root", gather_root, "--root-share", root_share],
                          env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
@@ -341,6 +343,14 @@ def test_bench_two_ranks_dry_run(gather_root):
     # both ranks' slots of the last step decoded on its root (rank 1 when the root rotates: 6 steps), the verdict sent to rank 0
     assert j["gather_check"] is True and j["config"]["gather"]["format"] == "edits"
     assert j["config"]["gather"]["root"] == ("rank 0" if gather_root == "0" else "step k to rank k mod N")
+    sh = j["config"]["shards"]
+    if gather_root == "rotate" or root_share == "equal":
+        assert sh == "equal" and j["config"]["pairs_per_step_all_gpus"] == 12800
+    else:
+        want0 = {"auto": 5120, "0": 0, "0.3": 1920}[root_share]
+        assert sh["rank_0"] == want0 and sh["other_ranks"] == (12800 - want0 + 63) // 64 * 64
+        assert j["config"]["pairs_per_step_all_gpus"] == sh["rank_0"] + sh["other_ranks"] >= 12800
+    assert j["roofline"]["window_rounds_per_launch"] > 0
 
 
 def test_full_bench_size_two_algorithms_agree(aligner):
