@@ -50,8 +50,9 @@ typedef struct scrg_params {
     int32_t W;               /* window length, 2..256; reference default 64 (genasm_cpu.cpp:7).
                                 W > 64 uses multi-word vectors (src/bitvector.hpp:45-48)           */
     int32_t O;               /* window overlap, 1 <= O < W; reference default 33 (genasm_cpu.cpp:9).
-                                W <= 64 with W-O <= 31 (e.g. the defaults) keeps the traceback table in registers;
-                                larger W-O or W needs table rows of 64 to 256 bits, kept in HBM               */
+                                W <= 64 with W-O <= 31 (e.g. the defaults) keeps the traceback table in 62 registers;
+                                32 <= W-O <= 63 with W <= 128 in 128 registers, built in two halves of 32 columns;
+                                beyond that the table rows are 128 to 256 bits wide and kept in HBM                */
     int32_t lanes_per_pair;  /* 1 = one pair per lane, 64 pairs per wavefront (the default for every W);
                                 64 = one pair per wavefront (lane = text column); 4/8/16/32 pack 64/lanes
                                 pairs into one wavefront (GenASM rows; for W > 64 only 32 and 64 exist).
