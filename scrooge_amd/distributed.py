@@ -299,8 +299,11 @@ class EditStreamGather:
 
     def start(self, k, ed, decode=None):
         """The streams, their lengths and run counts (or offsets, if they travel) of step k must already be in
-        `buffers(k)` (enqueued on the current stream).  decode = (aligner, read_len tensor, read_len_stride, params dict):
-        the root also enqueues the decoding of all slots (decode_all), ordered after the collective."""
+        `buffers(k)` (enqueued on the current stream).  decode = (aligner or a list of aligners — one per buffer set, so
+        that the decode launches of consecutive steps run side by side —, read_len tensor, read_len_stride, params dict):
+        the root also enqueues the decoding of all slots (decode_all), ordered after the collective.  read_len holds
+        world * n lengths in slot order when the stride is 1 (unequal shards: a padding pair has length 0), one length
+        for all when it is 0."""
         b = k % self.DEPTH
         dst = self.root_of(k)
         self._views(self.send[b])["ed"].copy_(ed)            # (int64 -> int32)
