@@ -148,6 +148,18 @@ def device_pairs(torch, n, read_len, err, ratio, seed, device, slack=0.15, chunk
 
 
 
+def root_share_plan(world, nominal, mode):
+    """-> (pairs rank 0 aligns, pairs every other rank aligns = the buffer size of all ranks) for a step of world x nominal
+    pairs.  mode: 'auto' = max(0, 1 - 0.2 (world - 1)) of an equal share for rank 0 (it also decodes all slots, ~0.2 of the
+    align work per pair: DESIGN.md section 4), or that fraction as a number; whole groups of 64 pairs; the step never has
+    fewer than world x nominal pairs."""
+    frac = max(0.0, 1.0 - 0.2 * (world - 1)) if mode == "auto" else min(1.0, max(0.0, float(mode)))
+    total = world * nominal
+    n0 = int(nominal * frac + 1e-6) // 64 * 64
+    n_other = (-(-(total - n0) // (world - 1)) + 63) // 64 * 64
+    return n0, n_other
+
+
 def kernel_sources_digest():
     """sha256 of the sources the one-pair-per-lane align kernel is made of: the PMC instruction count in profiles/ is only
     used for the roofline figure if it was measured on exactly this code."""
@@ -475,10 +487,7 @@ def main():
                 and args.root_share != "equal" and not args.lanes)
     n0 = n
     if share_on:
-        frac = max(0.0, 1.0 - 0.2 * (world - 1)) if args.root_share == "auto" else min(1.0, max(0.0, float(args.root_share)))
-        total_pairs = world * nominal
-        n0 = int(total_pairs / world * frac) // 64 * 64
-        n = (-(-(total_pairs - n0) // (world - 1)) + 63) // 64 * 64
+        n0, n = root_share_plan(world, nominal, args.root_share)
         if n0 >= n:
             share_on, n0, n = False, nominal, nominal
     n_real = n0 if (share_on and rank == 0) else n

@@ -59,3 +59,21 @@ def test_sorted_batches_keep_their_order():
     assert order == list(range(4000))                       # sort_by_length = 0: issue order = caller order
     order, chunks = plan([])
     assert order == [] and chunks == [0]
+
+
+def test_root_share_plan_of_the_bench():
+    """bench.py --root-share: what rank 0 aligns when it also decodes every rank's CIGARs (N > 1, root 0): whole groups of
+    64 pairs, the step never smaller than N x --pairs, rank 0 a pure collector from N = 6 on."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    assert bench.root_share_plan(2, 100000, "auto") == (80000, 120000)
+    assert bench.root_share_plan(4, 100000, "auto") == (40000, 120000)
+    assert bench.root_share_plan(8, 125000, "auto") == (0, 142912)
+    assert bench.root_share_plan(2, 6400, "0.3") == (1920, 10880)
+    for world in (2, 3, 4, 6, 8):
+        for nominal in (6400, 100000, 125000, 99999):
+            for mode in ("auto", "0", "0.5", "1"):
+                n0, n = bench.root_share_plan(world, nominal, mode)
+                assert n0 % 64 == 0 and n % 64 == 0 and n0 + (world - 1) * n >= world * nominal
+                assert n0 + (world - 1) * n < world * nominal + 64 * world
