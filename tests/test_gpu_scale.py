@@ -763,3 +763,11 @@ def test_bench_gather_on_rccl_single_rank(fmt):
         assert j["gather_without_decode"]["value"] > 0
     if fmt.startswith("edits"):
         assert 0.09 * 3000 < j["config"]["gather"]["stream_bytes_per_pair"] < 0.13 * 3000       # one byte per edit at 10 % error
+
+
+def test_host_pipeline_under_random_calls():
+    """The host entry points' pipeline (chunks, 4 or 8 slots, two collect threads, growing result arrays, device lists)
+    under a series of calls of random sizes, read lengths, W/O, output selections and device lists, every result compared
+    with the oracle (tests/tools/host_stress.py runs the long version: 550 calls clean)."""
+    from tests.tools import host_stress
+    host_stress.run(calls=24, seed=5, verbose=False)
