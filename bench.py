@@ -64,7 +64,7 @@ def parse():
     ap.add_argument("--no-decode", action="store_true",
                     help="N > 1, edit streams: leave the gathered CIGARs as edit streams on the root (default: the root restores "
                          "scrg_run pairs for every rank's pairs inside the timed region, scrg_decode_edit_stream)")
-    ap.add_argument("--sustained-steps", type=int, default=150,
+    ap.add_argument("--sustained-steps", type=int, default=600,
                     help="N = 1: after the timed region, time this many more pipelined steps for the 'sustained' field (0 = skip)")
     ap.add_argument("--streams", type=int, default=4, help="pipeline depth: consecutive steps rotate over this many streams/handles")
     ap.add_argument("--other-configs", default="auto", choices=["auto", "on", "off"],
