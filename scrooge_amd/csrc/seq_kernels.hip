@@ -144,9 +144,8 @@ __global__ __launch_bounds__(256) void compact_runs_kernel(uint64_t n_pairs, con
     // Long alignments: one wavefront per pair.  The slice starts 32-byte aligned, the destination at any run (2-byte)
     // boundary: an odd destination run index means every output dword straddles two source dwords
     // (v_alignbit by 16).  The bulk moves 16 bytes per lane with 16-byte aligned stores.
-    // Pairs are taken 64 at a time: if none of the 64 has more than 16 runs (150 bp reads have ~3), every lane copies
-    // its own pair; otherwise they are copied one after the other by whole wavefronts — `split` wavefronts share a
-    // group of 64 (each takes every split-th pair), so that a batch of few, long alignments still fills the GPU.
+    // Pairs are taken 64 at a time; `split` wavefronts share a group of 64 (each takes every split-th long alignment), so
+    // that a batch of few, long alignments still fills the GPU.
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t wave_all = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t wave = wave_all / split, n_waves = (((uint64_t)gridDim.x * blockDim.x) >> 6) / split;
@@ -161,15 +160,20 @@ __global__ __launch_bounds__(256) void compact_runs_kernel(uint64_t n_pairs, con
           my_src = pairs[mine].cigar_off;
           my_dst = dense_off[mine];
       }
-      if (!__any(my_cnt > 16)) {
-          if (sub == 0) {
-              const uint16_t* const s = runs + my_src;
-              uint16_t* const d = dense + my_dst;
-              for (uint64_t k = 0; k < my_cnt; k++) d[k] = s[k];
-          }
-          continue;
+      // alignments of up to 16 runs (150 bp reads have ~3): every lane copies its own pair; the longer ones of the group
+      // (a read-mapping batch: the candidates at the wrong locus, ~100 runs) are copied by the whole wavefront, one after
+      // the other, dealt to the `split` wavefronts that share the group
+      const bool big_me = my_cnt > 16;
+      if (sub == 0 && !big_me) {
+          const uint16_t* const s = runs + my_src;
+          uint16_t* const d = dense + my_dst;
+          for (uint64_t k = 0; k < my_cnt; k++) d[k] = s[k];
       }
-      for (uint32_t q = sub; q < 64 && g0 + q < n_pairs; q += split) {
+      uint64_t big = __ballot(big_me);
+      for (uint32_t ord = 0; big != 0; ord++) {
+        const uint32_t q = (uint32_t)__builtin_ctzll(big);
+        big &= big - 1;
+        if (ord % split != sub) continue;
         uint64_t cnt = __shfl(my_cnt, (int)q, 64);
         if (cnt == 0) continue;
         const uint64_t src_off = __shfl(my_src, (int)q, 64), dst_off = __shfl(my_dst, (int)q, 64);
