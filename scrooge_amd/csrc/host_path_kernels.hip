@@ -70,16 +70,19 @@ __global__ __launch_bounds__(256) void text_len_kernel(uint64_t n, const scrg_pa
             if (sub == 0) cnt64[mine] = my_cnt;
         }
         if (!want_text) continue;
-        if (!__any(my_cnt > 24)) {
-            if (sub == 0) {
-                uint64_t chars = 1;
-                const uint16_t* const s = runs + my_src;
-                for (uint64_t k = 0; k < my_cnt; k++) chars += run_chars(s[k]);
-                if (mine < n) len64[mine] = chars;
-            }
-            continue;
+        // short alignments: the lane's own; the long ones of the group: the whole wavefront, one after the other
+        const bool big_me = my_cnt > 24;
+        if (sub == 0 && !big_me) {
+            uint64_t chars = 1;
+            const uint16_t* const s = runs + my_src;
+            for (uint64_t k = 0; k < my_cnt; k++) chars += run_chars(s[k]);
+            if (mine < n) len64[mine] = chars;
         }
-        for (uint32_t q = sub; q < 64 && g0 + q < n; q += split) {
+        uint64_t big = __ballot(big_me);
+        for (uint32_t ord = 0; big != 0; ord++) {
+            const uint32_t q = (uint32_t)__builtin_ctzll(big);
+            big &= big - 1;
+            if (ord % split != sub) continue;
             const uint64_t cnt = __shfl(my_cnt, (int)q, 64), src = __shfl(my_src, (int)q, 64);
             const uint32_t* const s32 = reinterpret_cast<const uint32_t*>(runs + src);       // slices are 32-byte aligned
             uint32_t chars = 0;
@@ -142,16 +145,19 @@ __global__ __launch_bounds__(256) void render_text_kernel(uint64_t n, const uint
             my_src = run_off[mine];
             my_dst = text_off[mine];
         }
-        if (!__any(my_cnt > 24)) {                  // short alignments: one pair per lane, straight to memory
-            if (mine < n && sub == 0) {
-                uint8_t* o = text + my_dst;
-                const uint16_t* const s = dense + my_src;
-                for (uint64_t k = 0; k < my_cnt; k++) o += put_run(o, s[k]);
-                *o = 0;
-            }
-            continue;
+        // short alignments: one pair per lane, straight to memory; the long ones of the group: the whole wavefront
+        const bool big_me = my_cnt > 24;
+        if (mine < n && sub == 0 && !big_me) {
+            uint8_t* o = text + my_dst;
+            const uint16_t* const s = dense + my_src;
+            for (uint64_t k = 0; k < my_cnt; k++) o += put_run(o, s[k]);
+            *o = 0;
         }
-        for (uint32_t q = sub; q < 64 && g0 + q < n; q += split) {
+        uint64_t big = __ballot(big_me);
+        for (uint32_t ord = 0; big != 0; ord++) {
+            const uint32_t q = (uint32_t)__builtin_ctzll(big);
+            big &= big - 1;
+            if (ord % split != sub) continue;
             const uint64_t cnt = __shfl(my_cnt, (int)q, 64), src = __shfl(my_src, (int)q, 64);
             uint64_t dst = __shfl(my_dst, (int)q, 64);
             const uint16_t* const s = dense + src;
