@@ -41,10 +41,14 @@ a = scrooge_amd.Aligner(0)
 kn = [int(v) for v in os.environ.get("SCRG_KNOBS", "0,0,0").split(",")]
 a.params.reserved[0], a.params.lds_rows, a.params.waves_per_cu = kn[0], kn[1], kn[2]
 a.align_mapping(genome, reads[:1000], cands[:1000])     # warm-up / allocations
-t1 = time.time()
-res = a.align_mapping(genome, reads, cands, arrays=True)      # numpy arrays: no per-pair Python objects
-wall = time.time() - t1
-tm = a.last_timing
+first_call_s = None
+for rep in range(3):                                           # the first call of a size allocates (buffers, result arrays): steady state = the last
+    t1 = time.time()
+    res = a.align_mapping(genome, reads, cands, arrays=True)      # numpy arrays: no per-pair Python objects
+    wall = time.time() - t1
+    tm = a.last_timing
+    if first_call_s is None:
+        first_call_s = tm["total_ns"] / 1e9
 if os.environ.get("SCRG_STATS"):
     a.params.reserved[1] = 1
     a.align_mapping(genome, reads, cands)
@@ -72,6 +76,7 @@ ok = all(int(res["edit_distance"][i]) == eds[i] and got_c[i] == cigars[i] for i 
 print(json.dumps({"workload": "read mapping: %d Mbp chromosome, %d x 150 bp reads x 4 candidates" % (G // 1000000, n_reads),
                   "pairs": n_pairs, "kernel_pairs_per_s": n_pairs / (tm["kernel_ns"] * 1e-9), "kernel_ms": tm["kernel_ns"] / 1e6,
                   "library_total_s": tm["total_ns"] / 1e9, "end_to_end_pairs_per_s": n_pairs / (tm["total_ns"] * 1e-9),
+                  "first_call_library_total_s": first_call_s,
                   "python_wall_s": wall, "resident_genome": {"set_genome_s": set_s, "library_total_s": tm_r["total_ns"] / 1e9,
                   "end_to_end_pairs_per_s": n_pairs / (tm_r["total_ns"] * 1e-9), "identical_results": True}, "parity_sample_pairs": 4 * k, "bit_exact": ok,
                   "mean_ed_true_locus": float(np.mean(res["edit_distance"][0:4 * k:4])), "gen_s": gen_s}))
