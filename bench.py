@@ -12,8 +12,13 @@ than the result gather; rank 0, which also decodes every rank's CIGARs, aligns
 a smaller share of the step (--root-share).
 
     python bench.py --gpus 1 --steps 5 --warmup 1
+    python bench.py --gpus 8 --steps 5 --warmup 1          # starts its own 8 ranks (below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
         --master-port 29500 bench.py --gpus 8 --steps 5 --warmup 1
+
+Plain `python bench.py --gpus N` with N > 1 (no WORLD_SIZE in the environment) builds the libraries and then starts
+`python -m torch.distributed.run ... bench.py --no-build ...` as a fresh CHILD process — before this process has made
+any HIP call, and never by exec — relays the child's output and exits with its code.
 
 Prints ONE JSON line on rank 0.
 """
@@ -71,6 +76,10 @@ def parse():
                     help="after the timed region, also measure BASELINE configs[0] (4 M x 150 bp), configs[2] (read mapping, 1 M reads x 4 "
                          "candidates on a 100 Mbp chromosome) and configs[4] (40 k x 50 kb PacBio-error pairs), each with an oracle-checked sample; "
                          "auto = only in the default single-GPU run of the headline workload")
+    ap.add_argument("--host-api", default="auto", choices=["auto", "on", "off"],
+                    help="after the timed region, also time the host-pointer entry points (scrg_align_pairs on one of the timed batches, "
+                         "scrg_align_mapping_resident on configs[2]; PCIe-inclusive, reported as `host_api`, never `value`); auto = only in "
+                         "the default single-GPU run of the headline workload")
     ap.add_argument("--no-build", action="store_true",
                     help="never rebuild the library (profiling: nothing may fork a compiler under rocprofv3)")
     ap.add_argument("--stats", action="store_true", help="profiling only: print kernel round/step counters")
@@ -173,8 +182,9 @@ def kernel_sources_digest():
 
 
 def pmc_instruction_count():
-    """-> (VALU instructions per window round, source note) from the newest profiles/r*_pmc_sq_summary.json that was
-    measured on the current kernel sources, else (None, why)."""
+    """-> (dict from the newest profiles/r*_pmc_sq_summary.json that was measured on the current kernel sources, source note),
+    else (None, why).  The dict has valu_instructions_per_window_round, SQ_INSTS_VALU and window_rounds_per_launch of the
+    profiled launch and the workload it was (pairs, read_len, profile, seed)."""
     import glob
     want = kernel_sources_digest()
     stale = None
@@ -184,15 +194,21 @@ def pmc_instruction_count():
         except Exception:
             continue
         if pj.get("kernel_sources_sha256") == want and pj.get("valu_instructions_per_window_round"):
-            return float(pj["valu_instructions_per_window_round"]), "SQ_INSTS_VALU / window rounds, rocprofv3 --pmc, %s (same kernel sources: sha256 %s...)" % (os.path.basename(f), want[:12])
+            return pj, "SQ_INSTS_VALU / window rounds, rocprofv3 --pmc, %s (same kernel sources: sha256 %s...)" % (os.path.basename(f), want[:12])
         stale = stale or os.path.basename(f)
     return None, ("no PMC summary for the current kernel sources (sha256 %s...; newest file: %s): re-run scripts/collect_profiles.sh" % (want[:12], stale))
 
 
-def run_other_config(torch, scrooge_amd, device, local_rank, streams, name, n, L, profile, steps, warmup, check_pairs, seed, cores, W=64, O=33):
+def run_other_config(torch, scrooge_amd, device, local_rank, streams, name, n, L, profile, steps, warmup, check_pairs, seed, cores, W=64, O=33,
+                     len_range=None):
     """One more BASELINE configuration of the unstructured interface, measured the same way as the headline (pairs generated
     and packed on the GPU, lane-interleaved layout, steps = align kernel + run compaction rotating over the streams) after
-    the timed region, with the first `check_pairs` pairs of the last step compared, runs and all, with the CPU checker."""
+    the timed region, with `check_pairs` pairs of the last step compared, runs and all, with the CPU checker.
+
+    len_range = (lo, hi): a MIXED-LENGTH batch — read lengths uniform in [lo, hi] (L = hi is the slot size), every text its
+    read's source segment + 15 %; the pairs are issued longest read first, as the reference's callers sort them
+    (src/tests.cu:375-377) and as the host entry points do, so that the 64 pairs of a wavefront have similar lengths; the
+    checked pairs are spread over the whole batch."""
     from scrooge_amd import synth
     err, ratio = synth.PROFILES[profile]
     rows, tw, rw, text_len = device_pairs(torch, n, L, err, ratio, seed, device, chunk=max(256, min(8192, (1 << 28) // (L + 64))))
@@ -207,16 +223,24 @@ def run_other_config(torch, scrooge_amd, device, local_rank, streams, name, n, L
         st_.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(streams[0]):
         als[0].pack_planar_groups(rows.view(-1), n, row_words, seq, bad)
-    sample = rows[:check_pairs].cpu().numpy() if check_pairs else None
+    idx = torch.arange(n, dtype=torch.int64, device=device)
+    if len_range:
+        g = torch.Generator(device=device)
+        g.manual_seed(seed + 1)
+        rl = torch.sort(torch.randint(len_range[0], len_range[1] + 1, (n,), generator=g, device=device, dtype=torch.int64), descending=True).values
+        tl = torch.clamp((rl * 115 + 99) // 100, max=text_len)        # the read's source segment + 15 %
+        pick = (torch.arange(check_pairs, device=device) * (n // max(1, check_pairs))) if check_pairs else None
+    else:
+        rl, tl = torch.full_like(idx, L), torch.full_like(idx, text_len)
+        pick = torch.arange(check_pairs, device=device) if check_pairs else None
+    sample = rows[pick].cpu().numpy() if check_pairs else None
     torch.cuda.synchronize()
     del rows
     torch.cuda.empty_cache()
     assert int(bad.item()) == 0
     cap = (2 * L + 8 + 15) // 16 * 16
-    idx = torch.arange(n, dtype=torch.int64, device=device)
     first = (idx // G) * row_words * G + idx % G
-    desc = torch.stack([first * 32, torch.full_like(idx, text_len), (first + tw * G) * 32, torch.full_like(idx, L),
-                        idx * cap, torch.full_like(idx, cap)], dim=1).contiguous()
+    desc = torch.stack([first * 32, tl, (first + tw * G) * 32, rl, idx * cap, torch.full_like(idx, cap)], dim=1).contiguous()
     kw = dict(text_stride_words=G, read_stride_words=G, W=W, O=O)
     outs = [dict(runs=torch.empty(n * cap * 2, dtype=torch.uint8, device=device), ed=torch.empty(n, dtype=torch.int64, device=device),
                  n_runs=torch.empty(n, dtype=torch.int32, device=device), status=torch.empty(n, dtype=torch.int32, device=device))
@@ -248,20 +272,36 @@ def run_other_config(torch, scrooge_amd, device, local_rank, streams, name, n, L
     res = {"workload": name, "pairs": n, "read_len": L, "error_profile": profile, "W": W, "O": O, "steps": steps, "value": n * steps / dt, "unit": "pairs/s",
            "ms_per_step": dt / steps * 1e3, "runs_per_pair": total_runs / n,
            "step": "align kernel + run compaction, steps rotate over %d streams; measured after the timed region of the headline" % len(streams)}
+    if len_range:
+        res["read_len"] = {"min": int(rl.min().item()), "max": int(rl.max().item()), "mean": float(rl.double().mean().item()),
+                           "order": "longest read first (src/tests.cu:375-377)"}
+        res["bases_per_s"] = float(rl.sum().item()) * steps / dt
     if check_pairs:
         from oracle.pyoracle import Oracle, Reference
         k = check_pairs
+        vl = dict(text_lens=tl[pick].cpu().numpy(), read_lens=rl[pick].cpu().numpy()) if len_range else {}
         if Reference.available(W, O):
-            e_cpu, off_cpu, runs_cpu, ns = Reference(W, O).align_rows(sample, 0, text_len, tw * 32, L, threads=cores)
+            e_cpu, off_cpu, runs_cpu, ns = Reference(W, O).align_rows(sample, 0, text_len, tw * 32, L, threads=cores, **vl)
             against = "reference genasm_cpu.cpp (oracle/_ref%s)" % ("" if (W, O) == (64, 33) else ", built with -DCLI_W=%d -DCLI_O=%d" % (W, O))
         else:
-            e_cpu, off_cpu, runs_cpu, _, ns = Oracle(allow_compile=False).align_rows(sample, 0, text_len, tw * 32, L, W=W, O=O, threads=cores)
+            e_cpu, off_cpu, runs_cpu, _, ns = Oracle(allow_compile=False).align_rows(sample, 0, text_len, tw * 32, L, W=W, O=O, threads=cores, **vl)
             against = "oracle/liboracle.so (restatement)"
         o = outs[last]
-        cnt = o["n_runs"][:k].cpu().numpy().astype(np.uint64)
+        cnt_all = o["n_runs"].to(torch.int64)
+        off_all = torch.cumsum(cnt_all, 0) - cnt_all
+        cnt = cnt_all[pick].cpu().numpy().astype(np.uint64)
         off_gpu = np.concatenate([np.zeros(1, np.uint64), np.cumsum(cnt, dtype=np.uint64)])
-        runs_gpu = denses[last][: 2 * int(off_gpu[k])].cpu().numpy().reshape(-1, 2)
-        ok = bool((o["ed"][:k].cpu().numpy() == e_cpu).all() and (off_gpu == off_cpu).all() and np.array_equal(runs_gpu, runs_cpu))
+        if len_range:
+            # the checked pairs are spread over the batch: gather their runs from the dense array
+            starts = off_all[pick]
+            seg = torch.repeat_interleave(torch.arange(k, device=device), cnt_all[pick])
+            within = torch.arange(int(off_gpu[k]), device=device) - torch.from_numpy(off_gpu[:k].astype(np.int64)).to(device)[seg]
+            src = (starts[seg] + within) * 2
+            d_ = denses[last]
+            runs_gpu = torch.stack([d_[src], d_[src + 1]], dim=1).cpu().numpy()
+        else:
+            runs_gpu = denses[last][: 2 * int(off_gpu[k])].cpu().numpy().reshape(-1, 2)
+        ok = bool((o["ed"][pick].cpu().numpy() == e_cpu).all() and (off_gpu == off_cpu).all() and np.array_equal(runs_gpu, runs_cpu))
         res["parity"] = {"checked_pairs": k, "runs_bit_exact": ok, "against": against}
         res["cpu_pairs_per_s"] = k / (ns * 1e-9)
         res["cpu_threads"] = cores
@@ -273,7 +313,7 @@ def run_other_config(torch, scrooge_amd, device, local_rank, streams, name, n, L
     return res
 
 
-def run_mapping_config(torch, scrooge_amd, device, local_rank, streams, genome_len, n_reads, steps, warmup, check_reads, seed, cores):
+def run_mapping_config(torch, scrooge_amd, device, local_rank, streams, genome_len, n_reads, steps, warmup, check_reads, seed, cores, host_api=None):
     """BASELINE configs[2], the read-mapping interface through the device-pointer layer: one synthetic chromosome packed once
     (contiguous), n_reads x 150 bp Illumina-like reads x 4 candidates each (true locus, two shifted by 1-3 bases, one random
     locus), the text of a candidate = the genome suffix from its start (src/genasm_cpu.cpp:512-514); reads in lane-interleaved
@@ -386,9 +426,186 @@ def run_mapping_config(torch, scrooge_amd, device, local_rank, streams, genome_l
         res["cpu_pairs_per_s"] = k / (ns * 1e-9)
         res["cpu_threads"] = cores
         assert ok, "other_configs: GPU result differs from the CPU checker (read mapping)"
+    if host_api is not None:
+        # The library surface for this configuration (never `value`): scrg_align_mapping / scrg_align_mapping_resident with the
+        # genome, the reads and the candidate lists in host memory, results in host arrays — genasm_gpu::align_all(Genome_t&,
+        # vector<Read_t>&), src/genasm_gpu.cu:890-980 — compared with what the device-pointer path produced above.
+        pcie = host_api
+        genome_h = g_ascii[:genome_len].cpu().numpy()
+        reads_h = r_ascii.cpu().numpy()
+        cs_h = cand.reshape(-1).cpu().numpy().astype(np.uint64)
+        co_h = np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(n_c)
+        o = outs[last]
+        ed_ref = o["ed"].cpu().numpy()
+        cnt_ref = o["n_runs"].cpu().numpy().astype(np.uint64)
+        off_ref = np.concatenate([np.zeros(1, np.uint64), np.cumsum(cnt_ref, dtype=np.uint64)])
+        runs_ref = denses[last][: 2 * int(off_ref[n])].cpu().numpy().reshape(-1, 2)
+        ha = scrooge_amd.Aligner(local_rank)
+        h2d = n_reads * (rw * 8) + n * 16
+        hres = {"entry_points": "scrg_genome_set + scrg_align_mapping_resident / scrg_align_mapping (host pointers in, host arrays out; "
+                                "PCIe-inclusive; library clock scrg_result.total_ns)",
+                "reference": "genasm_gpu::align_all(Genome_t&, vector<Read_t>&), src/genasm_gpu.cu:890-980"}
+        t_ = time.perf_counter()
+        ha.set_genome_array(genome_h)
+        hres["genome_set_s"] = time.perf_counter() - t_
+
+        def check(res_, outputs):
+            ok_ = bool((res_["edit_distance"] == ed_ref).all())
+            if outputs != 1:
+                ok_ = ok_ and bool((res_["run_offset"] == off_ref).all()) and bool(np.array_equal(res_["runs"], runs_ref))
+            if outputs != 2:
+                co_, txt = res_["cigar_offset"], res_["cigar_text"]
+                k0 = 0
+                for i in range(256):
+                    c_ = int(cnt_ref[i])
+                    want = "".join("%d%s" % (runs_ref[k0 + j, 0], chr(runs_ref[k0 + j, 1])) for j in range(c_))
+                    k0 += c_
+                    ok_ = ok_ and txt[int(co_[i]): int(co_[i + 1]) - 1].decode() == want
+            return ok_
+
+        for name_, outputs in (("resident_runs_and_text", 0), ("resident_text_only", 1), ("resident_runs_only", 2)):
+            def call(outputs=outputs):
+                r_ = ha.align_mapping_rows(None, reads_h, L, co_h, cs_h, outputs=outputs)
+                return r_, ha.last_timing["total_ns"]
+            r_, st_ = host_call_stats(n, h2d, call)
+            st_["pcie_bound_s"] = max(h2d / (pcie[0] * 1e9), st_["d2h_bytes"] / (pcie[1] * 1e9))
+            st_["frac_of_pcie_bound"] = st_["pcie_bound_s"] / st_["steady_best_s"]
+            st_["identical_to_device_path"] = check(r_, outputs)
+            assert st_["identical_to_device_path"], "host API (read mapping, %s) differs from the device-pointer path" % name_
+            hres[name_] = st_
+            del r_
+        ha.clear_genome()
+
+        def call_staged():
+            r_ = ha.align_mapping_rows(genome_h, reads_h, L, co_h, cs_h, outputs=0)
+            return r_, ha.last_timing["total_ns"]
+        r_, st_ = host_call_stats(n, h2d + (genome_len + 3) // 4, call_staged, reps=3)
+        st_["identical_to_device_path"] = check(r_, 0)
+        assert st_["identical_to_device_path"]
+        hres["genome_staged_per_call_runs_and_text"] = st_
+        del r_
+        ha.close()
+        res["host_api"] = hres
     for a_ in als:
         a_.close()
     return res
+
+
+def pcie_probe(torch, device, mb=256):
+    """-> (H2D GB/s, D2H GB/s) of one pinned copy of `mb` MB each way (HIP events): the bound a host-pointer call is held to."""
+    nbytes = mb << 20
+    h = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+    d = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    out = []
+    for src, dst in ((h, d), (d, h)):
+        dst.copy_(src, non_blocking=True)
+        torch.cuda.synchronize()
+        a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a_.record()
+        dst.copy_(src, non_blocking=True)
+        b_.record()
+        torch.cuda.synchronize()
+        out.append(nbytes / (a_.elapsed_time(b_) * 1e-3) / 1e9)
+    return out[0], out[1]
+
+
+def host_call_stats(n_pairs, h2d_bytes, call, reps=4):
+    """Times `call()` (-> result dict of Aligner._collect_arrays, library clock in .last_timing via the closure) `reps` times:
+    the first call of a size allocates buffers and result arrays, the rest are the steady state (best and median)."""
+    times, res = [], None
+    for _ in range(reps):
+        res, total_ns = call()
+        times.append(total_ns * 1e-9)
+    n = n_pairs
+    total_runs = int(res["run_offset"][n]) if len(res["run_offset"]) else 0
+    total_text = int(res["cigar_offset"][n]) if len(res["cigar_offset"]) else 0
+    d2h = 28 * n + (2 * total_runs) + total_text + (8 * n if total_text else 0)
+    steady = sorted(times[1:])
+    best, med = steady[0], steady[len(steady) // 2]
+    return res, {"first_call_s": times[0], "steady_best_s": best, "steady_median_s": med,
+                 "pairs_per_s": n / best, "pairs_per_s_median": n / med, "first_call_pairs_per_s": n / times[0],
+                 "d2h_bytes": d2h, "h2d_bytes": h2d_bytes, "d2h_gbs": d2h / best / 1e9, "h2d_gbs": h2d_bytes / best / 1e9}
+
+
+def run_host_pairs(torch, scrooge_amd, local_rank, rows, tw, text_len, L, dev_ed, dev_cnt, dev_dense, pcie, sizes=(100000, 20000)):
+    """The library surface itself (never `value`): scrg_align_pairs — host strings in, edit distances + CIGAR runs + CIGAR
+    text out, what the reference's genasm_gpu::align_all(texts, queries) does (src/genasm_gpu.cu:982-1065) — on the pairs of
+    one of the timed batches (`rows`: the batch's ASCII in host memory), PCIe included.  Its results are compared with what
+    the device-pointer path produced for the same pairs in the timed region (which the CPU leg has checked)."""
+    out = {"entry_point": "scrg_align_pairs (host pointers in, host arrays out; PCIe-inclusive; library clock scrg_result.total_ns)",
+           "reference": "genasm_gpu::align_all(texts, queries), src/genasm_gpu.cu:982-1065 (kernel vs end to end: README.md:103-108)"}
+    ha = scrooge_amd.Aligner(local_rank)
+    ed_ref = dev_ed.cpu().numpy()
+    cnt_ref = dev_cnt.cpu().numpy().astype(np.uint64)
+    for n_ in sizes:
+        n_ = min(n_, rows.shape[0])
+        sub = rows[:n_]
+        h2d = n_ * (((text_len + 31) // 32 + (L + 31) // 32) * 8 + 8)
+        legs = {}
+        for name, outputs in (("runs_and_text", 0), ("text_only", 1), ("runs_only", 2)):
+            def call(outputs=outputs):
+                r_ = ha.align_pairs_rows(sub, 0, text_len, tw * 32, L, outputs=outputs)
+                return r_, ha.last_timing["total_ns"]
+            res, st = host_call_stats(n_, h2d, call)
+            st["pcie_bound_s"] = max(h2d / (pcie[0] * 1e9), st["d2h_bytes"] / (pcie[1] * 1e9))
+            st["frac_of_pcie_bound"] = st["pcie_bound_s"] / st["steady_best_s"]
+            ok = bool((res["edit_distance"] == ed_ref[:n_]).all())
+            if outputs != 1:
+                off = np.concatenate([np.zeros(1, np.uint64), np.cumsum(cnt_ref[:n_], dtype=np.uint64)])
+                ok = ok and bool((res["run_offset"] == off).all())
+                ok = ok and bool(np.array_equal(res["runs"], dev_dense[: 2 * int(off[n_])].cpu().numpy().reshape(-1, 2)))
+            if outputs != 2:
+                # the text is the "%d%c" rendering of the runs: total length and the first CIGARs, letter for letter
+                co, txt = res["cigar_offset"], res["cigar_text"]
+                dd = dev_dense[: 2 * int(cnt_ref[:64].sum())].cpu().numpy().reshape(-1, 2)
+                k0 = 0
+                for i in range(min(64, n_)):
+                    c_ = int(cnt_ref[i])
+                    want = "".join("%d%s" % (dd[k0 + j, 0], chr(dd[k0 + j, 1])) for j in range(c_))
+                    k0 += c_
+                    ok = ok and txt[int(co[i]): int(co[i + 1]) - 1].decode() == want
+            st["identical_to_device_path"] = ok
+            assert ok, "host API result differs from the device-pointer path (%s, %d pairs)" % (name, n_)
+            legs[name] = st
+            del res
+        out["%d_pairs" % n_] = legs
+    ha.close()
+    return out
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) without a launcher: build both libraries here, then run the N ranks as a fresh
+    child process tree (torch.distributed.run, one process per GPU) and pass its exit code on.  This process never touches
+    the GPU (no HIP call, no torch.cuda.is_available()): nothing that holds a device forks or execs anything."""
+    import socket
+    import subprocess
+    import scrooge_amd
+    if not args.no_build:
+        scrooge_amd.build_library()
+        if args.cpu_seconds > 0:
+            from oracle.pyoracle import build as build_oracle
+            build_oracle()
+    if os.environ.get("SCRG_BENCH_DRYRUN") != "1":
+        import torch
+        have = torch.cuda.device_count()           # (counting devices does not initialise the GPU)
+        if have < args.gpus:
+            raise SystemExit("bench.py --gpus %d: this node has %d GPU(s)" % (args.gpus, have))
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    argv = [a for a in sys.argv[1:] if a != "--no-build"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv + ["--no-build"]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # the host driver only supports dmabuf IPC (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.Popen(cmd, env=env, cwd=ROOT)        # stdout / stderr inherited: rank 0's JSON line is the child's
+    try:
+        rc = proc.wait()
+    except KeyboardInterrupt:
+        proc.terminate()
+        rc = proc.wait()
+    raise SystemExit(rc)
 
 
 STEP_TEXT = {
@@ -411,6 +628,8 @@ def main():
     args = parse()
     if not args.pairs:
         args.pairs = 125000 if args.gpus == 8 else 100000
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)                   # (does not return)
     import torch
     import torch.distributed as dist
 
@@ -464,6 +683,13 @@ def main():
         kw["waves_per_cu"] = args.waves_per_cu
     p = al.resolved_params(**kw)
     geom = al.query_launch(**kw)
+    # the kernels' own counters and the scheduling / ablation switches exist in profiling builds only (-DSCRG_STATS,
+    # -DSCRG_ABLATE: scripts/ab.sh, SCRG_LIB=ab_libs/lib_stats.so); the shipped library has none of that code
+    build_flags = int(scrooge_amd.load_library().scrg_build_flags())
+    have_stats = bool(build_flags & 1)
+    if args.stats and not have_stats:
+        raise SystemExit("--stats needs a library built with -DSCRG_STATS (scripts/ab.sh build stats -DSCRG_STATS; "
+                         "SCRG_LIB=ab_libs/lib_stats.so): the shipped kernels carry no counters")
     if args.stats:
         al.params.reserved[1] = 1
     if os.environ.get("SCRG_BENCH_DEBUG_FLAGS"):      # experiment knob: switches of scrg_params.reserved[0] that leave the results intact
@@ -477,7 +703,9 @@ def main():
             raise SystemExit("--ablate needs a library built with -DSCRG_ABLATE (scripts/ab.sh build ablate -DSCRG_ABLATE; "
                              "SCRG_LIB=ab_libs/lib_ablate.so): the shipped library has no ablation code paths")
 
-    # ---------------- synthetic batch, generated and packed on the GPU ----------------
+    # ---------------- synthetic batches, generated and packed on the GPU: ONE PER PIPELINE LANE ----------------
+    # Consecutive steps are independent batches: step k aligns batch k mod n_lanes (own seed, own sequence array, own
+    # descriptors and output buffers), so no launch in flight reads what another one reads.
     n = args.pairs
     L = args.read_len
     # Unequal shards (--root-share): every rank's buffers hold n pairs, n_real of them are real (the rest are empty reads,
@@ -494,36 +722,49 @@ def main():
     pairs_per_step_all = (n0 + (world - 1) * n) if share_on else world * n
     err, ratio = synth.PROFILES[args.profile]
     t_gen = time.time()
-    ascii_rows, tw, rw, text_len = device_pairs(torch, n, L, err, ratio, args.seed + 1000 * rank, device)
-    row_words = tw + rw
-    n_words = n * row_words
     groups = args.layout == "groups" or (args.layout == "auto" and p.lanes_per_pair == 1)
-    bad = torch.zeros(1, dtype=torch.int32, device=device)
     cap = (2 * L + 8 + 15) // 16 * 16                 # runs per pair slice (genasm_gpu.cu:906-911), 32-byte pieces
     idx = torch.arange(n, dtype=torch.int64, device=device)
     sidx = idx * 0 if os.environ.get("SCRG_BENCH_SAMESEQ") else idx     # experiment only: every pair reads pair 0's sequences
-    if groups:
-        # lane-interleaved groups of 64 pairs: word w of pair p at ((p // 64) * row_words + w) * 64 + p % 64
-        G = scrooge_amd.api.GROUP
-        seq = torch.zeros((n + G - 1) // G * G * row_words + scrooge_amd.api.SEQ_PAD_WORDS_GROUPS, dtype=torch.int64, device=device)
-        al.pack_planar_groups(ascii_rows.view(-1), n, row_words, seq, bad)
-        first = (sidx // G) * row_words * G + sidx % G            # word index of the text's first word
-        desc = torch.stack([first * 32, torch.full_like(idx, text_len), (first + tw * G) * 32, torch.full_like(idx, L),
-                            idx * cap, torch.full_like(idx, cap)], dim=1).contiguous()
-        kw["text_stride_words"] = kw["read_stride_words"] = G
-    else:
-        seq = torch.zeros(n_words + scrooge_amd.api.SEQ_PAD_WORDS, dtype=torch.int64, device=device)
-        al.pack_planar(ascii_rows.view(-1), seq, bad)
-        desc = torch.stack([sidx * row_words * 32, torch.full_like(idx, text_len),
-                            (sidx * row_words + tw) * 32, torch.full_like(idx, L),
-                            idx * cap, torch.full_like(idx, cap)], dim=1).contiguous()
-    torch.cuda.synchronize()
-    assert int(bad.item()) == 0
-    desc_full = desc
-    if n_real < n:
-        desc = desc.clone()
-        desc[n_real:, 1] = 0                                  # text_len
-        desc[n_real:, 3] = 0                                  # read_len
+    same_batch = os.environ.get("SCRG_BENCH_SAMEBATCH") == "1"           # experiment only: every lane aligns lane 0's batch (rounds 1-3)
+    keep_ascii = rank == 0 and world == 1 and args.cpu_seconds > 0        # the CPU leg checks every lane's batch
+    seqs, descs, descs_full, ascii_keep = [], [], [], []
+    bad = torch.zeros(1, dtype=torch.int32, device=device)
+    for b_ in range(n_lanes):
+        if b_ and same_batch:
+            seqs.append(seqs[0]); descs.append(descs[0]); descs_full.append(descs_full[0]); ascii_keep.append(ascii_keep[0])
+            continue
+        ascii_rows, tw, rw, text_len = device_pairs(torch, n, L, err, ratio, args.seed + 1000 * rank + 7919 * b_, device)
+        row_words = tw + rw
+        n_words = n * row_words
+        if groups:
+            # lane-interleaved groups of 64 pairs: word w of pair p at ((p // 64) * row_words + w) * 64 + p % 64
+            G = scrooge_amd.api.GROUP
+            seq = torch.zeros((n + G - 1) // G * G * row_words + scrooge_amd.api.SEQ_PAD_WORDS_GROUPS, dtype=torch.int64, device=device)
+            al.pack_planar_groups(ascii_rows.view(-1), n, row_words, seq, bad)
+            first = (sidx // G) * row_words * G + sidx % G            # word index of the text's first word
+            desc = torch.stack([first * 32, torch.full_like(idx, text_len), (first + tw * G) * 32, torch.full_like(idx, L),
+                                idx * cap, torch.full_like(idx, cap)], dim=1).contiguous()
+            kw["text_stride_words"] = kw["read_stride_words"] = G
+        else:
+            seq = torch.zeros(n_words + scrooge_amd.api.SEQ_PAD_WORDS, dtype=torch.int64, device=device)
+            al.pack_planar(ascii_rows.view(-1), seq, bad)
+            desc = torch.stack([sidx * row_words * 32, torch.full_like(idx, text_len),
+                                (sidx * row_words + tw) * 32, torch.full_like(idx, L),
+                                idx * cap, torch.full_like(idx, cap)], dim=1).contiguous()
+        torch.cuda.synchronize()
+        assert int(bad.item()) == 0
+        desc_full = desc
+        if n_real < n:
+            desc = desc.clone()
+            desc[n_real:, 1] = 0                                  # text_len
+            desc[n_real:, 3] = 0                                  # read_len
+        seqs.append(seq); descs.append(desc); descs_full.append(desc_full)
+        ascii_keep.append(ascii_rows if keep_ascii else None)    # (stays on the GPU until the CPU leg takes it, one lane at a time)
+        del ascii_rows
+    seq, desc, desc_full = seqs[0], descs[0], descs_full[0]
+    seq_total_gb = sum(seqs[b_].numel() for b_ in range(n_lanes) if not (same_batch and b_)) * 8 / 1e9
+    torch.cuda.empty_cache()
     # read lengths of all N x n pairs in slot order, for the root's decoder (one length for all unless shards are unequal)
     if share_on:
         rl_all = torch.full((world * n,), L, dtype=torch.int64, device=device)
@@ -534,20 +775,19 @@ def main():
                  n_runs=torch.empty(n, dtype=torch.int32, device=device),
                  status=torch.empty(n, dtype=torch.int32, device=device)) for _ in range(n_lanes)]
     runs, ed, n_runs, status = (outs[0][k] for k in ("runs", "ed", "n_runs", "status"))
-    # keep a host copy of a sample for the CPU leg before freeing the ASCII staging
-    # (the whole batch: the CPU leg checks every pair of it)
     sample_cap = n
-    sample_rows = ascii_rows.cpu() if (rank == 0 and world == 1 and args.cpu_seconds > 0) else None
-    del ascii_rows
-    torch.cuda.empty_cache()
     gen_s = time.time() - t_gen
 
-    # one untimed pass fixes the (deterministic) output sizes
-    al.align_device(n, seq, desc, runs, ed, n_runs, status, **kw)
-    torch.cuda.synchronize()
-    assert args.ablate or int(status.max().item()) == 0, "CIGAR slice overflow"
-    total_runs = int(n_runs.sum().item())
-    denses = [torch.empty(max(total_runs, 8) * 2, dtype=torch.uint8, device=device) for _ in range(n_lanes)]
+    # one untimed pass per lane fixes the (deterministic) output sizes
+    totals = []
+    for b_ in range(n_lanes):
+        o = outs[b_]
+        al.align_device(n, seqs[b_], descs[b_], o["runs"], o["ed"], o["n_runs"], o["status"], **kw)
+        torch.cuda.synchronize()
+        assert args.ablate or int(o["status"].max().item()) == 0, "CIGAR slice overflow"
+        totals.append(int(o["n_runs"].sum().item()))
+    total_runs = totals[0]
+    denses = [torch.empty(max(t_, 8) * 2, dtype=torch.uint8, device=device) for t_ in totals]
     gather = None
     decode_on = False
     decode_args = None
@@ -561,32 +801,36 @@ def main():
     if dist_on and edits:
         # CIGARs travel as edit streams (one byte per edit); rank 0 keeps them in that form
         from scrooge_amd.distributed import EditStreamGather
-        if gather_format == "edits":
-            t_len = torch.empty(n, dtype=torch.int32, device=device)
-            t_cnt = torch.empty(n, dtype=torch.int32, device=device)
-            al.align_device_edits(n, seq, desc, runs, ed, t_len, status, t_cnt, **kw)
-            torch.cuda.synchronize()
-            assert int(status.max().item()) == 0
-            assert torch.equal(t_cnt, n_runs), "run counts of the edit-stream kernel differ from the runs kernel's"
-            stream_bytes = int(((t_len.to(torch.int64) + 3) // 4 * 4).sum().item())
-            al.align_device(n, seq, desc, runs, ed, n_runs, status, **kw)
-            torch.cuda.synchronize()
-            del t_cnt
-        else:
-            bound = int(ed.sum().item()) + n * (L >> 6) + 4 * n + 64
-            tmp = torch.empty(bound, dtype=torch.uint8, device=device)
-            t_off = torch.empty(n, dtype=torch.int64, device=device)
-            t_len = torch.empty(n, dtype=torch.int32, device=device)
-            t_tot = torch.zeros(2, dtype=torch.int64, device=device)
-            al.encode_edit_stream(n, desc, runs, n_runs, tmp, t_off, t_len, t_tot)
-            torch.cuda.synchronize()
-            assert int(t_tot[1].item()) == 0
-            stream_bytes = int(t_tot[0].item())
-            del tmp, t_off
-        del t_len
+        # (sizes are exchanged once: the largest over the lanes' batches; what a step really sends travels in its lengths)
+        stream_bytes = 0
+        for b_ in range(n_lanes):
+            o = outs[b_]
+            if gather_format == "edits":
+                t_len = torch.empty(n, dtype=torch.int32, device=device)
+                t_cnt = torch.empty(n, dtype=torch.int32, device=device)
+                al.align_device_edits(n, seqs[b_], descs[b_], o["runs"], o["ed"], t_len, o["status"], t_cnt, **kw)
+                torch.cuda.synchronize()
+                assert int(o["status"].max().item()) == 0
+                assert torch.equal(t_cnt, o["n_runs"]), "run counts of the edit-stream kernel differ from the runs kernel's"
+                stream_bytes = max(stream_bytes, int(((t_len.to(torch.int64) + 3) // 4 * 4).sum().item()))
+                al.align_device(n, seqs[b_], descs[b_], o["runs"], o["ed"], o["n_runs"], o["status"], **kw)
+                torch.cuda.synchronize()
+                del t_cnt
+            else:
+                bound = int(o["ed"].sum().item()) + n * (L >> 6) + 4 * n + 64
+                tmp = torch.empty(bound, dtype=torch.uint8, device=device)
+                t_off = torch.empty(n, dtype=torch.int64, device=device)
+                t_len = torch.empty(n, dtype=torch.int32, device=device)
+                t_tot = torch.zeros(2, dtype=torch.int64, device=device)
+                al.encode_edit_stream(n, descs[b_], o["runs"], o["n_runs"], tmp, t_off, t_len, t_tot)
+                torch.cuda.synchronize()
+                assert int(t_tot[1].item()) == 0
+                stream_bytes = max(stream_bytes, int(t_tot[0].item()))
+                del tmp, t_off
+            del t_len
         gather = EditStreamGather(n, stream_bytes, device, dst="rotate" if args.gather_root == "rotate" else 0,
                                   depth=max(2, n_lanes), ordered=gather_format == "edits",
-                                  total_runs=total_runs if gather_format == "edits" else None)
+                                  total_runs=max(totals) if gather_format == "edits" else None)
         gather.prime()                               # (set-up: connections to every root exist before anything is timed)
         # the root's decoder: a handle of its own (its stream is the gather's decode stream), one read length for all pairs
         decode_on = gather_format == "edits" and not args.no_decode
@@ -599,12 +843,12 @@ def main():
     elif dist_on:
         from scrooge_amd.distributed import ResultGather
         packed_gather = gather_format == "packed"    # runs travel as one byte each; rank 0 restores scrg_run pairs
-        gather = ResultGather(n, total_runs, device, dst=0, depth=max(2, n_lanes), packed=packed_gather)
+        gather = ResultGather(n, max(totals), device, dst=0, depth=max(2, n_lanes), packed=packed_gather)
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(args.steps)]
-    # Consecutive steps are independent batches.  With two lanes, step k runs on stream k % 2 with its own
-    # library handle (work queue, spill area) and output buffers: its persistent wavefronts start as soon as
+    # Consecutive steps are independent batches (each lane has its own): step k runs on stream k % n_lanes with its own
+    # library handle (work queue, spill area), input batch and output buffers: its persistent wavefronts start as soon as
     # the previous step's wavefronts begin to retire, instead of after its last pair has finished.
     aligners = [al] + [scrooge_amd.Aligner(local_rank) for _ in range(n_lanes - 1)]
     for extra in aligners[1:]:
@@ -639,25 +883,25 @@ def main():
                 g = gather.buffers(j)
                 if k is not None:
                     ev[k][0].record()
-                aligners[b].align_device_edits(n, seq, desc, o["runs"], o["ed"], o["n_runs"], o["status"], g["cnt"], **kw)
+                aligners[b].align_device_edits(n, seqs[b], descs[b], o["runs"], o["ed"], o["n_runs"], o["status"], g["cnt"], **kw)
                 if k is not None:
                     ev[k][1].record()
                 r4 = (o["n_runs"].to(torch.int64) + 3) & -4
                 boff = torch.cumsum(r4, 0) - r4
                 g["len"].copy_(o["n_runs"])
-                aligners[b].compact_runs(n, desc, o["runs"], (r4 >> 1).to(torch.int32), boff >> 1, g["stream"])
+                aligners[b].compact_runs(n, descs[b], o["runs"], (r4 >> 1).to(torch.int32), boff >> 1, g["stream"])
                 gather.start(j, o["ed"], decode=decode_args if step.decode else None)
                 return
             if k is not None:
                 ev[k][0].record()
-            aligners[b].align_device(n, seq, desc, o["runs"], o["ed"], o["n_runs"], o["status"], **kw)
+            aligners[b].align_device(n, seqs[b], descs[b], o["runs"], o["ed"], o["n_runs"], o["status"], **kw)
             if k is not None:
                 ev[k][1].record()
             if dist_on and gather_format == "edits-from-runs":
                 # the same with the streams encoded from the kernel's runs (any W/O, any kernel)
                 gather.finish(j)
                 g = gather.buffers(j)
-                aligners[b].encode_edit_stream(n, desc, o["runs"], o["n_runs"], g["stream"], g["off"], g["len"], g["total"])
+                aligners[b].encode_edit_stream(n, descs[b], o["runs"], o["n_runs"], g["stream"], g["off"], g["len"], g["total"])
                 gather.start(j, o["ed"])
                 return
             cnt64 = o["n_runs"].to(torch.int64)
@@ -666,12 +910,12 @@ def main():
                 # the same with the runs themselves (--gather-format runs | packed)
                 gather.finish(j)                       # buffers of step j-DEPTH are free again
                 if packed_gather:
-                    aligners[b].compact_runs_packed(n, desc, o["runs"], o["n_runs"], dense_off, gather.send_runs[j % gather.DEPTH], **kw)
+                    aligners[b].compact_runs_packed(n, descs[b], o["runs"], o["n_runs"], dense_off, gather.send_runs[j % gather.DEPTH], **kw)
                 else:
-                    aligners[b].compact_runs(n, desc, o["runs"], o["n_runs"], dense_off, gather.send_runs[j % gather.DEPTH])
+                    aligners[b].compact_runs(n, descs[b], o["runs"], o["n_runs"], dense_off, gather.send_runs[j % gather.DEPTH])
                 gather.start(j, o["ed"], o["n_runs"])
             else:
-                aligners[b].compact_runs(n, desc, o["runs"], o["n_runs"], dense_off, denses[b])
+                aligners[b].compact_runs(n, descs[b], o["runs"], o["n_runs"], dense_off, denses[b])
 
     step.count = 0
     step.decode = decode_on
@@ -699,9 +943,10 @@ def main():
     if dist_on and gather_format == "edits" and rank == check_rank:
         # (the slices of the last step hold edit streams: make the runs for the checks below, outside the timed region)
         with torch.cuda.stream(streams[last]):
-            aligners[last].align_device(n, seq, desc, outs[last]["runs"], outs[last]["ed"], outs[last]["n_runs"], outs[last]["status"], **kw)
+            aligners[last].align_device(n, seqs[last], descs[last], outs[last]["runs"], outs[last]["ed"], outs[last]["n_runs"], outs[last]["status"], **kw)
         torch.cuda.synchronize()
     ed, n_runs, dense = outs[last]["ed"], outs[last]["n_runs"], denses[last]
+    total_runs = totals[last]                           # (of the batch the last step aligned)
     gather_check = None
     if gather is not None and rank == check_rank and os.environ.get("SCRG_BENCH_NOCOLL") != "1":
         # outside the timed region: what the root holds for itself after the last step's gather (scores, counts and the
@@ -709,7 +954,7 @@ def main():
         cnt64 = n_runs.to(torch.int64)
         dense_off = torch.cumsum(cnt64, 0) - cnt64
         torch.cuda.synchronize()                        # (torch's stream is not the handle's)
-        aligners[last].compact_runs(n, desc, outs[last]["runs"], n_runs, dense_off, dense)
+        aligners[last].compact_runs(n, descs[last], outs[last]["runs"], n_runs, dense_off, dense)
         torch.cuda.synchronize()
         if edits:
             # every rank's slot must decode (scrg_decode_edit_stream) into runs for reads of this length, with as many
@@ -746,8 +991,8 @@ def main():
                     print("gather check on rank %d, slot of rank %d: %s (undecodable pairs: %d)" % (rank, r, checks, n_bad), file=sys.stderr)
                     gather_check = False
         else:
-            ed_g, cnt_g, runs_g = gather.results(step.count - 1, 0)
-            gather_check = bool(torch.equal(ed_g, ed) and torch.equal(cnt_g, n_runs) and torch.equal(runs_g, dense[: runs_g.numel()]))
+            ed_g, cnt_g, runs_g = gather.results(step.count - 1, 0)        # (the buffers are sized for the largest batch of the lanes)
+            gather_check = bool(torch.equal(ed_g, ed) and torch.equal(cnt_g, n_runs) and torch.equal(runs_g[: 2 * total_runs], dense[: 2 * total_runs]))
     if dist_on and world > 1 and gather is not None:
         # the verdict travels to rank 0, which prints the line
         flag = torch.tensor([1 if gather_check in (True, None) else 0], dtype=torch.int32, device=device)
@@ -847,17 +1092,46 @@ def main():
         return
 
     # ---------------- work model for the roofline line ----------------
-    runs_per_pair = total_runs / n
+    runs_per_pair = totals[0] / n                 # (lane 0's batch: the one the stand-alone launches below and `serial` align)
     # CPU leg: bounded sample, also the source of dc_cells / text_used per pair and a parity check
     cpu = None
     dc_cells = tb_steps = text_used = windows = None
     parity = None
-    if sample_rows is not None:
+    host_api = None
+    pcie = None
+    default_run = (world == 1 and not dist_on and n == 100000 and L == 10000 and args.profile == "ont" and not args.serial
+                   and not args.stats and not args.ablate and not args.lanes)
+    want_host_api = keep_ascii and (args.host_api == "on" or (args.host_api == "auto" and default_run))
+    if keep_ascii:
         from oracle.pyoracle import Oracle, Reference
-        rows = sample_rows.numpy()
         r_off = tw * 32                       # a row = text slot, then read slot (device_pairs)
         cores = usable_cores()
         orc = Oracle(allow_compile=False)          # (built before the GPU was initialised, or prebuilt: never compile from here)
+        use_ref = Reference.available() and (p.W, p.O) == (64, 33)
+        against = "reference genasm_cpu.cpp (oracle/_ref)" if use_ref else "oracle/liboracle.so (restatement)"
+
+        def cpu_align(rows_, threads_):
+            if use_ref:
+                return Reference().align_rows(rows_, 0, text_len, r_off, L, threads=threads_)
+            e_, off_, runs_, _, ns_ = orc.align_rows(rows_, 0, text_len, r_off, L, W=p.W, O=p.O, threads=threads_)
+            return e_, off_, runs_, ns_
+
+        def compare(lane, m_, e_cpu, off_cpu, runs_cpu):
+            """the GPU results the timed region (or the steps after it) left in this lane's buffers against the CPU's, the
+            first m_ pairs: edit distances, run offsets and the runs themselves, array against array ({count, op} byte pairs,
+            the reference's CIGARs parsed in oracle/ref_driver.cpp)"""
+            o_ = outs[lane]
+            ed_all = o_["ed"][:m_].cpu().numpy()
+            cnt_gpu = o_["n_runs"][:m_].cpu().numpy().astype(np.uint64)
+            off_gpu = np.concatenate([np.zeros(1, np.uint64), np.cumsum(cnt_gpu, dtype=np.uint64)])
+            runs_gpu = denses[lane][: 2 * int(off_gpu[m_])].cpu().numpy().reshape(-1, 2)
+            ok_ed = bool((ed_all == e_cpu).all())
+            ok_off = bool((off_gpu == off_cpu).all())
+            ok_runs = ok_off and bool(np.array_equal(runs_gpu, runs_cpu))
+            return ok_ed, ok_off, ok_runs, int(off_cpu[m_])
+
+        # the lane of the last step first: work counters, the CPU baseline, the full comparison
+        rows = ascii_keep[last].cpu().numpy()
         # work counters (dc_cells, tb_steps, windows, text used) from this repo's restatement, on a small sample
         cal = min(sample_cap, max(2 * cores, 64))
         _, _, _, st, ns = orc.align_rows(rows[:cal], 0, text_len, r_off, L, W=p.W, O=p.O, threads=cores)
@@ -866,37 +1140,46 @@ def main():
         rate = cal / (ns * 1e-9)
         m = int(min(sample_cap, max(cal, rate * args.cpu_seconds)))
         # the CPU baseline: the reference itself (oracle/_ref, default knobs only) or the restatement, all usable cores
-        use_ref = Reference.available() and (p.W, p.O) == (64, 33)
-        if use_ref:
-            e_cpu, off_cpu, runs_cpu, ns = Reference().align_rows(rows[:m], 0, text_len, r_off, L, threads=cores)
-        else:
-            e_cpu, off_cpu, runs_cpu, _, ns = orc.align_rows(rows[:m], 0, text_len, r_off, L, W=p.W, O=p.O, threads=cores)
+        e_cpu, off_cpu, runs_cpu, ns = cpu_align(rows[:m], cores)
         cpu = {"value": m / (ns * 1e-9), "unit": "pairs/s", "cores": cores,
                "kind": "reference" if use_ref else "port",
-               "sample": "%s %d of the %d pairs of this workload, kernel-only time (%s), %d OpenMP threads"
-                         % ("all" if m == n else "the first", m, n,
+               "sample": "%s %d of the %d pairs of one of the %d batches of this workload, kernel-only time (%s), %d OpenMP threads"
+                         % ("all" if m == n else "the first", m, n, n_lanes,
                             "genasm_cpu.cpp:589-591 via oracle/_ref" if use_ref else "oracle/liboracle.so", cores)}
         # the same checker on ONE thread (SURVEY.md §8d asks for both), about two seconds' worth of pairs
         m1 = int(min(m, max(8, cpu["value"] / max(1, cores) * 2.0)))
-        if use_ref:
-            _, _, _, ns1 = Reference().align_rows(rows[:m1], 0, text_len, r_off, L, threads=1)
-        else:
-            _, _, _, _, ns1 = orc.align_rows(rows[:m1], 0, text_len, r_off, L, W=p.W, O=p.O, threads=1)
+        _, _, _, ns1 = cpu_align(rows[:m1], 1)
         cpu["single_thread"] = {"value": m1 / (ns1 * 1e-9), "unit": "pairs/s", "sample_pairs": m1}
-        # parity of the timed GPU results, EVERY pair the CPU leg aligned: edit distances, run offsets and the runs
-        # themselves, array against array ({count, op} byte pairs, the reference's CIGARs parsed in oracle/ref_driver.cpp)
-        ed_all = ed[:m].cpu().numpy()
-        cnt_gpu = n_runs[:m].cpu().numpy().astype(np.uint64)
-        off_gpu = np.concatenate([np.zeros(1, np.uint64), np.cumsum(cnt_gpu, dtype=np.uint64)])
-        runs_gpu = dense[: 2 * int(off_gpu[m])].cpu().numpy().reshape(-1, 2)
-        ok_ed = bool((ed_all == e_cpu).all())
-        ok_off = bool((off_gpu == off_cpu).all())
-        ok_runs = ok_off and bool(np.array_equal(runs_gpu, runs_cpu))
+        ok_ed, ok_off, ok_runs, n_cmp = compare(last, m, e_cpu, off_cpu, runs_cpu)
         parity = {"checked_pairs": m, "of_pairs": n, "edit_distances_equal": ok_ed, "run_counts_equal": ok_off,
-                  "runs_bit_exact": ok_runs, "runs_compared": int(off_cpu[m]),
-                  "against": "reference genasm_cpu.cpp (oracle/_ref)" if use_ref else "oracle/liboracle.so (restatement)"}
+                  "runs_bit_exact": ok_runs, "runs_compared": n_cmp, "against": against, "batch": "pipeline lane %d (the last step's)" % last}
         assert ok_ed and ok_runs, "GPU result differs from the CPU checker on the bench batch: %s" % parity
-        del rows, runs_gpu, runs_cpu
+        del runs_cpu, e_cpu, off_cpu
+        if want_host_api:
+            # the library surface on this very batch (its ASCII is in host memory now), compared with the results just checked
+            pcie = pcie_probe(torch, device)
+            host_api = {"pcie_probe_gbs": {"h2d": pcie[0], "d2h": pcie[1], "note": "one pinned 256 MB copy each way, HIP events"},
+                        "pairwise": run_host_pairs(torch, scrooge_amd, local_rank, rows, tw, text_len, L, outs[last]["ed"], outs[last]["n_runs"],
+                                                   denses[last], pcie)}
+        del rows
+        ascii_keep[last] = None
+        # the other lanes' batches (each lane aligns its own): what their last steps left, against the CPU path as well
+        others = []
+        for lane in range(n_lanes):
+            if lane == last or ascii_keep[lane] is None or same_batch:
+                continue
+            rows = ascii_keep[lane].cpu().numpy()
+            ascii_keep[lane] = None
+            e_cpu, off_cpu, runs_cpu, _ = cpu_align(rows[:m], cores)
+            ok_ed, ok_off, ok_runs, n_cmp = compare(lane, m, e_cpu, off_cpu, runs_cpu)
+            others.append({"batch": "pipeline lane %d" % lane, "checked_pairs": m, "edit_distances_equal": ok_ed,
+                           "run_counts_equal": ok_off, "runs_bit_exact": ok_runs, "runs_compared": n_cmp})
+            assert ok_ed and ok_runs, "GPU result differs from the CPU checker on the batch of pipeline lane %d" % lane
+            del rows, runs_cpu, e_cpu, off_cpu
+        parity["other_batches"] = others
+        parity["pairs_checked_all_batches"] = m * (1 + len(others))
+    ascii_keep = None
+    torch.cuda.empty_cache()
 
     # The N > 1 step writes CIGARs as edit streams (a different, lossless output format).  For a like-for-like
     # scaling figure the same step — align kernel with edit-stream output + compaction of the streams, pipelined
@@ -904,19 +1187,22 @@ def main():
     edit_stream_step = None
     if not dist_on and n_lanes > 1 and not args.ablate and not args.stats and p.lanes_per_pair == 1:
         lens = [torch.empty(n, dtype=torch.int32, device=device) for _ in range(n_lanes)]
-        aligners[0].align_device_edits(n, seq, desc, outs[0]["runs"], outs[0]["ed"], lens[0], outs[0]["status"], **kw)
-        torch.cuda.synchronize()
-        sbytes = int(((lens[0].to(torch.int64) + 3) & -4).sum().item())
-        sdense = [torch.empty(sbytes + 8, dtype=torch.uint8, device=device) for _ in range(n_lanes)]
+        sbytes_lane = []
+        for b_ in range(n_lanes):
+            aligners[0].align_device_edits(n, seqs[b_], descs[b_], outs[b_]["runs"], outs[b_]["ed"], lens[b_], outs[b_]["status"], **kw)
+            torch.cuda.synchronize()
+            sbytes_lane.append(int(((lens[b_].to(torch.int64) + 3) & -4).sum().item()))
+        sbytes = sum(sbytes_lane) / n_lanes
+        sdense = [torch.empty(sb_ + 8, dtype=torch.uint8, device=device) for sb_ in sbytes_lane]
 
         def edit_step(j):
             b = j % n_lanes
             o = outs[b]
             with torch.cuda.stream(streams[b]):
-                aligners[b].align_device_edits(n, seq, desc, o["runs"], o["ed"], lens[b], o["status"], **kw)
+                aligners[b].align_device_edits(n, seqs[b], descs[b], o["runs"], o["ed"], lens[b], o["status"], **kw)
                 r4 = (lens[b].to(torch.int64) + 3) & -4
                 boff = torch.cumsum(r4, 0) - r4
-                aligners[b].compact_runs(n, desc, o["runs"], (r4 >> 1).to(torch.int32), boff >> 1, sdense[b])
+                aligners[b].compact_runs(n, descs[b], o["runs"], (r4 >> 1).to(torch.int32), boff >> 1, sdense[b])
 
         for j in range(args.warmup):
             edit_step(j)
@@ -933,23 +1219,25 @@ def main():
         # the receiving side of the same step: one slot's streams back to scrg_run pairs (what the root of an N-GPU job does
         # for every rank's slot, all slots in one launch), checked against the runs kernel's output of the timed region
         with torch.cuda.stream(streams[0]):
-            aligners[0].align_device_edits(n, seq, desc, outs[0]["runs"], outs[0]["ed"], lens[0], outs[0]["status"], **kw)
+            # (lane 0's batch: its runs of the timed region are in denses[0], their counts in outs[0]["n_runs"])
+            n_runs0, tr0 = outs[0]["n_runs"], totals[0]
+            aligners[0].align_device_edits(n, seqs[0], descs[0], outs[0]["runs"], outs[0]["ed"], lens[0], outs[0]["status"], **kw)
             r4 = (lens[0].to(torch.int64) + 3) & -4
             boff = torch.cumsum(r4, 0) - r4
-            aligners[0].compact_runs(n, desc, outs[0]["runs"], (r4 >> 1).to(torch.int32), boff >> 1, sdense[0])
-            cnt64 = n_runs.to(torch.int64)
+            aligners[0].compact_runs(n, descs[0], outs[0]["runs"], (r4 >> 1).to(torch.int32), boff >> 1, sdense[0])
+            cnt64 = n_runs0.to(torch.int64)
             doff = torch.cumsum(cnt64, 0) - cnt64
-            back = torch.zeros(total_runs * 2 + 64, dtype=torch.uint8, device=device)
+            back = torch.zeros(tr0 * 2 + 64, dtype=torch.uint8, device=device)
             nbad = torch.zeros(1, dtype=torch.int32, device=device)
             rl1 = torch.tensor([L], dtype=torch.int64, device=device)
             dev_ = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
-            aligners[0].decode_edit_stream(n, sdense[0], boff, lens[0], rl1, 0, doff, back, n_runs, nbad, **kw)
+            aligners[0].decode_edit_stream(n, sdense[0], boff, lens[0], rl1, 0, doff, back, n_runs0, nbad, **kw)
             dev_[0].record()
             for _ in range(5):
-                aligners[0].decode_edit_stream(n, sdense[0], boff, lens[0], rl1, 0, doff, back, n_runs, nbad, **kw)
+                aligners[0].decode_edit_stream(n, sdense[0], boff, lens[0], rl1, 0, doff, back, n_runs0, nbad, **kw)
             dev_[1].record()
         torch.cuda.synchronize()
-        dec_ok = int(nbad.item()) == 0 and bool(torch.equal(back[: 2 * total_runs], dense[: 2 * total_runs]))
+        dec_ok = int(nbad.item()) == 0 and bool(torch.equal(back[: 2 * tr0], denses[0][: 2 * tr0]))
         assert dec_ok, "decoded edit streams differ from the runs of the timed region"
         edit_stream_step["decode_ms_per_slot"] = dev_[0].elapsed_time(dev_[1]) / 5
         edit_stream_step["decode_note"] = ("scrg_decode_edit_stream of this step's %d streams into the dense scrg_run array, one launch "
@@ -959,7 +1247,7 @@ def main():
     # window rounds of one launch (one round = one window of each of a wavefront's 64 pairs), from the kernel's own
     # counters: one more launch with the counters switched on, after everything that is timed
     rounds_live = None
-    if p.lanes_per_pair == 1 and not args.ablate and os.environ.get("SCRG_BENCH_NO_STATS_LAUNCH") != "1":      # (PMC passes: only plain launches)
+    if have_stats and p.lanes_per_pair == 1 and not args.ablate and os.environ.get("SCRG_BENCH_NO_STATS_LAUNCH") != "1":      # (PMC passes: only plain launches)
         keep = al.params.reserved[1]
         al.params.reserved[1] = 1
         with torch.cuda.stream(streams[0]):
@@ -981,10 +1269,9 @@ def main():
 
     # ---------------- the other single-GPU configurations of BASELINE.json, after everything that is timed ----------------
     other_configs = None
-    want_other = args.other_configs == "on" or (args.other_configs == "auto" and world == 1 and not dist_on and n == 100000 and L == 10000
-                                                and args.profile == "ont" and not args.serial and not args.stats and not args.ablate and not args.lanes)
+    want_other = args.other_configs == "on" or (args.other_configs == "auto" and default_run)
     if want_other:
-        del outs, denses, seq, desc, runs, ed, n_runs, status, dense
+        del outs, denses, seq, desc, desc_full, seqs, descs, descs_full, runs, ed, n_runs, status, dense
         torch.cuda.empty_cache()
         cores_ = usable_cores()
         chk = args.cpu_seconds > 0
@@ -992,10 +1279,20 @@ def main():
             run_other_config(torch, scrooge_amd, device, local_rank, streams,
                              "unstructured pairwise: 4 M x 150 bp Illumina-like pairs (BASELINE configs[0] shape at GPU scale)",
                              4000000, 150, "illumina", 6, 2, 20000 if chk else 0, args.seed + 11, cores_),
-            run_mapping_config(torch, scrooge_amd, device, local_rank, streams, 100000000, 1000000, 6, 2, 5000 if chk else 0, args.seed + 12, cores_),
+            run_mapping_config(torch, scrooge_amd, device, local_rank, streams, 100000000, 1000000, 6, 2, 5000 if chk else 0, args.seed + 12, cores_,
+                               host_api=pcie if want_host_api else None),
             run_other_config(torch, scrooge_amd, device, local_rank, streams,
                              "long-read stress: 40 k x 50 kb PacBio-error (15 %) pairs, the single-GPU share of BASELINE configs[4]",
                              40000, 50000, "pacbio15", 6, 2, 1500 if chk else 0, args.seed + 13, cores_),
+            # the workload of the reference's one published absolute number (README.md:103-108, DATASETS.md:51: PBSIM2 PacBio
+            # P6C4, 10 kb reads, accuracy 0.95, sub:ins:del 6:50:54 — 25 004 aligns/s kernel-only on an RTX 3060): SURVEY §8d "Cfg2b"
+            run_other_config(torch, scrooge_amd, device, local_rank, streams,
+                             "Cfg2b: 100 k x 10 kb PacBio-error pairs (5 %, sub:ins:del 6:50:54; the workload of the reference's README.md:103-108 figure)",
+                             100000, 10000, "pacbio", 10, 2, 2000 if chk else 0, args.seed + 16, cores_),
+            # a mixed-length batch of the headline's error profile: reads of 2 to 20 kb, issued longest first
+            run_other_config(torch, scrooge_amd, device, local_rank, streams,
+                             "mixed lengths: 100 k ONT-error pairs, read lengths uniform in 2 .. 20 kb, issued longest read first",
+                             100000, 20000, "ont", 10, 2, 2000 if chk else 0, args.seed + 17, cores_, len_range=(2000, 20000)),
             # two points of the reference's knob sweeps (scripts/profile.py:88-100 small overlaps, :180-185 W > 64) on the headline
             # workload: 32 <= W-O <= 63 runs on genasm_lane_wide_kernel (table in registers, built in two halves)
             run_other_config(torch, scrooge_amd, device, local_rank, streams,
@@ -1006,6 +1303,10 @@ def main():
                              args.seed + 15, cores_, W=128, O=65),
         ]
 
+    if host_api is not None and other_configs:
+        for oc in other_configs:
+            if "host_api" in oc:
+                host_api["read_mapping_configs2"] = oc.pop("host_api")
     pairs_total = pairs_per_step_all * args.steps
     value = pairs_total / dt
     if text_used is None:
@@ -1030,27 +1331,53 @@ def main():
     hbm = {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
            "algorithmic_bytes_per_pair": bytes_per_pair, "algorithmic_bytes_per_launch": launch_bytes,
            "note": "algorithmic bytes of a launch / its duration; `traffic` = HBM bytes per launch from the PMC counters (profiles/hbm_traffic.json)"}
-    instr, instr_src = (pmc_instruction_count() if p.lanes_per_pair == 1 else (None, "PMC summary exists for the one-pair-per-lane kernel only"))
+    pmc, instr_src = (pmc_instruction_count() if p.lanes_per_pair == 1 else (None, "PMC summary exists for the one-pair-per-lane kernel only"))
+    instr = float(pmc["valu_instructions_per_window_round"]) if pmc else None
     mix_roof = None          # what the chip sustains for THIS kernel's instruction mix (scripts/mix_roof.py from scripts/ubench/valu_rate.hip)
     try:
-        mj = json.load(open(os.path.join(ROOT, "profiles", "r03_mix_roof.json")))
-        if mj.get("kernel_sources_sha256") == kernel_sources_digest():
-            mix_roof = {"T_lane_ops_per_s": mj["roof"]["4 waves/SIMD"]["T_lane_ops_per_s"], "at": "4 wavefronts per SIMD",
-                        "source": "profiles/r03_mix_roof.json: static opcode mix of the kernel x per-class issue rates measured on this chip"}
+        import glob
+        for mf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_mix_roof.json")), reverse=True):
+            mj = json.load(open(mf))
+            if mj.get("kernel_sources_sha256") == kernel_sources_digest():
+                mix_roof = {"T_lane_ops_per_s": mj["roof"]["4 waves/SIMD"]["T_lane_ops_per_s"], "at": "4 wavefronts per SIMD",
+                            "source": "profiles/%s: static opcode mix of the kernel x per-class issue rates measured on this chip" % os.path.basename(mf)}
+                break
     except Exception:
         pass
-    if instr is not None and rounds_live:
-        lane_ops_launch = instr * rounds_live * 64.0
+    # The instructions one launch issues.  The profiled launch IS this run's stand-alone launch when the workload is the one
+    # the PMC passes ran (same pairs, read length, profile, seed: pipeline lane 0's batch): SQ_INSTS_VALU of that launch is
+    # used as counted.  Otherwise: instructions per window round x the window rounds of this launch — counted by the kernel
+    # itself in a -DSCRG_STATS build, else estimated from the CPU checker's window count (64 windows per round, + 0.5 % for
+    # the lanes that wait at the end of a wavefront's life).
+    lane_ops_launch, rounds, rounds_src = None, rounds_live, "the kernel's own counter (profiling build)"
+    if pmc is not None:
+        wl = pmc.get("workload") or {}
+        same_wl = (wl.get("pairs") == n and wl.get("read_len") == L and wl.get("profile") == args.profile and wl.get("seed") == args.seed
+                   and n_real == n and not same_batch)
+        if same_wl and pmc.get("SQ_INSTS_VALU"):
+            lane_ops_launch = float(pmc["SQ_INSTS_VALU"]) * 64.0
+            rounds = rounds_live or pmc.get("window_rounds_per_launch")
+            rounds_src = "SQ_INSTS_VALU of this very launch (same workload and seed), %s" % instr_src
+        elif rounds_live:
+            lane_ops_launch = instr * rounds_live * 64.0
+        elif windows is not None:
+            rounds = n * windows / 64.0 * 1.005
+            rounds_src = "estimated: pairs x windows per pair (CPU checker) / 64 x 1.005"
+            lane_ops_launch = instr * rounds * 64.0
+    if lane_ops_launch is not None:
         a_valu = lane_ops_launch / (kernel_ms * 1e-3)
         roofline = {"bound": "valu-issue", "achieved": a_valu / 1e12, "peak": VALU_PEAK_LANE_OPS / 1e12, "unit": "T int32 lane-ops/s",
                     "frac": a_valu / VALU_PEAK_LANE_OPS, "traffic": traffic, "kernel": kernel_name,
                     "valu_instructions_per_window_round": instr, "instruction_count_source": instr_src,
-                    "window_rounds_per_launch": rounds_live, "issued_lane_ops_per_launch": lane_ops_launch, "kernel_ms": kernel_ms,
+                    "window_rounds_per_launch": rounds, "window_rounds_source": rounds_src,
+                    "issued_lane_ops_per_launch": lane_ops_launch, "kernel_ms": kernel_ms,
                     "frac_at_step_rate": lane_ops_launch / (dt / args.steps) / VALU_PEAK_LANE_OPS if not dist_on else None,
+                    "frac_sustained": (lane_ops_launch / (sustained["ms_per_step"] * 1e-3) / VALU_PEAK_LANE_OPS) if sustained else None,
                     "mix_weighted_roof": mix_roof,
                     "note": "a launch that has the GPU to itself (1.5 wavefronts per SIMD: cannot fill the issue slots); frac_at_step_rate "
-                            "divides by ms_per_step of the pipelined timed region instead (2-3 launches share the SIMDs); peak prices every op "
-                            "as full-rate at 2.4 GHz — the mix-weighted issue roof of this instruction mix is in DESIGN.md §3.1",
+                            "divides by ms_per_step of the pipelined timed region instead (2-3 launches share the SIMDs), frac_sustained by the "
+                            "sustained step; peak prices every op as full-rate at 2.4 GHz — the mix-weighted issue roof of this instruction "
+                            "mix is in DESIGN.md §3.1",
                     "hbm": hbm}
     else:
         roofline = {"bound": "valu-issue", "achieved": None, "peak": VALU_PEAK_LANE_OPS / 1e12, "unit": "T int32 lane-ops/s", "frac": None,
@@ -1078,8 +1405,10 @@ def main():
                                "decoded_to_runs_inside_timed_region": bool(decode_on),
                                "bytes_per_rank_and_step": gather.wire if edits else None,
                                "stream_bytes_per_pair": (stream_bytes / n) if stream_bytes is not None else None} if dist_on else None),
-                   "pipeline": ("consecutive steps alternate between %d streams (own handle, work queue and output buffers each): "
-                                "a step's wavefronts start while the previous step's last pairs finish" % n_lanes) if n_lanes > 1
+                   "pipeline": ("consecutive steps rotate over %d streams, each with its own handle, work queue, output buffers and its OWN "
+                                "INPUT BATCH (%s): a step's wavefronts start while the previous step's last pairs finish"
+                                % (n_lanes, "experiment: all lanes share lane 0's batch" if same_batch else
+                                   "different seeds; %.2f GB of packed sequence in total" % seq_total_gb)) if n_lanes > 1
                                else "one stream: a step starts after the previous one has finished"},
         "gcups": value * L * L / 1e9,           # EQUIVALENT full-matrix GCUPS (pairs/s x L x L, the reference's convention, scripts/profile.py:426-427)
         "gcups_note": "equivalent full L x L matrix cells (the reference's convention); the cells the windowed algorithm really computes are in bit_cell_gcups",
@@ -1088,7 +1417,8 @@ def main():
         "kernel_ms_events_in_timed_region": events_ms,   # pipelined launches: includes waiting for the previous launch's wavefronts to retire
         "serial": serial,              # the same step without overlap between launches, measured after the timed region
         "sustained": sustained,        # the same pipelined step over many more steps (fill and drain amortised), after the timed region
-        "other_configs": other_configs,   # BASELINE configs[0], [2], [4] on this GPU, measured after the timed region, each with an oracle-checked sample
+        "other_configs": other_configs,   # BASELINE configs[0], [2], [4], Cfg2b, mixed lengths, two knob-sweep points on this GPU, measured after the timed region, each with an oracle-checked sample
+        "host_api": host_api,             # the host-pointer entry points (PCIe-inclusive; never `value`), after the timed region
         "edit_stream_step": edit_stream_step,   # the N > 1 step (CIGARs as edit streams) on this one GPU, without the collective
         "gather_without_decode": streams_only,  # N > 1: the same steps with the gathered CIGARs left as edit streams (after the timed region)
         "roofline": roofline,

@@ -72,9 +72,10 @@ typedef struct scrg_params {
                                 SCRG_OUT_TEXT: the CIGAR text only (runs stays empty, run_offset all zero);
                                 SCRG_OUT_RUNS: the runs only (cigar_text stays empty, cigar_offset all zero).
                                 What is not asked for does not cross PCIe                                   */
-    int32_t reserved[2];     /* [0]: experiment switches, 0 unless profiling (see scrg_debug_stats: unknown bits are
-                                rejected with SCRG_ERR_INVALID_ARG, so an uninitialised struct cannot silently
-                                change results); [1]: non-zero = collect the kernel's profiling counters    */
+    int32_t reserved[2];     /* [0]: 0, or one of two documented, result-neutral selections (32, 256: see
+                                scrg_debug_stats); every other bit is rejected with SCRG_ERR_INVALID_ARG, so an
+                                uninitialised struct cannot silently change anything; [1]: 0 (non-zero asks a
+                                profiling build, -DSCRG_STATS, for its counters; the shipped library rejects it) */
 } scrg_params;
 
 enum { SCRG_OUT_ALL = 0, SCRG_OUT_TEXT = 1, SCRG_OUT_RUNS = 2 };
@@ -114,6 +115,11 @@ const char *scrg_status_string(scrg_status s);
 void        scrg_set_log(int enabled);
 int         scrg_get_log(void);
 int         scrg_device_count(void);
+/* How this library was built: 0 for the shipped build; SCRG_BUILD_STATS if the kernels carry their profiling counters
+ * and scheduling switches (-DSCRG_STATS), SCRG_BUILD_ABLATE if also the ablation switches (-DSCRG_ABLATE: results wrong
+ * by design).  See scrg_debug_stats. */
+enum { SCRG_BUILD_STATS = 1, SCRG_BUILD_ABLATE = 2 };
+int         scrg_build_flags(void);
 
 /* ---------------------------------------------------------------------------
  * Host-pointer entry points (the drop-in path).
@@ -304,8 +310,10 @@ scrg_status scrg_unpack_runs(scrg_ctx *ctx, uint64_t n_runs, const uint8_t *d_pa
  *   is counted as bad, never read.  Read lengths are taken from d_read_len[p * read_len_stride] (stride 1: a plain
  *   array; 6: &d_pairs[0].read_len; 0: one length for all).
  *   With d_dense == NULL it only counts: d_n_runs[p] = runs of pair p.  Otherwise d_n_runs[p] is an input, the size
- *   of pair p's segment at d_dense + d_dense_offset[p] (d_dense 16-byte aligned), and the runs are written there —
- *   bit for bit the runs the align kernel produced for W/O of `params`.  (scrg_align_device_edits can deliver the
+ *   of pair p's segment at d_dense + d_dense_offset[p] (d_dense 16-byte aligned, room for dense_capacity runs), and the
+ *   runs are written there — bit for bit the runs the align kernel produced for W/O of `params`.  Counts and offsets
+ *   may come off a wire like the streams: a pair whose segment [d_dense_offset[p], + d_n_runs[p]) does not lie inside
+ *   [0, dense_capacity) is counted as bad and nothing of it is written.  (scrg_align_device_edits can deliver the
  *   run counts along with the streams, so that the receiver sizes the dense array by a prefix sum and decodes in ONE
  *   pass.)  *d_bad_count is incremented for every pair whose stream is not an alignment of a read of that length,
  *   or whose run count differs from d_n_runs[p]. */
@@ -317,8 +325,8 @@ scrg_status scrg_decode_edit_stream(scrg_ctx *ctx, const scrg_params *params, ui
                                     const uint8_t *d_stream, uint64_t stream_bytes,
                                     const uint64_t *d_stream_off, const uint32_t *d_stream_len,
                                     const uint64_t *d_read_len, uint64_t read_len_stride,
-                                    const uint64_t *d_dense_offset, scrg_run *d_dense, uint32_t *d_n_runs,
-                                    uint32_t *d_bad_count);
+                                    const uint64_t *d_dense_offset, scrg_run *d_dense, uint64_t dense_capacity,
+                                    uint32_t *d_n_runs, uint32_t *d_bad_count);
 /* The same two conversions for ONE pair on the host (no GPU, no handle): what a receiver without a GPU, or a
  * test, uses.  scrg_edit_stream_to_runs returns SCRG_ERR_INVALID_ARG for a malformed stream and
  * SCRG_ERR_CIGAR_OVERFLOW if runs_cap is too small (*n_runs is the number needed either way; runs may be NULL
@@ -353,23 +361,24 @@ scrg_status scrg_query_launch(scrg_ctx *ctx, const scrg_params *params,
  * the launch stream (milliseconds); blocks until that launch finished. */
 scrg_status scrg_last_kernel_ms(scrg_ctx *ctx, float *ms);
 
-/* Profiling aid: when params.reserved[1] != 0 the align kernel accumulates twelve counters per launch; this
- * reads them back (blocks on the stream).
+/* scrg_params.reserved[0] in the SHIPPED library: 0, or one of two selections between formulations that give identical
+ * results (kept because the parity tests compare them): 32 (lanes_per_pair = 8: GenASM rows only, no diagonal-major
+ * path) and 256 (32 <= W-O <= 63, W <= 128: the kernel that keeps the window table in HBM instead of the one that
+ * keeps it in registers).  scrg_params_resolve() and every entry point REJECT any other bit, and reserved[1] != 0.
+ *
+ * Profiling builds only (scripts/ab.sh; scrg_build_flags() tells): with -DSCRG_STATS the align kernels accumulate
+ * twelve counters per launch when reserved[1] != 0, read back by scrg_debug_stats (blocks on the stream):
  *   lanes_per_pair = 1 (genasm_lane_kernel): [0] window rounds (one window of each of a wavefront's 64 pairs),
  *     [1] rounds that took a short-window variant, [2..6] shader cycles summed over wavefronts: traceback pass 1,
  *     queue/fetch, window setup, table, traceback (both passes + CIGAR flush), [7] wavefront life times and
  *     [8..11] latest start, 2^62 - earliest start, latest end, 2^62 - earliest end on the 100 MHz wall clock.
  *   lanes_per_pair >= 4 (genasm_align_kernel): {window rounds, DC sweep steps, TB macro-steps, shader cycles for
  *     fetch / window setup / DC / TB / TB loop, rounds on the diagonal-major path, rounds that fell back from it,
- *     DC / TB cycles of the diagonal-major rounds (not included in the former)}.
- * params.reserved[0] holds experiment switches; scrg_params_resolve() and every entry point REJECT any bit other
- * than the ones that leave the results intact:
- *   lanes_per_pair = 1: 1 turns the wavefront priority rotation off, 64 / 128 launch workgroups of one / two
- *     wavefronts instead of four, 256 selects the kernel that keeps the window table in HBM where the one that
- *     keeps it in registers would serve (32 <= W-O <= 63, W <= 128);  lanes_per_pair = 8: 32 turns the
- *     diagonal-major path off.
- * (Ablation switches — skip the table, a traceback pass, the stores; results wrong by design — exist only in a
- * library built with -DSCRG_ABLATE for profiling, scripts/ab.sh; the shipped library has no such code path.) */
+ *     DC / TB cycles of the diagonal-major rounds (not included in the former)};
+ * and reserved[0] also accepts the scheduling switches 1 (one pair per lane: no wavefront priority rotation) and
+ * 64 / 128 (workgroups of one / two wavefronts instead of four).  With -DSCRG_ABLATE also 2, 4, 8, 16 (skip the table,
+ * a traceback pass, the stores: results wrong by design).  None of this code exists in the shipped kernels; there
+ * scrg_debug_stats returns SCRG_ERR_INVALID_ARG. */
 scrg_status scrg_debug_stats(scrg_ctx *ctx, uint64_t out[12]);
 
 #ifdef __cplusplus

@@ -323,15 +323,17 @@ int go_align_batch_ascii(size_t n_pairs,
 }
 
 /* The same batch for inputs that sit in ONE array of fixed-size rows (the staging layout of bench.py: a text slot and a
- * read slot per row) and results as arrays: edit distances, run offsets and the runs themselves as {count, op} byte pairs
+ * read slot per row; text_lens / read_lens, if not NULL, give every row's own lengths <= text_len / read_len, the slot
+ * sizes) and results as arrays: edit distances, run offsets and the runs themselves as {count, op} byte pairs
  * (the layout of the reference's CigarEntry_t, src/util.hpp:43-46) — a full-size batch is compared array against array,
  * with no per-pair objects on the caller's side.  runs_cap counts runs; GO_ERR_CAPACITY if they do not fit. */
-int go_align_batch_rows(size_t n_pairs, const char *rows, uint64_t row_stride,
-                        uint64_t text_off, uint64_t text_len, uint64_t read_off, uint64_t read_len,
-                        int W, int O, int threads,
-                        long long *edit_distances, uint64_t *run_offsets /* n_pairs + 1 */,
-                        uint8_t *runs_out, uint64_t runs_cap,
-                        go_stats *total_stats, long long *kernel_ns)
+int go_align_batch_rows_var(size_t n_pairs, const char *rows, uint64_t row_stride,
+                            uint64_t text_off, uint64_t text_len, uint64_t read_off, uint64_t read_len,
+                            const uint64_t *text_lens, const uint64_t *read_lens,
+                            int W, int O, int threads,
+                            long long *edit_distances, uint64_t *run_offsets /* n_pairs + 1 */,
+                            uint8_t *runs_out, uint64_t runs_cap,
+                            go_stats *total_stats, long long *kernel_ns)
 {
     if (W < 2 || W > GO_MAXW || O < 0 || O >= W)
         return GO_ERR_PARAMS;
@@ -347,9 +349,12 @@ int go_align_batch_rows(size_t n_pairs, const char *rows, uint64_t row_stride,
         int first_err = GO_OK;
         #pragma omp parallel for num_threads(threads) schedule(static)
         for (long long p = 0; p < (long long)n_pairs; p++) {
-            int e = encode_bases(rows + (size_t)p * row_stride + text_off, text_len, tc + (size_t)p * (text_len + 1));
+            const uint64_t tl = text_lens ? text_lens[p] : text_len, rl = read_lens ? read_lens[p] : read_len;
+            int e = (tl <= text_len && rl <= read_len) ? GO_OK : GO_ERR_PARAMS;
             if (e == GO_OK)
-                e = encode_bases(rows + (size_t)p * row_stride + read_off, read_len, rc_ + (size_t)p * (read_len + 1));
+                e = encode_bases(rows + (size_t)p * row_stride + text_off, tl, tc + (size_t)p * (text_len + 1));
+            if (e == GO_OK)
+                e = encode_bases(rows + (size_t)p * row_stride + read_off, rl, rc_ + (size_t)p * (read_len + 1));
             if (e != GO_OK) {
                 #pragma omp critical
                 if (first_err == GO_OK) first_err = e;
@@ -368,7 +373,8 @@ int go_align_batch_rows(size_t n_pairs, const char *rows, uint64_t row_stride,
             memset(&local, 0, sizeof(local));
             #pragma omp for schedule(dynamic)
             for (long long p = 0; p < (long long)n_pairs; p++) {
-                int e = go_align_codes(tc + (size_t)p * (text_len + 1), text_len, rc_ + (size_t)p * (read_len + 1), read_len, W, O,
+                const uint64_t tl = text_lens ? text_lens[p] : text_len, rl = read_lens ? read_lens[p] : read_len;
+                int e = go_align_codes(tc + (size_t)p * (text_len + 1), tl, rc_ + (size_t)p * (read_len + 1), rl, W, O,
                                        rr + (size_t)p * cap1, cap1, &nr[p], &edit_distances[p], &local);
                 if (e != GO_OK) {
                     #pragma omp critical
@@ -416,3 +422,14 @@ int go_align_batch_rows(size_t n_pairs, const char *rows, uint64_t row_stride,
     return status;
 }
 
+/* fixed lengths: every row holds a text of text_len and a read of read_len characters */
+int go_align_batch_rows(size_t n_pairs, const char *rows, uint64_t row_stride,
+                        uint64_t text_off, uint64_t text_len, uint64_t read_off, uint64_t read_len,
+                        int W, int O, int threads,
+                        long long *edit_distances, uint64_t *run_offsets /* n_pairs + 1 */,
+                        uint8_t *runs_out, uint64_t runs_cap,
+                        go_stats *total_stats, long long *kernel_ns)
+{
+    return go_align_batch_rows_var(n_pairs, rows, row_stride, text_off, text_len, read_off, read_len, NULL, NULL, W, O, threads,
+                                   edit_distances, run_offsets, runs_out, runs_cap, total_stats, kernel_ns);
+}

@@ -86,6 +86,14 @@ int go_align_batch_rows(size_t n_pairs, const char *rows, uint64_t row_stride,
                         long long *edit_distances, uint64_t *run_offsets,
                         uint8_t *runs_out, uint64_t runs_cap,
                         go_stats *total_stats, long long *kernel_ns);
+/* the same with every row's own lengths (NULL = the slot sizes text_len / read_len) */
+int go_align_batch_rows_var(size_t n_pairs, const char *rows, uint64_t row_stride,
+                        uint64_t text_off, uint64_t text_len, uint64_t read_off, uint64_t read_len,
+                            const uint64_t *text_lens, const uint64_t *read_lens,
+                        int W, int O, int threads,
+                        long long *edit_distances, uint64_t *run_offsets,
+                        uint8_t *runs_out, uint64_t runs_cap,
+                        go_stats *total_stats, long long *kernel_ns);
 
 #ifdef __cplusplus
 }

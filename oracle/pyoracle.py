@@ -83,11 +83,18 @@ def _marshal(texts, reads):
     return n, tp, tl, rp, rl, bufs, cp, eds
 
 
-def _align_rows(fn, rows, text_off, text_len, read_off, read_len, threads, knobs, with_stats):
+def _align_rows(fn, rows, text_off, text_len, read_off, read_len, threads, knobs, with_stats, text_lens=None, read_lens=None):
+    """fn: the *_var entry point; text_lens / read_lens: per-row lengths (uint64 arrays) or None = the slot sizes."""
     import numpy as np
     rows = np.ascontiguousarray(rows, dtype=np.uint8)
     n, stride = rows.shape
     assert text_off + text_len <= stride and read_off + read_len <= stride
+    if text_lens is not None:
+        text_lens = np.ascontiguousarray(text_lens, dtype=np.uint64)
+        assert text_lens.shape == (n,)
+    if read_lens is not None:
+        read_lens = np.ascontiguousarray(read_lens, dtype=np.uint64)
+        assert read_lens.shape == (n,)
     eds = np.zeros(n, dtype=np.int64)
     off = np.zeros(n + 1, dtype=np.uint64)
     cap = n * (2 * int(read_len) + 8)
@@ -96,7 +103,9 @@ def _align_rows(fn, rows, text_off, text_len, read_off, read_len, threads, knobs
     ns = C.c_longlong(0)
     vp = C.c_void_p
     args = [C.c_size_t(n), vp(rows.ctypes.data), C.c_uint64(stride), C.c_uint64(text_off), C.c_uint64(text_len),
-            C.c_uint64(read_off), C.c_uint64(read_len)] + [C.c_int(k) for k in knobs] + \
+            C.c_uint64(read_off), C.c_uint64(read_len),
+            vp(text_lens.ctypes.data if text_lens is not None else None),
+            vp(read_lens.ctypes.data if read_lens is not None else None)] + [C.c_int(k) for k in knobs] + \
            [C.c_int(int(threads)), vp(eds.ctypes.data), vp(off.ctypes.data), vp(runs.ctypes.data), C.c_uint64(cap)] + \
            ([C.byref(st)] if with_stats else []) + [C.byref(ns)]
     fn.restype = C.c_int
@@ -118,11 +127,12 @@ class Oracle:
             C.POINTER(C.c_char_p), C.POINTER(C.c_longlong), C.POINTER(GoStats),
             C.POINTER(C.c_longlong)]
 
-    def align_rows(self, rows, text_off, text_len, read_off, read_len, W=64, O=33, threads=1):
-        """A whole batch held in one 2-D uint8 array (a text slot and a read slot per row), results as arrays:
+    def align_rows(self, rows, text_off, text_len, read_off, read_len, W=64, O=33, threads=1, text_lens=None, read_lens=None):
+        """A whole batch held in one 2-D uint8 array (a text slot and a read slot per row; text_lens / read_lens: every
+        row's own lengths, None = the slot sizes), results as arrays:
         -> (edit distances int64 [n], run offsets uint64 [n + 1], runs uint8 [total, 2] = (count, op), stats dict, kernel_ns)"""
-        import numpy as np
-        return _align_rows(self.lib.go_align_batch_rows, rows, text_off, text_len, read_off, read_len, threads, (int(W), int(O)), True)
+        return _align_rows(self.lib.go_align_batch_rows_var, rows, text_off, text_len, read_off, read_len, threads, (int(W), int(O)), True,
+                           text_lens, read_lens)
 
     def align(self, texts, reads, W=64, O=33, threads=1):
         """-> (edit_distances, cigars, stats dict, kernel_ns)"""
@@ -165,9 +175,10 @@ class Reference:
             C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int,
             C.POINTER(C.c_char_p), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
 
-    def align_rows(self, rows, text_off, text_len, read_off, read_len, threads=1):
+    def align_rows(self, rows, text_off, text_len, read_off, read_len, threads=1, text_lens=None, read_lens=None):
         """Like Oracle.align_rows, through the reference itself -> (edit distances, run offsets, runs, kernel_ns)"""
-        e, off, runs, _, ns = _align_rows(self.lib.ref_align_rows, rows, text_off, text_len, read_off, read_len, threads, (), False)
+        e, off, runs, _, ns = _align_rows(self.lib.ref_align_rows_var, rows, text_off, text_len, read_off, read_len, threads, (), False,
+                                          text_lens, read_lens)
         return e, off, runs, ns
 
     def align(self, texts, reads, threads=1):

@@ -56,20 +56,24 @@ int ref_align_pairs(size_t n_pairs,
 /* The same call for inputs that sit in ONE array of fixed-size rows (bench.py's staging layout: a text slot and a read
  * slot per row), with the reference's CIGAR strings turned into arrays here: run offsets [n_pairs + 1] and the runs as
  * {count, op} byte pairs (CigarEntry_t, src/util.hpp:43-46), so that a full-size batch is compared array against array.
+ * text_lens / read_lens, if not null, give every row's own lengths (<= text_len / read_len, the slot sizes; else 4).
  * Returns 2 if a CIGAR does not parse or has a count above 255, 3 if runs_cap (in runs) is too small. */
-int ref_align_rows(size_t n_pairs, const char *rows, uint64_t row_stride,
-                   uint64_t text_off, uint64_t text_len, uint64_t read_off, uint64_t read_len,
-                   int threads,
-                   long long *edit_distances, uint64_t *run_offsets, uint8_t *runs_out, uint64_t runs_cap,
-                   long long *kernel_ns)
+int ref_align_rows_var(size_t n_pairs, const char *rows, uint64_t row_stride,
+                       uint64_t text_off, uint64_t text_len, uint64_t read_off, uint64_t read_len,
+                       const uint64_t *text_lens, const uint64_t *read_lens,
+                       int threads,
+                       long long *edit_distances, uint64_t *run_offsets, uint8_t *runs_out, uint64_t runs_cap,
+                       long long *kernel_ns)
 {
     genasm_cpu::enabled_algorithm_log = false;
     std::vector<std::string> t, q;
     t.reserve(2 * n_pairs);
     q.reserve(2 * n_pairs);
     for (size_t p = 0; p < n_pairs; p++) {
-        t.emplace_back(rows + p * row_stride + text_off, text_len);
-        q.emplace_back(rows + p * row_stride + read_off, read_len);
+        const uint64_t tl = text_lens ? text_lens[p] : text_len, rl = read_lens ? read_lens[p] : read_len;
+        if (tl > text_len || rl > read_len) return 4;
+        t.emplace_back(rows + p * row_stride + text_off, tl);
+        q.emplace_back(rows + p * row_stride + read_off, rl);
         t.emplace_back();               // (the dummy pair that defeats the reference's double increment, see above)
         q.emplace_back();
     }
@@ -110,6 +114,17 @@ int ref_align_rows(size_t n_pairs, const char *rows, uint64_t row_stride,
     if (kernel_ns)
         *kernel_ns = ns;
     return bad ? 2 : 0;
+}
+
+/* fixed lengths: every row holds a text of text_len and a read of read_len characters */
+int ref_align_rows(size_t n_pairs, const char *rows, uint64_t row_stride,
+                   uint64_t text_off, uint64_t text_len, uint64_t read_off, uint64_t read_len,
+                   int threads,
+                   long long *edit_distances, uint64_t *run_offsets, uint8_t *runs_out, uint64_t runs_cap,
+                   long long *kernel_ns)
+{
+    return ref_align_rows_var(n_pairs, rows, row_stride, text_off, text_len, read_off, read_len, nullptr, nullptr, threads,
+                              edit_distances, run_offsets, runs_out, runs_cap, kernel_ns);
 }
 
 /* Read-mapping overload (src/genasm_cpu.cpp:495-555): candidate k of read r

@@ -4,7 +4,7 @@ import ast, csv, glob, json, os, sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r03"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r04"
 sys.path.insert(0, root)
 import bench as _bench
 go = os.path.join(root, "gpurun_out")
@@ -85,6 +85,7 @@ if rounds:
     out["salu_instructions_per_window_round"] = sq["SQ_INSTS_SALU"] / rounds
     out["lds_instructions_per_window_round"] = sq["SQ_INSTS_LDS"] / rounds
 out["kernel_sources_sha256"] = _bench.kernel_sources_digest()      # bench.py uses the count only for exactly this kernel source
+out["workload"] = {"pairs": 100000, "read_len": 10000, "profile": "ont", "seed": 42}     # bench.py --serial: pipeline lane 0's batch
 out["effective_clock_ghz_profiled"] = None
 out["note"] = ("per launch of genasm_lane_kernel (100k x 10kb ONT pairs, one stream, lane-interleaved layout), rocprofv3 --pmc, "
                "averages over the 3 launches of `bench.py --serial --steps 2 --warmup 0`; a window round = one window of each of "

@@ -141,6 +141,7 @@ def load_library():
         "scrg_set_log": (None, [C.c_int]),
         "scrg_get_log": (C.c_int, []),
         "scrg_device_count": (C.c_int, []),
+        "scrg_build_flags": (C.c_int, []),
         "scrg_result_free": (None, [C.POINTER(Result)]),
         "scrg_result_pool_trim": (None, []),
         "scrg_align_pairs": (C.c_int32, [vp, C.POINTER(Params), u64, C.POINTER(C.c_char_p),
@@ -164,7 +165,7 @@ def load_library():
         "scrg_compact_runs_packed": (C.c_int32, [vp, vp, u64, vp, vp, vp, vp, vp]),
         "scrg_unpack_runs": (C.c_int32, [vp, u64, vp, vp]),
         "scrg_encode_edit_stream": (C.c_int32, [vp, u64, vp, vp, vp, vp, u64, vp, vp, vp]),
-        "scrg_decode_edit_stream": (C.c_int32, [vp, vp, u64, vp, u64, vp, vp, vp, u64, vp, vp, vp, vp]),
+        "scrg_decode_edit_stream": (C.c_int32, [vp, vp, u64, vp, u64, vp, vp, vp, u64, vp, vp, u64, vp, vp]),
         "scrg_edit_stream_to_runs": (C.c_int32, [C.POINTER(Params), u64, vp, u64, vp, u64, C.POINTER(u64)]),
         "scrg_edit_stream_to_runs_lane": (C.c_int32, [C.POINTER(Params), u64, vp, u64, vp, u64, C.POINTER(u64)]),
         "scrg_runs_to_edit_stream": (C.c_int32, [vp, u64, vp, u64, C.POINTER(u64)]),
@@ -187,7 +188,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "scrg_params_default", "scrg_params_resolve", "scrg_ctx_create", "scrg_ctx_destroy", "scrg_ctx_set_stream",
     "scrg_ctx_use_own_stream", "scrg_stream_create", "scrg_stream_destroy",
-    "scrg_last_error", "scrg_status_string", "scrg_set_log", "scrg_get_log", "scrg_device_count",
+    "scrg_last_error", "scrg_status_string", "scrg_set_log", "scrg_get_log", "scrg_device_count", "scrg_build_flags",
     "scrg_result_free", "scrg_result_pool_trim", "scrg_align_pairs", "scrg_align_mapping", "scrg_align_pairs_multi", "scrg_align_mapping_multi",
     "scrg_host_plan", "scrg_multi_release", "scrg_multi_last_error", "scrg_genome_set", "scrg_genome_clear",
     "scrg_align_mapping_resident", "scrg_pack_planar", "scrg_pack_planar_groups",
@@ -385,6 +386,56 @@ class Aligner:
         self._check(st, allow=(SCRG_ERR_CIGAR_OVERFLOW,))
         return self._finish(res, st, arrays, strict)
 
+    def align_pairs_rows(self, rows, text_off, text_lens, read_off, read_lens, strict=True, **kw):
+        """scrg_align_pairs on sequences that sit in ONE 2-D uint8 numpy array (row p: the text of pair p at byte
+        text_off, its read at byte read_off — bench.py's staging layout), lengths as integers or per-row arrays: the
+        pointer arrays are built with numpy, so a batch of 100 k x 10 kb pairs costs no per-pair Python objects.
+        -> the result as numpy arrays (see _collect_arrays); `last_timing` has the library's own clock."""
+        import numpy as np
+        rows = np.ascontiguousarray(rows, dtype=np.uint8)
+        n, stride = rows.shape
+        base = rows.ctypes.data + np.arange(n, dtype=np.uint64) * np.uint64(stride)
+        tp = (base + np.uint64(text_off)).astype(np.uint64)
+        qp = (base + np.uint64(read_off)).astype(np.uint64)
+        tl = np.ascontiguousarray(np.broadcast_to(np.asarray(text_lens, dtype=np.uint64), (n,)))
+        ql = np.ascontiguousarray(np.broadcast_to(np.asarray(read_lens, dtype=np.uint64), (n,)))
+        pp, up = C.POINTER(C.c_char_p), C.POINTER(C.c_uint64)
+        res = C.POINTER(Result)()
+        st = self.lib.scrg_align_pairs(self.h, C.byref(self._params(kw)), n, C.cast(tp.ctypes.data, pp), C.cast(tl.ctypes.data, up),
+                                       C.cast(qp.ctypes.data, pp), C.cast(ql.ctypes.data, up), C.byref(res))
+        self._check(st, allow=(SCRG_ERR_CIGAR_OVERFLOW,))
+        return self._finish(res, st, True, strict)
+
+    def align_mapping_rows(self, genome, read_rows, read_lens, cand_offsets, cand_start, strict=True, **kw):
+        """scrg_align_mapping (genome: bytes / uint8 array) or scrg_align_mapping_resident (genome=None) with the reads in
+        one 2-D uint8 numpy array (one read per row) and the candidates as numpy arrays (cand_offsets: n_reads + 1)."""
+        import numpy as np
+        read_rows = np.ascontiguousarray(read_rows, dtype=np.uint8)
+        nr, stride = read_rows.shape
+        rp = (read_rows.ctypes.data + np.arange(nr, dtype=np.uint64) * np.uint64(stride)).astype(np.uint64)
+        rl = np.ascontiguousarray(np.broadcast_to(np.asarray(read_lens, dtype=np.uint64), (nr,)))
+        co = np.ascontiguousarray(cand_offsets, dtype=np.uint64)
+        cs = np.ascontiguousarray(cand_start, dtype=np.uint64)
+        assert co.shape == (nr + 1,) and cs.shape == (int(co[nr]),)
+        pp, up = C.POINTER(C.c_char_p), C.POINTER(C.c_uint64)
+        res = C.POINTER(Result)()
+        if genome is None:
+            st = self.lib.scrg_align_mapping_resident(self.h, C.byref(self._params(kw)), nr, C.c_void_p(rp.ctypes.data), C.c_void_p(rl.ctypes.data),
+                                                      C.c_void_p(co.ctypes.data), C.c_void_p(cs.ctypes.data), None, C.byref(res))
+        else:
+            g = np.ascontiguousarray(np.frombuffer(genome, dtype=np.uint8) if isinstance(genome, (bytes, bytearray)) else genome, dtype=np.uint8)
+            st = self.lib.scrg_align_mapping(self.h, C.byref(self._params(kw)), C.cast(g.ctypes.data, C.c_char_p), g.size, nr,
+                                             C.cast(rp.ctypes.data, pp), C.cast(rl.ctypes.data, up), C.cast(co.ctypes.data, up),
+                                             C.cast(cs.ctypes.data, up), C.byref(res))
+        self._check(st, allow=(SCRG_ERR_CIGAR_OVERFLOW,))
+        return self._finish(res, st, True, strict)
+
+    def set_genome_array(self, genome_u8):
+        """set_genome for a uint8 numpy array (no copy into a bytes object)."""
+        import numpy as np
+        g = np.ascontiguousarray(genome_u8, dtype=np.uint8)
+        self._check(self.lib.scrg_genome_set(self.h, C.cast(g.ctypes.data, C.c_char_p), g.size))
+
     def align_pairs_multi(self, devices, texts, queries, arrays=False, strict=True, **kw):
         """scrg_align_pairs_multi: the same call spread over several GPUs (a device may be listed more than once)."""
         texts, queries = _bytes_list(texts), _bytes_list(queries)
@@ -520,6 +571,7 @@ class Aligner:
                                                      int(read_len_stride),
                                                      _ptr(dense_off_i64) if dense_off_i64 is not None else None,
                                                      _ptr(dense_u8) if dense_u8 is not None else None,
+                                                     int(dense_u8.numel() // 2) if dense_u8 is not None else 0,
                                                      _ptr(n_runs_i32), _ptr(bad_i32)))
 
     def ascii_to_twobit(self, count, lens, ascii_off, ascii, twobit_off, twobit, bad):

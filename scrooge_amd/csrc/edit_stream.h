@@ -223,8 +223,8 @@ hipError_t launch_encode_edits(uint64_t n_pairs, const scrg_pair_desc* d_pairs, 
                                uint32_t* d_len, uint64_t* d_total, hipStream_t s);
 hipError_t launch_decode_edits(uint64_t n_pairs, uint32_t W, uint32_t O, const uint8_t* d_stream, uint64_t stream_bytes,
                                const uint64_t* d_off, const uint32_t* d_len, const uint64_t* d_read_len,
-                               uint64_t read_len_stride, const uint64_t* d_dense_off, uint16_t* d_dense, uint32_t* d_n_runs,
-                               uint32_t* d_bad, void* sort_ws, size_t sort_temp_bytes, hipStream_t s);
+                               uint64_t read_len_stride, const uint64_t* d_dense_off, uint16_t* d_dense, uint64_t dense_cap,
+                               uint32_t* d_n_runs, uint32_t* d_bad, void* sort_ws, size_t sort_temp_bytes, hipStream_t s);
 size_t decode_sort_temp_bytes(uint64_t n_pairs);
 
 }  // namespace scrg

@@ -45,6 +45,7 @@ struct DecodeArgs {
     uint64_t read_len_stride;
     const uint64_t* dense_off;
     uint16_t* dense;
+    uint64_t dense_cap;         // runs `dense` has room for: a pair whose segment does not lie inside is reported, nothing of it written
     uint32_t* n_runs;
     uint32_t* bad;
     const uint32_t* order;      // optional: thread t takes pair order[t] (pairs sorted by stream length, longest first)
@@ -87,6 +88,12 @@ __global__ __launch_bounds__(256) void decode_edits_kernel(DecodeArgs a)
         if (STORE) {
             g0 = a.dense_off[p];
             cap = a.n_runs[p];
+            // run counts and offsets may come off a wire too: a segment that is not inside the dense array is never written
+            if (g0 > a.dense_cap || cap > a.dense_cap - g0) {
+                bad_input = true;
+                g0 = 0;
+                cap = 0;
+            }
         }
     }
     DecodeLane s;
@@ -268,8 +275,8 @@ size_t decode_sort_temp_bytes(uint64_t n_pairs)
 // bytes (256-byte aligned): the pairs are then taken longest stream first.
 hipError_t launch_decode_edits(uint64_t n_pairs, uint32_t W, uint32_t O, const uint8_t* d_stream, uint64_t stream_bytes,
                                const uint64_t* d_off, const uint32_t* d_len, const uint64_t* d_read_len,
-                               uint64_t read_len_stride, const uint64_t* d_dense_off, uint16_t* d_dense, uint32_t* d_n_runs,
-                               uint32_t* d_bad, void* sort_ws, size_t sort_temp_bytes, hipStream_t s)
+                               uint64_t read_len_stride, const uint64_t* d_dense_off, uint16_t* d_dense, uint64_t dense_cap,
+                               uint32_t* d_n_runs, uint32_t* d_bad, void* sort_ws, size_t sort_temp_bytes, hipStream_t s)
 {
     if (n_pairs == 0) return hipSuccess;
     const uint32_t* order = nullptr;
@@ -285,7 +292,7 @@ hipError_t launch_decode_edits(uint64_t n_pairs, uint32_t W, uint32_t O, const u
         if (e != hipSuccess) return e;
         order = idx_out;
     }
-    DecodeArgs a{n_pairs, W, O, d_stream, stream_bytes, d_off, d_len, d_read_len, read_len_stride, d_dense_off, d_dense, d_n_runs, d_bad, order};
+    DecodeArgs a{n_pairs, W, O, d_stream, stream_bytes, d_off, d_len, d_read_len, read_len_stride, d_dense_off, d_dense, dense_cap, d_n_runs, d_bad, order};
     const dim3 grid((unsigned)((n_pairs + 255) / 256)), block(256);
     if (d_dense) hipLaunchKernelGGL(decode_edits_kernel<true>, grid, block, 0, s, a);
     else hipLaunchKernelGGL(decode_edits_kernel<false>, grid, block, 0, s, a);

@@ -31,21 +31,42 @@ struct AlignArgs {
     int32_t lds_rows;
     uint32_t text_stride;         // words between consecutive words of a text / a read in seq (1 = contiguous;
     uint32_t read_stride;         //   64 = lane-interleaved groups, scrg_pack_planar_groups; lane kernel only)
-    uint64_t* stats;              // optional profiling counters {rounds, DC steps, TB macro-steps}; may be null
-    int32_t debug;                // experiment switches (params.reserved[0]); see SCRG_SAFE_SWITCHES / SCRG_ABL below
+    uint64_t* stats;              // profiling builds (-DSCRG_STATS) only: counters, may be null; never read by the shipped kernels
+    int32_t debug;                // params.reserved[0]: see SCRG_SAFE_SWITCHES / SCRG_SW / SCRG_ABL below
 };
 
-// scrg_params.reserved[0].  The switches that leave the results intact exist in every build: 1 (one pair per lane: no
-// wavefront priority rotation), 32 (lanes_per_pair = 8: no diagonal-major path), 64 / 128 (one pair per lane:
-// workgroups of one / two wavefronts).  The ABLATION switches (2, 4, 8, 16, and 1 for the GenASM-row kernel: skip the
-// table, the runs, the walk, the stores — results are wrong by design) are compiled in only with -DSCRG_ABLATE
-// (scripts/ab.sh build ablate -DSCRG_ABLATE; bench.py --ablate): the shipped library has no code path that produces
-// wrong results on request, and scrg_params_resolve() rejects any other bit.
+// scrg_params.reserved[0] / reserved[1].  The SHIPPED library has exactly two switches, both documented selections between
+// formulations that give identical results (the parity tests compare them): 32 (lanes_per_pair = 8: no diagonal-major
+// path) and 256 (32 <= W-O <= 63, W <= 128: the kernel with the window table in HBM instead of the one that keeps it in
+// registers).  Everything else is experiment plumbing and exists only in profiling builds (scripts/ab.sh):
+//   -DSCRG_STATS   the kernels' counters (reserved[1] != 0 -> scrg_debug_stats: window rounds, shader cycles per part,
+//                  wavefront life times) and the scheduling switches 1 (one pair per lane: no wavefront priority
+//                  rotation), 64 / 128 (workgroups of one / two wavefronts) — results intact;
+//   -DSCRG_ABLATE  (implies SCRG_STATS) the ablation switches 2, 4, 8, 16 and 1 for the GenASM-row kernel: skip the
+//                  table, the runs, the walk, the stores — results are WRONG by design (bench.py --ablate).
+// In the shipped build SCRG_TIMING / SCRG_SW / SCRG_ABL are compile-time false: no counter, no clock read, no exit
+// atomic and no switch test is left in the kernels, and scrg_params_resolve() rejects every other bit and reserved[1].
+#if defined(SCRG_ABLATE) && !defined(SCRG_STATS)
+#define SCRG_STATS 1
+#endif
+constexpr int32_t SCRG_SWITCH_NO_DIAG = 32;       // lanes_per_pair = 8: GenASM rows only (no diagonal-major path)
 constexpr int32_t SCRG_SWITCH_MW_TABLE = 256;     // 32 <= W-O <= 63, W <= 128: genasm_lane_mw_kernel (table in HBM) instead of genasm_lane_wide_kernel
-constexpr int32_t SCRG_SAFE_SWITCHES = 1 | 32 | 64 | 128 | SCRG_SWITCH_MW_TABLE;
+constexpr int32_t SCRG_SAFE_SWITCHES = SCRG_SWITCH_NO_DIAG | SCRG_SWITCH_MW_TABLE;
+#ifdef SCRG_STATS
+#define SCRG_TIMING(args) ((args).stats != nullptr)
+#define SCRG_SW(args, bit) (((args).debug & (bit)) != 0)
+constexpr bool SCRG_HAVE_STATS = true;
+#else
+#define SCRG_TIMING(args) false
+#define SCRG_SW(args, bit) false
+constexpr bool SCRG_HAVE_STATS = false;
+#endif
 #ifdef SCRG_ABLATE
 #define SCRG_ABL(args, bit) (((args).debug & (bit)) != 0)
 constexpr int32_t SCRG_ALLOWED_SWITCHES = 0x1ff;
+#elif defined(SCRG_STATS)
+#define SCRG_ABL(args, bit) false
+constexpr int32_t SCRG_ALLOWED_SWITCHES = SCRG_SAFE_SWITCHES | 1 | 64 | 128;
 #else
 #define SCRG_ABL(args, bit) false
 constexpr int32_t SCRG_ALLOWED_SWITCHES = SCRG_SAFE_SWITCHES;

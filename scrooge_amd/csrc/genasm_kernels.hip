@@ -92,7 +92,7 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
     uint32_t diag_skip = 0, diag_fails = 0;     // rounds to stay off the diagonal-major path after repeated failures
     bool force_column = false;                  // the next round must be column-major (some slot sat the last one out)
     uint64_t cy_fetch = 0, cy_setup = 0, cy_dc = 0, cy_tb = 0, cy_tbloop = 0;
-    const bool timing = a.stats != nullptr;
+    const bool timing = SCRG_TIMING(a);            // (compile-time false in the shipped build: genasm_kernels.h)
 
     for (;;) {
         const uint64_t tm0 = timing ? __builtin_readcyclecounter() : 0;
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
             const bool capable = has_pair && n == 64u && n_runs + 64u <= cigar_cap;   // (a window adds < 64 runs)
             const uint32_t n_live = (uint32_t)__popcll(__ballot(has_pair));
             const uint32_t n_cap = (uint32_t)__popcll(__ballot(capable));
-            bool try_diag = W == 64 && !(a.debug & 32) && !force_column && (n_cap == n_live || n_cap >= 5u * G);
+            bool try_diag = W == 64 && !(a.debug & SCRG_SWITCH_NO_DIAG) && !force_column && (n_cap == n_live || n_cap >= 5u * G);
             force_column = false;
             if (try_diag && diag_skip) {
                 diag_skip--;
@@ -830,7 +830,7 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
             cy_tb += tm4 - tm3;
         }
     }
-    if (a.stats && lane == 0) {
+    if (timing && lane == 0) {
         atomicAdd((unsigned long long*)&a.stats[0], (unsigned long long)st_rounds);
         atomicAdd((unsigned long long*)&a.stats[1], (unsigned long long)st_steps);
         atomicAdd((unsigned long long*)&a.stats[2], (unsigned long long)st_macro);

@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
     uint32_t mbase = 0;                // EDITS: matches pending at column c of the current window = mbase + c
     WindowWords twords = {0, 0, 0, 0}, pwords = {0, 0, 0, 0};     // the words of my next text / read window (loaded ahead)
     bool queue_empty = false;          // wave-uniform
-    const bool timing = a.stats != nullptr;
+    const bool timing = SCRG_TIMING(a);            // (compile-time false in the shipped build: genasm_kernels.h)
     uint64_t cy_fetch = 0, cy_setup = 0, cy_dc = 0, cy_tb = 0, cy_p1 = 0;
     uint32_t st_rounds = 0, st_gen = 0;
     const uint64_t rt0 = timing ? __builtin_amdgcn_s_memrealtime() : 0;      // 100 MHz wall clock: wavefront start
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
         // of a lone wave and the last one finishes 2.7x later, with the SIMD half idle at the end of a launch.
         // Rotating the priorities (set once per round from the clock and the wave slot: a different wavefront is on top
         // from round to round) lets the wavefronts of a SIMD progress, and finish, together.
-        if (!(a.debug & 1)) {
+        if (!SCRG_SW(a, 1)) {
             const uint32_t pr = ((uint32_t)(__builtin_readcyclecounter() >> 11) + wave_slot) & 3u;
             if (pr == 0) __builtin_amdgcn_s_setprio(0);
             else if (pr == 1) __builtin_amdgcn_s_setprio(1);
@@ -512,7 +512,7 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
             cy_tb += tm4 - tm3;
         }
     }
-    if (a.stats && lane == 0) {
+    if (timing && lane == 0) {
         atomicAdd((unsigned long long*)&a.stats[0], (unsigned long long)st_rounds);
         atomicAdd((unsigned long long*)&a.stats[1], (unsigned long long)st_gen);
         atomicAdd((unsigned long long*)&a.stats[2], (unsigned long long)cy_p1);
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
 hipError_t launch_align_lane(const AlignArgs& a, int grid, size_t lds_bytes, hipStream_t s, bool edits)
 {
     // grid counts wavefronts, lds_bytes is per wavefront
-    const unsigned wpg = (a.debug & 64) ? 1u : ((a.debug & 128) ? 2u : 4u);      // experiment: wavefronts per workgroup
+    const unsigned wpg = SCRG_SW(a, 64) ? 1u : (SCRG_SW(a, 128) ? 2u : 4u);      // (profiling builds: wavefronts per workgroup)
     const dim3 g((grid + wpg - 1) / wpg), b(64 * wpg);
     if (edits) hipLaunchKernelGGL(genasm_lane_kernel<true>, g, b, wpg * lds_bytes, s, a);
     else hipLaunchKernelGGL(genasm_lane_kernel<false>, g, b, wpg * lds_bytes, s, a);

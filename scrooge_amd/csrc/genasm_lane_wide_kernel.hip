@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256, WD_BLOCKS_PER_CU) void genasm_lane_wide_kernel
     const uint32_t wave_slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);
     for (;;) {
         // (priority rotation: see genasm_lane_kernel)
-        if (!(a.debug & 1)) {
+        if (!SCRG_SW(a, 1)) {
             const uint32_t pr = ((uint32_t)(__builtin_readcyclecounter() >> 11) + wave_slot) & 3u;
             if (pr == 0) __builtin_amdgcn_s_setprio(0);
             else if (pr == 1) __builtin_amdgcn_s_setprio(1);
@@ -595,7 +595,7 @@ __global__ __launch_bounds__(256, WD_BLOCKS_PER_CU) void genasm_lane_wide_kernel
         read_idx += j;
         st_rounds++;
     }
-    if (a.stats && lane == 0) atomicAdd((unsigned long long*)&a.stats[0], (unsigned long long)st_rounds);
+    if (SCRG_TIMING(a) && lane == 0) atomicAdd((unsigned long long*)&a.stats[0], (unsigned long long)st_rounds);
 }
 
 hipError_t launch_align_lane_wide(const AlignArgs& a, int grid, size_t lds_bytes, hipStream_t s, bool edits)

@@ -44,6 +44,7 @@ using scrg_int::parallel_for;
 struct scrg_ctx {
     int device = 0;
     int n_cus = 0;
+    bool counted = true;          // false: a handle the library made for itself (host path slots)
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
@@ -122,6 +123,18 @@ const char* scrg_status_string(scrg_status s)
 void scrg_set_log(int enabled) { g_log.store(enabled ? 1 : 0); }
 int scrg_get_log(void) { return g_log.load(); }
 
+int scrg_build_flags(void)
+{
+    int f = 0;
+#ifdef SCRG_STATS
+    f |= SCRG_BUILD_STATS;
+#endif
+#ifdef SCRG_ABLATE
+    f |= SCRG_BUILD_ABLATE;
+#endif
+    return f;
+}
+
 int scrg_device_count(void)
 {
     int n = 0;
@@ -132,7 +145,7 @@ int scrg_device_count(void)
     return n;
 }
 
-scrg_status scrg_ctx_create(int device, scrg_ctx** out)
+static scrg_status ctx_create_impl(int device, scrg_ctx** out, bool counted)
 {
     if (!out) return SCRG_ERR_INVALID_ARG;
     *out = nullptr;
@@ -148,19 +161,22 @@ scrg_status scrg_ctx_create(int device, scrg_ctx** out)
     if (!c) return SCRG_ERR_OOM;
     c->device = device;
     c->n_cus = prop.multiProcessorCount;
+    c->counted = counted;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&c->ev_start) != hipSuccess || hipEventCreate(&c->ev_stop) != hipSuccess) {
         delete c;
         return SCRG_ERR_HIP;
     }
     c->stream = c->own_stream;
-    g_live_ctx.fetch_add(1);
-    if (g_log.load())
+    if (counted) g_live_ctx.fetch_add(1);
+    if (counted && g_log.load())
         fprintf(stderr, "[scrooge_amd] device %d: %s, %d CUs, arch %s\n", device, prop.name, c->n_cus,
                 prop.gcnArchName);
     *out = c;
     return SCRG_OK;
 }
+
+scrg_status scrg_ctx_create(int device, scrg_ctx** out) { return ctx_create_impl(device, out, true); }
 
 void scrg_ctx_destroy(scrg_ctx* c)
 {
@@ -177,8 +193,9 @@ void scrg_ctx_destroy(scrg_ctx* c)
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    const bool counted = c->counted;
     delete c;
-    if (g_live_ctx.fetch_sub(1) == 1) g_pool.trim();      // last handle gone: give the recycled result arrays back
+    if (counted && g_live_ctx.fetch_sub(1) == 1) g_pool.trim();      // the caller's last handle gone: give the recycled result arrays back
 }
 
 scrg_status scrg_ctx_set_stream(scrg_ctx* c, void* hip_stream)
@@ -234,6 +251,7 @@ static bool resolve_params(const scrg_params* in, scrg_params* p)
     }
     // experiment switches: only those that leave the results intact, unless this is an ablation build (genasm_kernels.h)
     if (p->reserved[0] & ~scrg::SCRG_ALLOWED_SWITCHES) return false;
+    if (p->reserved[1] && !scrg::SCRG_HAVE_STATS) return false;       // the kernels' counters exist in -DSCRG_STATS builds only
     if (p->outputs < SCRG_OUT_ALL || p->outputs > SCRG_OUT_RUNS) return false;
     if (p->text_stride_words == 0) p->text_stride_words = 1;
     if (p->read_stride_words == 0) p->read_stride_words = 1;
@@ -444,6 +462,8 @@ scrg_status scrg_debug_stats(scrg_ctx* c, uint64_t out[12])
 {
     if (!c || !out) return SCRG_ERR_INVALID_ARG;
     memset(out, 0, 12 * sizeof(uint64_t));
+    if (!scrg::SCRG_HAVE_STATS)
+        return c->fail(SCRG_ERR_INVALID_ARG, "this library was built without -DSCRG_STATS: the kernels have no counters (scripts/ab.sh build stats -DSCRG_STATS)");
     if (!c->stats.p) return SCRG_OK;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -508,7 +528,7 @@ scrg_status scrg_encode_edit_stream(scrg_ctx* c, uint64_t n_pairs, const scrg_pa
 scrg_status scrg_decode_edit_stream(scrg_ctx* c, const scrg_params* params, uint64_t n_pairs, const uint8_t* d_stream,
                                     uint64_t stream_bytes, const uint64_t* d_stream_off, const uint32_t* d_stream_len,
                                     const uint64_t* d_read_len, uint64_t read_len_stride, const uint64_t* d_dense_offset,
-                                    scrg_run* d_dense, uint32_t* d_n_runs, uint32_t* d_bad_count)
+                                    scrg_run* d_dense, uint64_t dense_capacity, uint32_t* d_n_runs, uint32_t* d_bad_count)
 {
     if (!c) return SCRG_ERR_INVALID_ARG;
     scrg_params p;
@@ -529,7 +549,7 @@ scrg_status scrg_decode_edit_stream(scrg_ctx* c, const scrg_params* params, uint
         ws = c->sort_ws.p;
     }
     HIP_TRY(c, scrg::launch_decode_edits(n_pairs, (uint32_t)p.W, (uint32_t)p.O, d_stream, stream_bytes, d_stream_off, d_stream_len,
-                                         d_read_len, read_len_stride, d_dense_offset, reinterpret_cast<uint16_t*>(d_dense),
+                                         d_read_len, read_len_stride, d_dense_offset, reinterpret_cast<uint16_t*>(d_dense), dense_capacity,
                                          d_n_runs, d_bad_count, ws, temp_bytes, c->stream));
     return SCRG_OK;
 }
@@ -911,8 +931,13 @@ void scrg_multi_release(void)
     for (auto& ds : g_multi_states) scrg_host::state_free(ds.second);
     g_multi_states.clear();
     g_multi_busy.clear();
+    if (g_live_ctx.load() == 0) g_pool.trim();     // no handle of the caller's is alive either: give the recycled result arrays back
 }
 
 const char* scrg_multi_last_error(void) { return g_multi_error.c_str(); }
 
 }  // extern "C"
+
+namespace scrg_int {
+scrg_status ctx_create_internal(int device, scrg_ctx** out) { return ctx_create_impl(device, out, false); }
+}  // namespace scrg_int

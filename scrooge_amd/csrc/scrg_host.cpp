@@ -158,14 +158,26 @@ struct DeviceState {
     uint64_t slot_words = 0;
     Slot slot[MAXSLOT];
     std::mutex mu;                           // one call at a time per device state
+    // the last error text: written by the launch thread and both collect threads of a call
+    std::mutex err_mu;
     std::string err;
+    void set_err(const std::string& e)
+    {
+        std::lock_guard<std::mutex> g(err_mu);
+        err = e;
+    }
+    std::string get_err()
+    {
+        std::lock_guard<std::mutex> g(err_mu);
+        return err;
+    }
 };
 
 #define HTRY(ds, call)                                                                                   \
     do {                                                                                                 \
         hipError_t e__ = (call);                                                                         \
         if (e__ != hipSuccess) {                                                                         \
-            (ds)->err = std::string(#call) + ": " + hipGetErrorString(e__);                              \
+            (ds)->set_err(std::string(#call) + ": " + hipGetErrorString(e__));                           \
             (void)hipGetLastError();                                                                     \
             return e__ == hipErrorOutOfMemory ? SCRG_ERR_OOM : SCRG_ERR_HIP;                             \
         }                                                                                                \
@@ -194,16 +206,49 @@ scrg_status ensure_seq(DeviceState* ds, uint64_t genome_words, uint64_t slot_wor
     return SCRG_OK;
 }
 
-scrg_status pack_genome(DeviceState* ds, const char* genome, uint64_t genome_len)
+// A genome is packed ONCE per call, whatever the number of device states: into one pinned, portable staging buffer
+// (host threads), from which every device gets its copy — the H2D copies of all devices run side by side.  The staging
+// buffer is kept for the next call while it is small (a 100 Mbp chromosome is 25 MB) and released when it is not (a
+// 3 Gbp genome would otherwise pin 0.8 GB of host memory for good).
+constexpr size_t GENOME_STAGING_KEEP = 256u << 20;
+struct GenomeStaging {
+    std::mutex mu;
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        release();
+        hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocPortable);
+        if (e == hipSuccess) cap = bytes;
+        else p = nullptr;
+        return e;
+    }
+    void release()
+    {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+GenomeStaging g_genome_staging;
+
+scrg_status stage_genome(DeviceState* const* dss, int n_states, const char* genome, uint64_t genome_len)
 {
     const uint64_t words = (genome_len + 31) / 32;
-    ds->genome_ok = false;
-    scrg_status s = ensure_seq(ds, words, ds->slot_words);
-    if (s != SCRG_OK) return s;
-    Slot& sl = ds->slot[0];
+    for (int d = 0; d < n_states; d++) {
+        dss[d]->genome_ok = false;
+        scrg_status s = ensure_seq(dss[d], words, dss[d]->slot_words);
+        if (s != SCRG_OK) {
+            if (d) dss[0]->set_err(dss[d]->get_err());
+            return s;
+        }
+    }
+    DeviceState* const ds = dss[0];
+    std::lock_guard<std::mutex> g(g_genome_staging.mu);
     HTRY(ds, hipSetDevice(ds->device));
-    HTRY(ds, sl.h_seq.ensure((words + SCRG_SEQ_PAD_WORDS) * sizeof(uint64_t)));
-    uint64_t* const h = static_cast<uint64_t*>(sl.h_seq.p);
+    HTRY(ds, g_genome_staging.ensure((words + SCRG_SEQ_PAD_WORDS) * sizeof(uint64_t)));
+    uint64_t* const h = static_cast<uint64_t*>(g_genome_staging.p);
     const uint64_t PIECE = 1u << 15;                    // words per work item: 1 Mbase
     std::atomic<int> bad{0};
     parallel_for((words + PIECE - 1) / PIECE, [&](uint64_t i) {
@@ -213,14 +258,44 @@ scrg_status pack_genome(DeviceState* ds, const char* genome, uint64_t genome_len
     }, true);
     for (uint64_t w = words; w < words + SCRG_SEQ_PAD_WORDS; w++) h[w] = 0;
     if (bad.load()) {
-        ds->err = "genome contains characters other than ACGTacgt";
+        ds->set_err("genome contains characters other than ACGTacgt");
         return SCRG_ERR_BAD_BASE;
     }
-    HTRY(ds, hipMemcpyAsync(ds->d_seq.p, h, (words + SCRG_SEQ_PAD_WORDS) * sizeof(uint64_t), hipMemcpyHostToDevice, sl.stream));
-    HTRY(ds, hipStreamSynchronize(sl.stream));
-    ds->genome_len = genome_len;
-    ds->genome_ok = true;
-    return SCRG_OK;
+    scrg_status st = SCRG_OK;
+    int issued = 0;
+    for (int d = 0; d < n_states && st == SCRG_OK; d++) {
+        hipError_t e = hipSetDevice(dss[d]->device);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(dss[d]->d_seq.p, h, (words + SCRG_SEQ_PAD_WORDS) * sizeof(uint64_t), hipMemcpyHostToDevice, dss[d]->slot[0].stream);
+        if (e != hipSuccess) {
+            ds->set_err(std::string("genome upload: ") + hipGetErrorString(e));
+            (void)hipGetLastError();
+            st = SCRG_ERR_HIP;
+        } else {
+            issued = d + 1;
+        }
+    }
+    for (int d = 0; d < issued; d++) {
+        (void)hipSetDevice(dss[d]->device);
+        const hipError_t e = hipStreamSynchronize(dss[d]->slot[0].stream);
+        if (e != hipSuccess && st == SCRG_OK) {
+            ds->set_err(std::string("genome upload: ") + hipGetErrorString(e));
+            (void)hipGetLastError();
+            st = SCRG_ERR_HIP;
+        }
+        if (st == SCRG_OK) {
+            dss[d]->genome_len = genome_len;
+            dss[d]->genome_ok = true;
+        }
+    }
+    if (g_genome_staging.cap > GENOME_STAGING_KEEP) g_genome_staging.release();
+    return st;
+}
+
+scrg_status pack_genome(DeviceState* ds, const char* genome, uint64_t genome_len)
+{
+    DeviceState* one[1] = {ds};
+    return stage_genome(one, 1, genome, genome_len);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -276,6 +351,9 @@ struct Call {
             std::lock_guard<std::mutex> g(err_mu);
             err = what;
         }
+        // a collector that has just evaluated its wait predicate (under tot_mu) and not blocked yet must not miss this:
+        // pass through the mutex before notifying
+        { std::lock_guard<std::mutex> g(tot_mu); }
         tot_cv.notify_all();
     }
     bool failed() const { return status.load() != SCRG_OK; }
@@ -377,7 +455,7 @@ scrg_status stage1(DeviceState* ds, Slot& sl, Call& c, uint64_t chunk)
     const uint64_t read_words = r_groups * GROUP * rw, text_words = t_groups * GROUP * tw;
     const uint64_t seq_words = read_words + text_words + SEQ_PAD;
     if (seq_words > ds->slot_words) {
-        ds->err = "internal: chunk larger than its slot";
+        ds->set_err("internal: chunk larger than its slot");
         return SCRG_ERR_INVALID_ARG;
     }
     HTRY(ds, sl.h_seq.ensure(seq_words * sizeof(uint64_t)));
@@ -441,7 +519,7 @@ scrg_status stage1(DeviceState* ds, Slot& sl, Call& c, uint64_t chunk)
     }, true, c.threads_per_worker);
     for (uint64_t w = read_words + text_words; w < seq_words; w++) h[w] = 0;
     if (bad.load()) {
-        ds->err = "input contains characters other than ACGTacgt";
+        ds->set_err("input contains characters other than ACGTacgt");
         return SCRG_ERR_BAD_BASE;
     }
 
@@ -512,7 +590,7 @@ scrg_status stage1(DeviceState* ds, Slot& sl, Call& c, uint64_t chunk)
     scrg_status s = scrg_align_device(sl.ctx, &pp, n, d_seq, sl.d_desc.as<scrg_pair_desc>(), sl.d_slices.as<scrg_run>(), d_ed,
                                       sl.d_nruns.as<uint32_t>(), d_status);
     if (s != SCRG_OK) {
-        ds->err = scrg_last_error(sl.ctx);
+        ds->set_err(scrg_last_error(sl.ctx));
         return s;
     }
     HTRY(ds, scrg::launch_result_layout(n, sl.d_desc.as<scrg_pair_desc>(), sl.d_slices.as<uint16_t>(), sl.d_nruns.as<uint32_t>(),
@@ -558,7 +636,7 @@ scrg_status stage2(DeviceState* ds, Slot& sl, Call& c, uint64_t chunk)
     scrg_status s = scrg_compact_runs(sl.ctx, n, sl.d_desc.as<scrg_pair_desc>(), sl.d_slices.as<scrg_run>(), sl.d_nruns.as<uint32_t>(),
                                       d_runoff, sl.d_dense.as<scrg_run>());
     if (s != SCRG_OK) {
-        ds->err = scrg_last_error(sl.ctx);
+        ds->set_err(scrg_last_error(sl.ctx));
         return s;
     }
     if (c.want_text)
@@ -663,11 +741,19 @@ void worker(DeviceState* ds, Call* c, int dev_index, int n_dev)
     std::condition_variable cv;
     size_t ready = 0;            // chunks (local index) whose read-back has been enqueued: the collector may wait for them
     bool stop = false;
+    auto fail_with = [&](scrg_status s) {
+        const std::string e = ds->get_err();
+        c->fail(s, e.empty() ? std::string(scrg_status_string(s)) : e);
+        { std::lock_guard<std::mutex> g(mu); }      // (the launch thread may be between its predicate and its wait on cv)
+        cv.notify_all();
+    };
 
     // COLLECT threads: chunk i (local index) is taken by collector i mod NCOLLECT — a chunk's place in the result arrays
     // depends only on the totals of the chunks before it, which are known before it is read back
     std::vector<char> done(m, 0);
     auto collect = [&](size_t which) {
+        // (no exception leaves a thread: a std::bad_alloc in here would otherwise be std::terminate)
+        try {
         for (size_t i = which; i < m; i += NCOLLECT) {
             {
                 std::unique_lock<std::mutex> lk(mu);
@@ -676,7 +762,7 @@ void worker(DeviceState* ds, Call* c, int dev_index, int n_dev)
             }
             const int64_t ta = now_ns();
             scrg_status s = c->failed() ? (scrg_status)c->status.load() : stage3(ds, ds->slot[i % NS], *c, mine[i]);
-            if (s != SCRG_OK) c->fail(s, ds->err.empty() ? std::string(scrg_status_string(s)) : ds->err);
+            if (s != SCRG_OK) fail_with(s);
             if (timing)
                 fprintf(stderr, "[scrooge_amd host] dev %d chunk %zu collected at %.3f ms: stage3 %.3f ms\n", dev_index, i, (now_ns() - tw0) / 1e6,
                         (now_ns() - ta) / 1e6);
@@ -685,6 +771,13 @@ void worker(DeviceState* ds, Call* c, int dev_index, int n_dev)
                 done[i] = 1;
             }
             cv.notify_all();
+        }
+        } catch (const std::bad_alloc&) {
+            ds->set_err("host allocation failed while collecting results");
+            fail_with(SCRG_ERR_OOM);
+        } catch (...) {
+            ds->set_err("unexpected exception while collecting results");
+            fail_with(SCRG_ERR_INVALID_ARG);
         }
     };
     std::thread collectors[NCOLLECT];
@@ -698,7 +791,7 @@ void worker(DeviceState* ds, Call* c, int dev_index, int n_dev)
         const int64_t tb = now_ns();
         scrg_status s = stage2(ds, ds->slot[k % NS], *c, mine[k]);
         if (s != SCRG_OK) {
-            c->fail(s, ds->err.empty() ? std::string(scrg_status_string(s)) : ds->err);
+            fail_with(s);
             return false;
         }
         {
@@ -709,6 +802,7 @@ void worker(DeviceState* ds, Call* c, int dev_index, int n_dev)
         if (timing) fprintf(stderr, "[scrooge_amd host] dev %d chunk %zu stage2 at %.3f ms: %.3f ms\n", dev_index, k, (tb - tw0) / 1e6, (now_ns() - tb) / 1e6);
         return true;
     };
+    try {
     for (size_t i = 0; i < m && ok; i++) {
         if (c->failed()) break;
         const int64_t ta = now_ns();
@@ -722,7 +816,7 @@ void worker(DeviceState* ds, Call* c, int dev_index, int n_dev)
             fprintf(stderr, "[scrooge_amd host] dev %d chunk %zu stage1 at %.3f ms: %.3f ms (pack %.3f)\n", dev_index, i, (ta - tw0) / 1e6,
                     (now_ns() - ta) / 1e6, ds->slot[i % NS].t_pack_ns / 1e6);
         if (s != SCRG_OK) {
-            c->fail(s, ds->err.empty() ? std::string(scrg_status_string(s)) : ds->err);
+            fail_with(s);
             break;
         }
         while (ok && next2 <= i) {
@@ -735,6 +829,13 @@ void worker(DeviceState* ds, Call* c, int dev_index, int n_dev)
         }
     }
     while (ok && !c->failed() && next2 < m) ok = do_stage2(next2++);
+    } catch (const std::bad_alloc&) {
+        ds->set_err("host allocation failed while staging a chunk");
+        fail_with(SCRG_ERR_OOM);
+    } catch (...) {
+        ds->set_err("unexpected exception while staging a chunk");
+        fail_with(SCRG_ERR_INVALID_ARG);
+    }
     {
         std::lock_guard<std::mutex> g(mu);
         stop = true;
@@ -861,7 +962,7 @@ void* state_create(int device)
     for (int k = 0; k < MAXSLOT; k++) {
         Slot& sl = ds->slot[k];
         if (hipStreamCreateWithPriority(&sl.stream, hipStreamNonBlocking, prio[k]) != hipSuccess || hipEventCreateWithFlags(&sl.ev_tot, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming) != hipSuccess || scrg_ctx_create(device, &sl.ctx) != SCRG_OK ||
+            hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming) != hipSuccess || scrg_int::ctx_create_internal(device, &sl.ctx) != SCRG_OK ||
             scrg_ctx_set_stream(sl.ctx, sl.stream) != SCRG_OK) {
             state_free(ds);
             return nullptr;
@@ -887,6 +988,10 @@ void state_free(void* state)
     }
     ds->d_seq.release();
     delete ds;
+    {   // the genome staging buffer is not worth keeping pinned for a process that is letting go of its device states
+        std::lock_guard<std::mutex> g(g_genome_staging.mu);
+        g_genome_staging.release();
+    }
 }
 
 scrg_status genome_set(void* state, const char* genome, uint64_t genome_len, std::string* err)
@@ -894,9 +999,9 @@ scrg_status genome_set(void* state, const char* genome, uint64_t genome_len, std
     DeviceState* ds = static_cast<DeviceState*>(state);
     if (!ds) return SCRG_ERR_NO_DEVICE;
     std::lock_guard<std::mutex> g(ds->mu);
-    ds->err.clear();
+    ds->set_err("");
     scrg_status s = pack_genome(ds, genome, genome_len);
-    if (s != SCRG_OK && err) *err = ds->err;
+    if (s != SCRG_OK && err) *err = ds->get_err();
     return s;
 }
 
@@ -995,16 +1100,19 @@ scrg_status align(void* const* states, int n_states, const scrg_params& resolved
         }, true);
         for (uint64_t w : cw) slot_words = std::max(slot_words, w);
     }
+    for (int d = 0; d < n_states; d++) ds[d]->set_err("");
+    if (b.mapping && b.genome) {             // packed once, copied to every device side by side
+        const scrg_status s = stage_genome(ds.data(), n_states, b.genome, b.genome_len);
+        if (s != SCRG_OK) return bail(s, ds[0]->get_err());
+    }
     for (int d = 0; d < n_states; d++) {
-        ds[d]->err.clear();
         scrg_status s = SCRG_OK;
-        if (b.mapping && b.genome) s = pack_genome(ds[d], b.genome, b.genome_len);
-        else if (b.mapping && !ds[d]->genome_ok) {
-            ds[d]->err = "no resident genome: call scrg_genome_set first";
+        if (b.mapping && !ds[d]->genome_ok) {
+            ds[d]->set_err("no resident genome: call scrg_genome_set first");
             s = SCRG_ERR_INVALID_ARG;
         }
         if (s == SCRG_OK) s = ensure_seq(ds[d], ds[d]->genome_words, slot_words);
-        if (s != SCRG_OK) return bail(s, ds[d]->err);
+        if (s != SCRG_OK) return bail(s, ds[d]->get_err());
     }
     if (b.mapping) {
         const uint64_t glen = ds[0]->genome_len;

@@ -250,6 +250,10 @@ struct ResultPool {
 };
 inline ResultPool g_pool;
 
+// A handle for the library's own use (the slots of the host path): like scrg_ctx_create, but not counted among the
+// caller's handles — "destroying the last handle trims the result pool" is about the handles the caller made.
+scrg_status ctx_create_internal(int device, scrg_ctx** out);
+
 
 }  // namespace scrg_int
 

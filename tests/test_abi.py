@@ -90,13 +90,41 @@ def test_product_does_not_reference_oracle():
 
 
 def test_unknown_experiment_switches_are_rejected(lib):
-    """scrg_params.reserved[0]: only the switches that leave the results intact pass (1, 32, 64, 128, 256); the ablation
-    switches of the profiling build (2, 4, 8, 16: skip the table / the runs / the walk / the stores) and anything an
-    uninitialised struct might hold are SCRG_ERR_INVALID_ARG in the shipped library."""
+    """scrg_params.reserved[] in the SHIPPED library: only the two documented selections between formulations that give
+    identical results pass (32: no diagonal-major path for lanes_per_pair = 8; 256: the table-in-HBM kernel where the
+    table-in-registers one would serve).  The scheduling switches (1, 64, 128), the counters (reserved[1]) and the
+    ablation switches (2, 4, 8, 16) belong to the profiling builds (-DSCRG_STATS / -DSCRG_ABLATE, scripts/ab.sh); here
+    they, and anything an uninitialised struct might hold, are SCRG_ERR_INVALID_ARG — and the kernels contain none of
+    that code (scrg_build_flags() == 0)."""
     import ctypes as C
+    assert lib.scrg_build_flags() == 0, "the in-tree library must be the shipped build (no -DSCRG_STATS / -DSCRG_ABLATE)"
     p, out = api.Params(), api.Params()
-    for flags, ok in ((0, True), (1, True), (32, True), (64 | 1, True), (128, True), (2, False), (4, False), (8, False),
-                      (16, False), (0x7fffffff, False), (-1, False), (256, True), (512, False)):
+    for flags, ok in ((0, True), (32, True), (256, True), (32 | 256, True), (1, False), (64 | 1, False), (128, False), (64, False),
+                      (2, False), (4, False), (8, False), (16, False), (0x7fffffff, False), (-1, False), (512, False)):
         lib.scrg_params_default(C.byref(p))
         p.reserved[0] = flags
         assert (lib.scrg_params_resolve(C.byref(p), C.byref(out)) == api.SCRG_OK) == ok, flags
+    for r1 in (1, -1, 7):
+        lib.scrg_params_default(C.byref(p))
+        p.reserved[1] = r1
+        assert lib.scrg_params_resolve(C.byref(p), C.byref(out)) == api.SCRG_ERR_INVALID_ARG, r1
+
+
+def test_shipped_kernels_have_no_experiment_plumbing():
+    """The experiment plumbing is compiled out, not just switched off: in the shipped build SCRG_TIMING / SCRG_SW / SCRG_ABL
+    are the constant false (genasm_kernels.h), and no kernel source tests args.debug or args.stats directly except through
+    them (the one exception: the documented, result-neutral selection 32 of the GenASM-row kernel)."""
+    import re
+    csrc = os.path.join(ROOT, "scrooge_amd", "csrc")
+    hdr = open(os.path.join(csrc, "genasm_kernels.h")).read()
+    shipped = hdr[hdr.index("#else", hdr.index("#ifdef SCRG_STATS")):]
+    assert "#define SCRG_TIMING(args) false" in shipped and "#define SCRG_SW(args, bit) false" in shipped
+    assert "#define SCRG_ABL(args, bit) false" in hdr
+    for f in os.listdir(csrc):
+        if not f.endswith(".hip"):
+            continue
+        txt = re.sub(r"//[^\n]*", "", open(os.path.join(csrc, f)).read())
+        for m in re.finditer(r"\ba\.debug\b[^;\n]*", txt):
+            assert "SCRG_SWITCH_NO_DIAG" in m.group(0), (f, m.group(0))
+        for m in re.finditer(r"if\s*\(\s*a\.stats\b", txt):
+            raise AssertionError("%s tests a.stats directly: %s" % (f, m.group(0)))

@@ -330,11 +330,17 @@ def test_bench_two_ranks_dry_run(gather_root, root_share):
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, SCRG_BENCH_DRYRUN="1")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
-                          "--gpus", "2", "--steps", "5", "--warmup", "1", "--pairs", "6400", "--read-len", "2000",
-                          "--gather-root", gather_root, "--root-share", root_share],
-                         env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    # plain `python bench.py --gpus 2`: bench.py starts its own two ranks (a fresh torch.distributed.run child, started
+    # before this parent touches the GPU) — the form the driver uses; one case goes through an explicit launcher instead
+    args = [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1", "--pairs", "6400", "--read-len", "2000",
+            "--gather-root", gather_root, "--root-share", root_share]
+    if (gather_root, root_share) == ("0", "0.3"):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+               "--master-addr", "127.0.0.1", "--master-port", "29533"] + args
+    else:
+        cmd = [sys.executable] + args
+        env.pop("WORLD_SIZE", None)
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
     assert len(lines) == 1, out.stdout[-2000:]              # rank 0 only
