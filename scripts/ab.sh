@@ -7,7 +7,7 @@ mkdir -p $root/ab_libs
 if [ "$1" = build ]; then
   name=$2; shift; shift
   cd $root/scrooge_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result "$@" -shared \
-     -o $root/ab_libs/lib_$name.so genasm_kernels.hip genasm_kernel_multiword.hip genasm_lane_kernel.hip genasm_lane_mw_kernel.hip genasm_lane_wide_kernel.hip edit_stream_kernels.hip edit_stream_decode_kernel.hip host_path_kernels.hip \
+     -o $root/ab_libs/lib_$name.so genasm_kernels.hip genasm_kernel_multiword.hip genasm_lane_kernel.hip genasm_lane_mw_kernel.hip genasm_lane_wide_kernel.hip genasm_lane_parts_kernel.hip edit_stream_kernels.hip edit_stream_decode_kernel.hip host_path_kernels.hip \
      seq_kernels.hip scrg_api.cpp scrg_host.cpp scrg_io.cpp -lpthread 2>&1 | grep -E "error" -A3
   ls -la $root/ab_libs/lib_$name.so
 else

@@ -50,7 +50,7 @@ struct AlignArgs {
 #define SCRG_STATS 1
 #endif
 constexpr int32_t SCRG_SWITCH_NO_DIAG = 32;       // lanes_per_pair = 8: GenASM rows only (no diagonal-major path)
-constexpr int32_t SCRG_SWITCH_MW_TABLE = 256;     // 32 <= W-O <= 63, W <= 128: genasm_lane_mw_kernel (table in HBM) instead of genasm_lane_wide_kernel
+constexpr int32_t SCRG_SWITCH_MW_TABLE = 256;     // genasm_lane_mw_kernel (table in HBM) where genasm_lane_wide_kernel / genasm_lane_parts_kernel (table in registers) would serve
 constexpr int32_t SCRG_SAFE_SWITCHES = SCRG_SWITCH_NO_DIAG | SCRG_SWITCH_MW_TABLE;
 #ifdef SCRG_STATS
 #define SCRG_TIMING(args) ((args).stats != nullptr)
@@ -97,6 +97,18 @@ hipError_t launch_align_lane_mw(const AlignArgs& a, int grid, size_t lds_bytes, 
 SCRG_HD inline bool lane_wide_serves(int W, int tb_limit) { return W <= 128 && tb_limit >= 32 && tb_limit <= 63; }
 SCRG_HD inline unsigned lane_wide_lds_bytes(int W) { return 64u * (68u + 36u + (W <= 64 ? 40u : 80u)); }
 hipError_t launch_align_lane_wide(const AlignArgs& a, int grid, size_t lds_bytes, hipStream_t s, bool edits = false);
+// genasm_lane_parts_kernel (one pair per lane, 64 <= W-O <= 127, W <= 256: two-word table rows): the table in registers, built
+// in parts of 16 columns from checkpoints of the difference vectors.  LDS per wavefront and lane: CIGAR ring, 16 insertion-run
+// lengths, the window's Eq words for the four bases and "no match" (NW words each, slots of 16 or 32 bytes), the window's text.
+// HBM per wavefront: 8 checkpoints of 4 NW dwords per lane.
+SCRG_HD inline bool lane_parts_serves(int W, int tb_limit) { return W <= 256 && tb_limit >= 64 && tb_limit <= 127; }
+SCRG_HD inline unsigned lane_parts_lds_bytes(int W)
+{
+    const unsigned nw = ((unsigned)W + 63u) / 64u, slot = nw == 2u ? 16u : 32u;
+    return 64u * (68u + 20u + 5u * slot + 16u * nw);
+}
+SCRG_HD inline size_t lane_parts_checkpoint_bytes(int W) { return (size_t)8u * 4u * (((unsigned)W + 63u) / 64u) * 64u * 4u; }
+hipError_t launch_align_lane_parts(const AlignArgs& a, int grid, size_t lds_bytes, hipStream_t s, bool edits = false);
 
 SCRG_HD inline unsigned stored_row_dwords(int W, int tb_limit)
 {

@@ -80,6 +80,13 @@ __device__ __forceinline__ uint32_t ffbh_u32(uint32_t v)      // count leading z
     return r;
 }
 
+__device__ __forceinline__ uint32_t ffbl_u32(uint32_t v)      // count trailing zeros; 0xffffffff for v == 0
+{
+    uint32_t r;
+    asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+
 // SHORT_N = false: every lane of the wave has a full text window (n = 64); true: any n <= 64 per lane (the text ends
 // inside the window): columns >= n read the Eq word "no character matches", which leaves the boundary column
 // D[n][j] = m-j (genasm_cpu.cpp:239-245) as it is and gives table words that say "insertion" in every row — what the
@@ -101,10 +108,9 @@ __device__ __forceinline__ void lane_window_table(const Planes tw, const Planes 
                                                   const uint32_t stop, uint64_t (&tab)[LANE_TB_COLS],
                                                   const uint32_t eq_b, const uint32_t nomatch_b, const uint32_t swz)
 {
-    // tab[i] = ~(V1 | stop) in the upper dword, V0 | stop in the lower one (a register pair: the traceback shifts both
-    // with one 64-bit shift): stop has the one bit of the row at which this lane's walk ends (jlim), so a finished lane
-    // reads "deletion AND substitution" there — it stays put without a test, and the combination, which no cell of the
-    // matrix has, marks the columns it was no longer alive in
+    // tab[i] = ~(V1 | stop) in the upper dword, V0 in the lower one (a register pair: the traceback shifts both with one
+    // 64-bit shift): stop has the one bit of the row at which this lane's walk ends (jlim), so a finished lane reads
+    // "deletion" there — it stays put without a test; how many columns it was alive in follows from the masks (below)
     const uint64_t rlo = brev64(pw.lo), rhi = brev64(pw.hi);
     const uint64_t valid = ~0ull << (64u - m);                    // (m >= 1)
     const uint32_t rl0 = (uint32_t)rlo, rl1 = (uint32_t)(rlo >> 32), rh0 = (uint32_t)rhi, rh1 = (uint32_t)(rhi >> 32);
@@ -119,13 +125,18 @@ __device__ __forceinline__ void lane_window_table(const Planes tw, const Planes 
     }
     const uint32_t swl = 0u - (swz & 1u), swh = 0u - (swz >> 1);
     const uint32_t tl0 = (uint32_t)tw.lo ^ swl, tl1 = (uint32_t)(tw.lo >> 32) ^ swl, th0 = (uint32_t)tw.hi ^ swh, th1 = (uint32_t)(tw.hi >> 32) ^ swh;
-    // LDS address of column i's Eq word: eq_b | 8 * (2 * hi bit + lo bit)
+    // LDS address of column i's Eq word: eq_b | 8 * (2 * hi bit + lo bit).  The two planes are interleaved once per window so
+    // that a column's two bits sit next to each other — xe: bit b = lo bit, bit b + 1 = hi bit of every EVEN column b of the
+    // dword; xo: bit b - 1 = lo bit, bit b = hi bit of every ODD column b — and the address is one shift and one v_bitop3:
+    // 2 instructions per column instead of 4, for 8 per window.
+    const uint32_t xe0 = bitop3<TT_BFI>(tl0, th0 << 1, 0x55555555u), xo0 = bitop3<TT_BFI>(th0, tl0 >> 1, 0xaaaaaaaau);
+    const uint32_t xe1 = bitop3<TT_BFI>(tl1, th1 << 1, 0x55555555u), xo1 = bitop3<TT_BFI>(th1, tl1 >> 1, 0xaaaaaaaau);
     auto eq_addr = [&](int i) -> uint32_t {
-        const uint32_t tl = i < 32 ? tl0 : tl1, th = i < 32 ? th0 : th1;
         const int b = i & 31;
-        const uint32_t u = b >= 3 ? tl >> (b - 3) : tl << (3 - b);         // lo bit -> bit 3
-        const uint32_t v = b >= 4 ? th >> (b - 4) : th << (4 - b);         // hi bit -> bit 4
-        const uint32_t a = bitop3<TT_ANDOR>(bitop3<TT_BFI>(u, v, 8u), 24u, eq_b);
+        const uint32_t x = (b & 1) ? (i < 32 ? xo0 : xo1) : (i < 32 ? xe0 : xe1);
+        const int f = (b & 1) ? b - 1 : b;                                  // the field's low bit; it goes to bit 3
+        const uint32_t u = f >= 3 ? x >> (f - 3) : x << (3 - f);
+        const uint32_t a = bitop3<TT_ANDOR>(u, 24u, eq_b);
         return (!SHORT_N || (uint32_t)i < n) ? a : nomatch_b;
     };
     uint2 eqw[LANE_EQ_AHEAD];
@@ -151,7 +162,7 @@ __device__ __forceinline__ void lane_window_table(const Planes tw, const Planes 
             mv0 = (uint32_t)phs & xv0;
             mv1 = (uint32_t)(phs >> 32) & xv1;
             if (i < LANE_TB_COLS)
-                tab[i] = ((uint64_t)bitop3<TT_NOR3>(pv1, ph1, stop) << 32) | (bitop3<TT_V0>(pv1, ph1, xh1) | stop);
+                tab[i] = ((uint64_t)bitop3<TT_NOR3>(pv1, ph1, stop) << 32) | bitop3<TT_V0>(pv1, ph1, xh1);
         }
     }
 }
@@ -366,22 +377,27 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
                     const uint32_t nt1 = (uint32_t)(both >> 32), t0 = (uint32_t)both;
                     nDm = __builtin_amdgcn_alignbit(nDm, nt1, 31);
                     Xm = __builtin_amdgcn_alignbit(Xm, t0, 31);
-                    uint32_t scratch;                                          // j += sign bit of nt1: a deletion (or the stop row) keeps j
-                    asm("v_add_co_u32 %1, vcc, %2, %2\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(j), "=&v"(scratch) : "v"(nt1) : "vcc");
+                    j -= neg_mask(nt1);                                        // j += sign bit of nt1: a deletion (or the stop row) keeps j (v_ashrrev, v_sub: full rate)
                 }
             };
             if (SCRG_ABL(a, 8)) { j = jlim; nDm = ~0u; }                    // ablation (profiling only): no walk
             else if (TBL == (uint32_t)LANE_TB_COLS) walk(std::true_type{});
             else walk(std::false_type{});
             if (timing) cy_p1 += __builtin_readcyclecounter() - tm3;
-            // column i -> bit 31-i; only the ti columns the lane was alive in count (insertion runs are exact as recorded)
-            const uint32_t nsh = 32u - min(TBL, (uint32_t)LANE_TB_COLS);
-            // columns the lane was alive in: all before the first "deletion and substitution" (the stop row)
-            const uint32_t Draw = ~(nDm << nsh), Xraw = Xm << nsh;
-            ti = ffbh_u32((Draw & Xraw) | (0x80000000u >> min(TBL, (uint32_t)LANE_TB_COLS)));
+            // column i -> bit 31-i; only the ti columns the lane was alive in count (insertion runs are exact as recorded).
+            // A lane whose walk has not reached its last row (j < jlim) was alive in every column.  One that has (:307-310)
+            // stopped in the column after its last step that was not a deletion — a diagonal step took it to row jlim — or in
+            // the column of its last insertion run, if that run took it there (a dead lane reads "deletion, no insertion"
+            // from then on); with no such column at all it never moved: ti = 0.
+            const uint32_t TBc = min(TBL, (uint32_t)LANE_TB_COLS);
+            const uint32_t nsh = 32u - TBc;
+            const uint32_t notD = nDm << nsh, Xraw = Xm << nsh;
+            const uint32_t Draw = ~notD;
+            const uint32_t Im = ~nIm << nsh;
+            const uint32_t ti_stopped = (31u - ffbl_u32((notD >> 1) | Im)) & 31u;      // bit 31-c: the lane stopped in column c or later; none: 0
+            ti = j < jlim ? TBc : ti_stopped;
             const uint32_t A = ~(0xffffffffu >> ti);
             const uint32_t D = Draw & A, X = Xraw & A;
-            const uint32_t Im = ~nIm << nsh;
             const uint32_t B = ((D ^ (D >> 1)) | (X ^ (X >> 1)) | Im | 0x80000000u) & A;    // a D / X / = run starts here
             const uint32_t nD = (uint32_t)__builtin_popcount(D), nX = (uint32_t)__builtin_popcount(X);
             edits += j - ti + 2u * nD + nX;             // insertions (j - (ti - nD)) + deletions + substitutions

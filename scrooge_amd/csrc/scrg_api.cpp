@@ -302,6 +302,8 @@ static size_t lds_bytes_for(const scrg_params& p)
 {
     if (p.lanes_per_pair == 1 && scrg::lane_wide_serves(p.W, p.W - p.O) && !(p.reserved[0] & scrg::SCRG_SWITCH_MW_TABLE))
         return scrg::lane_wide_lds_bytes(p.W);       // genasm_lane_wide_kernel
+    if (p.lanes_per_pair == 1 && scrg::lane_parts_serves(p.W, p.W - p.O) && !(p.reserved[0] & scrg::SCRG_SWITCH_MW_TABLE))
+        return scrg::lane_parts_lds_bytes(p.W);      // genasm_lane_parts_kernel
     if (p.lanes_per_pair == 1 && (p.W > 64 || p.W - p.O > 31))
         return scrg::lane_mw_lds_bytes(p.W - p.O);   // genasm_lane_mw_kernel: CIGAR ring + insertion-run lengths (the table is in HBM)
     if (p.lanes_per_pair == 1) return 64 * (68 + 36 + 32 + 8);  // per lane: CIGAR staging ring (32 runs + 1 dword), insertion-run lengths of a window, Eq table (+ the "no match" word)
@@ -385,8 +387,11 @@ static scrg_status align_device_impl(scrg_ctx* c, const scrg_params* params, uin
     const size_t spill_rows = p.W > 64 ? (size_t)p.W + 1 : scrg::SPILL_ROWS;
     const size_t spill_row_dw = scrg::stored_row_dwords(p.W, p.W - p.O);
     const bool lane_wide = p.lanes_per_pair == 1 && scrg::lane_wide_serves(p.W, p.W - p.O) && !(p.reserved[0] & scrg::SCRG_SWITCH_MW_TABLE);
-    const bool lane_mw = !lane_wide && p.lanes_per_pair == 1 && (p.W > 64 || p.W - p.O > 31);      // rows of more than 32 bits: genasm_lane_mw_kernel
-    if (lane_mw)                         // its window tables: one slab of HBM per wavefront
+    const bool lane_parts = !lane_wide && p.lanes_per_pair == 1 && scrg::lane_parts_serves(p.W, p.W - p.O) && !(p.reserved[0] & scrg::SCRG_SWITCH_MW_TABLE);
+    const bool lane_mw = !lane_wide && !lane_parts && p.lanes_per_pair == 1 && (p.W > 64 || p.W - p.O > 31);      // the rest: genasm_lane_mw_kernel
+    if (lane_parts)                      // its checkpoints: one slab of HBM per wavefront (workgroups of four)
+        HIP_TRY(c, c->spill.ensure((size_t)((n_waves + 3) / 4 * 4) * scrg::lane_parts_checkpoint_bytes(p.W)));
+    else if (lane_mw)                    // its window tables: one slab of HBM per wavefront
         HIP_TRY(c, c->spill.ensure((size_t)n_waves * scrg::lane_mw_table_bytes(p.W - p.O)));
     else if (p.lanes_per_pair != 1)      // (genasm_lane_kernel keeps its table in registers: nothing spills)
         HIP_TRY(c, c->spill.ensure((size_t)n_waves * ppw * spill_rows * spill_row_dw * sizeof(uint32_t)));
@@ -419,6 +424,8 @@ static scrg_status align_device_impl(scrg_ctx* c, const scrg_params* params, uin
     HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));
     if (lane_wide)
         HIP_TRY(c, scrg::launch_align_lane_wide(a, n_waves, (size_t)lds, c->stream, edits));
+    else if (lane_parts)
+        HIP_TRY(c, scrg::launch_align_lane_parts(a, n_waves, (size_t)lds, c->stream, edits));
     else if (lane_mw)
         HIP_TRY(c, scrg::launch_align_lane_mw(a, n_waves, (size_t)lds, c->stream, edits));
     else if (p.W > 64)

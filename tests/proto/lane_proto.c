@@ -74,9 +74,19 @@ static void lane_dc(const uint8_t *t, int n, const uint8_t *q, int m, int TBL, u
 static unsigned lp_ffbh32(uint32_t v) { return v ? (unsigned)__builtin_clz(v) : 0xffffffffu; }   /* v_ffbh_u32 */
 static uint32_t lp_alignbit(uint32_t hi, uint32_t lo, unsigned s) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> s); }
 
+/* columns a lane was alive in, from the masks of pass 1 (column i <-> bit 31-i): notD = the step out of the column is
+ * not a deletion, Im = an insertion run starts in it (genasm_lane_kernel.hip: the table's V0 words carry no stop bit) */
+static uint32_t lane_alive_columns(uint32_t notD, uint32_t Im, uint32_t j, uint32_t jlim, uint32_t TBL)
+{
+    const uint32_t P = (notD >> 1) | Im;                          /* bit 31-c: the lane stopped in column c or later */
+    const uint32_t ffbl = P ? (uint32_t)__builtin_ctz(P) : 0xffffffffu;     /* v_ffbl_b32 */
+    const uint32_t stopped = (31u - ffbl) & 31u;                  /* (no such column: it never moved, 0) */
+    return j < jlim ? TBL : stopped;
+}
+
 /* The kernel's traceback (W-O <= 31), restated step by step: pass 1 walks the columns and records the path in
  * three masks + one byte per column, pass 2 turns the masks into runs.  nv1[i] = ~(V1 | stop), v0[i] = V0 (high
- * dwords: bit 31-j <-> pattern character j, with the stop bit); stop has the bit of row jlim. */
+ * dwords: bit 31-j <-> pattern character j); stop has the bit of row jlim. */
 static int lane_tb(const uint64_t *V1, const uint64_t *V0, int m, int TBL, size_t *tu, size_t *pu, run_sink *out, lane_stats *ls)
 {
     const uint32_t jlim = (uint32_t)(m < TBL ? m : TBL);    /* j < m && j < W-O, genasm_cpu.cpp:307-310 */
@@ -84,7 +94,7 @@ static int lane_tb(const uint64_t *V1, const uint64_t *V0, int m, int TBL, size_
     uint32_t j = 0, ti = 0, nDm = 0, Xm = 0, nIm = 0;
     uint8_t ilen[32];
     for (int i = 0; i < TBL; i++) {
-        const uint32_t nv1 = ~((uint32_t)(V1[i] >> 32) | stop), v0 = (uint32_t)(V0[i] >> 32) | stop;
+        const uint32_t nv1 = ~((uint32_t)(V1[i] >> 32) | stop), v0 = (uint32_t)(V0[i] >> 32);
         const uint32_t x = (nv1 | ~v0 | stop) << j;             /* not (insertion), or the stop row */
         const uint32_t ni = lp_ffbh32(x);
         ilen[i] = (uint8_t)ni;
@@ -97,11 +107,13 @@ static int lane_tb(const uint64_t *V1, const uint64_t *V0, int m, int TBL, size_
         ls->tb_columns++;
     }
     const unsigned nsh = 32u - (unsigned)TBL;
-    /* a finished lane reads "deletion and substitution" (the stop row): the first such column ends the walk */
-    const uint32_t Draw = ~(nDm << nsh), Xraw = Xm << nsh;
-    ti = lp_ffbh32((Draw & Xraw) | (0x80000000u >> TBL));
+    /* A lane that has not reached row jlim was alive in every column.  One that has stopped in the column after its last
+     * step that was not a deletion (a diagonal step took it there) or in the column of its last insertion run (if that
+     * run took it there); from then on it reads "deletion, no insertion" (the stop row).  (genasm_lane_kernel.hip) */
+    const uint32_t notD = nDm << nsh, Xraw = Xm << nsh, Draw = ~notD, Im = ~nIm << nsh;
+    ti = lane_alive_columns(notD, Im, j, jlim, (uint32_t)TBL);
     const uint32_t A = ti ? ~(0xffffffffu >> ti) : 0u;
-    const uint32_t D = Draw & A, X = Xraw & A, Im = ~nIm << nsh;
+    const uint32_t D = Draw & A, X = Xraw & A;
     const uint32_t B = ((D ^ (D >> 1)) | (X ^ (X >> 1)) | Im | 0x80000000u) & A;
     const int edits = (int)(j - ti + 2u * (unsigned)__builtin_popcount(D) + (unsigned)__builtin_popcount(X));
     uint32_t E = B | Im;
@@ -131,7 +143,7 @@ static int lane_tb_edits(const uint64_t *V1, const uint64_t *V0, int m, int TBL,
     uint32_t j = 0, ti = 0, nDm = 0, Xm = 0, nIm = 0;
     uint8_t ilen[32];
     for (int i = 0; i < TBL; i++) {
-        const uint32_t nv1 = ~((uint32_t)(V1[i] >> 32) | stop), v0 = (uint32_t)(V0[i] >> 32) | stop;
+        const uint32_t nv1 = ~((uint32_t)(V1[i] >> 32) | stop), v0 = (uint32_t)(V0[i] >> 32);
         const uint32_t x = (nv1 | ~v0 | stop) << j;
         const uint32_t ni = lp_ffbh32(x);
         ilen[i] = (uint8_t)ni;
@@ -144,10 +156,10 @@ static int lane_tb_edits(const uint64_t *V1, const uint64_t *V0, int m, int TBL,
         ls->tb_columns++;
     }
     const unsigned nsh = 32u - (unsigned)TBL;
-    const uint32_t Draw = ~(nDm << nsh), Xraw = Xm << nsh;
-    ti = lp_ffbh32((Draw & Xraw) | (0x80000000u >> TBL));
+    const uint32_t notD = nDm << nsh, Xraw = Xm << nsh, Draw = ~notD, Im = ~nIm << nsh;
+    ti = lane_alive_columns(notD, Im, j, jlim, (uint32_t)TBL);
     const uint32_t A = ti ? ~(0xffffffffu >> ti) : 0u;
-    const uint32_t D = Draw & A, X = Xraw & A, Im = ~nIm << nsh;
+    const uint32_t D = Draw & A, X = Xraw & A;
     const int edits = (int)(j - ti + 2u * (unsigned)__builtin_popcount(D) + (unsigned)__builtin_popcount(X));
     uint32_t E = D | X | Im;
     while (E) {

@@ -221,6 +221,48 @@ def test_table_in_two_halves(aligner, oracle, w, o):
         aligner.params = keep
 
 
+@pytest.mark.parametrize("w,o", [(256, 129), (160, 81), (192, 97), (224, 113), (128, 20), (128, 1), (129, 65), (130, 2), (200, 100), (255, 128),
+                                 (191, 64), (192, 128), (65, 1), (256, 192), (161, 81)])
+def test_table_in_parts(aligner, oracle, w, o):
+    """64 <= W-O <= 127 (the reference's large-window sweep points, scripts/profile.py:180-185: W = 160 ... 256 with
+    O = W/2 + 1; two-word table rows, src/bitvector.hpp:45-48): genasm_lane_parts_kernel builds the window's table in parts of
+    16 columns in registers, each part re-swept from a checkpoint of the difference vectors.  Runs that cross from one part into
+    the next are one run (long matches, long gaps), walks that end early never enter the later parts, texts that end inside a
+    window skip the chunks past their end, insertion runs of more than 64 rows (unrelated sequences) cross the words of a row.
+    Vectors of 2, 3 and 4 words.  The kernel it replaces for these W/O (table in HBM, reserved[0] = 256) gives the same results."""
+    t, q = synth.make_pairs(120, 3000, "ont", seed=w * 13 + o)
+    a, b = synth.make_pairs(40, 3500, "pacbio15", seed=w + o + 1)
+    c, d = synth.make_pairs(200, 600, "illumina", seed=w + o + 2)       # long match runs across the parts
+    t, q = t + a + c, q + b + d
+    rng = np.random.Generator(np.random.PCG64(w * 5 + o))
+    for _ in range(100):                       # unrelated sequences, ragged and empty inputs
+        t.append(synth.random_seq(int(rng.integers(0, 900)), rng))
+        q.append(synth.random_seq(int(rng.integers(0, 900)), rng))
+    for _ in range(40):                        # low-complexity sequences: long insertion / deletion runs, many ties
+        t.append(bytes(rng.choice(np.frombuffer(b"AC", np.uint8), int(rng.integers(1, 700)))))
+        q.append(bytes(rng.choice(np.frombuffer(b"AC", np.uint8), int(rng.integers(1, 700)))))
+    for _ in range(40):                        # one long gap
+        s = synth.random_seq(int(rng.integers(300, 1200)), rng)
+        cut, gap = int(rng.integers(10, 250)), int(rng.integers(10, 120))
+        t += [s, s[:cut] + s[cut + gap:]]
+        q += [s[:cut] + s[cut + gap:], s]
+    for _ in range(20):                        # reads much longer than their texts: whole windows of insertions
+        t.append(synth.random_seq(int(rng.integers(0, 60)), rng))
+        q.append(synth.random_seq(int(rng.integers(300, 800)), rng))
+    t += [b"", b"ACGT", b"A" * 600, b"A" * 10, b"ACGT" * 200]
+    q += [b"ACGT", b"", b"A" * 10, b"A" * 600, b"TGCA" * 200]
+    eds, cigars, _, _ = oracle.align(t, q, W=w, O=o, threads=8)
+    _check(aligner.align_pairs(t, q, W=w, O=o), eds, cigars, "W=%d O=%d" % (w, o))
+    p = aligner.make_params(W=w, O=o)
+    p.reserved[0] = 256
+    keep = aligner.params
+    aligner.params = p
+    try:
+        _check(aligner.align_pairs(t, q), eds, cigars, "W=%d O=%d, table in HBM" % (w, o))
+    finally:
+        aligner.params = keep
+
+
 def test_windows_over_64_limits(aligner):
     import scrooge_amd
     with pytest.raises(scrooge_amd.ScroogeError):
