@@ -72,7 +72,7 @@ typedef struct scrg_params {
                                 SCRG_OUT_TEXT: the CIGAR text only (runs stays empty, run_offset all zero);
                                 SCRG_OUT_RUNS: the runs only (cigar_text stays empty, cigar_offset all zero).
                                 What is not asked for does not cross PCIe                                   */
-    int32_t reserved[2];     /* [0]: 0, or one of two documented, result-neutral selections (32, 256: see
+    int32_t reserved[2];     /* [0]: 0, or documented, result-neutral selections (32, 256, 512, 1024: see
                                 scrg_debug_stats); every other bit is rejected with SCRG_ERR_INVALID_ARG, so an
                                 uninitialised struct cannot silently change anything; [1]: 0 (non-zero asks a
                                 profiling build, -DSCRG_STATS, for its counters; the shipped library rejects it) */
@@ -361,10 +361,12 @@ scrg_status scrg_query_launch(scrg_ctx *ctx, const scrg_params *params,
  * the launch stream (milliseconds); blocks until that launch finished. */
 scrg_status scrg_last_kernel_ms(scrg_ctx *ctx, float *ms);
 
-/* scrg_params.reserved[0] in the SHIPPED library: 0, or one of two selections between formulations that give identical
- * results (kept because the parity tests compare them): 32 (lanes_per_pair = 8: GenASM rows only, no diagonal-major
- * path) and 256 (32 <= W-O <= 63, W <= 128: the kernel that keeps the window table in HBM instead of the one that
- * keeps it in registers).  scrg_params_resolve() and every entry point REJECT any other bit, and reserved[1] != 0.
+/* scrg_params.reserved[0] in the SHIPPED library: 0, or selections between formulations that give identical results
+ * (kept because the parity tests compare them): 32 (lanes_per_pair = 8: GenASM rows only, no diagonal-major path),
+ * 256 (32 <= W-O <= 127: the kernel that keeps the window table in HBM instead of the one that keeps it in registers),
+ * 512 / 1024 (W <= 64, W-O <= 31, runs output: always / never the variant of the default kernel that splits a window's
+ * work over two wavefronts; by default a launch that cannot put two wavefronts on every SIMD takes it).
+ * scrg_params_resolve() and every entry point REJECT any other bit, and reserved[1] != 0.
  *
  * Profiling builds only (scripts/ab.sh; scrg_build_flags() tells): with -DSCRG_STATS the align kernels accumulate
  * twelve counters per launch when reserved[1] != 0, read back by scrg_debug_stats (blocks on the stream):

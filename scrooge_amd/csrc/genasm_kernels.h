@@ -35,10 +35,10 @@ struct AlignArgs {
     int32_t debug;                // params.reserved[0]: see SCRG_SAFE_SWITCHES / SCRG_SW / SCRG_ABL below
 };
 
-// scrg_params.reserved[0] / reserved[1].  The SHIPPED library has exactly two switches, both documented selections between
+// scrg_params.reserved[0] / reserved[1].  The SHIPPED library has four switches, all documented selections between
 // formulations that give identical results (the parity tests compare them): 32 (lanes_per_pair = 8: no diagonal-major
-// path) and 256 (32 <= W-O <= 63, W <= 128: the kernel with the window table in HBM instead of the one that keeps it in
-// registers).  Everything else is experiment plumbing and exists only in profiling builds (scripts/ab.sh):
+// path), 256 (the kernel with the window table in HBM where one that keeps it in registers would serve) and 512 / 1024
+// (the default kernel as two wavefronts per 64 pairs / as one, whatever the launch size).  Everything else is experiment plumbing and exists only in profiling builds (scripts/ab.sh):
 //   -DSCRG_STATS   the kernels' counters (reserved[1] != 0 -> scrg_debug_stats: window rounds, shader cycles per part,
 //                  wavefront life times) and the scheduling switches 1 (one pair per lane: no wavefront priority
 //                  rotation), 64 / 128 (workgroups of one / two wavefronts) — results intact;
@@ -51,7 +51,9 @@ struct AlignArgs {
 #endif
 constexpr int32_t SCRG_SWITCH_NO_DIAG = 32;       // lanes_per_pair = 8: GenASM rows only (no diagonal-major path)
 constexpr int32_t SCRG_SWITCH_MW_TABLE = 256;     // genasm_lane_mw_kernel (table in HBM) where genasm_lane_wide_kernel / genasm_lane_parts_kernel (table in registers) would serve
-constexpr int32_t SCRG_SAFE_SWITCHES = SCRG_SWITCH_NO_DIAG | SCRG_SWITCH_MW_TABLE;
+constexpr int32_t SCRG_SWITCH_SPLIT = 512;        // W <= 64, W-O <= 31, runs output: genasm_lane_split_kernel (a window's work on two wavefronts) whatever the launch size
+constexpr int32_t SCRG_SWITCH_NO_SPLIT = 1024;    // ... genasm_lane_kernel whatever the launch size (default: by launch size, scrg_api.cpp)
+constexpr int32_t SCRG_SAFE_SWITCHES = SCRG_SWITCH_NO_DIAG | SCRG_SWITCH_MW_TABLE | SCRG_SWITCH_SPLIT | SCRG_SWITCH_NO_SPLIT;
 #ifdef SCRG_STATS
 #define SCRG_TIMING(args) ((args).stats != nullptr)
 #define SCRG_SW(args, bit) (((args).debug & (bit)) != 0)
@@ -77,6 +79,10 @@ hipError_t launch_align_multiword(int lanes_per_pair, const AlignArgs& a, int gr
 // lanes_per_pair = 1: one pair per lane, 64 pairs per wavefront (genasm_lane_kernel.hip; W <= 64, W-O <= 31)
 // (edits: the pairs' slices receive edit streams instead of runs, n_runs their lengths in bytes — scrg_align_device_edits)
 hipError_t launch_align_lane(const AlignArgs& a, int grid, size_t lds_bytes, hipStream_t s, bool edits = false);
+// the same alignment (runs output) with a window's work split over a producer and a consumer wavefront (genasm_lane_kernel.hip:
+// genasm_lane_split_kernel): for launches that cannot fill the SIMDs.  grid counts producer wavefronts; 8 resident per CU.
+hipError_t launch_align_lane_split(const AlignArgs& a, int grid, hipStream_t s);
+constexpr int LANE_SPLIT_PRODUCERS_PER_CU = 8;
 
 // dwords of one stored row of R (the part the traceback can reach):
 //   W <= 64: the high dword of columns 0..31, or whole entries of all 64 columns when W-O > 31;

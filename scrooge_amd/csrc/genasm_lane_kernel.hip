@@ -546,6 +546,291 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// genasm_lane_split_kernel — the same alignment (runs output) with a window's work split over TWO wavefronts.
+//
+// A pair is a chain of ~330 windows, each of which needs the previous one's advance, so a wavefront that has a SIMD to itself
+// is bound by that chain — its instruction count times the issue interval of ONE wavefront (4.9 cycles, however empty the SIMD
+// is) plus the latencies nobody hides — not by issue slots: 25 000 ... 65 000 pairs (at most one wavefront per SIMD) take 1.93 ms
+// whatever their number.  The chain itself is only fetch -> window setup -> table -> traceback pass 1 (which yields the window's
+// advance): the SECOND pass (masks -> runs, the CIGAR ring, the stores, the retiring of a pair) depends on nothing the next
+// window needs.  So a workgroup is four PRODUCER wavefronts (everything up to pass 1) and four CONSUMER wavefronts (pass 2 and
+// all output), producer i handing consumer i one record per lane and window through LDS, double buffered, one s_barrier per
+// window round: the consumer works on window r - 1 while the producer computes window r, on issue slots the launch would have
+// left empty.  Measured (scripts/split_time.py, 10 kb pairs): 25 k and 50 k pairs 1.93 -> 1.50 ms (+29 %); 100 k pairs (539 of the
+// 1024 SIMDs hold two producers and two consumers) 2.51 ms against 2.52 ms — two wavefronts of this kernel on a SIMD already take
+// 1.3 x the time of one, and those SIMDs end the launch either way.  So the library takes this kernel for launches of at most one
+// wavefront per SIMD (scrg_api.cpp: the chunks of the host entry points, small batches) and genasm_lane_kernel otherwise — also
+// because it has about 3 % more instructions in total, which is what counts once launches fill the GPU or overlap.
+// Same results bit for bit (tests/test_gpu_parity.py::test_one_and_two_wavefronts_per_window_agree).
+//
+// The record of a lane and round (structure of arrays, one dword per field and lane): D, X, Im (the masks of pass 1, raw),
+// ti | flags (the lane holds a pair / this is its first window / its last), the pair's index, its edits so far; plus the
+// 31 insertion-run lengths of the window.
+constexpr uint32_t SPLIT_FIELDS = 6;
+constexpr uint32_t SPLIT_BUF_BYTES = SPLIT_FIELDS * 256u + 64u * LANE_SCRATCH_BYTES;                // 3840
+constexpr uint32_t SPLIT_PAIR_LDS_BYTES = 64u * (LANE_RING_BYTES + LANE_EQ_BYTES + LANE_NOMATCH_BYTES) + 2u * SPLIT_BUF_BYTES;     // 14592 per producer / consumer pair
+constexpr uint32_t SPLIT_WG_LDS_BYTES = 4u * SPLIT_PAIR_LDS_BYTES + 64u;                              // + the producers' "done" flags, two rounds x four
+constexpr uint32_t SPLIT_VALID = 1u << 8, SPLIT_FIRST = 1u << 9, SPLIT_LAST = 1u << 10;
+
+__global__ __launch_bounds__(512, 2) void genasm_lane_split_kernel(AlignArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    char* const lds_b = reinterpret_cast<char*>(lds);
+    uint8_t* const lds8 = reinterpret_cast<uint8_t*>(lds);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6, duo = wave & 3u;
+    const bool consumer = wave >= 4u;
+    const uint32_t duo_b = duo * SPLIT_PAIR_LDS_BYTES;                         // my producer / consumer pair's part of the workgroup's LDS
+    const uint32_t ring_b = duo_b + lane * LANE_RING_BYTES;
+    // (LDS ADDRESSES, multiples of 32: nothing static precedes the dynamic LDS)
+    const uint32_t eq_b = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds_b + duo_b + 64u * LANE_RING_BYTES + lane * LANE_EQ_BYTES;
+    const uint32_t nomatch_b = eq_b - lane * LANE_EQ_BYTES + 64u * LANE_EQ_BYTES + lane * LANE_NOMATCH_BYTES;
+    const uint32_t bufs_b = duo_b + 64u * (LANE_RING_BYTES + LANE_EQ_BYTES + LANE_NOMATCH_BYTES);
+    const uint32_t flags_w = (4u * SPLIT_PAIR_LDS_BYTES) >> 2;                 // dword index of done[2][4]
+    const uint32_t swz = (lane >> 3) & 3u;
+    const uint32_t W = (uint32_t)a.W;
+    const uint32_t TBL = (uint32_t)a.tb_limit;         // W - O, 1..31
+    const uint32_t TBc = min(TBL, (uint32_t)LANE_TB_COLS);
+    const uint32_t nsh = 32u - TBc;
+    auto rec_w = [&](uint32_t buf, uint32_t field) -> uint32_t { return ((bufs_b + buf * SPLIT_BUF_BYTES) >> 2) + field * 64u + lane; };
+    auto len_b = [&](uint32_t buf) -> uint32_t { return bufs_b + buf * SPLIT_BUF_BYTES + SPLIT_FIELDS * 256u + lane * LANE_SCRATCH_BYTES; };
+    auto all_done = [&](uint32_t r) -> bool {
+        const uint32_t f = flags_w + (r & 1u) * 4u;
+        return (lds[f] & lds[f + 1] & lds[f + 2] & lds[f + 3]) != 0u;
+    };
+
+    if (!consumer) {
+        // ================= producer: queue, window setup, table, traceback pass 1 =================
+        bool has_pair = false, active = true;
+        uint32_t pair = 0;
+        uint64_t text_off = 0, read_off = 0;
+        uint32_t text_len = 0, read_len = 0;
+        uint32_t ref_idx = 0, read_idx = 0, edits = 0;
+        WindowWords twords = {0, 0, 0, 0}, pwords = {0, 0, 0, 0};
+        bool queue_empty = false;          // wave-uniform
+        uint32_t st_rounds = 0;
+        const uint32_t wave_slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);
+        for (uint32_t r = 0;; r++) {
+            const uint32_t buf = r & 1u;
+            uint32_t first = 0;
+            if (active) {
+                if (!SCRG_SW(a, 1)) {
+                    const uint32_t pr = ((uint32_t)(__builtin_readcyclecounter() >> 11) + wave_slot) & 3u;
+                    if (pr == 0) __builtin_amdgcn_s_setprio(0);
+                    else if (pr == 1) __builtin_amdgcn_s_setprio(1);
+                    else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+                    else __builtin_amdgcn_s_setprio(3);
+                }
+                // a finished pair has been handed over with its last window: the lane is free (genasm_cpu.cpp:440-460)
+                has_pair = has_pair && read_idx < read_len;
+                for (;;) {
+                    const bool want = !has_pair && !queue_empty;
+                    if (!__any(want)) break;
+                    const uint64_t askers = __ballot(want);
+                    const int firstl = __ffsll((unsigned long long)askers) - 1;
+                    uint32_t base = 0;
+                    if ((int)lane == firstl) base = atomicAdd(a.counter, (uint32_t)__popcll(askers));
+                    base = (uint32_t)__shfl((int)base, firstl);
+                    const uint32_t idx = base + (uint32_t)__popcll(askers & ((1ull << lane) - 1ull));
+                    const bool got = want && idx < a.n_pairs;
+                    if (__any(want && idx >= a.n_pairs)) queue_empty = true;
+                    if (got) {
+                        const scrg_pair_desc pd = a.pairs[idx];
+                        pair = idx;
+                        text_off = pd.text_off;
+                        read_off = pd.read_off;
+                        text_len = pd.text_len > 0xffffffffull ? 0xffffffffu : (uint32_t)pd.text_len;
+                        read_len = (uint32_t)pd.read_len;
+                        ref_idx = read_idx = edits = 0;
+                        has_pair = true;
+                        first = SPLIT_FIRST;
+                        twords = load_window_words(a.seq, text_off, 0u, a.text_stride);
+                        pwords = load_window_words(a.seq, read_off, 0u, a.read_stride);
+                    }
+                    // (an empty read is a pair of no windows: it is handed over as first and last at once, below)
+                }
+                if (!__any(has_pair)) active = false;
+            }
+            if (active) {
+                // ---------------- window setup (genasm_cpu.cpp:417-420) ----------------
+                const bool live = has_pair && read_idx < read_len;           // (false only for an empty read)
+                const uint32_t n = (live && ref_idx < text_len) ? min(W, text_len - ref_idx) : 0u;
+                const uint32_t m = live ? min(W, read_len - read_idx) : 1u;
+                Planes tw = {0, 0}, pw = {0, 0};
+                if (live) {
+                    tw = window_planes(twords);
+                    pw = window_planes(pwords);
+                }
+                uint64_t tab[LANE_TB_COLS];
+                const uint32_t jlim = live ? min(m, TBL) : 0u;
+                const uint32_t stop = 0x80000000u >> jlim;
+                const bool short_n = __any(live && n != 64u);
+                if (short_n) lane_window_table<true>(tw, pw, n, m, stop, tab, eq_b, nomatch_b, swz);
+                else lane_window_table<false>(tw, pw, n, m, stop, tab, eq_b, nomatch_b, swz);
+                // ---------------- traceback pass 1 (genasm_cpu.cpp:290-409; see genasm_lane_kernel) ----------------
+                uint32_t j = 0, nDm = 0, Xm = 0, nIm = 0;
+                const uint32_t lb = len_b(buf);
+                auto walk = [&](auto full_tag) {
+                    constexpr bool FULL = decltype(full_tag)::value;
+#pragma unroll
+                    for (int i = 0; i < LANE_TB_COLS; i++) {
+                        if (!FULL && (uint32_t)i >= TBL) continue;         // (uniform)
+                        const uint32_t x = bitop3<TT_NIV>((uint32_t)(tab[i] >> 32), (uint32_t)tab[i], stop) << j;
+                        const uint32_t ni = ffbh_u32(x);
+                        lds8[lb + i] = (uint8_t)ni;
+                        nIm = __builtin_amdgcn_alignbit(nIm, x, 31);
+                        j += ni;
+                        const uint64_t both = tab[i] << j;
+                        const uint32_t nt1 = (uint32_t)(both >> 32), t0 = (uint32_t)both;
+                        nDm = __builtin_amdgcn_alignbit(nDm, nt1, 31);
+                        Xm = __builtin_amdgcn_alignbit(Xm, t0, 31);
+                        j -= neg_mask(nt1);
+                    }
+                };
+                if (TBL == (uint32_t)LANE_TB_COLS) walk(std::true_type{});
+                else walk(std::false_type{});
+                const uint32_t notD = nDm << nsh, Xraw = Xm << nsh;
+                const uint32_t Im = ~nIm << nsh;
+                const uint32_t ti_stopped = (31u - ffbl_u32((notD >> 1) | Im)) & 31u;
+                const uint32_t ti = j < jlim ? TBc : ti_stopped;
+                const uint32_t A = ~(0xffffffffu >> ti);
+                const uint32_t D = ~notD & A, X = Xraw & A;
+                edits += j - ti + 2u * (uint32_t)__builtin_popcount(D) + (uint32_t)__builtin_popcount(X);
+                ref_idx += ti;
+                read_idx += j;
+                // the next window's words, asked for now (a pair that is finished reads its padding)
+                twords = load_window_words(a.seq, text_off, ref_idx, a.text_stride);
+                pwords = load_window_words(a.seq, read_off, read_idx < read_len ? read_idx : 0u, a.read_stride);
+                const uint32_t last = (has_pair && read_idx >= read_len) ? SPLIT_LAST : 0u;
+                lds[rec_w(buf, 0)] = D;
+                lds[rec_w(buf, 1)] = X;
+                lds[rec_w(buf, 2)] = Im;
+                lds[rec_w(buf, 3)] = ti | (has_pair ? SPLIT_VALID : 0u) | first | last;
+                lds[rec_w(buf, 4)] = pair;
+                lds[rec_w(buf, 5)] = edits;
+                st_rounds++;
+            } else {
+                lds[rec_w(buf, 3)] = 0u;                                   // nothing for the consumer
+            }
+            if (lane == 0) lds[flags_w + buf * 4u + duo] = active ? 0u : 1u;
+            __syncthreads();
+            if (all_done(r)) break;
+        }
+        if (SCRG_TIMING(a) && lane == 0) atomicAdd((unsigned long long*)&a.stats[0], (unsigned long long)st_rounds);
+        return;
+    }
+
+    // ================= consumer: traceback pass 2, the CIGAR ring, the stores, retiring pairs =================
+    bool open = false;                 // my lane has a pair in progress
+    uint32_t pair = 0;
+    uint64_t cigar_off = 0;
+    uint32_t cigar_cap = 0;
+    int32_t nr = -1;                   // index of the last committed run; n_runs = nr + 1
+    uint32_t flushed = 0;              // runs below this index are in HBM (a multiple of 16)
+    auto write_piece = [&]() {
+        const uint32_t rd = (ring_b >> 2) + ((flushed & 16u) >> 1);
+        uint32_t w[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) w[k] = lds[rd + k];
+        if (flushed + 16u <= cigar_cap) {
+            uint4* const dst = reinterpret_cast<uint4*>(a.runs + cigar_off + flushed);
+            dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
+            dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
+        }
+        flushed += 16u;
+    };
+    auto flush_pieces = [&]() {
+        for (;;) {
+            const bool need = open && nr - (int32_t)flushed >= 16;
+            if (!__any(need)) break;
+            if (need) write_piece();
+        }
+    };
+    auto consume = [&](uint32_t buf) {
+        const uint32_t meta = lds[rec_w(buf, 3)];
+        if (!__any((meta & SPLIT_VALID) != 0u)) return;
+        const bool valid = (meta & SPLIT_VALID) != 0u;
+        const uint32_t ti = meta & 31u;
+        const uint32_t D = valid ? lds[rec_w(buf, 0)] : 0u, X = valid ? lds[rec_w(buf, 1)] : 0u, Im = valid ? lds[rec_w(buf, 2)] : 0u;
+        if (valid && (meta & SPLIT_FIRST)) {
+            pair = lds[rec_w(buf, 4)];
+            const scrg_pair_desc pd = a.pairs[pair];
+            cigar_off = pd.cigar_off;
+            cigar_cap = pd.cigar_cap > 0xffffffffull ? 0xffffffffu : (uint32_t)pd.cigar_cap;
+            nr = -1;
+            flushed = 0;
+            open = true;
+        }
+        const uint32_t A = ~(0xffffffffu >> ti);
+        const uint32_t B = ((D ^ (D >> 1)) | (X ^ (X >> 1)) | Im | 0x80000000u) & A;    // a D / X / = run starts here
+        const uint32_t scr_b = len_b(buf);
+        uint32_t E = valid ? (B | Im) : 0u;
+        uint32_t c = ffbh_u32(E);
+        uint32_t ni = lds8[scr_b + c];
+        uint32_t nr2 = 2u * (uint32_t)nr;          // byte offset of the last committed run
+        auto event = [&]() {
+            const uint32_t sh = 31u - c;
+            const uint32_t bit = 0x80000000u >> (c & 31u);
+            *reinterpret_cast<uint16_t*>(lds_b + ring_b + ((nr2 + 2u) & 62u)) = (uint16_t)(((uint32_t)'I' << 8) | ni);
+            nr2 += 2u * __builtin_amdgcn_ubfe(Im, sh, 1);
+            E = bitop3<TT_ANDN>(E, bit, bit);
+            const uint32_t nx = ffbh_u32(E);
+            ni = lds8[scr_b + nx];
+            const uint32_t len = min(nx, ti) - c;
+            const uint32_t w = (((uint32_t)'=' << 8) + len) + __builtin_amdgcn_ubfe(D, sh, 1) * (7u << 8) + __builtin_amdgcn_ubfe(X, sh, 1) * (27u << 8);
+            *reinterpret_cast<uint16_t*>(lds_b + ring_b + ((nr2 + 2u) & 62u)) = (uint16_t)w;
+            nr2 += 2u * __builtin_amdgcn_ubfe(B, sh, 1);
+            c = nx;
+        };
+        uint32_t trips = 0;
+        while (__any(E != 0u)) {
+            event();
+            event();
+            if (++trips == 3u) {
+                trips = 0;
+                nr = (int32_t)nr2 >> 1;
+                flush_pieces();
+            }
+        }
+        nr = (int32_t)nr2 >> 1;
+        flush_pieces();
+        // retire the pairs whose last window this was (genasm_cpu.cpp:440-460)
+        const bool fin = valid && (meta & SPLIT_LAST) != 0u;
+        if (__any(fin)) {
+            if (fin) {
+                const uint32_t n_runs = (uint32_t)(nr + 1);
+                while (n_runs - flushed >= 16u) write_piece();
+                const uint32_t rem = n_runs - flushed;
+                const uint32_t rd = (ring_b >> 2) + ((flushed & 16u) >> 1);
+                uint32_t* const dst = reinterpret_cast<uint32_t*>(a.runs + cigar_off + flushed);
+                for (uint32_t k = 0; 2u * k < rem; k++)
+                    if (flushed + 2u * k < cigar_cap) dst[k] = lds[rd + k];
+                a.ed[pair] = (int64_t)lds[rec_w(buf, 5)];
+                a.n_runs[pair] = n_runs;
+                a.status[pair] = n_runs > cigar_cap ? 1u : 0u;
+                open = false;
+            }
+        }
+    };
+    for (uint32_t r = 0;; r++) {
+        if (r != 0u) consume((r - 1u) & 1u);
+        __syncthreads();
+        if (all_done(r)) {
+            consume(r & 1u);
+            break;
+        }
+    }
+}
+
+hipError_t launch_align_lane_split(const AlignArgs& a, int grid, hipStream_t s)
+{
+    // grid counts PRODUCER wavefronts (64 pairs in flight each); a workgroup is four of them and their four consumers
+    const dim3 g((grid + 3) / 4), b(512);
+    hipLaunchKernelGGL(genasm_lane_split_kernel, g, b, SPLIT_WG_LDS_BYTES, s, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_align_lane(const AlignArgs& a, int grid, size_t lds_bytes, hipStream_t s, bool edits)
 {
     // grid counts wavefronts, lds_bytes is per wavefront

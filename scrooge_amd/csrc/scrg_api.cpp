@@ -381,6 +381,19 @@ static scrg_status align_device_impl(scrg_ctx* c, const scrg_params* params, uin
     if (s != SCRG_OK) return s;
     // no point in launching more slots than pairs
     const uint64_t need_waves = (n_pairs + ppw - 1) / ppw;
+    // One pair per lane, runs output, the default table (W <= 64, W-O <= 31): a launch of at most one wavefront per SIMD (65 536
+    // pairs on 1024 SIMDs) is bound by the chain of a pair's windows, not by issue slots — it runs with a window's work split
+    // over a producer and a consumer wavefront (genasm_lane_split_kernel: 1.93 -> 1.50 ms for 25 k ... 50 k x 10 kb pairs, the
+    // chunks of the host entry points included).  From two wavefronts on some SIMDs on the split gains nothing (100 k pairs:
+    // 2.51 vs 2.52 ms: those SIMDs are the last to finish either way), and launches that fill the GPU or overlap with others —
+    // and edit-stream output — keep the one-wavefront kernel (3 % fewer instructions).  reserved[0]: 512 / 1024 force one or the other.
+    bool lane_split = false;
+    if (!edits && p.lanes_per_pair == 1 && p.W <= 64 && p.W - p.O <= 31 && !(p.reserved[0] & scrg::SCRG_SWITCH_NO_SPLIT) &&
+        !(params && params->reserved[1])) {
+        const uint64_t simds = 4ull * (uint64_t)c->n_cus;
+        lane_split = (p.reserved[0] & scrg::SCRG_SWITCH_SPLIT) != 0 || ((!params || params->waves_per_cu == 0) && need_waves <= simds);
+        if (lane_split) n_waves = c->n_cus * scrg::LANE_SPLIT_PRODUCERS_PER_CU;
+    }
     if ((uint64_t)n_waves > need_waves) n_waves = (int32_t)need_waves;
 
     HIP_TRY(c, c->counter.ensure(sizeof(uint32_t)));
@@ -430,6 +443,8 @@ static scrg_status align_device_impl(scrg_ctx* c, const scrg_params* params, uin
         HIP_TRY(c, scrg::launch_align_lane_mw(a, n_waves, (size_t)lds, c->stream, edits));
     else if (p.W > 64)
         HIP_TRY(c, scrg::launch_align_multiword(p.lanes_per_pair, a, n_waves, (size_t)lds, c->stream));
+    else if (lane_split)
+        HIP_TRY(c, scrg::launch_align_lane_split(a, n_waves, c->stream));
     else if (p.lanes_per_pair == 1)
         HIP_TRY(c, scrg::launch_align_lane(a, n_waves, (size_t)lds, c->stream, edits));
     else

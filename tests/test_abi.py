@@ -90,17 +90,17 @@ def test_product_does_not_reference_oracle():
 
 
 def test_unknown_experiment_switches_are_rejected(lib):
-    """scrg_params.reserved[] in the SHIPPED library: only the two documented selections between formulations that give
-    identical results pass (32: no diagonal-major path for lanes_per_pair = 8; 256: the table-in-HBM kernel where the
-    table-in-registers one would serve).  The scheduling switches (1, 64, 128), the counters (reserved[1]) and the
+    """scrg_params.reserved[] in the SHIPPED library: only the documented selections between formulations that give
+    identical results pass (32: no diagonal-major path for lanes_per_pair = 8; 256: the table-in-HBM kernel where a
+    table-in-registers one would serve; 512 / 1024: the default kernel as two wavefronts per 64 pairs / as one).  The scheduling switches (1, 64, 128), the counters (reserved[1]) and the
     ablation switches (2, 4, 8, 16) belong to the profiling builds (-DSCRG_STATS / -DSCRG_ABLATE, scripts/ab.sh); here
     they, and anything an uninitialised struct might hold, are SCRG_ERR_INVALID_ARG — and the kernels contain none of
     that code (scrg_build_flags() == 0)."""
     import ctypes as C
     assert lib.scrg_build_flags() == 0, "the in-tree library must be the shipped build (no -DSCRG_STATS / -DSCRG_ABLATE)"
     p, out = api.Params(), api.Params()
-    for flags, ok in ((0, True), (32, True), (256, True), (32 | 256, True), (1, False), (64 | 1, False), (128, False), (64, False),
-                      (2, False), (4, False), (8, False), (16, False), (0x7fffffff, False), (-1, False), (512, False)):
+    for flags, ok in ((0, True), (32, True), (256, True), (32 | 256, True), (512, True), (1024, True), (1, False), (64 | 1, False), (128, False),
+                      (64, False), (2, False), (4, False), (8, False), (16, False), (0x7fffffff, False), (-1, False), (2048, False)):
         lib.scrg_params_default(C.byref(p))
         p.reserved[0] = flags
         assert (lib.scrg_params_resolve(C.byref(p), C.byref(out)) == api.SCRG_OK) == ok, flags

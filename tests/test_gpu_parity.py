@@ -263,6 +263,40 @@ def test_table_in_parts(aligner, oracle, w, o):
         aligner.params = keep
 
 
+@pytest.mark.parametrize("w,o", [(64, 33), (64, 40), (64, 60), (33, 2), (32, 17), (2, 1), (48, 24), (17, 9), (63, 32)])
+def test_one_and_two_wavefronts_per_window_agree(aligner, oracle, w, o):
+    """The default table (W <= 64, W-O <= 31) exists as one wavefront per 64 pairs (genasm_lane_kernel) and with a window's
+    work split over a producer and a consumer wavefront (genasm_lane_split_kernel: what a launch that cannot fill the SIMDs
+    takes by default, i.e. every small batch in this test suite).  reserved[0] = 512 / 1024 force one or the other: both must
+    give the CPU checker's results — long and short reads, unrelated and low-complexity sequences, ragged and empty inputs
+    (a pair of no windows is handed over as first and last at once), more pairs than one wavefront holds (lanes refill from
+    the queue while their neighbours are in the middle of a pair)."""
+    t, q = synth.make_pairs(200, 1500, "ont", seed=w * 11 + o)
+    a, b = synth.make_pairs(60, 2500, "pacbio15", seed=w + o + 5)
+    c, d = synth.make_pairs(300, 200, "illumina", seed=w + o + 6)
+    t, q = t + a + c, q + b + d
+    rng = np.random.Generator(np.random.PCG64(w * 7 + o))
+    for _ in range(150):
+        t.append(synth.random_seq(int(rng.integers(0, 500)), rng))
+        q.append(synth.random_seq(int(rng.integers(0, 500)), rng))
+    for _ in range(40):
+        t.append(bytes(rng.choice(np.frombuffer(b"AC", np.uint8), int(rng.integers(1, 400)))))
+        q.append(bytes(rng.choice(np.frombuffer(b"AC", np.uint8), int(rng.integers(1, 400)))))
+    t += [b"", b"ACGT", b"A" * 300, b"A" * 10, b"ACGT" * 100, b"", b"ACGT"] + [b"ACGT"] * 70
+    q += [b"ACGT", b"", b"A" * 10, b"A" * 300, b"TGCA" * 100, b"", b"A"] + [b""] * 70
+    eds, cigars, _, _ = oracle.align(t, q, W=w, O=o, threads=8)
+    for flags, name in ((512, "two wavefronts per window"), (1024, "one wavefront"), (0, "default")):
+        p = aligner.make_params(W=w, O=o)
+        p.reserved[0] = flags
+        keep = aligner.params
+        aligner.params = p
+        try:
+            _check(aligner.align_pairs(t, q), eds, cigars, "W=%d O=%d, %s" % (w, o, name))
+            _check(aligner.align_pairs(t, q, sort_by_length=0), eds, cigars, "W=%d O=%d, %s, caller order" % (w, o, name))
+        finally:
+            aligner.params = keep
+
+
 def test_windows_over_64_limits(aligner):
     import scrooge_amd
     with pytest.raises(scrooge_amd.ScroogeError):

@@ -385,7 +385,7 @@ def test_full_bench_size_two_algorithms_agree(aligner):
         desc = torch.stack([idx * (tw + rw) * 32, torch.full_like(idx, text_len), (idx * (tw + rw) + tw) * 32,
                             torch.full_like(idx, L), idx * cap, torch.full_like(idx, cap)], dim=1).contiguous()
         res = []
-        for lanes, flags in ((1, 0), (8, 0), (8, 32)):           # 32: diagonal path off
+        for lanes, flags in ((1, 0), (1, 1024), (8, 0), (8, 32)):           # 1024: one wavefront per 64 pairs (the default at this size: two); 32: diagonal path off
             p = aligner.make_params(lanes_per_pair=lanes)
             p.reserved[0] = flags
             keep, aligner.params = aligner.params, p
