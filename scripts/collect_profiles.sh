@@ -12,7 +12,7 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 python3 -c "import sys; sys.path.insert(0, '$root'); import scrooge_amd; scrooge_amd.build_library(); from oracle.pyoracle import build; build()" || exit 1
 export SCRG_LIB=$root/scrooge_amd/libscrooge_amd.so
 mkdir -p $root/gpurun_out/prof_$tag
-(cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $root/gpurun_out/prof_$tag -o prof --output-format csv -- \
+(cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $root/gpurun_out/prof_$tag -o prof --output-format csv -- \
     python3 $root/bench.py --no-build > $root/gpurun_out/prof_$tag/bench.json 2> $root/gpurun_out/prof_$tag/bench.err)
 tail -c 400 $root/gpurun_out/prof_$tag/bench.json; echo
 mkdir -p $root/gpurun_out/prof_${tag}_serial

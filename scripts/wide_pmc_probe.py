@@ -1,5 +1,5 @@
 """Three launches of the one-pair-per-lane aligner at a given W/O on the bench workload, for rocprofv3 --pmc
-(scripts/wide_pmc.sh), and the window rounds the kernel counted: python3 scripts/wide_pmc_probe.py W O [pairs]"""
+(scripts/wide_pmc.sh: the shipped library), and — run with a -DSCRG_STATS build, not under the profiler — the window rounds the kernel counted: python3 scripts/wide_pmc_probe.py W O [pairs]"""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -24,12 +24,14 @@ desc = torch.stack([first * 32, torch.full_like(idx, text_len), (first + tw * G)
 runs = torch.empty(n * cap * 2, dtype=torch.uint8, device=dev)
 ed = torch.empty(n, dtype=torch.int64, device=dev); nr = torch.empty(n, dtype=torch.int32, device=dev); st = torch.empty(n, dtype=torch.int32, device=dev)
 p = al.make_params(W=W, O=O, text_stride_words=G, read_stride_words=G)
-p.reserved[1] = 1
+stats = bool(scrooge_amd.load_library().scrg_build_flags() & 1)         # the kernels' own counters: a -DSCRG_STATS build only
+if stats:
+    p.reserved[1] = 1
 al.params = p
 ms = []
 for rep in range(3):
     al.align_device(n, seq, desc, runs, ed, nr, st)
     ms.append(al.last_kernel_ms())
-rounds = al.debug_stats_lane()["rounds"]
+rounds = al.debug_stats_lane()["rounds"] if stats else None
 print(json.dumps({"W": W, "O": O, "pairs": n, "read_len": L, "kernel_ms": ms, "window_rounds_per_launch": rounds,
-                  "windows_per_pair": rounds * 64 / n, "mean_edit_distance": float(ed.double().mean())}))
+                  "windows_per_pair": (rounds * 64 / n) if rounds else None, "mean_edit_distance": float(ed.double().mean())}))

@@ -280,3 +280,35 @@ def test_edit_stream_gather_rotating_root():
         for r in range(2):
             ed, stream, off = got[rank][k][r]
             assert ed == [100 * r + k, 7] and stream == [10 * r + k, 1, 2, 0, 99] and off == [0, 4]
+
+
+def test_bench_self_launch_relays_the_ranks_exit_code():
+    """`python bench.py --gpus 2` without a launcher (no WORLD_SIZE): the parent builds, then starts its two ranks as a fresh
+    torch.distributed.run child — it never touches the GPU itself — and exits with the child's code.  Without a GPU the ranks
+    refuse to run ("the HIP path has no CPU fallback"): what must come back is THEIR failure, promptly, not a hang and not the
+    old "WORLD_SIZE != --gpus" refusal of the parent."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the ranks would run (covered by tests/test_gpu_scale.py::test_bench_two_ranks_dry_run)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SCRG_BENCH_DRYRUN="1")
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--pairs", "640",
+                          "--read-len", "500", "--cpu-seconds", "0"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0
+    assert "needs a GPU" in out.stderr and "WORLD_SIZE" not in out.stderr.split("needs a GPU")[0][-300:]
+    assert not [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
+
+
+def test_bench_self_launch_refuses_more_ranks_than_gpus():
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("SCRG_BENCH_DRYRUN", None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64", "--no-build"], env=env, cwd=root,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "this node has" in out.stderr

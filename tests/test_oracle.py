@@ -95,3 +95,37 @@ def test_oracle_matches_reference_build_random(oracle):
     e2, c2, _ = ref.align(T, Q)
     assert e1 == e2
     assert c1 == c2
+
+
+def test_rows_interface_with_per_row_lengths(oracle):
+    """The array interface bench.py uses (a text slot and a read slot per row, results as run arrays) with every row's own
+    lengths — the mixed-length batches of bench.py's other_configs — gives what the per-pair interface gives, through the
+    restatement and, where it is built, through the reference itself (oracle/ref_driver.cpp: ref_align_rows_var)."""
+    import numpy as np
+    from scrooge_amd import synth
+    t, q = synth.make_pairs(40, 600, "ont", seed=77)
+    rows = np.zeros((40, 1536), np.uint8)
+    tl, rl = [], []
+    for k in range(40):
+        a, b = t[k][:300 + 9 * k], q[k][:200 + 10 * k]
+        if k == 7:
+            a, b = b"", b[:50]
+        if k == 9:
+            b = b""
+        rows[k, :len(a)] = np.frombuffer(a, np.uint8)
+        rows[k, 768:768 + len(b)] = np.frombuffer(b, np.uint8)
+        tl.append(len(a))
+        rl.append(len(b))
+    texts = [bytes(rows[k, :tl[k]]) for k in range(40)]
+    reads = [bytes(rows[k, 768:768 + rl[k]]) for k in range(40)]
+    for W, O in ((64, 33), (128, 65)):
+        eds, cigars, _, _ = oracle.align(texts, reads, W=W, O=O)
+        e, off, runs, st, _ = oracle.align_rows(rows, 0, 768, 768, 768, W=W, O=O, threads=2, text_lens=tl, read_lens=rl)
+        got = ["".join("%d%s" % (runs[j, 0], chr(runs[j, 1])) for j in range(int(off[k]), int(off[k + 1]))) for k in range(40)]
+        assert list(e) == eds and got == cigars
+        if Reference.available(W, O):
+            e2, off2, runs2, _ = Reference(W, O).align_rows(rows, 0, 768, 768, 768, threads=2, text_lens=tl, read_lens=rl)
+            assert list(e2) == eds and (off2 == off).all() and (runs2 == runs).all()
+    # a length beyond its slot is an error, not an overrun
+    with pytest.raises(RuntimeError):
+        oracle.align_rows(rows, 0, 768, 768, 768, text_lens=[769] * 40, read_lens=rl)
