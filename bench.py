@@ -1301,6 +1301,14 @@ def main():
             run_other_config(torch, scrooge_amd, device, local_rank, streams,
                              "knob sweep point W=128 O=65: 100 k x 10 kb ONT-error pairs", 100000, 10000, "ont", 10, 2, 2000 if chk else 0,
                              args.seed + 15, cores_, W=128, O=65),
+            # ... and two of its large-window points (:180-185; 64 <= W-O <= 127, vectors of 3 and 4 words): genasm_lane_parts_kernel
+            # (table in registers, in parts of 16 columns re-swept from checkpoints)
+            run_other_config(torch, scrooge_amd, device, local_rank, streams,
+                             "knob sweep point W=192 O=97: 100 k x 10 kb ONT-error pairs", 100000, 10000, "ont", 6, 2, 1000 if chk else 0,
+                             args.seed + 18, cores_, W=192, O=97),
+            run_other_config(torch, scrooge_amd, device, local_rank, streams,
+                             "knob sweep point W=256 O=129: 100 k x 10 kb ONT-error pairs", 100000, 10000, "ont", 6, 2, 1000 if chk else 0,
+                             args.seed + 19, cores_, W=256, O=129),
         ]
 
     if host_api is not None and other_configs:

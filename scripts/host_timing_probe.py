@@ -1,7 +1,7 @@
 """The host entry points' own timeline (SCRG_HOST_TIMING=1: stage times per chunk on stderr) for scrg_align_pairs on unique
 synthetic pairs held in one host array.   usage: python scripts/host_timing_probe.py [pairs=20000] [outputs=1] [reps=3]"""
 import os, sys, time
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 os.environ["SCRG_HOST_TIMING"] = "1"
 import numpy as np, torch
 import scrooge_amd, bench

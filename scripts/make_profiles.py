@@ -43,7 +43,7 @@ kernel_stats(os.path.join(go, "prof_%s" % tag), os.path.join(pr, "%s_kernel_stat
              "`python bench.py` (default command: 100k x 10kb pairs, steps rotate over 4 streams); bench line of the same run: "
              "value %.4g pairs/s, kernel_ms %.4g (stand-alone launches after the timed region), kernel_ms_events_in_timed_region %.4g; "
              "the launches beyond the warm-up and the 20 timed ones are the legs the same command runs after its timed region: 3 stand-alone, "
-             "150 `sustained`, and (genasm_lane_kernel<true>) the `edit_stream_step`"
+             "600 `sustained`, (genasm_lane_kernel<true>) the `edit_stream_step`, `other_configs` and the host-API legs"
              % ((b["value"], b["kernel_ms"], b["kernel_ms_events_in_timed_region"]) if b else (0, 0, 0)))
 bs = bench_line(os.path.join(go, "prof_%s_serial" % tag, "bench.json"))
 kernel_stats(os.path.join(go, "prof_%s_serial" % tag), os.path.join(pr, "%s_kernel_stats_serial.csv" % rnd),

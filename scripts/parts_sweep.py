@@ -2,7 +2,7 @@
 for these W/O (genasm_lane_mw_kernel, table in HBM: reserved[0] = 256) on the bench workload, single launches.
 usage: python scripts/parts_sweep.py [pairs=100000] [layout=linear|groups]"""
 import json, sys
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torch
 import scrooge_amd, bench
 from scrooge_amd import synth

@@ -1,7 +1,7 @@
 """Kernel time of one launch of the default table's two kernels (reserved[0] = 512: a window's work on two wavefronts, 1024: on one)
 on the bench workload; no result checks (for experiment builds).  usage: python scripts/split_time.py [pairs=100000]"""
 import sys
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torch
 import scrooge_amd, bench
 from scrooge_amd import synth

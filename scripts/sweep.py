@@ -5,11 +5,11 @@ configuration with the reference's column names where a knob has an equivalent h
 
 W and O are runtime parameters here (the reference recompiles per configuration, profile.py:131-142);
 supported range 2 <= W <= 256, 1 <= O < W (one pair per lane: W-O <= 31 genasm_lane_kernel, 32 <= W-O <= 63 and W <= 128
-genasm_lane_wide_kernel — table in registers, built in two halves —, beyond that genasm_lane_mw_kernel, table in HBM).  "threadblocks/sm" = persistent wavefronts per CU,
+genasm_lane_wide_kernel — table in registers, built in two halves —, 64 <= W-O <= 127 genasm_lane_parts_kernel — table in registers, in parts of 16 columns —, beyond that genasm_lane_mw_kernel, table in HBM).  "threadblocks/sm" = persistent wavefronts per CU,
 "used smem per threadblock (B)" = LDS bytes per wavefront; SENE/DENT/ET are always on (they do not
 change results)."""
 import csv, sys
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torch
 import scrooge_amd, bench
 from scrooge_amd import synth
@@ -40,12 +40,15 @@ configs += [(W, min(W // 2 + 1, W - 1), 0, 0, 0) for W in (16, 24, 32, 40, 48, 5
 configs += [(64, O, 0, 0, 0) for O in (36, 40, 48, 56, 60)]                                    # O sweep at W=64 (profile.py:88-100): lane kernel
 configs += [(64, O, 0, 0, 0) for O in (2, 16, 32)]                                              # small overlaps (W-O > 31): genasm_lane_wide_kernel (64-bit rows, table in registers in two halves)
 configs += [(64, O, 8, 13, 3) for O in (2, 16, 32)]                                             # the same on the GenASM-row kernel (G=8, WIDE storage)
-configs += [(W, W // 2 + 1, 0, 0, 0) for W in (80, 96, 112, 128, 160, 192, 224, 256)]         # W sweep past one word (profile.py:180-185): genasm_lane_wide_kernel up to W=128, genasm_lane_mw_kernel beyond
+configs += [(W, W // 2 + 1, 0, 0, 0) for W in (80, 96, 112, 128, 160, 192, 224, 256)]         # W sweep past one word (profile.py:180-185): genasm_lane_wide_kernel up to W=128, genasm_lane_parts_kernel beyond
 configs += [(128, 20, 0, 0, 0), (256, 1, 0, 0, 0)]                                               # rows of two and four words
 configs += [(W, W // 2 + 1, 32, 0, 0) for W in (96, 128, 192, 256)]                              # the same on the GenASM-row kernel with multi-word entries
 configs += [(128, 65, 64, 0, 0), (256, 129, 64, 0, 0), (256, 129, 32, 20, 0)]
 configs += [(64, 33, g, 13, w) for g, w in ((64, 16), (32, 16), (16, 16), (8, 11), (4, 6))]    # the GenASM-row lane mappings
 configs += [(64, 33, 1, 0, w) for w in (4, 8, 12, 16)]                                          # one pair per lane: waves per CU
+for _ in range(4):                     # (warm-up: the first launches of a process run at a lower clock)
+    al.align_device(n, seq, desc, runs, ed, nr, st)
+torch.cuda.synchronize()
 with open(out, "w", newline="") as f:
     wr = csv.writer(f)
     wr.writerow(["W", "O", "sene", "dent", "early termination", "threadblocks/sm", "lanes per pair", "lds rows",

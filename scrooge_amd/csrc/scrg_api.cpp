@@ -391,7 +391,7 @@ static scrg_status align_device_impl(scrg_ctx* c, const scrg_params* params, uin
     if (!edits && p.lanes_per_pair == 1 && p.W <= 64 && p.W - p.O <= 31 && !(p.reserved[0] & scrg::SCRG_SWITCH_NO_SPLIT) &&
         !(params && params->reserved[1])) {
         const uint64_t simds = 4ull * (uint64_t)c->n_cus;
-        lane_split = (p.reserved[0] & scrg::SCRG_SWITCH_SPLIT) != 0 || ((!params || params->waves_per_cu == 0) && need_waves <= simds);
+        lane_split = (p.reserved[0] & scrg::SCRG_SWITCH_SPLIT) != 0 || need_waves <= simds;
         if (lane_split) n_waves = c->n_cus * scrg::LANE_SPLIT_PRODUCERS_PER_CU;
     }
     if ((uint64_t)n_waves > need_waves) n_waves = (int32_t)need_waves;
