@@ -515,9 +515,23 @@ class Aligner:
     def set_stream(self, stream_handle):
         """stream_handle: a hipStream_t as an integer (0 = the device's null stream)."""
         self._check(self.lib.scrg_ctx_set_stream(self.h, C.c_void_p(stream_handle)))
+        self._stream = int(stream_handle)
 
     def use_own_stream(self):
         self._check(self.lib.scrg_ctx_use_own_stream(self.h))
+        self._stream = None
+
+    def restore_stream(self, saved):
+        """saved: what `stream_setting` returned — the handle enqueues where it did then."""
+        if saved is None:
+            self.use_own_stream()
+        else:
+            self.set_stream(saved)
+
+    @property
+    def stream_setting(self):
+        """None: the handle's own stream; else the hipStream_t (integer) given to set_stream."""
+        return getattr(self, "_stream", None)
 
     def pack_planar(self, ascii_u8, planar_u64, bad_u32):
         n_words = ascii_u8.numel() // 32

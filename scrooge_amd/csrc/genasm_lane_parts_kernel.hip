@@ -45,7 +45,6 @@ constexpr int PT_XH = bitop3_table([](int sum, int pv, int eq) { return (sum ^ p
 constexpr int PT_PH = bitop3_table([](int mv, int xh, int pv) { return mv | ~(xh | pv); });
 constexpr int PT_PVN = bitop3_table([](int mhs, int xv, int phs) { return mhs | ~(xv | phs); });
 constexpr int PT_NOR3 = bitop3_table([](int a, int b, int c) { return ~(a | b | c); });
-constexpr int PT_NIV = bitop3_table([](int nv1, int v0, int stop) { return nv1 | ~v0 | stop; });
 constexpr int PT_ANDN = bitop3_table([](int a, int b, int) { return a & ~b; });
 constexpr int PT_BFI = bitop3_table([](int a, int b, int c) { return (a & c) | (b & ~c); });
 constexpr int PT_ANDOR = bitop3_table([](int a, int b, int c) { return (a & b) | c; });
@@ -53,7 +52,6 @@ constexpr int PT_V0 = bitop3_table([](int pvn, int ph, int xh) { return pvn | ~(
 
 typedef uint32_t pt_u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) pt_u32x2 pt_lds_u32x2;
-typedef __attribute__((address_space(3))) uint32_t pt_lds_u32;
 __device__ __forceinline__ uint2 pt_lds_read64(uint32_t addr)
 {
     const pt_u32x2 v = *reinterpret_cast<const pt_lds_u32x2*>((uintptr_t)addr);
@@ -66,8 +64,6 @@ __device__ __forceinline__ void pt_lds_write64(uint32_t addr, uint2 v)
     w.y = v.y;
     *reinterpret_cast<pt_lds_u32x2*>((uintptr_t)addr) = w;
 }
-__device__ __forceinline__ uint32_t pt_lds_read32(uint32_t addr) { return *reinterpret_cast<const pt_lds_u32*>((uintptr_t)addr); }
-__device__ __forceinline__ void pt_lds_write32(uint32_t addr, uint32_t v) { *reinterpret_cast<pt_lds_u32*>((uintptr_t)addr) = v; }
 __device__ __forceinline__ uint32_t pt_ffbh(uint32_t v)      // count leading zeros; 0xffffffff for v == 0
 {
     uint32_t r;
@@ -478,6 +474,10 @@ __global__ __launch_bounds__(256, 2) void genasm_lane_parts_kernel(AlignArgs a)
             sweep_chunk(k, std::false_type{});
         }
         sweep_chunk(0, std::true_type{});
+        // the next part's checkpoint is asked for as soon as the vectors are free, so that the walk hides the round trip — where
+        // the registers allow: with four-word vectors the 16 dwords in flight across the walk would spill (20-26 registers)
+        constexpr bool PREFETCH = NW <= 3;
+        if (PREFETCH && P > 1u) load_checkpoint(1u, st);
 
         // ---------------- the parts: (table,) walk, runs ----------------
         uint32_t j = 0;                                    // pattern row of the walk
@@ -488,8 +488,9 @@ __global__ __launch_bounds__(256, 2) void genasm_lane_parts_kernel(AlignArgs a)
             const uint32_t ncols = min((uint32_t)PT_COLS, TBL - (uint32_t)PT_COLS * part);
             if (part != 0u) {
                 if (!__any(alive)) break;
-                load_checkpoint(part, st);
-                sweep_chunk((int32_t)part, std::true_type{});
+                if (!PREFETCH) load_checkpoint(part, st);
+                sweep_chunk((int32_t)part, std::true_type{});           // (st: the checkpoint in front of this chunk)
+                if (PREFETCH && part + 1u < P) load_checkpoint(part + 1u, st);
             }
             // pass 1 (see genasm_lane_kernel): the walk through this part's columns, on 128-bit rows
             const uint32_t j0 = j;

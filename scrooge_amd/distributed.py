@@ -394,10 +394,17 @@ class EditStreamGather:
             d = self.dec[b]
             d.update(len=ln, cnt=cnt, off=off, run_off=doff)
             d["bad"].zero_()
+            # the caller's handle enqueues on the decode stream for this one call only: whatever it aligned on before, it
+            # aligns on afterwards (a caller may pass the handle it also aligns with)
+            saved = aligner.stream_setting if self.is_cuda else None
             if self.is_cuda:
                 aligner.set_stream(dec_stream.cuda_stream)
-            aligner.decode_edit_stream(W * n * sim, self.recv_all[b], d["off"], ln, read_len, read_len_stride, doff, self.dense[b],
-                                       cnt, d["bad"], **(params or {}))
+            try:
+                aligner.decode_edit_stream(W * n * sim, self.recv_all[b], d["off"], ln, read_len, read_len_stride, doff, self.dense[b],
+                                           cnt, d["bad"], **(params or {}))
+            finally:
+                if self.is_cuda:
+                    aligner.restore_stream(saved)
             if self.is_cuda:
                 self.dec_event[b] = torch.cuda.Event()
                 self.dec_event[b].record(dec_stream)
@@ -408,6 +415,13 @@ class EditStreamGather:
         b = k % self.DEPTH
         d = dict(self.dec[b])
         d["runs"] = self.dense[b]
+        if self.is_cuda:
+            # the tensors were made (and are rewritten, DEPTH steps later) on the decode stream; whoever reads them on the
+            # current stream must be known to the caching allocator
+            cur = torch.cuda.current_stream()
+            for v in d.values():
+                if isinstance(v, torch.Tensor) and v.is_cuda:
+                    v.record_stream(cur)
         return d
 
     def decode(self, aligner, k, r, read_len, read_len_stride, **params):

@@ -362,9 +362,12 @@ def test_bench_two_ranks_dry_run(gather_root, root_share):
 def test_full_bench_size_two_algorithms_agree(aligner):
     """BASELINE configs[1] at full size (100k x 10 kb ONT-error pairs, generated on the GPU like bench.py):
     the lane-per-pair kernel (difference vectors, the default) and the diagonal-major and column-major window
-    paths of the G = 8 kernel (GenASM rows) are three independent formulations of the same table; every edit
+    paths of the G = 8 kernel (GenASM rows) are three independent formulations of the same table (the lane-per-pair kernel
+    in both of its forms: at this size the library's choice, and one wavefront per 64 pairs forced); every edit
     distance, run count and run must be identical between them, the edit distances must respect the read
-    length and error rate, and 500 sampled pairs must validate against their sequences."""
+    length and error rate, 500 sampled pairs must validate against their sequences — and the first 20 000 pairs are
+    compared, run for run, with the reference CPU path itself (oracle/_ref where it was built, else the restatement):
+    the full-batch comparison that every default `bench.py` run does, here inside the test suite."""
     import torch
     import bench
     import scrooge_amd
@@ -373,7 +376,8 @@ def test_full_bench_size_two_algorithms_agree(aligner):
     n, L = 100000, 10000
     err, ratio = synth.PROFILES["ont"]
     rows, tw, rw, text_len = bench.device_pairs(torch, n, L, err, ratio, 4242, dev)
-    sample = rows[:500].cpu().numpy()
+    n_ref = 20000
+    sample = rows[:n_ref].cpu().numpy()
     seq = torch.zeros(n * (tw + rw) + scrooge_amd.api.SEQ_PAD_WORDS, dtype=torch.int64, device=dev)
     bad = torch.zeros(1, dtype=torch.int32, device=dev)
     aligner.set_stream(0)
@@ -443,6 +447,17 @@ def test_full_bench_size_two_algorithms_agree(aligner):
         text = bytes(sample[k, :text_len])
         read = bytes(sample[k, tw * 32: tw * 32 + L])
         assert validate(text, read, cigar, int(ed0[k])) is None
+    # the reference CPU path on the first n_ref pairs: edit distances, run offsets and the runs as arrays
+    import numpy as np
+    from oracle.pyoracle import Oracle, Reference
+    if Reference.available():
+        e_cpu, off_cpu, runs_cpu, _ = Reference().align_rows(sample, 0, text_len, tw * 32, L, threads=16)
+    else:
+        e_cpu, off_cpu, runs_cpu, _, _ = Oracle().align_rows(sample, 0, text_len, tw * 32, L, threads=16)
+    cnt = np.asarray(c[:n_ref], dtype=np.uint64)
+    off_gpu = np.concatenate([np.zeros(1, np.uint64), np.cumsum(cnt, dtype=np.uint64)])
+    assert (ed0[:n_ref].cpu().numpy() == e_cpu).all() and (off_gpu == off_cpu).all()
+    assert np.array_equal(h[: 2 * int(off_gpu[n_ref])].reshape(-1, 2), runs_cpu)
 
 
 def _device_align(aligner, torch, seq, desc, n, cap, **kw):
