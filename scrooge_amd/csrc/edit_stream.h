@@ -134,11 +134,11 @@ struct DecodeLane {
     uint32_t pos, end;          // next stream byte, end of the stream
     uint32_t m, e;              // matches pending, the edit after them (EDIT_OP_NONE: no edit byte has arrived yet)
     uint32_t tailM;             // mask: stream used up, the rest of the read matches
-    uint32_t left;              // read characters from the start of the current window to the end of the read
-    uint32_t jl, ri, rj;        // window: read limit min(left, L); text / read characters it can still take
+    uint32_t R;                 // read characters not placed yet
+    uint32_t ri, rj;            // window: text / read characters it can still take (rj starts at min(R, L))
     uint32_t cur, prev_e;       // run n - 1 as a word; the edit it consists of if the next edit may join it, else 0
     uint32_t n;                 // runs started
-    uint32_t aliveM, bad;       // mask: the read is not finished; the stream is not an alignment of this read
+    uint32_t aliveM;            // mask: the read is not finished
 };
 
 SCRG_HD inline void decode_lane_init(DecodeLane& s, uint32_t W, uint32_t O, uint32_t pos, uint32_t end, uint32_t read_len)
@@ -147,17 +147,17 @@ SCRG_HD inline void decode_lane_init(DecodeLane& s, uint32_t W, uint32_t O, uint
     s.pos = pos;
     s.end = end;
     s.m = s.e = s.tailM = 0;
-    s.left = read_len;
-    s.jl = read_len < s.L ? read_len : s.L;
+    s.R = read_len;
     s.ri = s.L;
-    s.rj = s.jl;
+    s.rj = read_len < s.L ? read_len : s.L;
     s.cur = s.prev_e = s.n = 0;
     s.aliveM = read_len != 0 ? ~0u : 0u;
-    s.bad = 0;
 }
 
-// true when the pair is finished: every byte used, nothing pending (the counterpart of replay_edit_stream's last line)
-SCRG_HD inline bool decode_lane_clean(const DecodeLane& s) { return !s.bad && s.pos == s.end && s.m == 0 && s.e == EDIT_OP_NONE; }
+// true when the pair is finished: every byte used, nothing pending (the counterpart of replay_edit_stream's last line).
+// (A stream that overruns its read leaves matches or an edit pending, or bytes unused; one that ends early is completed by
+// the tail rule below — the read's remaining characters match — so a lane never waits for input that does not come.)
+SCRG_HD inline bool decode_lane_clean(const DecodeLane& s) { return s.pos == s.end && s.m == 0 && s.e == EDIT_OP_NONE; }
 
 template <typename Put>
 SCRG_HD inline uint32_t decode_lane_step(DecodeLane& s, const uint32_t bn0, Put&& put)      // -> 1 if the byte at pos was consumed
@@ -173,10 +173,9 @@ SCRG_HD inline uint32_t decode_lane_step(DecodeLane& s, const uint32_t bn0, Put&
     s.pos -= takeM;
     // the stream is used up (once per pair): the matches after the last edit are implied by the read length (op-0 bytes
     // pending are part of them; more of them than the read has left means the stream overruns the read: m then stays
-    // non-zero to the end and the pair is reported)
+    // non-zero to the end and the pair is reported).  From here on m >= R, so the lane ends exactly when its read does.
     const uint32_t tail_now = fetchM & ~hasM;
-    const uint32_t rest = s.left - (s.jl - s.rj);
-    s.m = es_sel(s.m < rest ? rest : s.m, s.m, tail_now);
+    s.m = es_sel(s.m < s.R ? s.R : s.m, s.m, tail_now);
     s.tailM |= tail_now;
     const uint32_t readyM = es_nz_mask(s.e) | s.tailM;
     // ---- the matches that fit the window: always a new run
@@ -184,6 +183,7 @@ SCRG_HD inline uint32_t decode_lane_step(DecodeLane& s, const uint32_t bn0, Put&
     s.m -= t;
     s.ri -= t;
     s.rj -= t;
+    s.R -= t;
     const uint32_t tnzM = es_nz_mask(t);
     const uint32_t wm = EQW | t;
     put(s.n, wm);                                                    // (t == 0: a free slot, rewritten by the next run)
@@ -194,27 +194,22 @@ SCRG_HD inline uint32_t decode_lane_step(DecodeLane& s, const uint32_t bn0, Put&
     const uint32_t doM = es_nz_mask(es_min(es_min(s.e, s.ri), s.rj)) & ~es_nz_mask(s.m);
     const uint32_t sameM = ~es_nz_mask(s.e ^ s.prev_e);
     const uint32_t mergeM = doM & sameM, newM = doM & ~sameM;
-    const uint32_t opw = ((0x44495800u >> (((s.e << 3) + 24u) & 31u)) & 0xff00u) | 1u;      // 'X', 'I', 'D' for e = 1, 2, 3
+    const uint32_t opw = (((0x44495800u >> ((s.e << 3) & 31u)) & 0xffu) << 8) | 1u;        // 'X', 'I', 'D' for e = 1, 2, 3 (bit field, shift-or)
     s.cur = es_sel(s.cur + 1u, es_sel(opw, s.cur, newM), mergeM);
     put(s.n + mergeM, s.cur);                                        // run n - 1 grows, or run n starts (or nothing changes)
     s.n -= newM;
     s.prev_e = es_sel(s.e, s.prev_e, doM);
     s.ri -= s.e & doM & 1u;                                          // X and D consume a text character,
-    s.rj -= (6u >> s.e) & doM & 1u;                                  // X and I a read character
+    const uint32_t jstep = (6u >> s.e) & doM & 1u;                   // X and I a read character
+    s.rj -= jstep;
+    s.R -= jstep;
     s.e &= ~doM;
     // ---- the window is full (genasm_cpu.cpp:307-310): the next one starts where it stopped, its run is flushed (:400-403)
     const uint32_t endM = ~es_nz_mask(es_min(s.ri, s.rj)) & s.aliveM;
-    s.left -= (s.jl - s.rj) & endM;
     s.prev_e &= ~endM;
-    const uint32_t jl_new = es_min(s.left, s.L);
-    s.jl = es_sel(jl_new, s.jl, endM);
     s.ri = es_sel(s.L, s.ri, endM);
-    s.rj = es_sel(jl_new, s.rj, endM);
-    s.aliveM &= es_nz_mask(s.left);
-    // nothing left to place and the read is not finished: not an alignment of this read
-    const uint32_t stuck = s.tailM & ~es_nz_mask(s.m) & ~endM & s.aliveM;
-    s.bad |= stuck;
-    s.aliveM &= ~stuck;
+    s.rj = es_sel(es_min(s.R, s.L), s.rj, endM);
+    s.aliveM &= es_nz_mask(s.R);                                     // (R = 0 ends the window too: rj <= R)
     return takeM & 1u;
 }
 

@@ -30,7 +30,7 @@ constexpr uint32_t DEC_RING = 64;                     // runs per lane in LDS
 constexpr uint32_t DEC_PIECE = 32;                    // runs per store pass: 64 bytes
 constexpr uint32_t DEC_OUT_STRIDE = 2u * DEC_RING + 16u;    // 16-byte aligned rows, lanes spread over the banks
 constexpr uint32_t DEC_WAVE_LDS = 64u * DEC_OUT_STRIDE;
-constexpr uint32_t DEC_FLUSH_AT = 48;                 // final runs in one lane's ring that start a store pass
+constexpr uint32_t DEC_FLUSH_AT = 32;                 // final runs in one lane's ring that start a store pass (looked at once per epoch: + <= 32 runs until the next look)
 constexpr int DEC_STEPS_PER_CHECK = 4;                // steps between two looks at the buffers (<= 2 runs and 1 byte per step)
 constexpr uint32_t DEC_EPOCH = 4;                     // iterations between two block moves: 16 steps, at most 16 bytes
 
@@ -212,8 +212,13 @@ __global__ __launch_bounds__(256) void decode_edits_kernel(DecodeArgs a)
             have -= took;
         }
         SCRG_DEC_T(t1);
-        if ((iter & (DEC_EPOCH - 1u)) == DEC_EPOCH - 1u) advance_blocks();       // (before this iteration's stores: the wait in it covers older ones only)
-        if (STORE) flush_pieces();
+        // Stores and the waits for stream blocks share one counter (vmcnt), and the wait in front of a block move cannot tell
+        // the stores of a data-dependent pass from the loads it is after: it waits for everything.  So the store passes run in
+        // the FIRST iteration of an epoch and the block move in the LAST: a store has three iterations (~2 us) to be
+        // acknowledged before anybody waits (passes in any iteration: the wait of the next move met stores a few hundred
+        // nanoseconds old — 8 slots 2.99 ms with stores against 1.99 ms without; now see DESIGN.md §3.7).
+        if ((iter & (DEC_EPOCH - 1u)) == DEC_EPOCH - 1u) advance_blocks();
+        if (STORE && (iter & (DEC_EPOCH - 1u)) == 0u) flush_pieces();
         SCRG_DEC_T(t2);
         top_up();
         SCRG_DEC_T(t3);

@@ -21,7 +21,7 @@ def run(calls=150, seed=1, verbose=True):
     t0 = time.time()
     for it in range(calls):
         kind = int(rng.integers(0, 4))
-        W, O = [(64, 33), (64, 33), (64, 2), (128, 65), (48, 24), (64, 40), (96, 49)][int(rng.integers(0, 7))]
+        W, O = [(64, 33), (64, 33), (64, 2), (128, 65), (48, 24), (64, 40), (96, 49), (192, 97), (256, 129)][int(rng.integers(0, 9))]
         outputs = int(rng.integers(0, 3))
         devices = [None, None, [0, 0], [0, 0, 0]][int(rng.integers(0, 4))]
         sort = int(rng.integers(0, 2))

@@ -41,7 +41,8 @@ for kw in ({}, {"sort_by_length": 0}, {"lanes_per_pair": 8, "lds_rows": 7}):
 m = min(len(T), 20000)
 for W, O in ((64, 63), (64, 40), (33, 2), (48, 24), (32, 17), (17, 9), (5, 2), (2, 1), (63, 32), (40, 9),
              (64, 2), (64, 20), (64, 1), (64, 32), (40, 5), (33, 1), (50, 18),         # this row: W-O > 31
-             (128, 65), (96, 49), (256, 129), (200, 50), (130, 1)):                      # W > 64: multi-word vectors
+             (128, 65), (96, 49), (256, 129), (200, 50), (130, 1),                       # W > 64: multi-word vectors
+             (160, 81), (192, 97), (128, 20), (224, 113), (255, 128)):                   # 64 <= W-O <= 127: the table in parts
     e2, c2, _, _ = Oracle().align(T[:m], Q[:m], W=W, O=O, threads=16)
     got = a.align_pairs(T[:m], Q[:m], W=W, O=O)
     bad = [i for i in range(m) if got[i].edit_distance != e2[i] or got[i].cigar != c2[i]]
@@ -54,7 +55,7 @@ import torch
 from tests.test_edit_stream import py_encode
 dev = torch.device("cuda", 0)
 a.set_stream(0)
-for W, O in ((64, 33), (48, 24), (33, 2), (64, 63), (64, 2), (50, 18), (128, 65), (256, 100)):
+for W, O in ((64, 33), (48, 24), (33, 2), (64, 63), (64, 2), (50, 18), (128, 65), (256, 100), (256, 129), (160, 81)):
     m = min(len(T), 12000)
     e2, c2, _, _ = Oracle().align(T[:m], Q[:m], W=W, O=O, threads=16)
     tw = (max(len(x) for x in T[:m]) + 31) // 32
