@@ -235,6 +235,11 @@ scrg_status scrg_pack_planar(scrg_ctx *ctx, const char *d_ascii, uint64_t n_word
  * ceil(n_rows / 64) * 64 * words_per_row words plus SCRG_SEQ_PAD_WORDS_STRIDED(64) readable words of padding. */
 scrg_status scrg_pack_planar_groups(scrg_ctx *ctx, const char *d_ascii, uint64_t n_rows, uint64_t words_per_row,
                                     uint64_t *d_planar, uint32_t *d_bad_count);
+/* The same packing of ONE sequence on the host, with the packer the host entry points use on their threads (AVX2 or scalar
+ * code, chosen at run time; no GPU, no handle): word w of the sequence goes to planar[w * stride_words] (stride 0 = 1), the
+ * words past the sequence up to n_words are zeroed.  SCRG_ERR_BAD_BASE if a byte is not one of ACGTacgt (the reference asserts,
+ * src/genasm_cpu.cpp:487-489).  A caller that stages its own device arrays can use it; the CPU tests hold it to the layout above. */
+scrg_status scrg_pack_planar_host(const char *ascii, uint64_t n_bases, uint64_t *planar, uint64_t stride_words, uint64_t n_words);
 #define SCRG_SEQ_PAD_WORDS_STRIDED(stride) (2 * (stride) + 2)
 
 /* One alignment problem.  Offsets are in bases from the start of d_seq: base k of a sequence with offset

@@ -161,6 +161,7 @@ def load_library():
         "scrg_genome_clear": (None, [vp]),
         "scrg_align_mapping_resident": (C.c_int32, [vp, vp, u64, vp, vp, vp, vp, vp, vp]),
         "scrg_pack_planar": (C.c_int32, [vp, vp, u64, vp, vp]),
+        "scrg_pack_planar_host": (C.c_int32, [vp, u64, vp, u64, u64]),
         "scrg_pack_planar_groups": (C.c_int32, [vp, vp, u64, u64, vp, vp]),
         "scrg_compact_runs_packed": (C.c_int32, [vp, vp, u64, vp, vp, vp, vp, vp]),
         "scrg_unpack_runs": (C.c_int32, [vp, u64, vp, vp]),
@@ -191,7 +192,7 @@ EXPORTED_SYMBOLS = [
     "scrg_last_error", "scrg_status_string", "scrg_set_log", "scrg_get_log", "scrg_device_count", "scrg_build_flags",
     "scrg_result_free", "scrg_result_pool_trim", "scrg_align_pairs", "scrg_align_mapping", "scrg_align_pairs_multi", "scrg_align_mapping_multi",
     "scrg_host_plan", "scrg_multi_release", "scrg_multi_last_error", "scrg_genome_set", "scrg_genome_clear",
-    "scrg_align_mapping_resident", "scrg_pack_planar", "scrg_pack_planar_groups",
+    "scrg_align_mapping_resident", "scrg_pack_planar", "scrg_pack_planar_host", "scrg_pack_planar_groups",
     "scrg_align_device", "scrg_align_device_edits", "scrg_compact_runs", "scrg_compact_runs_packed", "scrg_unpack_runs",
     "scrg_encode_edit_stream", "scrg_decode_edit_stream", "scrg_edit_stream_to_runs", "scrg_edit_stream_to_runs_lane", "scrg_runs_to_edit_stream", "scrg_ascii_to_twobit", "scrg_query_launch",
     "scrg_last_kernel_ms", "scrg_debug_stats"]

@@ -947,6 +947,12 @@ scrg_status scrg_host_plan(const scrg_params* params, int32_t n_devices, uint64_
     });
 }
 
+scrg_status scrg_pack_planar_host(const char* ascii, uint64_t n_bases, uint64_t* planar, uint64_t stride_words, uint64_t n_words)
+{
+    if ((n_bases && !ascii) || (n_words && !planar) || 32 * n_words < n_bases) return SCRG_ERR_INVALID_ARG;
+    return scrg_host::pack_planar_host(ascii, n_bases, planar, stride_words, n_words) ? SCRG_ERR_BAD_BASE : SCRG_OK;
+}
+
 void scrg_multi_release(void)
 {
     std::lock_guard<std::mutex> g(g_multi_mu);

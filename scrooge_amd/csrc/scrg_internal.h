@@ -278,6 +278,7 @@ struct Batch {                       // one call, caller order
     uint64_t genome_len = 0;
 };
 
+bool pack_planar_host(const char* ascii, uint64_t n_bases, uint64_t* planar, uint64_t stride_words, uint64_t n_words);     // true: a byte other than ACGTacgt
 void* state_create(int device);                 // per-device buffers, streams and handles of the path; nullptr if that fails
 void state_free(void* state);
 scrg_status genome_set(void* state, const char* genome, uint64_t genome_len, std::string* err);

@@ -77,3 +77,39 @@ def test_root_share_plan_of_the_bench():
                 n0, n = bench.root_share_plan(world, nominal, mode)
                 assert n0 % 64 == 0 and n % 64 == 0 and n0 + (world - 1) * n >= world * nominal
                 assert n0 + (world - 1) * n < world * nominal + 64 * world
+
+
+def test_host_packer_matches_the_layout():
+    """scrg_pack_planar_host — the packer of the host entry points (AVX2 or scalar, chosen at run time) — against the definition of the planar layout (include/scrooge_amd.h: bit k of the low dword of word w = bit 0 of
+    base 32 w + k's code, high dword = bit 1; A0 C1 G2 T3, lower case too; zero past the end) for lengths around every
+    block size, with a stride, and its verdict on bytes that are not bases (the reference asserts, src/genasm_cpu.cpp:487-489)."""
+    import ctypes as C
+    import numpy as np
+    import scrooge_amd
+    from scrooge_amd import api
+    scrooge_amd.build_library()
+    lib = api.load_library()
+    rng = np.random.Generator(np.random.PCG64(11))
+    code = {65: 0, 67: 1, 71: 2, 84: 3, 97: 0, 99: 1, 103: 2, 116: 3}
+    letters = np.frombuffer(b"ACGTacgt", np.uint8)
+    for n in [0, 1, 31, 32, 33, 63, 64, 65, 95, 127, 128, 129, 191, 200, 1000, 4097]:
+        for stride in (1, 3):
+            seq = letters[rng.integers(0, 8, n)]
+            n_words = (n + 31) // 32 + 2
+            out = np.full(n_words * stride + 1, 0x5555555555555555, dtype=np.uint64)
+            buf = seq.tobytes() + b"#"             # (one byte past the end must not be looked at)
+            st = lib.scrg_pack_planar_host(C.c_char_p(buf), n, out.ctypes.data_as(C.c_void_p), stride, n_words)
+            assert st == api.SCRG_OK, (n, stride)
+            want = np.zeros(n_words, dtype=np.uint64)
+            for k in range(n):
+                c = code[int(seq[k])]
+                want[k // 32] |= np.uint64((c & 1) << (k % 32)) | np.uint64((c >> 1) << (32 + k % 32))
+            assert (out[0: n_words * stride: stride] == want).all(), (n, stride)
+            if stride > 1:
+                assert (out[1: n_words * stride: stride] == 0x5555555555555555).all()      # only its own words are written
+        for pos in sorted(set([0, n // 2, n - 1])) if n else []:
+            bad = bytearray(letters[rng.integers(0, 8, n)].tobytes())
+            for b in (ord("N"), 0, 0x20, 0xC1, ord("B"), ord("@"), ord("U")):
+                bad[pos] = b
+                out = np.zeros((n + 31) // 32 + 1, dtype=np.uint64)
+                assert lib.scrg_pack_planar_host(C.c_char_p(bytes(bad)), n, out.ctypes.data_as(C.c_void_p), 1, len(out)) == api.SCRG_ERR_BAD_BASE, (n, pos, b)
