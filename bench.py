@@ -200,7 +200,7 @@ def pmc_instruction_count():
 
 
 def run_other_config(torch, scrooge_amd, device, local_rank, streams, name, n, L, profile, steps, warmup, check_pairs, seed, cores, W=64, O=33,
-                     len_range=None):
+                     len_range=None, waves_per_cu=0):
     """One more BASELINE configuration of the unstructured interface, measured the same way as the headline (pairs generated
     and packed on the GPU, lane-interleaved layout, steps = align kernel + run compaction rotating over the streams) after
     the timed region, with `check_pairs` pairs of the last step compared, runs and all, with the CPU checker.
@@ -242,6 +242,8 @@ def run_other_config(torch, scrooge_amd, device, local_rank, streams, name, n, L
     first = (idx // G) * row_words * G + idx % G
     desc = torch.stack([first * 32, tl, (first + tw * G) * 32, rl, idx * cap, torch.full_like(idx, cap)], dim=1).contiguous()
     kw = dict(text_stride_words=G, read_stride_words=G, W=W, O=O)
+    if waves_per_cu:
+        kw["waves_per_cu"] = waves_per_cu
     outs = [dict(runs=torch.empty(n * cap * 2, dtype=torch.uint8, device=device), ed=torch.empty(n, dtype=torch.int64, device=device),
                  n_runs=torch.empty(n, dtype=torch.int32, device=device), status=torch.empty(n, dtype=torch.int32, device=device))
             for _ in streams]
@@ -1291,8 +1293,10 @@ def main():
                              100000, 10000, "pacbio", 10, 2, 2000 if chk else 0, args.seed + 16, cores_),
             # a mixed-length batch of the headline's error profile: reads of 2 to 20 kb, issued longest first
             run_other_config(torch, scrooge_amd, device, local_rank, streams,
-                             "mixed lengths: 100 k ONT-error pairs, read lengths uniform in 2 .. 20 kb, issued longest read first",
-                             100000, 20000, "ont", 10, 2, 2000 if chk else 0, args.seed + 17, cores_, len_range=(2000, 20000)),
+                             "mixed lengths: 100 k ONT-error pairs, read lengths uniform in 2 .. 20 kb, issued longest read first, 4 persistent "
+                             "wavefronts per CU (scrg_params.waves_per_cu: with fewer wavefronts than groups of 64 pairs the work queue hands the "
+                             "short pairs at the end of the order to the lanes that finish first)",
+                             100000, 20000, "ont", 10, 2, 2000 if chk else 0, args.seed + 17, cores_, len_range=(2000, 20000), waves_per_cu=4),
             # two points of the reference's knob sweeps (scripts/profile.py:88-100 small overlaps, :180-185 W > 64) on the headline
             # workload: 32 <= W-O <= 63 runs on genasm_lane_wide_kernel (table in registers, built in two halves)
             run_other_config(torch, scrooge_amd, device, local_rank, streams,
