@@ -511,7 +511,7 @@ def pcie_probe(torch, device, mb=256):
     return out[0], out[1]
 
 
-def host_call_stats(n_pairs, h2d_bytes, call, reps=4):
+def host_call_stats(n_pairs, h2d_bytes, call, reps=6):
     """Times `call()` (-> result dict of Aligner._collect_arrays, library clock in .last_timing via the closure) `reps` times:
     the first call of a size allocates buffers and result arrays, the rest are the steady state (best and median)."""
     times, res = [], None

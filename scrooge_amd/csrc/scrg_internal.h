@@ -181,7 +181,7 @@ template <typename F> void parallel_for(uint64_t n, F f, bool heavy = false, uns
 
 // Result arrays are recycled: a batch of millions of pairs returns hundreds of MB, and freshly mapped pages cost
 // more (first-touch faults) than filling them.  scrg_result_free() parks the big arrays here, the next call of
-// similar size takes them back.  At most 12 blocks / 2 GB are kept; everything else goes to malloc/free.
+// similar size takes them back.  At most 12 blocks / 2 GB are kept, the most recently returned ones (the oldest are freed).
 struct ResultPool {
     struct Block { void* p; size_t cap; };
     std::mutex mu;
@@ -230,15 +230,24 @@ struct ResultPool {
         if (!user) return;
         void* p = static_cast<char*>(user) - sizeof(size_t) * 2;
         const size_t cap = static_cast<size_t*>(p)[0];
-        if (cap >= kMinPooled) {
+        if (cap < kMinPooled || cap > kMaxHeld) {
+            free(p);
+            return;
+        }
+        // the newest block stays, the oldest go: a caller that moves from big batches to small ones must not find the
+        // pool full of blocks it no longer asks for (a fresh 90 MB array costs 20 ms of first-touch faults per call)
+        std::vector<void*> evicted;
+        {
             std::lock_guard<std::mutex> g(mu);
-            if (blocks.size() < kMaxBlocks && held + cap <= kMaxHeld) {
-                blocks.push_back({p, cap});
-                held += cap;
-                return;
+            blocks.push_back({p, cap});
+            held += cap;
+            while (blocks.size() > kMaxBlocks || held > kMaxHeld) {
+                held -= blocks.front().cap;
+                evicted.push_back(blocks.front().p);
+                blocks.erase(blocks.begin());
             }
         }
-        free(p);
+        for (void* q : evicted) free(q);
     }
     void trim()
     {
