@@ -215,20 +215,29 @@ scrg_status ensure_seq(DeviceState* ds, uint64_t genome_words, uint64_t slot_wor
 constexpr size_t GENOME_STAGING_KEEP = 256u << 20;
 struct GenomeStaging {
     std::mutex mu;
+    HostPinned buf;                    // (registered memory is portable: every device copies from it)
     void* p = nullptr;
     size_t cap = 0;
     hipError_t ensure(size_t bytes)
     {
         if (bytes <= cap) return hipSuccess;
         release();
-        hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocPortable);
+        hipError_t e = bytes >= HostPinned::kRegisterMin ? buf.ensure(bytes) : hipErrorInvalidValue;
+        if (e == hipSuccess && buf.registered) {
+            p = buf.p;
+            cap = buf.cap;
+            return hipSuccess;
+        }
+        buf.release();                 // small, or not registered: portable memory from HIP itself
+        e = hipHostMalloc(&p, bytes, hipHostMallocPortable);
         if (e == hipSuccess) cap = bytes;
         else p = nullptr;
         return e;
     }
     void release()
     {
-        if (p) (void)hipHostFree(p);
+        if (buf.p) buf.release();
+        else if (p) (void)hipHostFree(p);
         p = nullptr;
         cap = 0;
     }

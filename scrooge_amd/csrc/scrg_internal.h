@@ -51,27 +51,6 @@ struct DevBuf {
     template <typename T> T* as() const { return static_cast<T*>(p); }
 };
 
-struct HostPinned {
-    void* p = nullptr;
-    size_t cap = 0;
-    hipError_t ensure(size_t bytes)
-    {
-        if (bytes <= cap) return hipSuccess;
-        if (p) (void)hipHostFree(p);
-        p = nullptr;
-        cap = 0;
-        hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
-        if (e == hipSuccess) cap = bytes;
-        return e;
-    }
-    void release()
-    {
-        if (p) (void)hipHostFree(p);
-        p = nullptr;
-        cap = 0;
-    }
-};
-
 inline int64_t now_ns()
 {
     return std::chrono::duration_cast<std::chrono::nanoseconds>(
@@ -178,6 +157,60 @@ template <typename F> void parallel_for(uint64_t n, F f, bool heavy = false, uns
     const uint64_t chunk = std::max<uint64_t>(1, n / (nt * 16));
     ThreadPool::get().run(n, chunk, nt - 1, f);
 }
+
+// Host memory the copy engines read and write directly.  Large buffers are ordinary memory — 2 MB aligned, huge-page advised,
+// faulted in by all threads — made known to HIP with hipHostRegister: copies to and from it run at the same rate as with
+// hipHostMalloc memory (scripts/ubench/d2h_rate.hip: 56 GB/s both ways at any offset and size), and getting it costs a fraction
+// (320 MB: 65 ms from hipHostMalloc; 20 ms of page faults spread over the threads + 0.6 ms to register) — what the FIRST call of a
+// process pays for its staging areas.  Small ones (and any the registration refuses) come from hipHostMalloc.
+struct HostPinned {
+    void* p = nullptr;
+    size_t cap = 0;
+    bool registered = false;
+    static constexpr size_t kRegisterMin = 4u << 20, kHugePage = 2u << 20;
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        release();
+        if (bytes >= kRegisterMin) {
+            const size_t total = (bytes + kHugePage - 1) / kHugePage * kHugePage;
+            char* const q = static_cast<char*>(aligned_alloc(kHugePage, total));
+            if (q) {
+                (void)madvise(q, total, MADV_HUGEPAGE);
+                const size_t pages = total / 4096, PER = 512;                  // 2 MB per work item
+                parallel_for((pages + PER - 1) / PER, [&](uint64_t i) {
+                    for (size_t k = i * PER; k < std::min(pages, (i + 1) * PER); k++) *reinterpret_cast<volatile char*>(q + k * 4096) = 0;
+                }, true);
+                if (hipHostRegister(q, total, hipHostRegisterPortable) == hipSuccess) {
+                    p = q;
+                    cap = total;
+                    registered = true;
+                    return hipSuccess;
+                }
+                (void)hipGetLastError();
+                free(q);
+            }
+        }
+        hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+        if (e == hipSuccess) cap = bytes;
+        else p = nullptr;
+        return e;
+    }
+    void release()
+    {
+        if (p) {
+            if (registered) {
+                (void)hipHostUnregister(p);
+                free(p);
+            } else {
+                (void)hipHostFree(p);
+            }
+        }
+        p = nullptr;
+        cap = 0;
+        registered = false;
+    }
+};
 
 // Result arrays are recycled: a batch of millions of pairs returns hundreds of MB, and freshly mapped pages cost
 // more (first-touch faults) than filling them.  scrg_result_free() parks the big arrays here, the next call of

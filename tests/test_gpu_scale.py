@@ -792,3 +792,35 @@ def test_host_pipeline_under_random_calls():
     with the oracle (tests/tools/host_stress.py runs the long version: 550 calls clean)."""
     from tests.tools import host_stress
     host_stress.run(calls=24, seed=5, verbose=False)
+
+
+@pytest.mark.parametrize("order", ["ascending", "descending"])
+def test_host_results_grow_while_chunks_arrive(aligner, oracle, order):
+    """A call with large result arrays (> 8 MB of runs, > 8 MB of text) in caller order (sort_by_length = 0).  Ascending read
+    lengths: the first chunk's bytes per pair underestimate the call, so the result arrays are replaced (moved) while other
+    chunks are being collected; descending: the estimate holds.  Every pair against the oracle, all three output selections."""
+    t, q = [], []
+    for L, n_distinct, rep in ((1000, 200, 20), (4000, 100, 30), (12000, 60, 50)):
+        a, b = synth.make_pairs(n_distinct, L, "ont", seed=L + 5)
+        t += a * rep
+        q += b * rep
+    if order == "descending":
+        t, q = t[::-1], q[::-1]
+    n = len(t)
+    eds, cigars, _, _ = oracle.align(t, q, threads=16)
+    want_text = b"".join(c.encode() + b"\0" for c in cigars)
+    runs_of = {}
+    for outputs in (0, 1, 2):
+        r = aligner.align_pairs(t, q, arrays=True, outputs=outputs, sort_by_length=0)
+        assert (r["edit_distance"] == np.array(eds)).all() and not r["status"].any()
+        if outputs != 2:
+            assert int(r["cigar_offset"][n]) == len(want_text) > (8 << 20)
+            assert r["cigar_text"] == want_text, (order, outputs)
+        if outputs != 1:
+            assert int(r["run_offset"][n]) * 2 > (8 << 20)
+            runs_of[outputs] = r["runs"].tobytes()
+            ro = np.asarray(r["run_offset"]).astype(np.int64)
+    assert runs_of[0] == runs_of[2]
+    runs = np.frombuffer(runs_of[0], dtype=np.uint8).reshape(-1, 2)
+    for i in list(range(0, n, 97)) + [n - 1]:
+        assert "".join("%d%s" % (int(c), chr(int(o))) for c, o in runs[ro[i]:ro[i + 1]]) == cigars[i]
