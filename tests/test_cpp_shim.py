@@ -57,6 +57,22 @@ def test_shim_matches_reference_answers():
     assert p.stdout.strip().splitlines() == EXPECTED
 
 
+@pytest.mark.gpu
+def test_shim_converts_large_results_in_parallel():
+    """More than 8 MB of CIGAR text: the strings of the reference's result type are filled by several threads
+    (include/scrooge_amd.hpp, detail::to_alignments); every pair against the C ABI's own arrays (tests/proto/shim_large.cpp)."""
+    scrooge_amd.build_library()
+    libdir = os.path.join(ROOT, "scrooge_amd")
+    exe = "/tmp/scrg_shim_large"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "proto", "shim_large.cpp"), "-L" + libdir, "-lscrooge_amd", "-Wl,-rpath," + libdir,
+                           "-pthread", "-o", exe])
+    p = subprocess.run([exe], capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout + p.stderr
+    out = p.stdout.strip()
+    assert out.endswith("mismatches=0") and int(out.split("text_mb=")[1].split()[0]) >= 8, out
+
+
 PIPE_EXE = "/tmp/scrg_pipeline_example"
 
 
