@@ -521,7 +521,7 @@ def host_call_stats(n_pairs, h2d_bytes, call, reps=6):
     n = n_pairs
     total_runs = int(res["run_offset"][n]) if len(res["run_offset"]) else 0
     total_text = int(res["cigar_offset"][n]) if len(res["cigar_offset"]) else 0
-    d2h = 28 * n + (2 * total_runs) + total_text + (8 * n if total_text else 0)
+    d2h = (12 if total_text else 8) * n + 2 * total_runs + total_text       # per pair: edit distance, run count (+ text length) as 32 bits each
     steady = sorted(times[1:])
     best, med = steady[0], steady[len(steady) // 2]
     return res, {"first_call_s": times[0], "steady_best_s": best, "steady_median_s": med,

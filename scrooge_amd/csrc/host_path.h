@@ -24,9 +24,10 @@ struct HostDescArgs {
 
 hipError_t launch_build_desc(const HostDescArgs& a, hipStream_t s);
 size_t host_scan_temp_bytes(uint64_t n);
-hipError_t launch_result_layout(uint64_t n, const scrg_pair_desc* pairs, const uint16_t* runs, const uint32_t* n_runs, uint64_t* cnt64,
-                                uint64_t* len64, uint64_t* run_off, uint64_t* text_off, uint64_t* totals, void* temp, size_t temp_bytes,
-                                int want_text, int n_cus, hipStream_t s);
+// (wire: 3 n uint32 — edit distance | run count, bit 31 = the slice overflowed | text length — what goes back to the host)
+hipError_t launch_result_layout(uint64_t n, const scrg_pair_desc* pairs, const uint16_t* runs, const uint32_t* n_runs, const int64_t* ed,
+                                const uint32_t* status, uint64_t* cnt64, uint64_t* len64, uint64_t* run_off, uint64_t* text_off,
+                                uint64_t* totals, uint32_t* wire, void* temp, size_t temp_bytes, int want_text, int n_cus, hipStream_t s);
 hipError_t launch_render_text(uint64_t n, const uint16_t* dense, const uint64_t* run_off, const uint64_t* cnt64, const uint64_t* text_off,
                               uint8_t* text, int n_cus, hipStream_t s);
 

@@ -97,14 +97,24 @@ __global__ __launch_bounds__(256) void text_len_kernel(uint64_t n, const scrg_pa
     }
 }
 
-// totals[0] = all runs, totals[1] = all text bytes of the chunk (the offsets are exclusive prefix sums)
-__global__ void totals_kernel(uint64_t n, const uint64_t* cnt64, const uint64_t* run_off, const uint64_t* len64, const uint64_t* text_off,
-                              uint64_t* totals, int want_text)
+// totals[0] = all runs, totals[1] = all text bytes of the chunk (the offsets are exclusive prefix sums); and what of the
+// per-pair results travels to the host: 12 bytes per pair instead of the 28 of the four arrays the caller gets — the edit
+// distance as 32 bits, the run count with the "slice overflowed" flag in bit 31, the text length; the host makes the
+// offsets from the counts again (scrg_host.cpp, stage 3).  For read mapping that is a tenth of all the bytes that come back.
+__global__ __launch_bounds__(256) void wire_totals_kernel(uint64_t n, const int64_t* __restrict__ ed, const uint32_t* __restrict__ status,
+                                                          const uint64_t* __restrict__ cnt64, const uint64_t* __restrict__ run_off,
+                                                          const uint64_t* __restrict__ len64, const uint64_t* __restrict__ text_off,
+                                                          uint64_t* __restrict__ totals, uint32_t* __restrict__ wire, int want_text)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) {
         totals[0] = n ? run_off[n - 1] + cnt64[n - 1] : 0;
         totals[1] = (n && want_text) ? text_off[n - 1] + len64[n - 1] : 0;
     }
+    if (i >= n) return;
+    wire[i] = (uint32_t)ed[i];
+    wire[n + i] = (uint32_t)cnt64[i] | (status[i] ? 0x80000000u : 0u);
+    if (want_text) wire[2 * n + i] = (uint32_t)len64[i];
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -227,9 +237,9 @@ size_t host_scan_temp_bytes(uint64_t n)
 }
 
 // cnt64 / len64 -> run_off / text_off (exclusive sums) and the two totals
-hipError_t launch_result_layout(uint64_t n, const scrg_pair_desc* pairs, const uint16_t* runs, const uint32_t* n_runs, uint64_t* cnt64,
-                                uint64_t* len64, uint64_t* run_off, uint64_t* text_off, uint64_t* totals, void* temp, size_t temp_bytes,
-                                int want_text, int n_cus, hipStream_t s)
+hipError_t launch_result_layout(uint64_t n, const scrg_pair_desc* pairs, const uint16_t* runs, const uint32_t* n_runs, const int64_t* ed,
+                                const uint32_t* status, uint64_t* cnt64, uint64_t* len64, uint64_t* run_off, uint64_t* text_off,
+                                uint64_t* totals, uint32_t* wire, void* temp, size_t temp_bytes, int want_text, int n_cus, hipStream_t s)
 {
     if (n == 0) return hipMemsetAsync(totals, 0, 16, s);
     uint32_t split = 1;
@@ -243,7 +253,8 @@ hipError_t launch_result_layout(uint64_t n, const scrg_pair_desc* pairs, const u
         e = hipcub::DeviceScan::ExclusiveSum(temp, tb, len64, text_off, (int)n, s);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(totals_kernel, dim3(1), dim3(64), 0, s, n, cnt64, run_off, len64, text_off, totals, want_text);
+    hipLaunchKernelGGL(wire_totals_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, ed, status, cnt64, run_off, len64, text_off, totals,
+                       wire, want_text);
     return hipGetLastError();
 }
 

@@ -312,11 +312,15 @@ scrg_status pack_genome(DeviceState* ds, const char* genome, uint64_t genome_len
 // ---------------------------------------------------------------------------------------------------------------
 // a call
 // ---------------------------------------------------------------------------------------------------------------
-// A chunk's per-pair results, on the device and in the host staging area: [ed 8n | status 4n (+pad) | run_off 8n | text_off 8n]
+// A chunk's per-pair results on the device: [ed 8n | status 4n (+pad) | run_off 8n | text_off 8n] (what the kernels write and
+// read), and what of them crosses PCIe, the "wire": [ed 4n | run count, bit 31 = overflow 4n | text length 4n] at o_wire
+// (wire_totals_kernel) — the offsets are made again on the host from the counts (stage 3).
 struct PerPairLayout {
-    size_t o_st, o_ro, o_to, bytes;
-    explicit PerPairLayout(uint64_t n) : o_st(8 * n), o_ro((8 * n + 4 * n + 15) & ~(size_t)15), o_to(o_ro + 8 * n), bytes(o_ro + 16 * n) {}
-    size_t host_runs() const { return (bytes + 256 + 4095) & ~(size_t)4095; }      // staging area: where the runs (then the text) start
+    size_t o_st, o_ro, o_to, o_wire, bytes, wire_bytes;
+    explicit PerPairLayout(uint64_t n)
+        : o_st(8 * n), o_ro((8 * n + 4 * n + 15) & ~(size_t)15), o_to(o_ro + 8 * n), o_wire((o_to + 8 * n + 255) & ~(size_t)255), bytes(o_wire + 12 * n),
+          wire_bytes(12 * n) {}
+    size_t host_runs() const { return (wire_bytes + 256 + 4095) & ~(size_t)4095; }      // staging area: [wire | runs (then the text)]
 };
 
 struct Grow {                          // a result array that the chunks' collectors fill, each chunk at its own offset
@@ -604,10 +608,9 @@ scrg_status stage1(DeviceState* ds, Slot& sl, Call& c, uint64_t chunk)
         ds->set_err(scrg_last_error(sl.ctx));
         return s;
     }
-    HTRY(ds, scrg::launch_result_layout(n, sl.d_desc.as<scrg_pair_desc>(), sl.d_slices.as<uint16_t>(), sl.d_nruns.as<uint32_t>(),
-                                        sl.d_cnt64.as<uint64_t>(), sl.d_len64.as<uint64_t>(), d_runoff,
-                                        d_textoff, sl.d_tot.as<uint64_t>(), sl.d_temp.p, temp_bytes, c.want_text, ds->n_cus,
-                                        sl.stream));
+    HTRY(ds, scrg::launch_result_layout(n, sl.d_desc.as<scrg_pair_desc>(), sl.d_slices.as<uint16_t>(), sl.d_nruns.as<uint32_t>(), d_ed, d_status,
+                                        sl.d_cnt64.as<uint64_t>(), sl.d_len64.as<uint64_t>(), d_runoff, d_textoff, sl.d_tot.as<uint64_t>(),
+                                        reinterpret_cast<uint32_t*>(d_pp + lay.o_wire), sl.d_temp.p, temp_bytes, c.want_text, ds->n_cus, sl.stream));
     HTRY(ds, hipMemcpyAsync(sl.h_tot.p, sl.d_tot.p, 16, hipMemcpyDeviceToHost, sl.stream));
     HTRY(ds, hipEventRecord(sl.ev_tot, sl.stream));
     return SCRG_OK;
@@ -654,7 +657,7 @@ scrg_status stage2(DeviceState* ds, Slot& sl, Call& c, uint64_t chunk)
         HTRY(ds, scrg::launch_render_text(n, sl.d_dense.as<uint16_t>(), d_runoff, sl.d_cnt64.as<uint64_t>(), d_textoff, d_text, ds->n_cus, sl.stream));
     // (whole multiples of 256 bytes to page-aligned host addresses: the buffers have the slack)
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    HTRY(ds, hipMemcpyAsync(h, d_pp, up(c.want_text ? lay.bytes : lay.o_to), hipMemcpyDeviceToHost, sl.stream));
+    HTRY(ds, hipMemcpyAsync(h, d_pp + lay.o_wire, up(c.want_text ? 12 * n : 8 * n), hipMemcpyDeviceToHost, sl.stream));
     if (c.want_runs && c.want_text && sl.tot_runs + sl.tot_text)
         HTRY(ds, hipMemcpyAsync(h + o_runs, sl.d_dense.p, up(text_rel + sl.tot_text), hipMemcpyDeviceToHost, sl.stream));
     else if (c.want_runs && sl.tot_runs)
@@ -688,7 +691,7 @@ scrg_status stage3(DeviceState* ds, Slot& sl, Call& c, uint64_t chunk)
     }
     const uint64_t n = sl.n, first = sl.first;
     const PerPairLayout lay(n);
-    const size_t o_st = lay.o_st, o_ro = lay.o_ro, o_to = lay.o_to, o_runs = lay.host_runs();
+    const size_t o_runs = lay.host_runs();
     const size_t o_text = o_runs + ((2 * sl.tot_runs + 15) & ~(size_t)15);
     const char* const h = static_cast<const char*>(sl.h_out.p);
     const double per_pair_scale = 1.08 * (double)c.n / (double)std::max<uint64_t>(1, n);
@@ -712,18 +715,46 @@ scrg_status stage3(DeviceState* ds, Slot& sl, Call& c, uint64_t chunk)
             else memcpy(c.text.p + base_text + (i - n_r) * CH, h + o_text + (i - n_r) * CH, std::min(CH, tb - (i - n_r) * CH));
         }, true, c.threads_per_worker);
     }
-    const int64_t* const ed = reinterpret_cast<const int64_t*>(h);
-    const uint32_t* const st = reinterpret_cast<const uint32_t*>(h + o_st);
-    const uint64_t* const ro = reinterpret_cast<const uint64_t*>(h + o_ro);
-    const uint64_t* const to = reinterpret_cast<const uint64_t*>(h + o_to);
+    // the wire (PerPairLayout): edit distances, run counts with the overflow flag, text lengths; the offsets are their prefix
+    // sums — blocks of 16 k pairs: the blocks' sums side by side, their scan, then the offsets inside every block
+    const uint32_t* const w_ed = reinterpret_cast<const uint32_t*>(h);
+    const uint32_t* const w_cnt = w_ed + n;
+    const uint32_t* const w_len = w_cnt + n;
+    const uint64_t BLK = 1u << 14, nb = (n + BLK - 1) / BLK;
+    std::vector<uint64_t> br(nb + 1, 0), bt(nb + 1, 0);
+    parallel_for(nb, [&](uint64_t k) {
+        uint64_t ar = 0, at = 0;
+        for (uint64_t i = k * BLK; i < std::min(n, (k + 1) * BLK); i++) {
+            ar += w_cnt[i] & 0x7fffffffu;
+            if (c.want_text) at += w_len[i];
+        }
+        br[k + 1] = ar;
+        bt[k + 1] = at;
+    }, true, c.threads_per_worker);
+    for (uint64_t k = 0; k < nb; k++) {
+        br[k + 1] += br[k];
+        bt[k + 1] += bt[k];
+    }
     std::atomic<int> ovf{0};
-    parallel_for(n, [&](uint64_t i) {
-        c.iss_ed[first + i] = ed[i];
-        c.iss_status[first + i] = st[i] ? (uint32_t)SCRG_ERR_CIGAR_OVERFLOW : (uint32_t)SCRG_OK;
-        if (st[i]) ovf.store(1, std::memory_order_relaxed);
-        c.iss_run_off[first + i] = base_runs + ro[i];
-        c.iss_text_off[first + i] = c.want_text ? base_text + to[i] : 0;
-    }, false, c.threads_per_worker);
+    parallel_for(nb, [&](uint64_t k) {
+        uint64_t ar = base_runs + br[k], at = base_text + bt[k];
+        bool any = false;
+        for (uint64_t i = k * BLK; i < std::min(n, (k + 1) * BLK); i++) {
+            const uint32_t cw = w_cnt[i];
+            c.iss_ed[first + i] = (int64_t)w_ed[i];
+            c.iss_status[first + i] = (cw >> 31) ? (uint32_t)SCRG_ERR_CIGAR_OVERFLOW : (uint32_t)SCRG_OK;
+            any |= (cw >> 31) != 0;
+            c.iss_run_off[first + i] = ar;
+            c.iss_text_off[first + i] = c.want_text ? at : 0;
+            ar += cw & 0x7fffffffu;
+            if (c.want_text) at += w_len[i];
+        }
+        if (any) ovf.store(1, std::memory_order_relaxed);
+    }, true, c.threads_per_worker);
+    if (br[nb] != sl.tot_runs || (c.want_text && bt[nb] != sl.tot_text)) {
+        ds->set_err("internal: a chunk's per-pair sizes do not add up to its totals");
+        return SCRG_ERR_HIP;
+    }
     if (ovf.load()) c.any_overflow.store(1);
     return SCRG_OK;
 }
