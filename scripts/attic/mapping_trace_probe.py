@@ -1,7 +1,7 @@
 """Steady-state resident read-mapping calls (1 M x 150 bp reads x 4 candidates on a 100 Mbp genome) for a rocprofv3
 kernel + memory-copy trace: python3 scripts/mapping_trace_probe.py [reads] [outputs: 0 runs + text, 1 text, 2 runs]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import scrooge_amd
 from scrooge_amd import synth
