@@ -1,0 +1,6 @@
+for rep in 1 2 3; do for v in "$@"; do
+  SCRG_LIB=$PWD/ab_libs/lib_$v.so python scripts/decode_timing.py --slots 8 --reps 10 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.readline())
+print('$v', {k:(round(v['count_only_ms'],3),round(v['decode_ms'],3)) for k,v in d.items() if k.startswith('slots_')})"
+done; done

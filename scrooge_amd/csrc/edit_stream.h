@@ -159,14 +159,21 @@ SCRG_HD inline void decode_lane_init(DecodeLane& s, uint32_t W, uint32_t O, uint
 // the tail rule below — the read's remaining characters match — so a lane never waits for input that does not come.)
 SCRG_HD inline bool decode_lane_clean(const DecodeLane& s) { return s.pos == s.end && s.m == 0 && s.e == EDIT_OP_NONE; }
 
-template <typename Put>
-SCRG_HD inline uint32_t decode_lane_step(DecodeLane& s, const uint32_t bn0, Put&& put)      // -> 1 if the byte at pos was consumed
+struct DecodeNoTake {
+    SCRG_HD void operator()(uint32_t) const {}
+};
+
+// on_take(takeM) is called as soon as it is known whether the byte at pos is consumed (takeM = ~0) or not (0): the GPU
+// decoder asks for the byte of the NEXT step there, a whole step before it is looked at.
+template <typename Put, typename OnTake = DecodeNoTake>
+SCRG_HD inline uint32_t decode_lane_step(DecodeLane& s, const uint32_t bn0, Put&& put, OnTake&& on_take = OnTake())      // -> 1 if the byte at pos was consumed
 {
     constexpr uint32_t EQW = (uint32_t)'=' << 8;
     // ---- the next stream byte, if nothing is pending (an edit byte completes the pending item, an op-0 byte only adds matches)
     const uint32_t fetchM = ~(es_nz_mask(s.e) | s.tailM) & s.aliveM;
     const uint32_t hasM = es_neg_mask(s.pos - s.end);                // pos < end
     const uint32_t takeM = fetchM & hasM;
+    on_take(takeM);
     const uint32_t e_new = bn0 >> 6;
     s.m += ((bn0 & 63u) + ((bn0 - 64u) >> 31)) & takeM;              // len, + 1 for op 0
     s.e = es_sel(e_new, s.e, takeM);
@@ -194,7 +201,12 @@ SCRG_HD inline uint32_t decode_lane_step(DecodeLane& s, const uint32_t bn0, Put&
     const uint32_t doM = es_nz_mask(es_min(es_min(s.e, s.ri), s.rj)) & ~es_nz_mask(s.m);
     const uint32_t sameM = ~es_nz_mask(s.e ^ s.prev_e);
     const uint32_t mergeM = doM & sameM, newM = doM & ~sameM;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // byte 1 = byte e of "\0XID", byte 0 = 1: one v_perm_b32 (selector bytes: 0x0C = zero, 4 + e = byte e of the first operand, 0 = byte 0 of the second)
+    const uint32_t opw = __builtin_amdgcn_perm(0x44495800u, 1u, 0x0C0C0400u + (s.e << 8));
+#else
     const uint32_t opw = (((0x44495800u >> ((s.e << 3) & 31u)) & 0xffu) << 8) | 1u;        // 'X', 'I', 'D' for e = 1, 2, 3 (bit field, shift-or)
+#endif
     s.cur = es_sel(s.cur + 1u, es_sel(opw, s.cur, newM), mergeM);
     put(s.n + mergeM, s.cur);                                        // run n - 1 grows, or run n starts (or nothing changes)
     s.n -= newM;

@@ -8,15 +8,17 @@
 // stream byte, its matches cut at the window limits, the edit, the window end — O(edits + windows) steps per pair, no
 // per-base work, about 90 VALU instructions per step and no branch: the lanes of a wavefront are at 64 different places
 // of their streams, so every conditional would be taken by some lane every time).  Around it:
-//   in : a lane reads its own stream in aligned 16-byte blocks, two blocks ahead, all lanes at the same iterations (a
-//        block is touched a whole epoch of 16 steps after its load was issued); the bytes are consumed through a 64-bit
-//        shift register that is topped up one dword at a time.  No LDS, no cross-lane traffic; a 64-byte sector of the
+//   in : a lane reads its own stream in aligned 16-byte blocks, all lanes at the same iterations (a block is touched a
+//        whole epoch of 16 steps after its load was issued), into a ring of two blocks per lane in LDS; a step looks at one
+//        byte of it, asked for (ds_read_u8) a whole step earlier — as soon as the step before knows whether it consumes its
+//        own byte.  (Round 3 and the first half of round 4 kept three blocks in registers and fed a 64-bit shift register one
+//        dword at a time through a select tree: 49 of the 383 VALU instructions per four steps.)  A 64-byte sector of the
 //        gathered buffer is asked for four times within ~100 steps and is served by the L2 after the first.
 //   out: runs are staged in a 64-run ring per lane in LDS, indexed by the run's position in the OUTPUT array modulo 64,
 //        and leave as aligned 64-byte pieces (four 16-byte stores per lane); only the first and the last piece of a
 //        pair, which it shares with its neighbours in the dense array, go out run by run.  Pieces are written when ONE
 //        lane's ring is three quarters full, by every lane that has a whole piece: fewer, fuller passes.
-// 9 KB of LDS per wavefront (count-only: none).  Bound: VALU issue, next to 0.1 GB read + 0.43 GB written per 100 k
+// 10 KB of LDS per wavefront (count-only: 3 KB).  Bound: VALU issue, next to 0.1 GB read + 0.43 GB written per 100 k
 // 10 kb pairs.
 #include <hipcub/hipcub.hpp>
 
@@ -28,7 +30,9 @@ namespace {
 
 constexpr uint32_t DEC_RING = 64;                     // runs per lane in LDS
 constexpr uint32_t DEC_PIECE = 32;                    // runs per store pass: 64 bytes
-constexpr uint32_t DEC_OUT_STRIDE = 2u * DEC_RING + 16u;    // 16-byte aligned rows, lanes spread over the banks
+constexpr uint32_t DEC_IN_RING = 32;                   // bytes of the lane's stream in LDS: two aligned 16-byte blocks
+constexpr uint32_t DEC_OUT_STRIDE = 2u * DEC_RING + DEC_IN_RING;      // a lane's row: [64 runs | 32 stream bytes]; 16-byte aligned; 4 wavefronts x 10 KB x 4 workgroups = the CU's 160 KB (they fit: 16 wavefronts per CU)
+constexpr uint32_t DEC_COUNT_STRIDE = DEC_IN_RING + 16u;              // count only: the stream bytes alone
 constexpr uint32_t DEC_WAVE_LDS = 64u * DEC_OUT_STRIDE;
 constexpr uint32_t DEC_FLUSH_AT = 32;                 // final runs in one lane's ring that start a store pass (looked at once per epoch: + <= 32 runs until the next look)
 constexpr int DEC_STEPS_PER_CHECK = 4;                // steps between two looks at the buffers (<= 2 runs and 1 byte per step)
@@ -60,12 +64,13 @@ typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 template <bool STORE>
 __global__ __launch_bounds__(256) void decode_edits_kernel(DecodeArgs a)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t lds_all[STORE ? 4 * DEC_WAVE_LDS : 16];
+    __shared__ __attribute__((aligned(16))) uint8_t lds_all[STORE ? 4 * DEC_WAVE_LDS : 4 * 64 * DEC_COUNT_STRIDE];
     const uint32_t lane = threadIdx.x & 63u;
     // On the root of an N > 1 job this kernel shares the SIMDs with the aligner's wavefronts, and its own run time is set by
     // its longest lanes: it goes first.  (The align kernel rotates its priorities 0..3; 3 here is at least a tie.)
     __builtin_amdgcn_s_setprio(3);
     uint8_t* const out_me = lds_all + (STORE ? (threadIdx.x >> 6) * DEC_WAVE_LDS + lane * DEC_OUT_STRIDE : 0u);
+    uint8_t* const in_me = STORE ? out_me + 2u * DEC_RING : lds_all + threadIdx.x * DEC_COUNT_STRIDE;
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = tid < a.n_pairs;
     // Longest streams first: the pairs of a wavefront then need about the same number of steps (the wavefront runs until
@@ -100,54 +105,42 @@ __global__ __launch_bounds__(256) void decode_edits_kernel(DecodeArgs a)
     decode_lane_init(s, a.W, a.O, 0u, len, rl);
     if (!valid) s.aliveM = 0;
 
-    // ---- input: my stream, in aligned 16-byte blocks, through a 64-bit shift register ----
+    // ---- input: my stream, in aligned 16-byte blocks, through a ring of two blocks in LDS ----
     const uint64_t limit16 = (a.stream_bytes + 15u) & ~15ull;   // whole 16-byte blocks of the buffer may be read
     const uint64_t stream_end = off + len;
-    uint64_t blk = off & ~15ull;                                 // the block in `cur`
+    uint64_t blk = off & ~15ull;                                 // the older block of the ring
     auto load_block = [&](uint64_t at) -> u32x4_t {
         u32x4_t v = {0u, 0u, 0u, 0u};
         if (at < stream_end && at < limit16) v = *reinterpret_cast<const u32x4_t*>(a.stream + at);
         return v;
     };
-    // Three blocks in registers: the one being used, the next, and the one after that, which is being LOADED.  Blocks move
-    // up (and the next load is issued) only every DEC_EPOCH iterations, for all lanes at once: a block is first touched a
-    // whole epoch after its load was issued, so the wait in front of the move costs nothing — issued lane by lane as
-    // blocks run out, some lane's load would be seconds old at every look and the wavefront would wait for memory each time.
-    // (A lane uses at most 16 bytes per epoch; after the move it has at least 20 loaded bytes in front of it.)
-    u32x4_t cur = load_block(blk), nxt = load_block(blk + 16u), nx2 = load_block(blk + 32u);
-    uint32_t di = ((uint32_t)off & 15u) >> 2;                    // the dword of cur:nxt that goes into the shift register next (0..7)
-    uint64_t sr = 0;                                             // the next `have` bytes of the stream, lowest first
-    uint32_t have = 0;
+    // The ring holds the block the lane is in and the next one; the one after that is being LOADED into registers.  Blocks
+    // move up (the loaded one into the ring, the next load issued) only every DEC_EPOCH iterations, for all lanes at once: a
+    // block is first touched a whole epoch after its load was issued, so the wait in front of the move costs nothing — issued
+    // lane by lane as blocks run out, some lane's load would be seconds old at every look and the wavefront would wait for
+    // memory each time.  rp = my position relative to the first block; base = the older ring block's.  At a move rp < base + 32
+    // (a lane uses at most 16 bytes per epoch and was inside the older block after the move before), after it rp < base + 16.
+    uint32_t rp = (uint32_t)off & 15u, base = 0;
+    u32x4_t nx2;
+    {
+        const u32x4_t b0 = load_block(blk), b1 = load_block(blk + 16u);
+        nx2 = load_block(blk + 32u);
+        *reinterpret_cast<u32x4_t*>(in_me) = b0;
+        *reinterpret_cast<u32x4_t*>(in_me + 16u) = b1;
+    }
     auto advance_blocks = [&]() {
-        const bool rot = di >= 4u;
+        const bool rot = rp - base >= 16u;
         if (__any(rot)) {
             if (rot) {
-                cur = nxt;
-                nxt = nx2;
-                di -= 4u;
+                *reinterpret_cast<u32x4_t*>(in_me + (base & 16u)) = nx2;       // over the block that has been used up
+                base += 16u;
                 blk += 16u;
                 nx2 = load_block(blk + 32u);
             }
         }
     };
-    // one more dword for every lane that is down to four bytes or fewer (a lane uses at most four between two calls)
-    auto top_up = [&]() {
-        const uint32_t hiM = 0u - ((di >> 2) & 1u), b1M = 0u - ((di >> 1) & 1u), b0M = 0u - (di & 1u);
-        const uint32_t x = es_sel(nxt.x, cur.x, hiM), y = es_sel(nxt.y, cur.y, hiM), z = es_sel(nxt.z, cur.z, hiM), w = es_sel(nxt.w, cur.w, hiM);
-        const uint32_t d = es_sel(es_sel(w, z, b0M), es_sel(y, x, b0M), b1M);
-        const uint32_t wantM = es_neg_mask(have - 5u);          // have <= 4
-        sr |= (uint64_t)(d & wantM) << (8u * (have & 7u));
-        have += 4u & wantM;
-        di += 1u & wantM;
-    };
-    top_up();
-    {   // the stream need not start at a dword
-        const uint32_t skip = (uint32_t)off & 3u;
-        sr >>= 8u * skip;
-        have -= skip;
-    }
-    top_up();
-    advance_blocks();            // (di <= 3 from here on at every move, <= 7 in between: four top-ups per epoch)
+    auto byte_at = [&](uint32_t r) -> uint32_t { return in_me[r & (DEC_IN_RING - 1u)]; };
+    uint32_t bn = byte_at(rp);                                   // the byte the next step looks at
 
     // ---- output: run k of the pair is element g0 + k of the dense array; ring slot = that index modulo 64 ----
     const uint32_t slot0 = (uint32_t)g0 & (DEC_RING - 1u);
@@ -207,20 +200,26 @@ __global__ __launch_bounds__(256) void decode_edits_kernel(DecodeArgs a)
         SCRG_DEC_T(t0);
 #pragma unroll
         for (int it = 0; it < DEC_STEPS_PER_CHECK; it++) {
-            const uint32_t took = decode_lane_step(s, (uint32_t)sr & 0xffu, put);
-            sr >>= 8u * took;
-            have -= took;
+            // the blocks move before the LAST step of an epoch asks for its successor's byte: that byte may be the first of
+            // the block that arrives with the move (15 steps since the move before: rp < base + 31, the step's own byte is in
+            // the ring and already on its way)
+            if (it == DEC_STEPS_PER_CHECK - 1 && (iter & (DEC_EPOCH - 1u)) == DEC_EPOCH - 1u) advance_blocks();
+            uint32_t next = 0;
+            (void)decode_lane_step(s, bn, put, [&](uint32_t takeM) {
+                rp -= takeM;
+                next = byte_at(rp);
+                __builtin_amdgcn_sched_barrier(0);       // (left alone, the scheduler sinks the read to its use, a step later: every step then waits for LDS)
+            });
+            bn = next;
         }
         SCRG_DEC_T(t1);
         // Stores and the waits for stream blocks share one counter (vmcnt), and the wait in front of a block move cannot tell
         // the stores of a data-dependent pass from the loads it is after: it waits for everything.  So the store passes run in
-        // the FIRST iteration of an epoch and the block move in the LAST: a store has three iterations (~2 us) to be
+        // the FIRST iteration of an epoch and the block move in the LAST (above): a store has three iterations (~2 us) to be
         // acknowledged before anybody waits (passes in any iteration: the wait of the next move met stores a few hundred
         // nanoseconds old — 8 slots 2.99 ms with stores against 1.99 ms without; now see DESIGN.md §3.7).
-        if ((iter & (DEC_EPOCH - 1u)) == DEC_EPOCH - 1u) advance_blocks();
         if (STORE && (iter & (DEC_EPOCH - 1u)) == 0u) flush_pieces();
         SCRG_DEC_T(t2);
-        top_up();
         SCRG_DEC_T(t3);
         SCRG_DEC_ACC(pc_steps, t0, t1);
         SCRG_DEC_ACC(pc_flush, t1, t2);
