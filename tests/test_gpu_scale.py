@@ -824,3 +824,68 @@ def test_host_results_grow_while_chunks_arrive(aligner, oracle, order):
     runs = np.frombuffer(runs_of[0], dtype=np.uint8).reshape(-1, 2)
     for i in list(range(0, n, 97)) + [n - 1]:
         assert "".join("%d%s" % (int(c), chr(int(o))) for c, o in runs[ro[i]:ro[i + 1]]) == cigars[i]
+
+
+def test_decode_large_launch_stores_pieces_together(aligner):
+    """scrg_decode_edit_stream on more than 200 000 pairs in one launch — what the root of an N > 1 job decodes per step —
+    stores the 64-byte pieces of the dense array by the wavefront together (edit_stream_decode_kernel.hip:
+    write_whole_pieces), smaller launches lane by lane.  2 100 ragged pairs (empty reads and texts, error-free pairs among
+    them) replicated 100 times through the offset arrays: every replica's runs must be those of scrg_compact_runs, and the
+    small launch must agree with the large one."""
+    import torch
+    import scrooge_amd
+    dev = torch.device("cuda", 0)
+    t, q = synth.make_pairs(1500, 1500, "ont", seed=91)
+    t2, q2 = synth.make_pairs(600, 700, "pacbio15", seed=92)
+    t, q = t + t2, q + q2
+    q[3], t[8] = b"", b""
+    q[12] = t[12][:1500]
+    n0, R = len(t), 100
+    tw, rw = (max(len(x) for x in t) + 31) // 32, (1500 + 31) // 32
+    rows = np.zeros((n0, (tw + rw) * 32), dtype=np.uint8)
+    for k in range(n0):
+        rows[k, :len(t[k])] = np.frombuffer(t[k], dtype=np.uint8)
+        rows[k, tw * 32: tw * 32 + len(q[k])] = np.frombuffer(q[k], dtype=np.uint8)
+    cap = (2 * 1500 + 8 + 15) // 16 * 16
+    idx = torch.arange(n0, dtype=torch.int64, device=dev)
+    aligner.set_stream(0)
+    try:
+        seq = torch.zeros(n0 * (tw + rw) + scrooge_amd.api.SEQ_PAD_WORDS, dtype=torch.int64, device=dev)
+        bad = torch.zeros(1, dtype=torch.int32, device=dev)
+        aligner.pack_planar(torch.from_numpy(rows).to(dev).view(-1), seq, bad)
+        rl = torch.tensor([len(x) for x in q], device=dev)
+        desc = torch.stack([idx * (tw + rw) * 32, torch.tensor([len(x) for x in t], device=dev), (idx * (tw + rw) + tw) * 32, rl,
+                            idx * cap, torch.full_like(idx, cap)], dim=1).contiguous()
+        runs = torch.zeros(n0 * cap * 2, dtype=torch.uint8, device=dev)
+        ed = torch.empty(n0, dtype=torch.int64, device=dev)
+        nr = torch.empty(n0, dtype=torch.int32, device=dev)
+        st = torch.empty(n0, dtype=torch.int32, device=dev)
+        aligner.align_device(n0, seq, desc, runs, ed, nr, st)
+        assert int(st.max().item()) == 0
+        stream = torch.zeros(n0 * 1024 + 64, dtype=torch.uint8, device=dev)
+        s_off = torch.empty(n0, dtype=torch.int64, device=dev)
+        s_len = torch.empty(n0, dtype=torch.int32, device=dev)
+        tot = torch.empty(2, dtype=torch.int64, device=dev)
+        aligner.encode_edit_stream(n0, desc, runs, nr, stream, s_off, s_len, tot)
+        cnt = nr.to(torch.int64)
+        total = int(cnt.sum().item())
+        off = torch.cumsum(cnt, 0) - cnt
+        want = torch.zeros(total * 2 + 8, dtype=torch.uint8, device=dev)
+        aligner.compact_runs(n0, desc, runs, nr, off, want)
+        nbad = torch.zeros(1, dtype=torch.int32, device=dev)
+        small = torch.zeros(total * 2 + 8, dtype=torch.uint8, device=dev)
+        aligner.decode_edit_stream(n0, stream, s_off, s_len, rl.contiguous(), 1, off, small, nr, nbad)
+        assert int(nbad.item()) == 0 and torch.equal(small, want)
+        n = n0 * R
+        assert n > 200000
+        cnt_rep = nr.repeat(R)
+        c64 = cnt_rep.to(torch.int64)
+        off_rep = torch.cumsum(c64, 0) - c64
+        big = torch.zeros(R * total * 2 + 64, dtype=torch.uint8, device=dev)
+        aligner.decode_edit_stream(n, stream, s_off.repeat(R), s_len.repeat(R), rl.repeat(R).contiguous(), 1, off_rep, big, cnt_rep, nbad)
+        torch.cuda.synchronize()
+        assert int(nbad.item()) == 0
+        assert torch.equal(big[: R * total * 2].view(R, total * 2), want[: total * 2].unsqueeze(0).expand(R, -1))
+        assert int(big[R * total * 2:].max().item()) == 0                 # nothing past the last pair's segment
+    finally:
+        aligner.use_own_stream()
