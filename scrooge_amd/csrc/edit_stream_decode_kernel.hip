@@ -332,7 +332,7 @@ hipError_t launch_decode_edits(uint64_t n_pairs, uint32_t W, uint32_t O, const u
     }
     // Stored together, the pieces cost a third of the write time when launches fill the GPU (8 slots of 100 k pairs: 2.83 -> 2.47 ms,
     // 4 slots 1.64 -> 1.43) and a few more instructions per pass, which is what a launch of <= 2 wavefronts per SIMD feels
-    // (1 slot: 1.06 -> 1.15 ms): by the size of the launch.
+    // (1 slot: 1.06 -> 1.15 ms): by the size of the launch (200 000 pairs = three wavefronts on every SIMD of an MI355X).
     const uint32_t together = n_pairs > 200000 ? 1u : 0u;
     DecodeArgs a{n_pairs, W, O, d_stream, stream_bytes, d_off, d_len, d_read_len, read_len_stride, d_dense_off, d_dense, dense_cap, d_n_runs, d_bad, order, together};
     const dim3 grid((unsigned)((n_pairs + 255) / 256)), block(256);
