@@ -1386,11 +1386,30 @@ def main():
                     "frac_at_step_rate": lane_ops_launch / (dt / args.steps) / VALU_PEAK_LANE_OPS if not dist_on else None,
                     "frac_sustained": (lane_ops_launch / (sustained["ms_per_step"] * 1e-3) / VALU_PEAK_LANE_OPS) if sustained else None,
                     "mix_weighted_roof": mix_roof,
-                    "note": "a launch that has the GPU to itself (1.5 wavefronts per SIMD: cannot fill the issue slots); frac_at_step_rate "
-                            "divides by ms_per_step of the pipelined timed region instead (2-3 launches share the SIMDs), frac_sustained by the "
-                            "sustained step; peak prices every op as full-rate at 2.4 GHz — the mix-weighted issue roof of this instruction "
-                            "mix is in DESIGN.md §3.1",
+                    "note": "`achieved` counts the VALU instructions the kernel REALLY ISSUED (SQ_INSTS_VALU from rocprofv3 --pmc, x 64 lanes) "
+                            "over the duration of a launch that has the GPU to itself (1.5 wavefronts per SIMD: cannot fill the issue slots); "
+                            "frac_at_step_rate divides by ms_per_step of the pipelined timed region instead (2-3 launches share the SIMDs), "
+                            "frac_sustained by the sustained step; peak prices every op as full-rate at 2.4 GHz — the mix-weighted issue roof "
+                            "of this instruction mix is `mix_weighted_roof` (DESIGN.md §3.1).  SURVEY.md §8(d)'s op count (7 64-bit ops per "
+                            "R[i][d] cell of genasm_cpu.cpp:247-251 = 14 lane-ops x dc_cells + the traceback) is `frac_reference_ops`: it reads "
+                            "ABOVE 1 at the step rate, and that is not skipped work — the kernel does not run the reference's per-distance "
+                            "recurrence; it carries the same table as Myers/Hyyro difference vectors (all 64 rows and every distance d of a "
+                            "text column in 19 VALU instructions, no loop over d), which issues ~3.6x fewer lane-ops for the same R table, and "
+                            "this same run compares every pair of every timed batch (edit distances, run counts, all runs) byte for byte "
+                            "with the reference CPU path (`parity`)",
                     "hbm": hbm}
+        if dc_cells is not None:
+            # what SURVEY.md §8(d) asks `achieved` to be computed from: 14 int32 lane-ops per GenASM-DC cell + ~13 per traceback step
+            ref_lane_ops_pair = 14.0 * dc_cells + 13.0 * (tb_steps or 0)
+            ref_launch = ref_lane_ops_pair * n_real
+            roofline["reference_ops"] = {
+                "lane_ops_per_pair": ref_lane_ops_pair, "formula": "14 x dc_cells + 13 x tb_steps (SURVEY.md §8d; counted by the CPU checker on this batch)",
+                "issued_over_reference": lane_ops_launch / ref_launch,
+                "frac_reference_ops": ref_launch / (kernel_ms * 1e-3) / VALU_PEAK_LANE_OPS,
+                "frac_reference_ops_at_step_rate": (ref_launch / (dt / args.steps) / VALU_PEAK_LANE_OPS) if not dist_on else None,
+                "note": "the reference formulation's op count for the same pairs priced at this kernel's times: > 1 at the step rate because "
+                        "the kernel issues issued_over_reference x as many lane-ops as that formulation would need, not because work is skipped"}
+            roofline["frac_reference_ops"] = roofline["reference_ops"]["frac_reference_ops_at_step_rate"] or roofline["reference_ops"]["frac_reference_ops"]
     else:
         roofline = {"bound": "valu-issue", "achieved": None, "peak": VALU_PEAK_LANE_OPS / 1e12, "unit": "T int32 lane-ops/s", "frac": None,
                     "traffic": traffic, "kernel": kernel_name, "window_rounds_per_launch": rounds_live,

@@ -9,7 +9,9 @@
  *   genasm_gpu::align_all(Genome_t&, vector<Read_t>&, long long* ns)
  *       -> scrg_align_mapping()
  *   __global__ genasm_gpu::ascii_to_twobit_strings(count, lens, ascii, twobit)
- *       -> scrg_ascii_to_twobit()          (same byte layout, src/genasm_gpu.cu:631-685)
+ *       -> scrg_ascii_to_twobit()          (same byte layout, src/genasm_gpu.cu:631-685; the kernel itself, with the
+ *                                           reference's signature, is in include/compat/genasm_gpu.hpp for hipcc-compiled
+ *                                           callers: both are made of include/scrooge_amd_device.hpp)
  *   genasm_gpu::enabled_algorithm_log
  *       -> scrg_set_log() / scrg_get_log()
  *

@@ -82,7 +82,7 @@ def build_library(force=False):
         return so
     src_dir = os.path.join(HERE, "csrc")
     srcs = [os.path.join(src_dir, f) for f in os.listdir(src_dir) if not f.startswith(".")] + \
-        [os.path.join(HERE, "..", "include", "scrooge_amd.h"), os.path.join(HERE, "..", "include", "scrooge_amd_io.h")]
+        [os.path.join(HERE, "..", "include", f) for f in ("scrooge_amd.h", "scrooge_amd_io.h", "scrooge_amd_device.hpp")]
     stamp = so + ".sources.sha256"
     digest = _source_digest(srcs)
 

@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include "genasm_kernels.h"
+#include "../../include/scrooge_amd_device.hpp"
 
 namespace scrg {
 
@@ -106,23 +107,8 @@ __global__ __launch_bounds__(256) void ascii_to_twobit_kernel(uint64_t count, co
         const char* src = ascii + ascii_off[s];
         uint8_t* dst = twobit + twobit_off[s];
         for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < nbytes;
-             b += (uint64_t)gridDim.x * blockDim.x) {
-            uint32_t out = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint64_t p = 4 * b + k;
-                uint32_t code = 0;
-                if (p < len) {
-                    const uint32_t c = (uint8_t)src[p];
-                    const uint32_t u = c & 0xdfu;
-                    if (!(u == 'A' || u == 'C' || u == 'G' || u == 'T')) bad++;
-                    const uint32_t x = (c >> 1) & 3u;
-                    code = x ^ (x >> 1);
-                }
-                out |= code << (6 - 2 * k);
-            }
-            dst[b] = (uint8_t)out;
-        }
+             b += (uint64_t)gridDim.x * blockDim.x)
+            dst[b] = scrooge_amd::device::twobit_quad(src, len, b, &bad);      // (include/scrooge_amd_device.hpp: shared with the reference-named kernel)
     }
     if (bad) atomicAdd(bad_count, bad);
 }

@@ -107,3 +107,45 @@ def test_compat_headers_offer_the_reference_surface(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True)
     has_gpu = scrooge_amd.load_library().scrg_device_count() > 0
     assert r.returncode == (0 if has_gpu else 2), r.stdout + r.stderr
+
+
+# ---- the reference's third export: __global__ genasm_gpu::ascii_to_twobit_strings (src/genasm_gpu.hpp:9) ----
+TWOBIT_SRC = os.path.join(ROOT, "tests", "proto", "twobit_caller.hip")
+TWOBIT_EXE = "/tmp/scrg_twobit_caller"
+# the six strings of the reference's own test (src/tests.cu:583-590), then mixed case and lengths around a workgroup's stride
+TWOBIT_INPUTS = ["", "A", "ACGT", "ACGTA", "AAAAAAAACCCCCCCCGGGGGGGGTTTTTTTT", "AAAAAAAACCCCCCCCGGGGGGGGTTTTTTTTA",
+                 "acgtTGCA", "T" * 127, "GATTACA" * 37, "C" * 128 + "G", "TTTTGGGGCCCCAAAA" * 64 + "ACG"]
+
+
+def _twobit_expected(seq):
+    """4 bases per byte, the first base of a quad in bits 7..6, the tail zero-padded (src/genasm_gpu.cu:640-669)."""
+    code = {"A": 0, "C": 1, "G": 2, "T": 3}
+    out = bytearray((len(seq) + 3) // 4)
+    for k, ch in enumerate(seq.upper()):
+        out[k // 4] |= code[ch] << (6 - 2 * (k % 4))
+    return out.hex()
+
+
+def build_twobit_caller():
+    """hipcc, against include/compat only (the kernel is compiled in the CALLER's translation unit from the compat header)."""
+    scrooge_amd.build_library()
+    libdir = os.path.join(ROOT, "scrooge_amd")
+    p = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-std=c++17", "-Wall", "-Werror",
+                        "-I" + os.path.join(ROOT, "include", "compat"), "-I" + os.path.join(ROOT, "include"), TWOBIT_SRC,
+                        "-L" + libdir, "-lscrooge_amd", "-Wl,-rpath," + libdir, "-o", TWOBIT_EXE], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+
+
+def test_third_export_compiles_with_hipcc_against_the_compat_headers():
+    """Runs everywhere: a tests.cu:582-647-shaped caller of the exported kernel compiles and links for gfx950."""
+    build_twobit_caller()
+    assert os.path.exists(TWOBIT_EXE)
+
+
+@pytest.mark.gpu
+def test_third_export_packs_the_references_strings():
+    """The kernel launched as src/tests.cu:626 launches it (<<<32, 32>>>), on the six strings of src/tests.cu:583-590 and more."""
+    build_twobit_caller()
+    r = subprocess.run([TWOBIT_EXE] + [s or "-" for s in TWOBIT_INPUTS], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.split("\n")[:len(TWOBIT_INPUTS)] == [_twobit_expected(s) for s in TWOBIT_INPUTS]
