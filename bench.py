@@ -80,6 +80,18 @@ def parse():
                     help="after the timed region, also time the host-pointer entry points (scrg_align_pairs on one of the timed batches, "
                          "scrg_align_mapping_resident on configs[2]; PCIe-inclusive, reported as `host_api`, never `value`); auto = only in "
                          "the default single-GPU run of the headline workload")
+    ap.add_argument("--diagnose", default="auto", choices=["auto", "on", "off"],
+                    help="N > 1 (edit streams, decode on): after the timed region, measure in the same run what the open design questions "
+                         "of the multi-GPU step need — the same steps under the other policies (root 0 with equal shards / with the "
+                         "'auto' root share, rotating root), without the decode, the gather alone (achieved GB/s per peer into rank 0, all "
+                         "peers at once and one at a time) and every rank's own N=1-equivalent rate — reported as `diagnose` and "
+                         "`per_gpu_value`; auto = on when N > 1")
+    ap.add_argument("--deadline", type=float, default=1500.0,
+                    help="hard limit in seconds for the whole run (0 = none): a rank that is still running then — e.g. stalled in a "
+                         "collective — prints where it was and exits with code 124 (the launcher tears the other ranks down); the "
+                         "self-launching parent (`python bench.py --gpus N`) kills its child's process group at deadline + 30 s and, with "
+                         "--attempts > 1, starts a FRESH child (never a re-exec of a process that touched the GPU)")
+    ap.add_argument("--attempts", type=int, default=1, help="self-launch only: fresh children to try when one hits the deadline")
     ap.add_argument("--no-build", action="store_true",
                     help="never rebuild the library (profiling: nothing may fork a compiler under rocprofv3)")
     ap.add_argument("--stats", action="store_true", help="profiling only: print kernel round/step counters")
@@ -601,13 +613,60 @@ def self_launch(args):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # the host driver only supports dmabuf IPC (RCCL across processes)
     env.setdefault("OMP_NUM_THREADS", "1")
-    proc = subprocess.Popen(cmd, env=env, cwd=ROOT)        # stdout / stderr inherited: rank 0's JSON line is the child's
-    try:
-        rc = proc.wait()
-    except KeyboardInterrupt:
-        proc.terminate()
-        rc = proc.wait()
+    import signal
+    rc = 124
+    for attempt in range(max(1, args.attempts)):
+        # a fresh child per attempt, in its own process group (so that a stalled job can be ended as a whole); stdout / stderr
+        # inherited: rank 0's JSON line is the child's
+        proc = subprocess.Popen(cmd, env=env, cwd=ROOT, start_new_session=True)
+        try:
+            rc = proc.wait(timeout=(args.deadline + 30.0) if args.deadline > 0 else None)
+            break
+        except subprocess.TimeoutExpired:
+            print("bench.py --gpus %d: attempt %d did not finish within --deadline %.0f s (+30): ending its process group"
+                  % (args.gpus, attempt + 1, args.deadline), file=sys.stderr)
+            for sig in (signal.SIGTERM, signal.SIGKILL):
+                try:
+                    os.killpg(proc.pid, sig)
+                except ProcessLookupError:
+                    break
+                try:
+                    proc.wait(timeout=20)
+                    break
+                except subprocess.TimeoutExpired:
+                    continue
+            rc = 124
+        except KeyboardInterrupt:
+            os.killpg(proc.pid, signal.SIGTERM)
+            rc = proc.wait()
+            break
     raise SystemExit(rc)
+
+
+PHASE = ["start"]
+
+
+def set_phase(text):
+    PHASE[0] = text
+
+
+def arm_deadline(seconds, rank):
+    """In-rank watchdog (also under an explicit launcher, where no parent of ours exists): a daemon timer that ends THIS process
+    with code 124 — no re-exec, no new GPU work — when the run is still going after `seconds`, saying which phase it was in
+    (a rank stalled in a collective never returns to Python, so the main thread cannot do this itself)."""
+    if seconds <= 0:
+        return None
+    import threading
+
+    def fire():
+        print("bench.py: rank %d still running after --deadline %.0f s (phase: %s): exiting with code 124" % (rank, seconds, PHASE[0]),
+              file=sys.stderr, flush=True)
+        os._exit(124)
+
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
+    return t
 
 
 STEP_TEXT = {
@@ -641,6 +700,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    stall = os.environ.get("SCRG_BENCH_TEST_STALL")      # test only (tests/test_distributed_cpu.py): a rank that never comes back
+    watchdog = None if stall == "no-watchdog" else arm_deadline(args.deadline, rank)
+    if stall and (stall != "rank1" or rank == 1):
+        set_phase("test stall (SCRG_BENCH_TEST_STALL)")
+        while True:
+            time.sleep(1.0)
+    import datetime
+    pg_timeout = datetime.timedelta(seconds=max(60.0, min(args.deadline if args.deadline > 0 else 1800.0, 1800.0)))
     if world != args.gpus:
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d): for N > 1 launch with `python -m torch.distributed.run "
                          "--nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`"
@@ -665,12 +732,13 @@ def main():
     if force_gather:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=device, timeout=pg_timeout)
     elif world > 1:
+        set_phase("process group set-up")
         if dryrun:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=pg_timeout)
         else:
-            dist.init_process_group("nccl", device_id=device)    # nccl == RCCL on ROCm
+            dist.init_process_group("nccl", device_id=device, timeout=pg_timeout)    # nccl == RCCL on ROCm
 
     al = scrooge_amd.Aligner(local_rank)
     al.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -870,57 +938,64 @@ def main():
     for a_, st_ in zip(aligners, streams):
         a_.set_stream(st_.cuda_stream)
 
+    # what a step does is read from `cur`, so that the diagnostics after the timed region can run the same steps under another
+    # policy (another gather object / root, other shards, no decode, no collective at all)
+    cur = {"fmt": gather_format if dist_on else "local", "gather": gather, "descs": descs, "decode_args": decode_args,
+           "denses": denses}
+
     def step(k=None):
         j = step.count
         step.count += 1
         b = j % n_lanes
         o = outs[b]
+        fmt, gather_, descs_ = cur["fmt"], cur["gather"], cur["descs"]
         with torch.cuda.stream(streams[b]):
-            if dist_on and gather_format == "edits":
+            if fmt == "edits":
                 # The align kernel writes every pair's CIGAR as an edit stream into the pair's slice; the slices are
                 # gathered into the step's send buffer (4-byte aligned, pair order) and one RCCL collective takes
                 # scores + streams to rank 0 over xGMI; one buffer set per pipelined step, so the gather of this step
                 # overlaps the next steps' align kernels
-                gather.finish(j)                       # buffers of step j-DEPTH are free again (gathered, and decoded on their root)
-                g = gather.buffers(j)
+                gather_.finish(j)                       # buffers of step j-DEPTH are free again (gathered, and decoded on their root)
+                g = gather_.buffers(j)
                 if k is not None:
                     ev[k][0].record()
-                aligners[b].align_device_edits(n, seqs[b], descs[b], o["runs"], o["ed"], o["n_runs"], o["status"], g["cnt"], **kw)
+                aligners[b].align_device_edits(n, seqs[b], descs_[b], o["runs"], o["ed"], o["n_runs"], o["status"], g["cnt"], **kw)
                 if k is not None:
                     ev[k][1].record()
                 r4 = (o["n_runs"].to(torch.int64) + 3) & -4
                 boff = torch.cumsum(r4, 0) - r4
                 g["len"].copy_(o["n_runs"])
-                aligners[b].compact_runs(n, descs[b], o["runs"], (r4 >> 1).to(torch.int32), boff >> 1, g["stream"])
-                gather.start(j, o["ed"], decode=decode_args if step.decode else None)
+                aligners[b].compact_runs(n, descs_[b], o["runs"], (r4 >> 1).to(torch.int32), boff >> 1, g["stream"])
+                gather_.start(j, o["ed"], decode=cur["decode_args"] if step.decode else None)
                 return
             if k is not None:
                 ev[k][0].record()
-            aligners[b].align_device(n, seqs[b], descs[b], o["runs"], o["ed"], o["n_runs"], o["status"], **kw)
+            aligners[b].align_device(n, seqs[b], descs_[b], o["runs"], o["ed"], o["n_runs"], o["status"], **kw)
             if k is not None:
                 ev[k][1].record()
-            if dist_on and gather_format == "edits-from-runs":
+            if fmt == "edits-from-runs":
                 # the same with the streams encoded from the kernel's runs (any W/O, any kernel)
-                gather.finish(j)
-                g = gather.buffers(j)
-                aligners[b].encode_edit_stream(n, descs[b], o["runs"], o["n_runs"], g["stream"], g["off"], g["len"], g["total"])
-                gather.start(j, o["ed"])
+                gather_.finish(j)
+                g = gather_.buffers(j)
+                aligners[b].encode_edit_stream(n, descs_[b], o["runs"], o["n_runs"], g["stream"], g["off"], g["len"], g["total"])
+                gather_.start(j, o["ed"])
                 return
             cnt64 = o["n_runs"].to(torch.int64)
             dense_off = torch.cumsum(cnt64, 0) - cnt64
-            if dist_on:
+            if fmt in ("packed", "runs"):
                 # the same with the runs themselves (--gather-format runs | packed)
-                gather.finish(j)                       # buffers of step j-DEPTH are free again
+                gather_.finish(j)                       # buffers of step j-DEPTH are free again
                 if packed_gather:
-                    aligners[b].compact_runs_packed(n, descs[b], o["runs"], o["n_runs"], dense_off, gather.send_runs[j % gather.DEPTH], **kw)
+                    aligners[b].compact_runs_packed(n, descs_[b], o["runs"], o["n_runs"], dense_off, gather_.send_runs[j % gather_.DEPTH], **kw)
                 else:
-                    aligners[b].compact_runs(n, descs[b], o["runs"], o["n_runs"], dense_off, gather.send_runs[j % gather.DEPTH])
-                gather.start(j, o["ed"], o["n_runs"])
+                    aligners[b].compact_runs(n, descs_[b], o["runs"], o["n_runs"], dense_off, gather_.send_runs[j % gather_.DEPTH])
+                gather_.start(j, o["ed"], o["n_runs"])
             else:
-                aligners[b].compact_runs(n, descs[b], o["runs"], o["n_runs"], dense_off, denses[b])
+                aligners[b].compact_runs(n, descs_[b], o["runs"], o["n_runs"], dense_off, cur["denses"][b])
 
     step.count = 0
     step.decode = decode_on
+    set_phase("warm-up steps")
     for _ in range(args.warmup):
         step()
     if gather is not None:
@@ -928,6 +1003,7 @@ def main():
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
+    set_phase("timed region (%d steps)" % args.steps)
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(k)
@@ -939,6 +1015,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    set_phase("checks after the timed region")
     last = (step.count - 1) % n_lanes
     # the rank that holds the last step's gathered results checks them (rank 0 unless the root rotates)
     check_rank = gather.root_of(step.count - 1) if (gather is not None and edits) else 0
@@ -1027,6 +1104,186 @@ def main():
                         "ms_per_step": float(tso.item()) / args.steps * 1e3,
                         "note": "the same steps without the root's decoding (gathered CIGARs stay edit streams); measured after the timed region"}
         step.decode = decode_on
+    # ---------------- N > 1: the diagnostics of the multi-GPU step, after everything that is timed ----------------
+    # One run on a multi-GPU node should answer the open design questions at once: root 0 against a rotating
+    # root, equal shards against the root-share plan, what the decode costs, what the links carry, what every GPU does alone.
+    diagnose = None
+    per_gpu_value = None
+    want_diag = (dist_on and gather_format == "edits" and decode_on and p.lanes_per_pair == 1 and
+                 (args.diagnose == "on" or (args.diagnose == "auto" and world > 1)))
+    if want_diag:
+        set_phase("diagnostics: sizes of the full batches")
+        K = max(2, args.steps)
+        gather.finish_all()
+        torch.cuda.synchronize()
+        # stream bytes / run totals of the FULL batches (every pair real): what any policy may have to carry
+        sb_full, rt_full = 0, 0
+        t_len = torch.empty(n, dtype=torch.int32, device=device)
+        t_cnt = torch.empty(n, dtype=torch.int32, device=device)
+        for b_ in range(n_lanes):
+            o = outs[b_]
+            with torch.cuda.stream(streams[b_]):
+                aligners[b_].align_device_edits(n, seqs[b_], descs_full[b_], o["runs"], o["ed"], t_len, o["status"], t_cnt, **kw)
+            torch.cuda.synchronize()
+            sb_full = max(sb_full, int(((t_len.to(torch.int64) + 3) // 4 * 4).sum().item()))
+            rt_full = max(rt_full, int(t_cnt.to(torch.int64).sum().item()))
+        del t_len, t_cnt
+        dense_local = [torch.empty(max(rt_full, 8) * 2, dtype=torch.uint8, device=device) for _ in range(n_lanes)]
+
+        def all_max(x):
+            t_ = torch.tensor([x], dtype=torch.float64, device=device)
+            dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+            return float(t_.item())
+
+        def timed_steps(pairs_step, after=None):
+            """warm-up, barrier, K steps, barrier: job pairs/s under whatever `cur` says (max over ranks of the time)"""
+            for _ in range(2):
+                step()
+            if cur["gather"] is not None:
+                cur["gather"].finish_all()
+            dist.barrier()
+            torch.cuda.synchronize()
+            t_ = time.perf_counter()
+            for _ in range(K):
+                step()
+            if cur["gather"] is not None:
+                cur["gather"].finish_all()
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            d_ = all_max(time.perf_counter() - t_)
+            return {"value": pairs_step * K / d_, "unit": "pairs/s", "ms_per_step": d_ / K * 1e3, "pairs_per_step_all_gpus": pairs_step, "steps": K}
+
+        def policy(root, shards):
+            """the same steps with the results gathered to `root` (0 | "rotate") and the step's pairs split `shards`
+            ("equal": every rank aligns --pairs; "auto": root_share_plan) — None if this run's buffers cannot hold it"""
+            if shards == "equal":
+                real0 = real_other = nominal
+            else:
+                real0, real_other = root_share_plan(world, nominal, "auto")
+            if max(real0, real_other) > n:
+                return {"skipped": "the buffers of this run hold %d pairs per rank; this policy needs %d (start with --root-share auto)" % (n, max(real0, real_other))}
+            mine = real0 if rank == 0 else real_other
+            descs_p = []
+            for b_ in range(n_lanes):
+                d_ = descs_full[b_].clone()
+                d_[mine:, 1] = 0
+                d_[mine:, 3] = 0
+                descs_p.append(d_)
+            rl_p = torch.zeros((world, n), dtype=torch.int64, device=device)
+            rl_p[0, :real0] = L
+            rl_p[1:, :real_other] = L
+            g_ = EditStreamGather(n, sb_full, device, dst=root, depth=max(2, n_lanes), ordered=True, total_runs=rt_full)
+            g_.prime()
+            keep = dict(cur)
+            cur.update(fmt="edits", gather=g_, descs=descs_p, decode_args=(decoders, rl_p.reshape(-1), 1, dict(kw)))
+            step.decode = True
+            try:
+                res_ = timed_steps(real0 + (world - 1) * real_other)
+                # the decode of the last step on its root must have found every stream an alignment of a read of its length
+                flag = 1
+                if rank == g_.root_of(step.count - 1):
+                    flag = 1 if int(g_.decoded(step.count - 1)["bad"].item()) == 0 else 0
+                ft = torch.tensor([flag], dtype=torch.int32, device=device)
+                dist.all_reduce(ft, op=dist.ReduceOp.MIN)
+                res_["every_slot_decoded"] = bool(int(ft.item()))
+                res_["shards"] = {"rank_0": real0, "other_ranks": real_other}
+                res_["root"] = "rank 0" if root == 0 else "step k to rank k mod N"
+            finally:
+                cur.clear()
+                cur.update(keep)
+                step.decode = decode_on
+                del g_, descs_p, rl_p
+                torch.cuda.empty_cache()
+            return res_
+
+        diagnose = {"steps": K, "note": "measured after the timed region, same pipeline, same batches; `value` of the line is the configured policy"}
+        set_phase("diagnostics: root 0, equal shards")
+        diagnose["root0_equal_shards"] = policy(0, "equal")
+        set_phase("diagnostics: root 0, root-share plan")
+        diagnose["root0_auto_shards"] = policy(0, "auto")
+        set_phase("diagnostics: rotating root")
+        diagnose["rotating_root_equal_shards"] = policy("rotate", "equal")
+        diagnose["gather_without_decode"] = streams_only
+        # ---- the links: the gather alone (nothing else on the GPUs), all peers at once, then one peer at a time ----
+        set_phase("diagnostics: the gather alone")
+        gather.finish_all()
+        host_stage = gather.host_stage
+        reps = 2 if host_stage else 10
+        dist.barrier()
+        torch.cuda.synchronize()
+        t_ = time.perf_counter()
+        for k_ in range(reps):
+            b_ = k_ % gather.DEPTH
+            if host_stage:
+                hs = [torch.empty(gather.wire, dtype=torch.uint8) for _ in range(world)] if rank == 0 else None
+                dist.gather(gather.send[b_].cpu(), hs, dst=0)
+            else:
+                dist.gather(gather.send[b_], gather.recv[b_] if rank == 0 else None, dst=0)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        d_ = all_max(time.perf_counter() - t_)
+        links = {"bytes_per_rank_and_gather": gather.wire, "gathers": reps, "ms_per_gather": d_ / reps * 1e3,
+                 "GBs_per_peer_all_at_once": gather.wire * reps / d_ / 1e9,
+                 "GBs_into_rank_0": (world - 1) * gather.wire * reps / d_ / 1e9,
+                 "backend": dist.get_backend() + (" (dry run: staged through the host, not a link figure)" if host_stage else "")}
+        set_phase("diagnostics: one peer at a time")
+        one = []
+        for r_ in range(1, world):
+            dist.barrier()
+            torch.cuda.synchronize()
+            t_ = time.perf_counter()
+            if rank == r_:
+                for k_ in range(reps):
+                    dist.send(gather.send[0].cpu() if host_stage else gather.send[0], dst=0)
+            elif rank == 0:
+                buf_ = torch.empty(gather.wire, dtype=torch.uint8) if host_stage else gather.recv[0][r_]
+                for k_ in range(reps):
+                    dist.recv(buf_, src=r_)
+            torch.cuda.synchronize()
+            dist.barrier()
+            d1 = all_max(time.perf_counter() - t_)
+            one.append({"peer": r_, "GBs": gather.wire * reps / d1 / 1e9, "ms_per_message": d1 / reps * 1e3})
+        links["one_peer_at_a_time"] = one
+        links["xgmi_link_peak_GBs"] = 76.8            # MI355X_MICROARCH.md: 7 links x 153.6 GB/s bidirectional per GPU = 76.8 GB/s per direction and peer
+        diagnose["links"] = links
+        # ---- every rank alone: the N = 1 step (align kernel + run compaction, no collective), all ranks at the same time ----
+        set_phase("diagnostics: every rank's own step")
+        descs_eq = []
+        for b_ in range(n_lanes):
+            d_ = descs_full[b_].clone()
+            d_[nominal:, 1] = 0
+            d_[nominal:, 3] = 0
+            descs_eq.append(d_)
+        keep = dict(cur)
+        cur.update(fmt="local", gather=None, descs=descs_eq, denses=dense_local)
+        try:
+            for _ in range(2):
+                step()
+            dist.barrier()
+            torch.cuda.synchronize()
+            t_ = time.perf_counter()
+            for _ in range(K):
+                step()
+            torch.cuda.synchronize()
+            mine_rate = nominal * K / (time.perf_counter() - t_)
+        finally:
+            cur.clear()
+            cur.update(keep)
+        rates = [torch.zeros(1, dtype=torch.float64, device=device) for _ in range(world)]
+        dist.all_gather(rates, torch.tensor([mine_rate], dtype=torch.float64, device=device))
+        rates = [float(x.item()) for x in rates]
+        per_gpu_value = {"per_rank": rates, "min": min(rates), "mean": sum(rates) / world, "max": max(rates), "unit": "pairs/s",
+                         "pairs_per_rank_and_step": nominal, "steps": K,
+                         "note": "the N = 1 step of BENCH (align kernel + run compaction, same pipeline, no collective), all ranks at the "
+                                 "same time: what N x this would be with a free gather"}
+        diagnose["efficiency_vs_per_gpu_value"] = {k_: (v_["value"] / (world * per_gpu_value["mean"]) if isinstance(v_, dict) and "value" in v_ else None)
+                                                   for k_, v_ in diagnose.items() if k_.endswith("_shards")}
+        diagnose["efficiency_vs_per_gpu_value"]["configured"] = pairs_per_step_all * args.steps / dt / (world * per_gpu_value["mean"])
+        del dense_local, descs_eq
+        torch.cuda.empty_cache()
+        set_phase("after the diagnostics")
     # reference point outside the timed region: the same step on ONE stream (no overlap between launches)
     serial = None
     if n_lanes > 1 and not dist_on and not args.stats:
@@ -1452,6 +1709,8 @@ def main():
         "host_api": host_api,             # the host-pointer entry points (PCIe-inclusive; never `value`), after the timed region
         "edit_stream_step": edit_stream_step,   # the N > 1 step (CIGARs as edit streams) on this one GPU, without the collective
         "gather_without_decode": streams_only,  # N > 1: the same steps with the gathered CIGARs left as edit streams (after the timed region)
+        "per_gpu_value": per_gpu_value,         # N > 1: every rank's own N=1-equivalent step rate (compare with BENCH's `value`)
+        "diagnose": diagnose,                   # N > 1: the same steps under the other policies, the gather alone, per-peer GB/s (after the timed region)
         "roofline": roofline,
         "cpu_baseline": cpu,
         "parity": parity,

@@ -387,10 +387,11 @@ class Aligner:
         self._check(st, allow=(SCRG_ERR_CIGAR_OVERFLOW,))
         return self._finish(res, st, arrays, strict)
 
-    def align_pairs_rows(self, rows, text_off, text_lens, read_off, read_lens, strict=True, **kw):
+    def align_pairs_rows(self, rows, text_off, text_lens, read_off, read_lens, strict=True, devices=None, **kw):
         """scrg_align_pairs on sequences that sit in ONE 2-D uint8 numpy array (row p: the text of pair p at byte
         text_off, its read at byte read_off — bench.py's staging layout), lengths as integers or per-row arrays: the
         pointer arrays are built with numpy, so a batch of 100 k x 10 kb pairs costs no per-pair Python objects.
+        devices: a device list -> scrg_align_pairs_multi (a device may be listed more than once).
         -> the result as numpy arrays (see _collect_arrays); `last_timing` has the library's own clock."""
         import numpy as np
         rows = np.ascontiguousarray(rows, dtype=np.uint8)
@@ -402,6 +403,13 @@ class Aligner:
         ql = np.ascontiguousarray(np.broadcast_to(np.asarray(read_lens, dtype=np.uint64), (n,)))
         pp, up = C.POINTER(C.c_char_p), C.POINTER(C.c_uint64)
         res = C.POINTER(Result)()
+        if devices is not None:
+            dv = (C.c_int32 * len(devices))(*devices)
+            st = self.lib.scrg_align_pairs_multi(dv, len(devices), C.byref(self._params(kw)), n, C.cast(tp.ctypes.data, pp),
+                                                 C.cast(tl.ctypes.data, up), C.cast(qp.ctypes.data, pp), C.cast(ql.ctypes.data, up), C.byref(res))
+            if st not in (SCRG_OK, SCRG_ERR_CIGAR_OVERFLOW):
+                raise ScroogeError(st, (self.lib.scrg_multi_last_error() or b"").decode())
+            return self._finish(res, st, True, strict)
         st = self.lib.scrg_align_pairs(self.h, C.byref(self._params(kw)), n, C.cast(tp.ctypes.data, pp), C.cast(tl.ctypes.data, up),
                                        C.cast(qp.ctypes.data, pp), C.cast(ql.ctypes.data, up), C.byref(res))
         self._check(st, allow=(SCRG_ERR_CIGAR_OVERFLOW,))

@@ -312,3 +312,46 @@ def test_bench_self_launch_refuses_more_ranks_than_gpus():
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64", "--no-build"], env=env, cwd=root,
                          capture_output=True, text=True, timeout=300)
     assert out.returncode != 0 and "this node has" in out.stderr
+
+
+def test_bench_rank_watchdog_ends_a_stalled_rank():
+    """--deadline: a rank that is still running when the deadline passes (here: one that never returns, SCRG_BENCH_TEST_STALL; on
+    hardware: one stalled in a collective) says which phase it was in and exits with code 124 by itself — no re-exec, no new
+    GPU work."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SCRG_BENCH_TEST_STALL="1")
+    env.pop("WORLD_SIZE", None)
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--no-build", "--deadline", "3"], env=env, cwd=root,
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 124 and time.time() - t0 < 60
+    assert "still running after --deadline 3 s (phase: test stall" in out.stderr
+
+
+def test_bench_self_launch_ends_a_stalled_job():
+    """`python bench.py --gpus 2` whose ranks stall: with the ranks' own watchdogs the job ends with their code; with the
+    watchdogs off (a rank wedged so hard that no thread of it runs) the PARENT ends the child's whole process group at
+    deadline + 30 s and exits with 124 — never by re-executing anything that touched a GPU (it starts a fresh child per
+    attempt, and by default there is one attempt)."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SCRG_BENCH_DRYRUN="1", SCRG_BENCH_TEST_STALL="1")
+    env.pop("WORLD_SIZE", None)
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--no-build", "--deadline", "5"], env=env, cwd=root,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and time.time() - t0 < 120
+    assert "still running after --deadline 5 s" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
+    # the ranks' watchdogs off: the parent's limit (deadline + 30 s) ends the whole process group
+    env["SCRG_BENCH_TEST_STALL"] = "no-watchdog"
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--no-build", "--deadline", "2"], env=env, cwd=root,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 124 and 30 < time.time() - t0 < 150
+    assert "did not finish within --deadline 2 s (+30): ending its process group" in out.stderr

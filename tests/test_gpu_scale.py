@@ -357,6 +357,25 @@ def test_bench_two_ranks_dry_run(gather_root, root_share):
         assert sh["rank_0"] == want0 and sh["other_ranks"] == (12800 - want0 + 63) // 64 * 64
         assert j["config"]["pairs_per_step_all_gpus"] == sh["rank_0"] + sh["other_ranks"] >= 12800
     assert j["roofline"]["kernel"].startswith("genasm_lane_kernel") and j["roofline"]["hbm"]["achieved"] > 0
+    # the diagnostics of the multi-GPU step, in the same line (--diagnose auto = on for N > 1): the same steps under the other
+    # policies, the gather alone, every peer's rate into rank 0, every rank's own N = 1-equivalent rate
+    d = j["diagnose"]
+    for key in ("root0_equal_shards", "root0_auto_shards", "rotating_root_equal_shards"):
+        assert key in d
+        if "skipped" in d[key]:
+            assert key == "root0_auto_shards" and sh == "equal"         # buffers sized for equal shards cannot hold the larger ones
+        else:
+            assert d[key]["value"] > 0 and d[key]["every_slot_decoded"] is True and d[key]["steps"] >= 2
+    assert d["root0_equal_shards"]["shards"] == {"rank_0": 6400, "other_ranks": 6400}
+    assert d["rotating_root_equal_shards"]["root"] == "step k to rank k mod N"
+    assert d["gather_without_decode"] == j["gather_without_decode"] and j["gather_without_decode"]["value"] > 0
+    ln = d["links"]
+    assert ln["GBs_per_peer_all_at_once"] > 0 and ln["bytes_per_rank_and_gather"] == j["config"]["gather"]["bytes_per_rank_and_step"]
+    assert [x["peer"] for x in ln["one_peer_at_a_time"]] == [1] and ln["one_peer_at_a_time"][0]["GBs"] > 0
+    pg = j["per_gpu_value"]
+    assert len(pg["per_rank"]) == 2 and pg["min"] > 0 and pg["pairs_per_rank_and_step"] == 6400
+    assert d["efficiency_vs_per_gpu_value"]["configured"] > 0
+    assert j["config"]["rccl_ranks"] == 2
 
 
 def test_full_bench_size_two_algorithms_agree(aligner):
@@ -889,3 +908,44 @@ def test_decode_large_launch_stores_pieces_together(aligner):
         assert int(big[R * total * 2:].max().item()) == 0                 # nothing past the last pair's segment
     finally:
         aligner.use_own_stream()
+
+
+def _run_tool(args, timeout):
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable] + args, cwd=root, capture_output=True, text=True, timeout=timeout)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert lines, (out.stdout[-1500:], out.stderr[-3000:])
+    j = json.loads(lines[-1])
+    assert out.returncode == 0 and j["ok"], (j.get("checks"), out.stderr[-2000:])
+    return j
+
+
+def test_config4_full_size_one_gpu():
+    """BASELINE configs[3] AT ITS SIZE — 1 M x 10 kb ONT-error pairs — on the one GPU there is, as the eight shards of 125 000 an
+    8-GPU job aligns (tests/tools/config3_full.py): every shard through the real N > 1 step (edit-stream kernel + run counts,
+    compaction into the wire buffer, the RCCL gather on a one-rank group) into one eight-slot receive buffer, ONE decode launch
+    over all 1 M pairs.  Every pair is held to the size-independent properties (validateCigarString, src/tests.cu:27-169, as
+    tensor arithmetic), edit distance == edit bytes of its stream, decoded runs == the runs kernel's bytes; 20 000 pairs
+    spread over all eight shards run for run against the reference CPU path (src/genasm_cpu.cpp:411-438 via oracle/_ref).
+    The same 1 M pairs then go through ONE scrg_align_pairs_multi call with eight logical devices and must give the same
+    arrays."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    j = _run_tool([os.path.join(root, "tests", "tools", "config3_full.py"), "--multi"], timeout=1100)
+    assert j["checks"]["properties_hold_for_every_pair"] and j["checks"]["run_for_run_with_the_reference"]
+    assert j["checks"]["multi_runs_equal"] and j["reference_pairs"]["checked"] >= 20000
+    assert 700 < j["mean_edit_distance"] < 1300 and j["total_runs"] > 1.9e9
+
+
+def test_config5_full_size_one_gpu():
+    """BASELINE configs[4] at >= 10 000 pairs: 10 240 x 50 kb PacBio-error (15 %) pairs, ~1 650 windows per pair
+    (src/genasm_cpu.cpp:411-438), generated and packed on the GPU like bench.py's other_configs leg: every pair held to the
+    size-independent properties, 1 500 pairs run for run against the reference CPU path, the edit-stream kernel decoded
+    back to the same runs."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    j = _run_tool([os.path.join(root, "tests", "tools", "config3_full.py"), "--shards", "1", "--pairs", "10240", "--read-len", "50000",
+                   "--profile", "pacbio15", "--ref-pairs", "1500", "--seed", "50"], timeout=900)
+    assert j["checks"]["properties_hold_for_every_pair"] and j["checks"]["run_for_run_with_the_reference"]
+    assert j["reference_pairs"]["checked"] >= 1500 and 5500 < j["mean_edit_distance"] < 11000
