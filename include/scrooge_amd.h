@@ -126,6 +126,13 @@ int         scrg_device_count(void);
  * by design).  See scrg_debug_stats. */
 enum { SCRG_BUILD_STATS = 1, SCRG_BUILD_ABLATE = 2 };
 int         scrg_build_flags(void);
+/* The version of THIS interface.  It goes up whenever an entry point changes its arguments under the same name (version 5:
+ * scrg_decode_edit_stream takes the capacity of its output array) — such a change still links against code compiled with the
+ * older header and would shift every later argument.  scrg_abi_version() is what the loaded library was built with; a binding
+ * compares it with the SCRG_ABI_VERSION it was compiled against before anything else (include/scrooge_amd.hpp throws,
+ * scrooge_amd/api.py raises). */
+#define SCRG_ABI_VERSION 5
+int         scrg_abi_version(void);
 
 /* ---------------------------------------------------------------------------
  * Host-pointer entry points (the drop-in path).
@@ -362,8 +369,12 @@ scrg_status scrg_ascii_to_twobit(scrg_ctx *ctx, uint64_t count, const uint64_t *
                                  const uint64_t *d_twobit_off, uint8_t *d_twobit,
                                  uint32_t *d_bad_count);
 
-/* Launch geometry actually used for params on this device (for the bench's
- * roofline line): persistent wavefronts, pairs per wavefront, LDS bytes. */
+/* Launch geometry for params on this device (for the bench's roofline line): persistent wavefronts, pairs per
+ * wavefront, LDS bytes per wavefront.  It describes the kernel a launch that FILLS the GPU takes.  One exception is
+ * decided per launch, by its size: with the default table (W <= 64, W-O <= 31, runs output) and waves_per_cu left at 0, a
+ * launch of at most one wavefront per SIMD (n_pairs <= 64 x 4 x CUs) runs as workgroups of 512 threads — four producer and
+ * four consumer wavefronts, 58 432 bytes of LDS per workgroup, two workgroups per CU.  A caller that sizes co-resident
+ * work from these numbers sets waves_per_cu explicitly: the launch then has exactly the geometry reported here. */
 scrg_status scrg_query_launch(scrg_ctx *ctx, const scrg_params *params,
                               int32_t *n_waves, int32_t *pairs_per_wave, int32_t *lds_bytes,
                               int32_t *n_cus);

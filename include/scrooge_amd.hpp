@@ -139,10 +139,21 @@ inline std::vector<Alignment_t> to_alignments(const scrg_result* r)
 
 // One GPU, explicitly: a handle per (thread, device), for callers that place work themselves or keep a genome resident.
 // (The free functions below, the reference's surface, use every visible GPU.)
+namespace detail {
+// the loaded library must speak the interface this header declares (scrg_abi_version, scrooge_amd.h)
+inline void check_abi()
+{
+    if (scrg_abi_version() != SCRG_ABI_VERSION)
+        throw std::runtime_error("scrooge_amd: libscrooge_amd.so has interface version " + std::to_string(scrg_abi_version()) +
+                                 ", this program was compiled against version " + std::to_string(SCRG_ABI_VERSION));
+}
+}  // namespace detail
+
 class Handle {
 public:
     explicit Handle(int device = 0)
     {
+        detail::check_abi();
         scrg_status s = scrg_ctx_create(device, &ctx_);
         if (s != SCRG_OK) throw std::runtime_error(std::string("scrooge_amd: ") + scrg_status_string(s));
         scrg_params_default(&params_);
@@ -265,6 +276,7 @@ namespace detail {
 // the free functions (the reference's surface) use EVERY visible GPU: scrg_align_pairs_multi / scrg_align_mapping_multi
 inline std::vector<int32_t> all_devices()
 {
+    check_abi();
     const int n = scrg_device_count();
     if (n <= 0) throw std::runtime_error(std::string("scrooge_amd: ") + scrg_status_string(SCRG_ERR_NO_DEVICE));
     std::vector<int32_t> d((size_t)n);

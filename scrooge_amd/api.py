@@ -18,6 +18,7 @@ SCRG_ERR_NO_DEVICE = 3
 SCRG_ERR_HIP = 4
 SCRG_ERR_OOM = 5
 SCRG_ERR_CIGAR_OVERFLOW = 6
+SCRG_ABI_VERSION = 5          # include/scrooge_amd.h (tests/test_abi.py holds the two equal)
 SEQ_PAD_WORDS = 4
 GROUP = 64                     # rows per group of the lane-interleaved layout
 SEQ_PAD_WORDS_GROUPS = 2 * GROUP + 2
@@ -142,6 +143,7 @@ def load_library():
         "scrg_get_log": (C.c_int, []),
         "scrg_device_count": (C.c_int, []),
         "scrg_build_flags": (C.c_int, []),
+        "scrg_abi_version": (C.c_int, []),
         "scrg_result_free": (None, [C.POINTER(Result)]),
         "scrg_result_pool_trim": (None, []),
         "scrg_align_pairs": (C.c_int32, [vp, C.POINTER(Params), u64, C.POINTER(C.c_char_p),
@@ -182,6 +184,11 @@ def load_library():
         fn = getattr(lib, name)   # AttributeError if the library lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
+    # the signatures above are those of interface version SCRG_ABI_VERSION (include/scrooge_amd.h): a library built from other
+    # sources (SCRG_LIB, a stale copy) must say so instead of taking shifted arguments
+    if lib.scrg_abi_version() != SCRG_ABI_VERSION:
+        raise ScroogeError(SCRG_ERR_INVALID_ARG, "%s has interface version %d, this binding speaks version %d"
+                           % (so, lib.scrg_abi_version(), SCRG_ABI_VERSION))
     _LIB = lib
     return lib
 
@@ -189,7 +196,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "scrg_params_default", "scrg_params_resolve", "scrg_ctx_create", "scrg_ctx_destroy", "scrg_ctx_set_stream",
     "scrg_ctx_use_own_stream", "scrg_stream_create", "scrg_stream_destroy",
-    "scrg_last_error", "scrg_status_string", "scrg_set_log", "scrg_get_log", "scrg_device_count", "scrg_build_flags",
+    "scrg_last_error", "scrg_status_string", "scrg_set_log", "scrg_get_log", "scrg_device_count", "scrg_build_flags", "scrg_abi_version",
     "scrg_result_free", "scrg_result_pool_trim", "scrg_align_pairs", "scrg_align_mapping", "scrg_align_pairs_multi", "scrg_align_mapping_multi",
     "scrg_host_plan", "scrg_multi_release", "scrg_multi_last_error", "scrg_genome_set", "scrg_genome_clear",
     "scrg_align_mapping_resident", "scrg_pack_planar", "scrg_pack_planar_host", "scrg_pack_planar_groups",
@@ -351,10 +358,12 @@ class Aligner:
             out = {"edit_distance": arr(r.edit_distance, n, np.int64),
                    "status": arr(r.pair_status, n, np.uint32),
                    "run_offset": run_offset,
-                   "runs": np.frombuffer(C.string_at(r.runs, 2 * total_runs), dtype=np.uint8).reshape(-1, 2).copy()
+                   # (views of the library's arrays copied with numpy: ctypes.string_at takes no more than 2 GB, a batch of a
+                   # million 10 kb pairs has 4.3 GB of runs)
+                   "runs": arr(C.cast(r.runs, C.POINTER(C.c_uint8)), 2 * total_runs, np.uint8).reshape(-1, 2)
                            if total_runs else np.zeros((0, 2), np.uint8),      # columns: count, op
                    "cigar_offset": cigar_offset,
-                   "cigar_text": C.string_at(r.cigar_text, int(cigar_offset[n])) if n else b""}
+                   "cigar_text": arr(C.cast(r.cigar_text, C.POINTER(C.c_uint8)), int(cigar_offset[n]), np.uint8).tobytes() if n else b""}
             self.last_timing = {"kernel_ns": int(r.kernel_ns), "pack_ns": int(r.pack_ns),
                                 "total_ns": int(r.total_ns)}
         finally:
@@ -594,7 +603,7 @@ class Aligner:
                                                      int(read_len_stride),
                                                      _ptr(dense_off_i64) if dense_off_i64 is not None else None,
                                                      _ptr(dense_u8) if dense_u8 is not None else None,
-                                                     int(dense_u8.numel() // 2) if dense_u8 is not None else 0,
+                                                     int(dense_u8.numel() * dense_u8.element_size() // 2) if dense_u8 is not None else 0,      # capacity in runs (2 bytes each), whatever the tensor's element type
                                                      _ptr(n_runs_i32), _ptr(bad_i32)))
 
     def ascii_to_twobit(self, count, lens, ascii_off, ascii, twobit_off, twobit, bad):

@@ -37,6 +37,14 @@ constexpr uint32_t DEC_WAVE_LDS = 64u * DEC_OUT_STRIDE;
 constexpr uint32_t DEC_FLUSH_AT = 32;                 // final runs in one lane's ring that start a store pass (looked at once per epoch: + <= 32 runs until the next look)
 constexpr int DEC_STEPS_PER_CHECK = 4;                // steps between two looks at the buffers (<= 2 runs and 1 byte per step)
 constexpr uint32_t DEC_EPOCH = 4;                     // iterations between two block moves: 16 steps, at most 16 bytes
+// The output ring is looked at ONCE per epoch.  After a look a lane holds fewer than DEC_FLUSH_AT final runs; until the next
+// look it commits at most 2 runs per step (an '=' run and an edit run: the stream "=X=X=X..." does exactly that), i.e.
+// 2 * DEC_EPOCH * DEC_STEPS_PER_CHECK more, plus the slot the free-running put() writes ahead — all of which must fit the ring, or
+// a put() would overwrite a run that has not been stored yet.  Today that is 32 + 32 = 64 = DEC_RING exactly: no headroom, so the
+// constants are tied together here (tests/test_gpu_scale.py::test_decode_two_runs_per_step_fills_the_ring drives the worst case).
+static_assert(DEC_FLUSH_AT + 2u * DEC_EPOCH * (uint32_t)DEC_STEPS_PER_CHECK <= DEC_RING,
+              "decoder: runs pending after a look + runs committed until the next look must fit the output ring");
+static_assert(DEC_PIECE <= DEC_FLUSH_AT && DEC_RING % DEC_PIECE == 0u, "decoder: a store pass takes whole pieces of the ring");
 
 struct DecodeArgs {
     uint64_t n_pairs;

@@ -43,6 +43,15 @@ constexpr uint32_t LANE_SCRATCH_BYTES = 36;      // insertion-run length of each
 constexpr uint32_t LANE_EQ_BYTES = 32;           // Eq of the window's pattern for each of the four bases, 8 bytes each
 constexpr uint32_t LANE_NOMATCH_BYTES = 8;       // the Eq word of "no character matches" (columns past the end of the text)
 constexpr uint32_t LANE_WAVE_LDS_BYTES = 64u * (LANE_RING_BYTES + LANE_SCRATCH_BYTES + LANE_EQ_BYTES + LANE_NOMATCH_BYTES);
+// The Eq words of a wavefront are stored SLOT-MAJOR: base c of lane l at eq region + c * 512 + l * 8, the region a multiple of
+// 2048 bytes.  The LDS bank of a read then depends on the lane only (512 = two rows of 64 banks), so the 64 reads of one
+// ds_read_b64 never collide whatever mix of bases the lanes look up, and a column's address is still one shift and one
+// v_bitop3: (x >> s) & 0x600 | (region + l * 8), the mask in an SGPR.  (Until round 4 a lane's four words were 32 contiguous
+// bytes and lanes eight apart shared banks: 3.6 conflict cycles per LDS instruction, SQ_LDS_BANK_CONFLICT.)
+constexpr uint32_t LANE_EQ_SLOT_STRIDE = 512;                          // 64 lanes x 8 bytes
+constexpr uint32_t LANE_EQ_REGION_BYTES = 4u * LANE_EQ_SLOT_STRIDE;    // 2048 per wavefront
+constexpr uint32_t LANE_EQ_FIELD_MASK = 3u * LANE_EQ_SLOT_STRIDE;      // 0x600: the base's two bits as an address field
+constexpr uint32_t LANE_REST_BYTES = LANE_WAVE_LDS_BYTES - LANE_EQ_REGION_BYTES;      // ring + scratch + "no match" words of a wavefront
 constexpr int LANE_EQ_AHEAD = 8;                 // Eq words are read from LDS this many columns ahead of their use
 
 // truth tables (inputs a, b, c in that order)
@@ -80,6 +89,29 @@ __device__ __forceinline__ uint32_t ffbh_u32(uint32_t v)      // count leading z
     return r;
 }
 
+// q + 2 * bit as ONE instruction, and as written (the optimiser otherwise sums the bits of an iteration first and rebuilds every
+// slot offset from the offset at the start of the iteration: one more instruction per slot)
+__device__ __forceinline__ uint32_t add_twice(uint32_t q, uint32_t bit)
+{
+    uint32_t r;
+    asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(r) : "v"(bit), "v"(q));
+    return r;
+}
+
+__device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c)      // a * b + c for a, b < 2^24, as written (v_mad_u32_u24)
+{
+    uint32_t r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+    return r;
+}
+
+__device__ __forceinline__ uint32_t add3(uint32_t a, uint32_t b, uint32_t c)       // a + b + c (c wave-uniform), as written (v_add3_u32)
+{
+    uint32_t r;
+    asm("v_add3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+    return r;
+}
+
 __device__ __forceinline__ uint32_t ffbl_u32(uint32_t v)      // count trailing zeros; 0xffffffff for v == 0
 {
     uint32_t r;
@@ -97,16 +129,14 @@ __device__ __forceinline__ uint32_t ffbl_u32(uint32_t v)      // count trailing 
 // window), Pv = Mv = 0 — so no carry starts below the pattern, "0 comes in" at its lowest bit, and the rows the
 // traceback reads are always the upper dword.
 //
-// Eq of a column is LOOKED UP: the four possible words (pattern == A / C / G / T) are written to 32 bytes of LDS per
-// lane once per window, and a column reads the one its text character selects — address = table | 8 * character from
-// two right shifts and two v_bitop3_b32 with inline constants, the ds_read_b64 itself does not occupy the VALU.
-// (Computing it per column costs 2 v_bfe_i32 + 2 v_xor + 2 v_bitop3; the reads are issued LANE_EQ_AHEAD columns early.)
-// Slot c ^ swz of a lane holds base c, swz = (lane >> 3) & 3, so the lanes that share LDS banks (8 apart) use
-// different slots for the same base; the swizzle is folded into the text planes once per window.
+// Eq of a column is LOOKED UP: the four possible words (pattern == A / C / G / T) are written to LDS once per window
+// (slot-major, LANE_EQ_SLOT_STRIDE above), and a column reads the one its text character selects — address =
+// lane's column of the region | 512 * character from one shift and one v_bitop3_b32, the ds_read_b64 itself does not occupy
+// the VALU.  (Computing Eq per column costs 2 v_bfe_i32 + 2 v_xor + 2 v_bitop3; the reads are issued LANE_EQ_AHEAD columns early.)
 template <bool SHORT_N>
 __device__ __forceinline__ void lane_window_table(const Planes tw, const Planes pw, const uint32_t n, const uint32_t m,
                                                   const uint32_t stop, uint64_t (&tab)[LANE_TB_COLS],
-                                                  const uint32_t eq_b, const uint32_t nomatch_b, const uint32_t swz)
+                                                  const uint32_t eq_b, const uint32_t nomatch_b)
 {
     // tab[i] = ~(V1 | stop) in the upper dword, V0 in the lower one (a register pair: the traceback shifts both with one
     // 64-bit shift): stop has the one bit of the row at which this lane's walk ends (jlim), so a finished lane reads
@@ -115,28 +145,26 @@ __device__ __forceinline__ void lane_window_table(const Planes tw, const Planes 
     const uint64_t valid = ~0ull << (64u - m);                    // (m >= 1)
     const uint32_t rl0 = (uint32_t)rlo, rl1 = (uint32_t)(rlo >> 32), rh0 = (uint32_t)rhi, rh1 = (uint32_t)(rhi >> 32);
     const uint32_t iv0 = ~(uint32_t)valid, iv1 = ~(uint32_t)(valid >> 32);
-    {   // base c = 2*hi + lo: Eq_c = (lo plane == c&1) & (hi plane == c>>1), and 1 below the pattern; slot c ^ swz
-        const uint32_t x = eq_b | (swz << 3);
-        lds_write64(x ^ 0u, make_uint2(~(rl0 | rh0) | iv0, ~(rl1 | rh1) | iv1));
-        lds_write64(x ^ 8u, make_uint2((rl0 & ~rh0) | iv0, (rl1 & ~rh1) | iv1));
-        lds_write64(x ^ 16u, make_uint2((~rl0 & rh0) | iv0, (~rl1 & rh1) | iv1));
-        lds_write64(x ^ 24u, make_uint2((rl0 & rh0) | iv0, (rl1 & rh1) | iv1));
+    {   // base c = 2*hi + lo: Eq_c = (lo plane == c&1) & (hi plane == c>>1), and 1 below the pattern; slot c of my column of the region
+        lds_write64(eq_b, make_uint2(~(rl0 | rh0) | iv0, ~(rl1 | rh1) | iv1));
+        lds_write64(eq_b + LANE_EQ_SLOT_STRIDE, make_uint2((rl0 & ~rh0) | iv0, (rl1 & ~rh1) | iv1));
+        lds_write64(eq_b + 2u * LANE_EQ_SLOT_STRIDE, make_uint2((~rl0 & rh0) | iv0, (~rl1 & rh1) | iv1));
+        lds_write64(eq_b + 3u * LANE_EQ_SLOT_STRIDE, make_uint2((rl0 & rh0) | iv0, (rl1 & rh1) | iv1));
         if (SHORT_N) lds_write64(nomatch_b, make_uint2(iv0, iv1));
     }
-    const uint32_t swl = 0u - (swz & 1u), swh = 0u - (swz >> 1);
-    const uint32_t tl0 = (uint32_t)tw.lo ^ swl, tl1 = (uint32_t)(tw.lo >> 32) ^ swl, th0 = (uint32_t)tw.hi ^ swh, th1 = (uint32_t)(tw.hi >> 32) ^ swh;
-    // LDS address of column i's Eq word: eq_b | 8 * (2 * hi bit + lo bit).  The two planes are interleaved once per window so
+    const uint32_t tl0 = (uint32_t)tw.lo, tl1 = (uint32_t)(tw.lo >> 32), th0 = (uint32_t)tw.hi, th1 = (uint32_t)(tw.hi >> 32);
+    // LDS address of column i's Eq word: eq_b | 512 * (2 * hi bit + lo bit).  The two planes are interleaved once per window so
     // that a column's two bits sit next to each other — xe: bit b = lo bit, bit b + 1 = hi bit of every EVEN column b of the
-    // dword; xo: bit b - 1 = lo bit, bit b = hi bit of every ODD column b — and the address is one shift and one v_bitop3:
-    // 2 instructions per column instead of 4, for 8 per window.
+    // dword; xo: bit b - 1 = lo bit, bit b = hi bit of every ODD column b — and the address is one shift (the field to bits
+    // 9..10) and one v_bitop3: 2 instructions per column instead of 4, for 8 per window.
     const uint32_t xe0 = bitop3<TT_BFI>(tl0, th0 << 1, 0x55555555u), xo0 = bitop3<TT_BFI>(th0, tl0 >> 1, 0xaaaaaaaau);
     const uint32_t xe1 = bitop3<TT_BFI>(tl1, th1 << 1, 0x55555555u), xo1 = bitop3<TT_BFI>(th1, tl1 >> 1, 0xaaaaaaaau);
     auto eq_addr = [&](int i) -> uint32_t {
         const int b = i & 31;
         const uint32_t x = (b & 1) ? (i < 32 ? xo0 : xo1) : (i < 32 ? xe0 : xe1);
-        const int f = (b & 1) ? b - 1 : b;                                  // the field's low bit; it goes to bit 3
-        const uint32_t u = f >= 3 ? x >> (f - 3) : x << (3 - f);
-        const uint32_t a = bitop3<TT_ANDOR>(u, 24u, eq_b);
+        const int f = (b & 1) ? b - 1 : b;                                  // the field's low bit; it goes to bit 9
+        const uint32_t u = f >= 9 ? x >> (f - 9) : x << (9 - f);
+        const uint32_t a = bitop3<TT_ANDOR>(u, LANE_EQ_FIELD_MASK, eq_b);
         return (!SHORT_N || (uint32_t)i < n) ? a : nomatch_b;
     };
     uint2 eqw[LANE_EQ_AHEAD];
@@ -183,15 +211,17 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
     char* const lds_b = reinterpret_cast<char*>(lds);
 
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave_b = (threadIdx.x >> 6) * LANE_WAVE_LDS_BYTES;      // my wavefront's part of the workgroup's LDS
+    // LDS of a workgroup: the wavefronts' Eq regions first (2048 bytes each, slot-major: the dynamic LDS starts at address 0
+    // because nothing static precedes it, so every region is a multiple of 2048), then each wavefront's ring, insertion-run
+    // lengths and "no match" words
+    const uint32_t wave = threadIdx.x >> 6, wpg = blockDim.x >> 6;
+    const uint32_t wave_b = wpg * LANE_EQ_REGION_BYTES + wave * LANE_REST_BYTES;
     const uint32_t ring_b = wave_b + lane * LANE_RING_BYTES;
     const uint32_t scr_b = wave_b + 64u * LANE_RING_BYTES + lane * LANE_SCRATCH_BYTES;
     uint8_t* const lds8 = reinterpret_cast<uint8_t*>(lds);
-    // (an LDS ADDRESS, a multiple of 32: the dynamic LDS starts at a multiple of 32 because nothing static precedes it)
-    const uint32_t eq_b = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds_b +
-                          wave_b + 64u * (LANE_RING_BYTES + LANE_SCRATCH_BYTES) + lane * LANE_EQ_BYTES;
-    const uint32_t swz = (lane >> 3) & 3u;
-    const uint32_t nomatch_b = eq_b - lane * LANE_EQ_BYTES + 64u * LANE_EQ_BYTES + lane * LANE_NOMATCH_BYTES;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds_b;      // (an LDS ADDRESS: 0)
+    const uint32_t eq_b = lds0 + wave * LANE_EQ_REGION_BYTES + lane * 8u;
+    const uint32_t nomatch_b = lds0 + wave_b + 64u * (LANE_RING_BYTES + LANE_SCRATCH_BYTES) + lane * LANE_NOMATCH_BYTES;
     const uint32_t W = (uint32_t)a.W;
     const uint32_t TBL = (uint32_t)a.tb_limit;         // W - O, 1..31
 
@@ -229,11 +259,12 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
         }
         flushed += EDITS ? 32u : 16u;
     };
-    // write out every piece that consists of finished runs only (the run at index nr may still grow)
+    // Write out a whole piece of committed output where a lane has one.  ONE piece per lane and look is enough: after a look a lane
+    // holds at most 16 unwritten runs (EDITS: 31 bytes), between two looks it commits at most 12 more (EDITS: 20 bytes), so a
+    // single piece brings it back under the threshold — no second test, no loop.
     auto flush_pieces = [&]() {
-        for (;;) {
-            const bool need = has_pair && (EDITS ? pos - flushed >= 32u : nr - (int32_t)flushed >= 16);
-            if (!__any(need)) break;
+        const bool need = has_pair && (EDITS ? pos - flushed >= 32u : nr - (int32_t)flushed >= 16);
+        if (__any(need)) {
             if (need) write_piece();
         }
     };
@@ -337,10 +368,10 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
 #pragma unroll
             for (int i = 0; i < LANE_TB_COLS; i++) tab[i] = ((uint64_t)~stop << 32) | (((uint32_t)tw.lo * (uint32_t)(i + 1)) | stop);
         } else if (short_n) {
-            lane_window_table<true>(tw, pw, n, m, stop, tab, eq_b, nomatch_b, swz);
+            lane_window_table<true>(tw, pw, n, m, stop, tab, eq_b, nomatch_b);
             st_gen++;
         } else {
-            lane_window_table<false>(tw, pw, n, m, stop, tab, eq_b, nomatch_b, swz);
+            lane_window_table<false>(tw, pw, n, m, stop, tab, eq_b, nomatch_b);
         }
         const uint64_t tm3 = timing ? __builtin_readcyclecounter() : 0;
 
@@ -489,20 +520,21 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
             uint32_t E = SCRG_ABL(a, 4) ? 0u : (B | Im);                  // (ablation, profiling only: no runs)
             uint32_t c = ffbh_u32(E);
             uint32_t ni = lds8[scr_b + c];
-            uint32_t nr2 = 2u * (uint32_t)nr;          // byte offset of the last committed run
+            uint32_t q = 2u * (uint32_t)nr + 2u;       // byte offset of the next free slot (the run after the last committed one)
             auto event = [&]() {
                 const uint32_t sh = 31u - c;
                 const uint32_t bit = 0x80000000u >> (c & 31u);
-                *reinterpret_cast<uint16_t*>(lds_b + ring_b + ((nr2 + 2u) & 62u)) = (uint16_t)(((uint32_t)'I' << 8) | ni);
-                nr2 += 2u * __builtin_amdgcn_ubfe(Im, sh, 1);
+                *reinterpret_cast<uint16_t*>(lds_b + ring_b + (q & 62u)) = (uint16_t)(((uint32_t)'I' << 8) | ni);
+                q = add_twice(q, __builtin_amdgcn_ubfe(Im, sh, 1));
                 E = bitop3<TT_ANDN>(E, bit, bit);
                 const uint32_t nx = ffbh_u32(E);
                 ni = lds8[scr_b + nx];
-                const uint32_t len = min(nx, ti) - c;                       // up to the next event or the end of the walk
-                // '=' 0x3D, 'X' 0x58 = '=' + 27, 'D' 0x44 = '=' + 7
-                const uint32_t w = (((uint32_t)'=' << 8) + len) + __builtin_amdgcn_ubfe(D, sh, 1) * (7u << 8) + __builtin_amdgcn_ubfe(X, sh, 1) * (27u << 8);
-                *reinterpret_cast<uint16_t*>(lds_b + ring_b + ((nr2 + 2u) & 62u)) = (uint16_t)w;
-                nr2 += 2u * __builtin_amdgcn_ubfe(B, sh, 1);
+                // the run's length = min(nx, ti) - c (up to the next event or the end of the walk) = min(nx, ti) + sh - 31; its letter
+                // '=' 0x3D, 'X' 0x58 = '=' + 27, 'D' 0x44 = '=' + 7: two multiply-adds on top of sh and one three-operand add
+                const uint32_t w = add3(mad24(__builtin_amdgcn_ubfe(X, sh, 1), 27u << 8, mad24(__builtin_amdgcn_ubfe(D, sh, 1), 7u << 8, sh)),
+                                        min(nx, ti), ((uint32_t)'=' << 8) - 31u);
+                *reinterpret_cast<uint16_t*>(lds_b + ring_b + (q & 62u)) = (uint16_t)w;
+                q = add_twice(q, __builtin_amdgcn_ubfe(B, sh, 1));
                 c = nx;
             };
             uint32_t trips = 0;
@@ -511,11 +543,11 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
                 event();                                   // independent work in flight (a finished lane commits nothing)
                 if (++trips == 3u) {                       // <= 12 new runs between checks + 1 speculative slot: the 32-run ring cannot wrap
                     trips = 0;
-                    nr = (int32_t)nr2 >> 1;
+                    nr = ((int32_t)q >> 1) - 1;
                     flush_pieces();
                 }
             }
-            nr = (int32_t)nr2 >> 1;
+            nr = ((int32_t)q >> 1) - 1;
             flush_pieces();
             }
         }
@@ -581,14 +613,15 @@ __global__ __launch_bounds__(512, 2) void genasm_lane_split_kernel(AlignArgs a)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6, duo = wave & 3u;
     const bool consumer = wave >= 4u;
-    const uint32_t duo_b = duo * SPLIT_PAIR_LDS_BYTES;                         // my producer / consumer pair's part of the workgroup's LDS
+    // LDS of a workgroup: the four producers' Eq regions first (slot-major, 2048 bytes each, see LANE_EQ_SLOT_STRIDE), then
+    // each producer / consumer pair's ring, "no match" words and record buffers
+    const uint32_t duo_b = 4u * LANE_EQ_REGION_BYTES + duo * (SPLIT_PAIR_LDS_BYTES - LANE_EQ_REGION_BYTES);
     const uint32_t ring_b = duo_b + lane * LANE_RING_BYTES;
-    // (LDS ADDRESSES, multiples of 32: nothing static precedes the dynamic LDS)
-    const uint32_t eq_b = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds_b + duo_b + 64u * LANE_RING_BYTES + lane * LANE_EQ_BYTES;
-    const uint32_t nomatch_b = eq_b - lane * LANE_EQ_BYTES + 64u * LANE_EQ_BYTES + lane * LANE_NOMATCH_BYTES;
-    const uint32_t bufs_b = duo_b + 64u * (LANE_RING_BYTES + LANE_EQ_BYTES + LANE_NOMATCH_BYTES);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds_b;      // (an LDS ADDRESS: 0)
+    const uint32_t eq_b = lds0 + duo * LANE_EQ_REGION_BYTES + lane * 8u;
+    const uint32_t nomatch_b = lds0 + duo_b + 64u * LANE_RING_BYTES + lane * LANE_NOMATCH_BYTES;
+    const uint32_t bufs_b = duo_b + 64u * (LANE_RING_BYTES + LANE_NOMATCH_BYTES);
     const uint32_t flags_w = (4u * SPLIT_PAIR_LDS_BYTES) >> 2;                 // dword index of done[2][4]
-    const uint32_t swz = (lane >> 3) & 3u;
     const uint32_t W = (uint32_t)a.W;
     const uint32_t TBL = (uint32_t)a.tb_limit;         // W - O, 1..31
     const uint32_t TBc = min(TBL, (uint32_t)LANE_TB_COLS);
@@ -666,8 +699,8 @@ __global__ __launch_bounds__(512, 2) void genasm_lane_split_kernel(AlignArgs a)
                 const uint32_t jlim = live ? min(m, TBL) : 0u;
                 const uint32_t stop = 0x80000000u >> jlim;
                 const bool short_n = __any(live && n != 64u);
-                if (short_n) lane_window_table<true>(tw, pw, n, m, stop, tab, eq_b, nomatch_b, swz);
-                else lane_window_table<false>(tw, pw, n, m, stop, tab, eq_b, nomatch_b, swz);
+                if (short_n) lane_window_table<true>(tw, pw, n, m, stop, tab, eq_b, nomatch_b);
+                else lane_window_table<false>(tw, pw, n, m, stop, tab, eq_b, nomatch_b);
                 // ---------------- traceback pass 1 (genasm_cpu.cpp:290-409; see genasm_lane_kernel) ----------------
                 uint32_t j = 0, nDm = 0, Xm = 0, nIm = 0;
                 const uint32_t lb = len_b(buf);
@@ -740,10 +773,9 @@ __global__ __launch_bounds__(512, 2) void genasm_lane_split_kernel(AlignArgs a)
         }
         flushed += 16u;
     };
-    auto flush_pieces = [&]() {
-        for (;;) {
-            const bool need = open && nr - (int32_t)flushed >= 16;
-            if (!__any(need)) break;
+    auto flush_pieces = [&]() {                      // (one piece per lane and look: see genasm_lane_kernel)
+        const bool need = open && nr - (int32_t)flushed >= 16;
+        if (__any(need)) {
             if (need) write_piece();
         }
     };
@@ -768,19 +800,19 @@ __global__ __launch_bounds__(512, 2) void genasm_lane_split_kernel(AlignArgs a)
         uint32_t E = valid ? (B | Im) : 0u;
         uint32_t c = ffbh_u32(E);
         uint32_t ni = lds8[scr_b + c];
-        uint32_t nr2 = 2u * (uint32_t)nr;          // byte offset of the last committed run
+        uint32_t q = 2u * (uint32_t)nr + 2u;       // byte offset of the next free slot (see genasm_lane_kernel)
         auto event = [&]() {
             const uint32_t sh = 31u - c;
             const uint32_t bit = 0x80000000u >> (c & 31u);
-            *reinterpret_cast<uint16_t*>(lds_b + ring_b + ((nr2 + 2u) & 62u)) = (uint16_t)(((uint32_t)'I' << 8) | ni);
-            nr2 += 2u * __builtin_amdgcn_ubfe(Im, sh, 1);
+            *reinterpret_cast<uint16_t*>(lds_b + ring_b + (q & 62u)) = (uint16_t)(((uint32_t)'I' << 8) | ni);
+            q = add_twice(q, __builtin_amdgcn_ubfe(Im, sh, 1));
             E = bitop3<TT_ANDN>(E, bit, bit);
             const uint32_t nx = ffbh_u32(E);
             ni = lds8[scr_b + nx];
-            const uint32_t len = min(nx, ti) - c;
-            const uint32_t w = (((uint32_t)'=' << 8) + len) + __builtin_amdgcn_ubfe(D, sh, 1) * (7u << 8) + __builtin_amdgcn_ubfe(X, sh, 1) * (27u << 8);
-            *reinterpret_cast<uint16_t*>(lds_b + ring_b + ((nr2 + 2u) & 62u)) = (uint16_t)w;
-            nr2 += 2u * __builtin_amdgcn_ubfe(B, sh, 1);
+            const uint32_t w = add3(mad24(__builtin_amdgcn_ubfe(X, sh, 1), 27u << 8, mad24(__builtin_amdgcn_ubfe(D, sh, 1), 7u << 8, sh)),
+                                    min(nx, ti), ((uint32_t)'=' << 8) - 31u);
+            *reinterpret_cast<uint16_t*>(lds_b + ring_b + (q & 62u)) = (uint16_t)w;
+            q = add_twice(q, __builtin_amdgcn_ubfe(B, sh, 1));
             c = nx;
         };
         uint32_t trips = 0;
@@ -789,11 +821,11 @@ __global__ __launch_bounds__(512, 2) void genasm_lane_split_kernel(AlignArgs a)
             event();
             if (++trips == 3u) {
                 trips = 0;
-                nr = (int32_t)nr2 >> 1;
+                nr = ((int32_t)q >> 1) - 1;
                 flush_pieces();
             }
         }
-        nr = (int32_t)nr2 >> 1;
+        nr = ((int32_t)q >> 1) - 1;
         flush_pieces();
         // retire the pairs whose last window this was (genasm_cpu.cpp:440-460)
         const bool fin = valid && (meta & SPLIT_LAST) != 0u;

@@ -123,6 +123,8 @@ const char* scrg_status_string(scrg_status s)
 void scrg_set_log(int enabled) { g_log.store(enabled ? 1 : 0); }
 int scrg_get_log(void) { return g_log.load(); }
 
+int scrg_abi_version(void) { return SCRG_ABI_VERSION; }
+
 int scrg_build_flags(void)
 {
     int f = 0;
@@ -388,10 +390,14 @@ static scrg_status align_device_impl(scrg_ctx* c, const scrg_params* params, uin
     // 2.51 vs 2.52 ms: those SIMDs are the last to finish either way), and launches that fill the GPU or overlap with others —
     // and edit-stream output — keep the one-wavefront kernel (3 % fewer instructions).  reserved[0]: 512 / 1024 force one or the other.
     bool lane_split = false;
+    // A caller that set scrg_params.waves_per_cu itself (co-resident work sized from scrg_query_launch, a work queue shorter than
+    // the batch) gets exactly that geometry: the split form, which has its own (two workgroups of eight wavefronts per CU), is
+    // then only taken when asked for.
+    const bool user_waves = params && params->waves_per_cu > 0;
     if (!edits && p.lanes_per_pair == 1 && p.W <= 64 && p.W - p.O <= 31 && !(p.reserved[0] & scrg::SCRG_SWITCH_NO_SPLIT) &&
         !(params && params->reserved[1])) {
         const uint64_t simds = 4ull * (uint64_t)c->n_cus;
-        lane_split = (p.reserved[0] & scrg::SCRG_SWITCH_SPLIT) != 0 || need_waves <= simds;
+        lane_split = (p.reserved[0] & scrg::SCRG_SWITCH_SPLIT) != 0 || (need_waves <= simds && !user_waves);
         if (lane_split) n_waves = c->n_cus * scrg::LANE_SPLIT_PRODUCERS_PER_CU;
     }
     if ((uint64_t)n_waves > need_waves) n_waves = (int32_t)need_waves;

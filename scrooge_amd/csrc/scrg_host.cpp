@@ -257,6 +257,11 @@ scrg_status stage_genome(DeviceState* const* dss, int n_states, const char* geno
     }
     DeviceState* const ds = dss[0];
     std::lock_guard<std::mutex> g(g_genome_staging.mu);
+    // a staging area larger than GENOME_STAGING_KEEP is given back on EVERY way out of this function (a rejected 3 Gbp genome
+    // must not leave 0.8 GB pinned until the next call)
+    struct ReleaseOversize {
+        ~ReleaseOversize() { if (g_genome_staging.cap > GENOME_STAGING_KEEP) g_genome_staging.release(); }
+    } release_oversize;
     HTRY(ds, hipSetDevice(ds->device));
     HTRY(ds, g_genome_staging.ensure((words + SCRG_SEQ_PAD_WORDS) * sizeof(uint64_t)));
     uint64_t* const h = static_cast<uint64_t*>(g_genome_staging.p);
@@ -299,7 +304,6 @@ scrg_status stage_genome(DeviceState* const* dss, int n_states, const char* geno
             dss[d]->genome_ok = true;
         }
     }
-    if (g_genome_staging.cap > GENOME_STAGING_KEEP) g_genome_staging.release();
     return st;
 }
 
@@ -635,8 +639,10 @@ scrg_status stage2(DeviceState* ds, Slot& sl, Call& c, uint64_t chunk)
     if (scrg_last_kernel_ms(sl.ctx, &ms) == SCRG_OK) c.kernel_ns.fetch_add((int64_t)((double)ms * 1e6));
     c.pack_ns.fetch_add(sl.t_pack_ns);
     const uint64_t n = sl.n;
-    // staging: [ed 8n | status 4n (+pad) | run_off 8n | text_off 8n | runs 2R (+pad) | text T]; on the device the per-pair
-    // arrays are one buffer in this layout and runs + text another: two read-backs per chunk
+    // host staging of a chunk: [wire: ed 4n | run count + overflow bit 4n | text length 4n (absent without text)] [runs 2R (+pad)]
+    // [text T] (PerPairLayout: host_runs() follows from wire_bytes); on the device the per-pair arrays are one buffer
+    // ([ed 8n | status 4n | run_off 8n | text_off 8n | wire]) and runs + text another: two read-backs per chunk, the first of
+    // the wire only
     const PerPairLayout lay(n);
     const size_t o_runs = lay.host_runs(), text_rel = (2 * sl.tot_runs + 15) & ~(size_t)15;
     const size_t o_text = o_runs + text_rel, total = o_text + sl.tot_text + 512;

@@ -31,6 +31,16 @@ def test_header_symbols_exported(lib):
     assert sorted(api.EXPORTED_SYMBOLS) == names
 
 
+def test_interface_version_is_one_number(lib):
+    """scrg_abi_version(): the header's SCRG_ABI_VERSION, the binding's constant and what the library reports are the same
+    number — an entry point that changes its arguments under the same name (scrg_decode_edit_stream gained the capacity of
+    its output array) bumps it, and a binding refuses a library of another version instead of passing shifted arguments."""
+    hdr = open(os.path.join(ROOT, "include", "scrooge_amd.h")).read()
+    want = int(re.search(r"#define\s+SCRG_ABI_VERSION\s+(\d+)", hdr).group(1))
+    assert lib.scrg_abi_version() == want == api.SCRG_ABI_VERSION
+    assert "check_abi()" in open(os.path.join(ROOT, "include", "scrooge_amd.hpp")).read()
+
+
 def test_io_header_symbols_exported(lib):
     from scrooge_amd import io as sio
     names = declared_symbols("scrooge_amd_io.h")

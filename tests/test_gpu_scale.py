@@ -910,6 +910,62 @@ def test_decode_large_launch_stores_pieces_together(aligner):
         aligner.use_own_stream()
 
 
+def test_decode_two_runs_per_step_fills_the_ring(aligner):
+    """The decoder's worst case for its output ring (edit_stream_decode_kernel.hip: DEC_FLUSH_AT + 2 runs per step until the
+    next look == DEC_RING, tied together by a static_assert): streams of "1 match, then an X" bytes commit TWO runs per step
+    for hundreds of steps in a row ("1=1X1=1X..."), next to streams of "1 match, then an I / a D" and to ordinary ones, in both
+    store forms (lane by lane: <= 200 000 pairs; 64-byte pieces by the wavefront together: more).  Expected runs: the host
+    replay of the same streams (scrg_edit_stream_to_runs: plain loop, no GPU)."""
+    import torch
+    import scrooge_amd
+    dev = torch.device("cuda", 0)
+    api = scrooge_amd.api
+    cases = []          # (stream bytes, read length)
+    for k in (70, 129, 500, 2001):
+        cases.append((bytes([0x41]) * k, 2 * k))                      # k x "1=1X": 2 runs per step, 2k runs + the window breaks
+        cases.append((bytes([0x81]) * k, 2 * k))                      # k x "1=1I"
+        cases.append((bytes([0xC1]) * (k - 1), k))                    # (k - 1) x "1=1D", then the last match (an alignment never ends in a deletion, genasm_cpu.cpp:307)
+        cases.append((bytes([0x41, 0x81, 0xC1, 0x42]) * k, 8 * k))    # mixed, 2 runs per step
+    cases.append((b"", 0))
+    cases.append((b"", 77))                                           # no edits: 77 matches
+    want_runs = []
+    for st_, rl_ in cases:
+        cig = api.edit_stream_to_cigar(st_, rl_)
+        import re
+        want_runs.append(bytes(b for cnt, op in re.findall(r"(\d+)([=XID])", cig) for b in (int(cnt), ord(op))))
+    n0 = len(cases)
+    offs, blob = [], bytearray()
+    for st_, _ in cases:
+        offs.append(len(blob))
+        blob += st_ + bytes((-len(st_)) % 4)
+    stream = torch.tensor(list(blob) + [0] * 64, dtype=torch.uint8, device=dev)
+    s_off = torch.tensor(offs, dtype=torch.int64, device=dev)
+    s_len = torch.tensor([len(c[0]) for c in cases], dtype=torch.int32, device=dev)
+    rl = torch.tensor([c[1] for c in cases], dtype=torch.int64, device=dev)
+    cnt0 = torch.tensor([len(w) // 2 for w in want_runs], dtype=torch.int32, device=dev)
+    want0 = torch.tensor(list(b"".join(want_runs)), dtype=torch.uint8, device=dev)
+    total = int(want0.numel()) // 2
+    aligner.set_stream(0)
+    try:
+        for R in (1, 40, 9000):                                      # 26, 1 040 and 234 000 pairs: both store forms
+            cnt = cnt0.repeat(R)
+            c64 = cnt.to(torch.int64)
+            off = torch.cumsum(c64, 0) - c64
+            got = torch.zeros(R * total * 2 + 64, dtype=torch.uint8, device=dev)
+            counted = torch.zeros(R * n0, dtype=torch.int32, device=dev)
+            nbad = torch.zeros(1, dtype=torch.int32, device=dev)
+            aligner.decode_edit_stream(R * n0, stream, s_off.repeat(R), s_len.repeat(R), rl.repeat(R).contiguous(), 1, None, None, counted, nbad)
+            torch.cuda.synchronize()
+            assert int(nbad.item()) == 0 and torch.equal(counted, cnt), R
+            aligner.decode_edit_stream(R * n0, stream, s_off.repeat(R), s_len.repeat(R), rl.repeat(R).contiguous(), 1, off, got, cnt, nbad)
+            torch.cuda.synchronize()
+            assert int(nbad.item()) == 0, R
+            assert torch.equal(got[: R * total * 2].view(R, total * 2), want0.unsqueeze(0).expand(R, -1)), R
+            assert int(got[R * total * 2:].max().item()) == 0
+    finally:
+        aligner.use_own_stream()
+
+
 def _run_tool(args, timeout):
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
