@@ -762,7 +762,7 @@ def main():
                          "SCRG_LIB=ab_libs/lib_stats.so): the shipped kernels carry no counters")
     if args.stats:
         al.params.reserved[1] = 1
-    if os.environ.get("SCRG_BENCH_DEBUG_FLAGS"):      # experiment knob: switches of scrg_params.reserved[0] that leave the results intact
+    if os.environ.get("SCRG_BENCH_DEBUG_FLAGS"):      # experiment knob: switches of scrg_params.reserved[0] that leave the results intact (test / profiling builds only: SCRG_LIB=ab_libs/lib_select.so)
         al.params.reserved[0] = int(os.environ["SCRG_BENCH_DEBUG_FLAGS"])
     if args.ablate:
         al.params.reserved[0] = args.ablate     # results are wrong by design; parity checks are skipped

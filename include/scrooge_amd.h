@@ -78,10 +78,10 @@ typedef struct scrg_params {
                                 SCRG_OUT_TEXT: the CIGAR text only (runs stays empty, run_offset all zero);
                                 SCRG_OUT_RUNS: the runs only (cigar_text stays empty, cigar_offset all zero).
                                 What is not asked for does not cross PCIe                                   */
-    int32_t reserved[2];     /* [0]: 0, or documented, result-neutral selections (32, 256, 512, 1024: see
-                                scrg_debug_stats); every other bit is rejected with SCRG_ERR_INVALID_ARG, so an
-                                uninitialised struct cannot silently change anything; [1]: 0 (non-zero asks a
-                                profiling build, -DSCRG_STATS, for its counters; the shipped library rejects it) */
+    int32_t reserved[2];     /* must be 0: the shipped library rejects every bit of both with SCRG_ERR_INVALID_ARG, so an
+                                uninitialised struct cannot silently change anything.  (Other BUILDS of the same sources
+                                give them a meaning — the test build, -DSCRG_SELECT, selects between formulations that give
+                                identical results; profiling builds add counters and ablations: see scrg_debug_stats.)   */
 } scrg_params;
 
 enum { SCRG_OUT_ALL = 0, SCRG_OUT_TEXT = 1, SCRG_OUT_RUNS = 2 };
@@ -121,10 +121,11 @@ const char *scrg_status_string(scrg_status s);
 void        scrg_set_log(int enabled);
 int         scrg_get_log(void);
 int         scrg_device_count(void);
-/* How this library was built: 0 for the shipped build; SCRG_BUILD_STATS if the kernels carry their profiling counters
- * and scheduling switches (-DSCRG_STATS), SCRG_BUILD_ABLATE if also the ablation switches (-DSCRG_ABLATE: results wrong
- * by design).  See scrg_debug_stats. */
-enum { SCRG_BUILD_STATS = 1, SCRG_BUILD_ABLATE = 2 };
+/* How this library was built: 0 for the shipped build; SCRG_BUILD_SELECT for the test build, whose scrg_params.reserved[0]
+ * selects between formulations that give identical results (-DSCRG_SELECT); SCRG_BUILD_STATS if the kernels also carry their
+ * profiling counters and scheduling switches (-DSCRG_STATS), SCRG_BUILD_ABLATE if also the ablation switches
+ * (-DSCRG_ABLATE: results wrong by design).  See scrg_debug_stats. */
+enum { SCRG_BUILD_STATS = 1, SCRG_BUILD_ABLATE = 2, SCRG_BUILD_SELECT = 4 };
 int         scrg_build_flags(void);
 /* The version of THIS interface.  It goes up whenever an entry point changes its arguments under the same name (version 5:
  * scrg_decode_edit_stream takes the capacity of its output array) — such a change still links against code compiled with the
@@ -383,14 +384,17 @@ scrg_status scrg_query_launch(scrg_ctx *ctx, const scrg_params *params,
  * the launch stream (milliseconds); blocks until that launch finished. */
 scrg_status scrg_last_kernel_ms(scrg_ctx *ctx, float *ms);
 
-/* scrg_params.reserved[0] in the SHIPPED library: 0, or selections between formulations that give identical results
- * (kept because the parity tests compare them): 32 (lanes_per_pair = 8: GenASM rows only, no diagonal-major path),
- * 256 (32 <= W-O <= 127: the kernel that keeps the window table in HBM instead of the one that keeps it in registers),
- * 512 / 1024 (W <= 64, W-O <= 31, runs output: always / never the variant of the default kernel that splits a window's
- * work over two wavefronts; by default a launch that cannot put two wavefronts on every SIMD takes it).
- * scrg_params_resolve() and every entry point REJECT any other bit, and reserved[1] != 0.
+/* scrg_params.reserved[] in the SHIPPED library: both must be 0; scrg_params_resolve() and every entry point REJECT anything
+ * else, and none of the code below exists in the shipped kernels or in the shipped kernel selection.
  *
- * Profiling builds only (scripts/ab.sh; scrg_build_flags() tells): with -DSCRG_STATS the align kernels accumulate
+ * Test build only (-DSCRG_SELECT: ab_libs/lib_select.so, scrooge_amd.build_library("select"); scrg_build_flags() tells):
+ * reserved[0] selects between formulations that give identical results, for the parity tests that compare them —
+ * 32 (lanes_per_pair = 8: GenASM rows only, no diagonal-major path), 256 (32 <= W-O <= 127: the kernel that keeps the
+ * window table in HBM instead of the one that keeps it in registers), 512 / 1024 (W <= 64, W-O <= 31, runs output: always /
+ * never the variant of the default kernel that splits a window's work over two wavefronts; by default a launch that cannot
+ * put two wavefronts on every SIMD takes it).
+ *
+ * Profiling builds only (scripts/ab.sh; they include the selections above): with -DSCRG_STATS the align kernels accumulate
  * twelve counters per launch when reserved[1] != 0, read back by scrg_debug_stats (blocks on the stream):
  *   lanes_per_pair = 1 (genasm_lane_kernel): [0] window rounds (one window of each of a wavefront's 64 pairs),
  *     [1] rounds that took a short-window variant, [2..6] shader cycles summed over wavefronts: traceback pass 1,

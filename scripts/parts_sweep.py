@@ -10,7 +10,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 groups = len(sys.argv) > 2 and sys.argv[2] == "groups"
 L = 10000
 dev = torch.device("cuda", 0)
-al = scrooge_amd.Aligner(0); al.set_stream(0)
+scrooge_amd.build_library(variant="select")          # the kernel selection switches exist in the test build only
+al = scrooge_amd.Aligner(0, variant="select"); al.set_stream(0)
 err, ratio = synth.PROFILES["ont"]
 rows_a, tw, rw, text_len = bench.device_pairs(torch, n, L, err, ratio, 42, dev)
 bad = torch.zeros(1, dtype=torch.int32, device=dev)

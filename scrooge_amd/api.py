@@ -57,8 +57,14 @@ class Result(C.Structure):
                 ("kernel_ns", C.c_int64), ("pack_ns", C.c_int64), ("total_ns", C.c_int64)]
 
 
-def library_path():
-    # SCRG_LIB selects another build of the same library (kernel A/B experiments)
+def library_path(variant=None):
+    """The shipped library, or — variant="select" — the TEST build of the same sources (-DSCRG_SELECT: ab_libs/lib_select.so),
+    in which scrg_params.reserved[0] selects between formulations that give identical results; the parity tests that compare
+    formulations load it next to the shipped one.  SCRG_LIB names another build of the shipped library (kernel A/B)."""
+    if variant == "select":
+        return os.path.join(HERE, "..", "ab_libs", "lib_select.so")
+    if variant is not None:
+        raise ValueError("unknown library variant %r" % (variant,))
     return os.environ.get("SCRG_LIB") or os.path.join(HERE, "libscrooge_amd.so")
 
 
@@ -72,14 +78,15 @@ def _source_digest(srcs):
     return h.hexdigest()
 
 
-def build_library(force=False):
-    """Compile the HIP kernels + host code for gfx950 (hipcc cross-compiles without a GPU).
+def build_library(force=False, variant=None):
+    """Compile the HIP kernels + host code for gfx950 (hipcc cross-compiles without a GPU); variant="select": the test build
+    (library_path).
 
     Whether the built library is current is decided by the CONTENT of the sources (a digest kept next to the
     library), not by modification times: a copy of the tree (the snapshot a GPU box gets) keeps the contents but
-    not necessarily the order of the time stamps, and a needless rebuild costs 20 s and needs a compiler."""
-    so = library_path()
-    if os.environ.get("SCRG_LIB"):
+    not necessarily the order of the time stamps, and a needless rebuild costs a minute and needs a compiler."""
+    so = library_path(variant)
+    if variant is None and os.environ.get("SCRG_LIB"):
         return so
     src_dir = os.path.join(HERE, "csrc")
     srcs = [os.path.join(src_dir, f) for f in os.listdir(src_dir) if not f.startswith(".")] + \
@@ -103,18 +110,25 @@ def build_library(force=False):
             if force or is_stale():
                 # (make echoes the compiler command: keep it off stdout, which callers such as bench.py reserve for their
                 # own output; -B because make's own idea of freshness is the time stamps)
-                subprocess.check_call(["make", "-C", src_dir, "--no-print-directory", "-B"], stdout=sys.stderr)
+                cmd = ["make", "-C", src_dir, "--no-print-directory", "-B"] + (["VARIANT=%s" % variant] if variant else [])
+                subprocess.check_call(cmd, stdout=sys.stderr)
                 with open(stamp, "w") as fh:
                     fh.write(digest + "\n")
     return so
 
 
-def load_library():
-    """Load libscrooge_amd.so; raises (never falls back) when it is missing."""
+_VARIANT_LIBS = {}
+
+
+def load_library(variant=None):
+    """Load libscrooge_amd.so (variant="select": the test build, a second handle next to it); raises (never falls back) when
+    it is missing."""
     global _LIB
-    if _LIB is not None:
+    if variant is None and _LIB is not None:
         return _LIB
-    so = library_path()
+    if variant is not None and variant in _VARIANT_LIBS:
+        return _VARIANT_LIBS[variant]
+    so = library_path(variant)
     # PyTorch-ROCm ships its own libamdhip64.so; whichever HIP runtime is loaded first serves the whole
     # process.  If this library pulled in /opt/rocm's copy first, a later `import torch` finds no GPU.
     # So when torch is installed, let it load its runtime before us (SCRG_NO_TORCH_PRELOAD=1 skips this).
@@ -189,7 +203,10 @@ def load_library():
     if lib.scrg_abi_version() != SCRG_ABI_VERSION:
         raise ScroogeError(SCRG_ERR_INVALID_ARG, "%s has interface version %d, this binding speaks version %d"
                            % (so, lib.scrg_abi_version(), SCRG_ABI_VERSION))
-    _LIB = lib
+    if variant is None:
+        _LIB = lib
+    else:
+        _VARIANT_LIBS[variant] = lib
     return lib
 
 
@@ -277,8 +294,8 @@ class Aligner:
     ``Alignment(cigar, edit_distance)`` in the reference's result order.
     """
 
-    def __init__(self, device=0, **params):
-        self.lib = load_library()
+    def __init__(self, device=0, variant=None, **params):
+        self.lib = load_library(variant)
         h = C.c_void_p()
         st = self.lib.scrg_ctx_create(int(device), C.byref(h))
         if st != SCRG_OK:

@@ -32,28 +32,41 @@ struct AlignArgs {
     uint32_t text_stride;         // words between consecutive words of a text / a read in seq (1 = contiguous;
     uint32_t read_stride;         //   64 = lane-interleaved groups, scrg_pack_planar_groups; lane kernel only)
     uint64_t* stats;              // profiling builds (-DSCRG_STATS) only: counters, may be null; never read by the shipped kernels
-    int32_t debug;                // params.reserved[0]: see SCRG_SAFE_SWITCHES / SCRG_SW / SCRG_ABL below
+    int32_t debug;                // params.reserved[0] (always 0 in the shipped build): see SCRG_SEL / SCRG_SW / SCRG_ABL below
 };
 
-// scrg_params.reserved[0] / reserved[1].  The SHIPPED library has four switches, all documented selections between
-// formulations that give identical results (the parity tests compare them): 32 (lanes_per_pair = 8: no diagonal-major
-// path), 256 (the kernel with the window table in HBM where one that keeps it in registers would serve) and 512 / 1024
-// (the default kernel as two wavefronts per 64 pairs / as one, whatever the launch size).  Everything else is experiment plumbing and exists only in profiling builds (scripts/ab.sh):
-//   -DSCRG_STATS   the kernels' counters (reserved[1] != 0 -> scrg_debug_stats: window rounds, shader cycles per part,
-//                  wavefront life times) and the scheduling switches 1 (one pair per lane: no wavefront priority
+// scrg_params.reserved[0] / reserved[1].  The SHIPPED library accepts neither: scrg_params_resolve() rejects every bit.
+// Everything they can do is experiment and test plumbing and exists only in other builds of the same sources (scripts/ab.sh;
+// scrooge_amd.build_library(variant=...) for the test build):
+//   -DSCRG_SELECT  the test build (ab_libs/lib_select.so): reserved[0] selects between formulations that give IDENTICAL results,
+//                  which the parity tests compare — 32 (lanes_per_pair = 8: no diagonal-major path), 256 (the kernel with the
+//                  window table in HBM where one that keeps it in registers would serve), 512 / 1024 (the default kernel as two
+//                  wavefronts per 64 pairs / as one, whatever the launch size);
+//   -DSCRG_STATS   (implies SELECT) the kernels' counters (reserved[1] != 0 -> scrg_debug_stats: window rounds, shader cycles
+//                  per part, wavefront life times) and the scheduling switches 1 (one pair per lane: no wavefront priority
 //                  rotation), 64 / 128 (workgroups of one / two wavefronts) — results intact;
-//   -DSCRG_ABLATE  (implies SCRG_STATS) the ablation switches 2, 4, 8, 16 and 1 for the GenASM-row kernel: skip the
-//                  table, the runs, the walk, the stores — results are WRONG by design (bench.py --ablate).
-// In the shipped build SCRG_TIMING / SCRG_SW / SCRG_ABL are compile-time false: no counter, no clock read, no exit
-// atomic and no switch test is left in the kernels, and scrg_params_resolve() rejects every other bit and reserved[1].
+//   -DSCRG_ABLATE  (implies STATS) the ablation switches 2, 4, 8, 16 and 1 for the GenASM-row kernel: skip the table, the
+//                  runs, the walk, the stores — results are WRONG by design (bench.py --ablate).
+// In the shipped build SCRG_TIMING / SCRG_SW / SCRG_ABL / SCRG_SEL are compile-time false: no counter, no clock read, no exit
+// atomic and no switch test is left in the kernels or in the kernel selection.
 #if defined(SCRG_ABLATE) && !defined(SCRG_STATS)
 #define SCRG_STATS 1
+#endif
+#if defined(SCRG_STATS) && !defined(SCRG_SELECT)
+#define SCRG_SELECT 1
 #endif
 constexpr int32_t SCRG_SWITCH_NO_DIAG = 32;       // lanes_per_pair = 8: GenASM rows only (no diagonal-major path)
 constexpr int32_t SCRG_SWITCH_MW_TABLE = 256;     // genasm_lane_mw_kernel (table in HBM) where genasm_lane_wide_kernel / genasm_lane_parts_kernel (table in registers) would serve
 constexpr int32_t SCRG_SWITCH_SPLIT = 512;        // W <= 64, W-O <= 31, runs output: genasm_lane_split_kernel (a window's work on two wavefronts) whatever the launch size
 constexpr int32_t SCRG_SWITCH_NO_SPLIT = 1024;    // ... genasm_lane_kernel whatever the launch size (default: by launch size, scrg_api.cpp)
 constexpr int32_t SCRG_SAFE_SWITCHES = SCRG_SWITCH_NO_DIAG | SCRG_SWITCH_MW_TABLE | SCRG_SWITCH_SPLIT | SCRG_SWITCH_NO_SPLIT;
+#ifdef SCRG_SELECT
+#define SCRG_SEL(flags, bit) (((flags) & (bit)) != 0)
+constexpr bool SCRG_HAVE_SELECT = true;
+#else
+#define SCRG_SEL(flags, bit) false
+constexpr bool SCRG_HAVE_SELECT = false;
+#endif
 #ifdef SCRG_STATS
 #define SCRG_TIMING(args) ((args).stats != nullptr)
 #define SCRG_SW(args, bit) (((args).debug & (bit)) != 0)
@@ -65,13 +78,16 @@ constexpr bool SCRG_HAVE_STATS = false;
 #endif
 #ifdef SCRG_ABLATE
 #define SCRG_ABL(args, bit) (((args).debug & (bit)) != 0)
-constexpr int32_t SCRG_ALLOWED_SWITCHES = 0x1ff;
+constexpr int32_t SCRG_ALLOWED_SWITCHES = 0x1ff | SCRG_SAFE_SWITCHES;
 #elif defined(SCRG_STATS)
 #define SCRG_ABL(args, bit) false
 constexpr int32_t SCRG_ALLOWED_SWITCHES = SCRG_SAFE_SWITCHES | 1 | 64 | 128;
-#else
+#elif defined(SCRG_SELECT)
 #define SCRG_ABL(args, bit) false
 constexpr int32_t SCRG_ALLOWED_SWITCHES = SCRG_SAFE_SWITCHES;
+#else
+#define SCRG_ABL(args, bit) false
+constexpr int32_t SCRG_ALLOWED_SWITCHES = 0;
 #endif
 
 hipError_t launch_align(int lanes_per_pair, const AlignArgs& a, int grid, size_t lds_bytes, hipStream_t s);

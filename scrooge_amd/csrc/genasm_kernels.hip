@@ -181,7 +181,7 @@ __global__ __launch_bounds__(64, (G >= 8 ? 3 : 2)) void genasm_align_kernel(Alig
             const bool capable = has_pair && n == 64u && n_runs + 64u <= cigar_cap;   // (a window adds < 64 runs)
             const uint32_t n_live = (uint32_t)__popcll(__ballot(has_pair));
             const uint32_t n_cap = (uint32_t)__popcll(__ballot(capable));
-            bool try_diag = W == 64 && !(a.debug & SCRG_SWITCH_NO_DIAG) && !force_column && (n_cap == n_live || n_cap >= 5u * G);
+            bool try_diag = W == 64 && !SCRG_SEL(a.debug, SCRG_SWITCH_NO_DIAG) && !force_column && (n_cap == n_live || n_cap >= 5u * G);
             force_column = false;
             if (try_diag && diag_skip) {
                 diag_skip--;

@@ -259,13 +259,26 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
         }
         flushed += EDITS ? 32u : 16u;
     };
-    // Write out a whole piece of committed output where a lane has one.  ONE piece per lane and look is enough: after a look a lane
-    // holds at most 16 unwritten runs (EDITS: 31 bytes), between two looks it commits at most 12 more (EDITS: 20 bytes), so a
-    // single piece brings it back under the threshold — no second test, no loop.
+    // Write out a whole piece of committed output where a lane has one: one piece per lane and look.
+    //
+    // WHEN matters more than how.  Loads and stores share one counter (vmcnt) and complete in order, so a store that is
+    // issued after the next window's words have been asked for (they are asked for right after traceback pass 1) makes the wait
+    // for those words at the start of the next round a wait for the store as well — several hundred cycles per round for a
+    // wavefront that has its SIMD to itself (ablation: 0.1 of 2.6 ms).  So the regular look is BEFORE the table (7 k cycles
+    // without a memory instruction: the stores are long done when the loads are issued), and the second traceback pass only
+    // looks when a ring is really about to run full (ring_guard, below): in well under a tenth of the rounds.
+    // Bound: after the regular look a lane holds at most 15 unwritten runs (EDITS: 31 bytes).
     auto flush_pieces = [&]() {
-        const bool need = has_pair && (EDITS ? pos - flushed >= 32u : nr - (int32_t)flushed >= 16);
+        const bool need = has_pair && (EDITS ? pos - flushed >= 32u : nr - (int32_t)flushed >= 15);
         if (__any(need)) {
             if (need) write_piece();
+        }
+    };
+    // Inside the second pass, before a trip that may commit `add` more runs (EDITS: bytes; plus the slots written ahead): only a
+    // lane whose ring could not take them makes the wavefront look — then every lane that has a whole piece writes it.
+    auto ring_guard = [&](uint32_t fill, uint32_t limit) {      // fill: runs (EDITS: bytes) committed and not yet written out
+        if (__any(has_pair && fill >= limit)) {
+            if (has_pair && fill >= (EDITS ? 32u : 16u)) write_piece();
         }
     };
 
@@ -351,12 +364,16 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
         // ---------------- window setup (genasm_cpu.cpp:417-420) ----------------
         const uint32_t n = (has_pair && ref_idx < text_len) ? min(W, text_len - ref_idx) : 0u;
         const uint32_t m = has_pair ? min(W, read_len - read_idx) : 1u;      // >= 1 for live pairs
-        // (the words were loaded when the pair was fetched, or before the previous round's second traceback pass)
-        Planes tw = {0, 0}, pw = {0, 0};
-        if (has_pair) {
-            tw = window_planes(twords);
-            pw = window_planes(pwords);
-        }
+        // (the words were loaded when the pair was fetched, or before the previous round's second traceback pass.  EVERY lane
+        // takes them, not only those that hold a pair: a lane without one computes a table of garbage that its walk never reads —
+        // jlim = 0 freezes it in row 0 — and the wait for the loads is then unconditional, i.e. over when the stores below are
+        // issued: a wait inside `if (has_pair)` leaves the compiler unsure whether the loads have landed, and it would wait
+        // again — now for the stores too — in front of the first table instruction that reuses one of their registers)
+        const Planes tw = window_planes(twords), pw = window_planes(pwords);
+        // (the planes are in registers — the loads have landed — before any store below is issued: the scheduler is not to sink
+        // the funnel shifts, and with them the wait, behind the stores)
+        asm volatile("" :: "v"(tw.lo), "v"(tw.hi), "v"(pw.lo), "v"(pw.hi) : "memory");
+        flush_pieces();                             // (the stores of this round: issued here, done long before pass 1 ends)
         const uint64_t tm2 = timing ? __builtin_readcyclecounter() : 0;
 
         // ---------------- the window's table: all distances at once (genasm_cpu.cpp:210-288) ----------------
@@ -505,50 +522,52 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
                     ni = lds8[scr_b + nx];
                     c = nx;
                 };
+                // a trip commits at most 2 x 5 bytes and writes 4 more ahead: 31 left by the regular look + two trips fit the
+                // 64-byte ring; from the third trip on a lane with 50 or more bytes pending makes the wavefront look
                 uint32_t trips = 0;
                 while (__any(E != 0u)) {
+                    if (trips >= 2u) ring_guard(pos - flushed, 50u);
                     event();
                     event();
-                    if (++trips == 2u) {                       // <= 4 x 5 new bytes between checks + 4 speculative ones: the 64-byte ring cannot wrap
-                        trips = 0;
-                        flush_pieces();
-                    }
+                    trips++;
                 }
-                flush_pieces();
                 mbase += ti;                                   // the next window starts at its column 0
             } else {
+            // The length byte of an insertion run is asked for TWO events before it is used (c0 / c1: the columns of the next
+            // two events, n0 / n1 their bytes): a wavefront that has its SIMD to itself would otherwise wait for LDS once per event.
             uint32_t E = SCRG_ABL(a, 4) ? 0u : (B | Im);                  // (ablation, profiling only: no runs)
-            uint32_t c = ffbh_u32(E);
-            uint32_t ni = lds8[scr_b + c];
+            uint32_t c0 = ffbh_u32(E);
+            uint32_t n0 = lds8[scr_b + c0];
+            E = bitop3<TT_ANDN>(E, 0x80000000u >> (c0 & 31u), 0u);
+            uint32_t c1 = ffbh_u32(E);
+            uint32_t n1 = lds8[scr_b + c1];
             uint32_t q = 2u * (uint32_t)nr + 2u;       // byte offset of the next free slot (the run after the last committed one)
-            auto event = [&]() {
+            // one event: column c with its length byte ni; nx = the column of the event after it; E holds nx and the events after it
+            auto event = [&](uint32_t& c, uint32_t& ni, const uint32_t nx) {
                 const uint32_t sh = 31u - c;
-                const uint32_t bit = 0x80000000u >> (c & 31u);
                 *reinterpret_cast<uint16_t*>(lds_b + ring_b + (q & 62u)) = (uint16_t)(((uint32_t)'I' << 8) | ni);
                 q = add_twice(q, __builtin_amdgcn_ubfe(Im, sh, 1));
-                E = bitop3<TT_ANDN>(E, bit, bit);
-                const uint32_t nx = ffbh_u32(E);
-                ni = lds8[scr_b + nx];
                 // the run's length = min(nx, ti) - c (up to the next event or the end of the walk) = min(nx, ti) + sh - 31; its letter
                 // '=' 0x3D, 'X' 0x58 = '=' + 27, 'D' 0x44 = '=' + 7: two multiply-adds on top of sh and one three-operand add
                 const uint32_t w = add3(mad24(__builtin_amdgcn_ubfe(X, sh, 1), 27u << 8, mad24(__builtin_amdgcn_ubfe(D, sh, 1), 7u << 8, sh)),
                                         min(nx, ti), ((uint32_t)'=' << 8) - 31u);
                 *reinterpret_cast<uint16_t*>(lds_b + ring_b + (q & 62u)) = (uint16_t)w;
                 q = add_twice(q, __builtin_amdgcn_ubfe(B, sh, 1));
-                c = nx;
+                // the event after nx takes this one's place
+                E = bitop3<TT_ANDN>(E, 0x80000000u >> (nx & 31u), 0u);
+                c = ffbh_u32(E);
+                ni = lds8[scr_b + c];
             };
+            // a trip commits at most 4 runs and writes one slot ahead: the 15 left by the regular look + four trips fit the 32-run
+            // ring; from the fifth trip on a lane with 27 or more runs pending makes the wavefront look
             uint32_t trips = 0;
-            while (__any(E != 0u)) {
-                event();                                   // two events per trip: half the loop branches, twice the
-                event();                                   // independent work in flight (a finished lane commits nothing)
-                if (++trips == 3u) {                       // <= 12 new runs between checks + 1 speculative slot: the 32-run ring cannot wrap
-                    trips = 0;
-                    nr = ((int32_t)q >> 1) - 1;
-                    flush_pieces();
-                }
+            while (__any(c0 < 32u)) {                      // (a lane without events left has c0 = 0xffffffff: it commits nothing)
+                if (trips >= 4u) ring_guard((q >> 1) - flushed, 27u);
+                event(c0, n0, c1);                         // two events per trip: half the loop branches, twice the
+                event(c1, n1, c0);                         // independent work in flight
+                trips++;
             }
             nr = ((int32_t)q >> 1) - 1;
-            flush_pieces();
             }
         }
         st_rounds++;

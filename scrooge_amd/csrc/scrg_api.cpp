@@ -134,6 +134,9 @@ int scrg_build_flags(void)
 #ifdef SCRG_ABLATE
     f |= SCRG_BUILD_ABLATE;
 #endif
+#ifdef SCRG_SELECT
+    f |= SCRG_BUILD_SELECT;
+#endif
     return f;
 }
 
@@ -281,7 +284,7 @@ static bool resolve_params(const scrg_params* in, scrg_params* p)
         if (p->lanes_per_pair == 0) p->lanes_per_pair = 1;
         if (p->lds_rows == 0) p->lds_rows = 12;
         // 32 <= W-O <= 63: genasm_lane_wide_kernel.hip, whose table takes 128 registers: two wavefronts per SIMD
-        if (p->lanes_per_pair == 1 && p->waves_per_cu == 0 && scrg::lane_wide_serves(p->W, tbl) && !(p->reserved[0] & scrg::SCRG_SWITCH_MW_TABLE))
+        if (p->lanes_per_pair == 1 && p->waves_per_cu == 0 && scrg::lane_wide_serves(p->W, tbl) && !SCRG_SEL(p->reserved[0], scrg::SCRG_SWITCH_MW_TABLE))
             p->waves_per_cu = 8;
     }
     // 11 and 12 wavefronts per CU align equally fast (the kernel is issue-bound); 11 leaves VGPRs and LDS on
@@ -302,9 +305,9 @@ static bool resolve_params(const scrg_params* in, scrg_params* p)
 
 static size_t lds_bytes_for(const scrg_params& p)
 {
-    if (p.lanes_per_pair == 1 && scrg::lane_wide_serves(p.W, p.W - p.O) && !(p.reserved[0] & scrg::SCRG_SWITCH_MW_TABLE))
+    if (p.lanes_per_pair == 1 && scrg::lane_wide_serves(p.W, p.W - p.O) && !SCRG_SEL(p.reserved[0], scrg::SCRG_SWITCH_MW_TABLE))
         return scrg::lane_wide_lds_bytes(p.W);       // genasm_lane_wide_kernel
-    if (p.lanes_per_pair == 1 && scrg::lane_parts_serves(p.W, p.W - p.O) && !(p.reserved[0] & scrg::SCRG_SWITCH_MW_TABLE))
+    if (p.lanes_per_pair == 1 && scrg::lane_parts_serves(p.W, p.W - p.O) && !SCRG_SEL(p.reserved[0], scrg::SCRG_SWITCH_MW_TABLE))
         return scrg::lane_parts_lds_bytes(p.W);      // genasm_lane_parts_kernel
     if (p.lanes_per_pair == 1 && (p.W > 64 || p.W - p.O > 31))
         return scrg::lane_mw_lds_bytes(p.W - p.O);   // genasm_lane_mw_kernel: CIGAR ring + insertion-run lengths (the table is in HBM)
@@ -388,16 +391,16 @@ static scrg_status align_device_impl(scrg_ctx* c, const scrg_params* params, uin
     // over a producer and a consumer wavefront (genasm_lane_split_kernel: 1.93 -> 1.50 ms for 25 k ... 50 k x 10 kb pairs, the
     // chunks of the host entry points included).  From two wavefronts on some SIMDs on the split gains nothing (100 k pairs:
     // 2.51 vs 2.52 ms: those SIMDs are the last to finish either way), and launches that fill the GPU or overlap with others —
-    // and edit-stream output — keep the one-wavefront kernel (3 % fewer instructions).  reserved[0]: 512 / 1024 force one or the other.
+    // and edit-stream output — keep the one-wavefront kernel (3 % fewer instructions).  (Test build, -DSCRG_SELECT: reserved[0] = 512 / 1024 force one or the other.)
     bool lane_split = false;
     // A caller that set scrg_params.waves_per_cu itself (co-resident work sized from scrg_query_launch, a work queue shorter than
     // the batch) gets exactly that geometry: the split form, which has its own (two workgroups of eight wavefronts per CU), is
     // then only taken when asked for.
     const bool user_waves = params && params->waves_per_cu > 0;
-    if (!edits && p.lanes_per_pair == 1 && p.W <= 64 && p.W - p.O <= 31 && !(p.reserved[0] & scrg::SCRG_SWITCH_NO_SPLIT) &&
+    if (!edits && p.lanes_per_pair == 1 && p.W <= 64 && p.W - p.O <= 31 && !SCRG_SEL(p.reserved[0], scrg::SCRG_SWITCH_NO_SPLIT) &&
         !(params && params->reserved[1])) {
         const uint64_t simds = 4ull * (uint64_t)c->n_cus;
-        lane_split = (p.reserved[0] & scrg::SCRG_SWITCH_SPLIT) != 0 || (need_waves <= simds && !user_waves);
+        lane_split = SCRG_SEL(p.reserved[0], scrg::SCRG_SWITCH_SPLIT) || (need_waves <= simds && !user_waves);
         if (lane_split) n_waves = c->n_cus * scrg::LANE_SPLIT_PRODUCERS_PER_CU;
     }
     if ((uint64_t)n_waves > need_waves) n_waves = (int32_t)need_waves;
@@ -405,8 +408,8 @@ static scrg_status align_device_impl(scrg_ctx* c, const scrg_params* params, uin
     HIP_TRY(c, c->counter.ensure(sizeof(uint32_t)));
     const size_t spill_rows = p.W > 64 ? (size_t)p.W + 1 : scrg::SPILL_ROWS;
     const size_t spill_row_dw = scrg::stored_row_dwords(p.W, p.W - p.O);
-    const bool lane_wide = p.lanes_per_pair == 1 && scrg::lane_wide_serves(p.W, p.W - p.O) && !(p.reserved[0] & scrg::SCRG_SWITCH_MW_TABLE);
-    const bool lane_parts = !lane_wide && p.lanes_per_pair == 1 && scrg::lane_parts_serves(p.W, p.W - p.O) && !(p.reserved[0] & scrg::SCRG_SWITCH_MW_TABLE);
+    const bool lane_wide = p.lanes_per_pair == 1 && scrg::lane_wide_serves(p.W, p.W - p.O) && !SCRG_SEL(p.reserved[0], scrg::SCRG_SWITCH_MW_TABLE);
+    const bool lane_parts = !lane_wide && p.lanes_per_pair == 1 && scrg::lane_parts_serves(p.W, p.W - p.O) && !SCRG_SEL(p.reserved[0], scrg::SCRG_SWITCH_MW_TABLE);
     const bool lane_mw = !lane_wide && !lane_parts && p.lanes_per_pair == 1 && (p.W > 64 || p.W - p.O > 31);      // the rest: genasm_lane_mw_kernel
     if (lane_parts)                      // its checkpoints: one slab of HBM per wavefront (workgroups of four)
         HIP_TRY(c, c->spill.ensure((size_t)((n_waves + 3) / 4 * 4) * scrg::lane_parts_checkpoint_bytes(p.W)));

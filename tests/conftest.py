@@ -44,3 +44,16 @@ def aligner():
     a = scrooge_amd.Aligner(0)
     yield a
     a.close()
+
+
+@pytest.fixture(scope="session")
+def aligner_select():
+    """The TEST build of the same sources (-DSCRG_SELECT, ab_libs/lib_select.so: scrg_params.reserved[0] selects between
+    formulations that give identical results; the shipped library accepts no switch) next to the shipped one — for the parity
+    tests that compare formulations.  Built here if the snapshot did not bring it."""
+    import scrooge_amd
+    scrooge_amd.build_library(variant="select")
+    a = scrooge_amd.Aligner(0, variant="select")
+    assert a.lib.scrg_build_flags() == 4            # SCRG_BUILD_SELECT and nothing else: no counters, no ablations
+    yield a
+    a.close()

@@ -100,16 +100,17 @@ def test_product_does_not_reference_oracle():
 
 
 def test_unknown_experiment_switches_are_rejected(lib):
-    """scrg_params.reserved[] in the SHIPPED library: only the documented selections between formulations that give
-    identical results pass (32: no diagonal-major path for lanes_per_pair = 8; 256: the table-in-HBM kernel where a
-    table-in-registers one would serve; 512 / 1024: the default kernel as two wavefronts per 64 pairs / as one).  The scheduling switches (1, 64, 128), the counters (reserved[1]) and the
-    ablation switches (2, 4, 8, 16) belong to the profiling builds (-DSCRG_STATS / -DSCRG_ABLATE, scripts/ab.sh); here
-    they, and anything an uninitialised struct might hold, are SCRG_ERR_INVALID_ARG — and the kernels contain none of
-    that code (scrg_build_flags() == 0)."""
+    """scrg_params.reserved[] in the SHIPPED library: nothing passes.  The selections between formulations that give
+    identical results (32: no diagonal-major path for lanes_per_pair = 8; 256: the table-in-HBM kernel where a
+    table-in-registers one would serve; 512 / 1024: the default kernel as two wavefronts per 64 pairs / as one) belong to the
+    test build (-DSCRG_SELECT, ab_libs/lib_select.so), the scheduling switches (1, 64, 128), the counters (reserved[1]) and the
+    ablation switches (2, 4, 8, 16) to the profiling builds (-DSCRG_STATS / -DSCRG_ABLATE, scripts/ab.sh); here they, and
+    anything an uninitialised struct might hold, are SCRG_ERR_INVALID_ARG — and the kernels and the kernel selection contain
+    none of that code (scrg_build_flags() == 0)."""
     import ctypes as C
-    assert lib.scrg_build_flags() == 0, "the in-tree library must be the shipped build (no -DSCRG_STATS / -DSCRG_ABLATE)"
+    assert lib.scrg_build_flags() == 0, "the in-tree library must be the shipped build (no -DSCRG_SELECT / -DSCRG_STATS / -DSCRG_ABLATE)"
     p, out = api.Params(), api.Params()
-    for flags, ok in ((0, True), (32, True), (256, True), (32 | 256, True), (512, True), (1024, True), (1, False), (64 | 1, False), (128, False),
+    for flags, ok in ((0, True), (32, False), (256, False), (32 | 256, False), (512, False), (1024, False), (1, False), (64 | 1, False), (128, False),
                       (64, False), (2, False), (4, False), (8, False), (16, False), (0x7fffffff, False), (-1, False), (2048, False)):
         lib.scrg_params_default(C.byref(p))
         p.reserved[0] = flags
@@ -120,21 +121,42 @@ def test_unknown_experiment_switches_are_rejected(lib):
         assert lib.scrg_params_resolve(C.byref(p), C.byref(out)) == api.SCRG_ERR_INVALID_ARG, r1
 
 
+def test_the_test_build_accepts_the_four_selections_and_nothing_else():
+    """ab_libs/lib_select.so — the same sources with -DSCRG_SELECT, what the parity tests that compare formulations load
+    (tests/conftest.py: aligner_select): the four result-neutral selections pass, every other switch and the counters do not."""
+    import ctypes as C
+    scrooge_amd.build_library(variant="select")
+    sel = scrooge_amd.load_library("select")
+    assert sel.scrg_build_flags() == 4 and sel.scrg_abi_version() == api.SCRG_ABI_VERSION
+    p, out = api.Params(), api.Params()
+    for flags, ok in ((0, True), (32, True), (256, True), (32 | 256, True), (512, True), (1024, True), (1, False), (64, False), (128, False),
+                      (2, False), (4, False), (8, False), (16, False), (2048, False), (-1, False)):
+        sel.scrg_params_default(C.byref(p))
+        p.reserved[0] = flags
+        assert (sel.scrg_params_resolve(C.byref(p), C.byref(out)) == api.SCRG_OK) == ok, flags
+    sel.scrg_params_default(C.byref(p))
+    p.reserved[1] = 1
+    assert sel.scrg_params_resolve(C.byref(p), C.byref(out)) == api.SCRG_ERR_INVALID_ARG
+
+
 def test_shipped_kernels_have_no_experiment_plumbing():
-    """The experiment plumbing is compiled out, not just switched off: in the shipped build SCRG_TIMING / SCRG_SW / SCRG_ABL
-    are the constant false (genasm_kernels.h), and no kernel source tests args.debug or args.stats directly except through
-    them (the one exception: the documented, result-neutral selection 32 of the GenASM-row kernel)."""
+    """The experiment plumbing is compiled out, not just switched off: in the shipped build SCRG_TIMING / SCRG_SW / SCRG_ABL /
+    SCRG_SEL are the constant false (genasm_kernels.h), no kernel source tests args.debug or args.stats except through them,
+    and the kernel selection (scrg_api.cpp) tests scrg_params.reserved[0] only through SCRG_SEL."""
     import re
     csrc = os.path.join(ROOT, "scrooge_amd", "csrc")
     hdr = open(os.path.join(csrc, "genasm_kernels.h")).read()
-    shipped = hdr[hdr.index("#else", hdr.index("#ifdef SCRG_STATS")):]
+    shipped = hdr[hdr.index("#else", hdr.index("#ifdef SCRG_STATS\n#define SCRG_TIMING")):]
     assert "#define SCRG_TIMING(args) false" in shipped and "#define SCRG_SW(args, bit) false" in shipped
-    assert "#define SCRG_ABL(args, bit) false" in hdr
+    assert "#define SCRG_ABL(args, bit) false" in hdr and "#define SCRG_SEL(flags, bit) false" in hdr
+    assert "constexpr int32_t SCRG_ALLOWED_SWITCHES = 0;" in hdr
     for f in os.listdir(csrc):
-        if not f.endswith(".hip"):
+        if not f.endswith((".hip", ".cpp")):
             continue
         txt = re.sub(r"//[^\n]*", "", open(os.path.join(csrc, f)).read())
-        for m in re.finditer(r"\ba\.debug\b[^;\n]*", txt):
-            assert "SCRG_SWITCH_NO_DIAG" in m.group(0), (f, m.group(0))
+        for m in re.finditer(r"[^\n;]*\ba\.debug\b[^;\n]*", txt):
+            assert "SCRG_SEL(a.debug" in m.group(0) or "a.debug = " in m.group(0), (f, m.group(0))
         for m in re.finditer(r"if\s*\(\s*a\.stats\b", txt):
             raise AssertionError("%s tests a.stats directly: %s" % (f, m.group(0)))
+        for m in re.finditer(r"[^\n;]*reserved\[0\]\s*&[^;\n]*", txt):
+            assert "SCRG_ALLOWED_SWITCHES" in m.group(0), (f, m.group(0))        # (the one place: what resolve rejects)

@@ -185,12 +185,12 @@ def test_windows_over_64_vs_oracle(aligner, oracle, w, o, g):
 
 @pytest.mark.parametrize("w,o", [(64, 2), (64, 1), (64, 16), (64, 32), (63, 20), (40, 5), (33, 1), (128, 65), (96, 49), (80, 41),
                                  (112, 57), (128, 96), (100, 40), (65, 2), (127, 64)])
-def test_table_in_two_halves(aligner, oracle, w, o):
+def test_table_in_two_halves(aligner, aligner_select, oracle, w, o):
     """32 <= W-O <= 63, W <= 128 (the reference's small-overlap and W > 64 sweep points, scripts/profile.py:88-100,
     180-185): genasm_lane_wide_kernel builds the window's table in two halves of 32 columns in registers.  Runs that
     cross from the first half into the second are one run (long matches on low-error reads, long gaps), walks that end
     in the first half never enter the second, texts that end inside a window take the short-window variant.  The
-    kernel it replaces for these W/O (table in HBM, reserved[0] = 256) gives the same results."""
+    kernel it replaces for these W/O (table in HBM: reserved[0] = 256 in the test build of the library) gives the same results."""
     t, q = synth.make_pairs(150, 2000, "ont", seed=w * 13 + o)
     a, b = synth.make_pairs(40, 2500, "pacbio15", seed=w + o + 1)
     c, d = synth.make_pairs(300, 300, "illumina", seed=w + o + 2)       # long match runs across the halves
@@ -211,25 +211,26 @@ def test_table_in_two_halves(aligner, oracle, w, o):
     q += [b"ACGT", b"", b"A" * 10, b"A" * 300, b"TGCA" * 100]
     eds, cigars, _, _ = oracle.align(t, q, W=w, O=o, threads=8)
     _check(aligner.align_pairs(t, q, W=w, O=o), eds, cigars, "W=%d O=%d" % (w, o))
-    p = aligner.make_params(W=w, O=o)
+    # (the kernel selection switch exists in the test build only: ab_libs/lib_select.so, conftest.aligner_select)
+    p = aligner_select.make_params(W=w, O=o)
     p.reserved[0] = 256
-    keep = aligner.params
-    aligner.params = p
+    keep = aligner_select.params
+    aligner_select.params = p
     try:
-        _check(aligner.align_pairs(t, q), eds, cigars, "W=%d O=%d, table in HBM" % (w, o))
+        _check(aligner_select.align_pairs(t, q), eds, cigars, "W=%d O=%d, table in HBM" % (w, o))
     finally:
-        aligner.params = keep
+        aligner_select.params = keep
 
 
 @pytest.mark.parametrize("w,o", [(256, 129), (160, 81), (192, 97), (224, 113), (128, 20), (128, 1), (129, 65), (130, 2), (200, 100), (255, 128),
                                  (191, 64), (192, 128), (65, 1), (256, 192), (161, 81)])
-def test_table_in_parts(aligner, oracle, w, o):
+def test_table_in_parts(aligner, aligner_select, oracle, w, o):
     """64 <= W-O <= 127 (the reference's large-window sweep points, scripts/profile.py:180-185: W = 160 ... 256 with
     O = W/2 + 1; two-word table rows, src/bitvector.hpp:45-48): genasm_lane_parts_kernel builds the window's table in parts of
     16 columns in registers, each part re-swept from a checkpoint of the difference vectors.  Runs that cross from one part into
     the next are one run (long matches, long gaps), walks that end early never enter the later parts, texts that end inside a
     window skip the chunks past their end, insertion runs of more than 64 rows (unrelated sequences) cross the words of a row.
-    Vectors of 2, 3 and 4 words.  The kernel it replaces for these W/O (table in HBM, reserved[0] = 256) gives the same results."""
+    Vectors of 2, 3 and 4 words.  The kernel it replaces for these W/O (table in HBM: reserved[0] = 256 in the test build of the library) gives the same results."""
     t, q = synth.make_pairs(120, 3000, "ont", seed=w * 13 + o)
     a, b = synth.make_pairs(40, 3500, "pacbio15", seed=w + o + 1)
     c, d = synth.make_pairs(200, 600, "illumina", seed=w + o + 2)       # long match runs across the parts
@@ -253,21 +254,22 @@ def test_table_in_parts(aligner, oracle, w, o):
     q += [b"ACGT", b"", b"A" * 10, b"A" * 600, b"TGCA" * 200]
     eds, cigars, _, _ = oracle.align(t, q, W=w, O=o, threads=8)
     _check(aligner.align_pairs(t, q, W=w, O=o), eds, cigars, "W=%d O=%d" % (w, o))
-    p = aligner.make_params(W=w, O=o)
+    # (the kernel selection switch exists in the test build only: ab_libs/lib_select.so, conftest.aligner_select)
+    p = aligner_select.make_params(W=w, O=o)
     p.reserved[0] = 256
-    keep = aligner.params
-    aligner.params = p
+    keep = aligner_select.params
+    aligner_select.params = p
     try:
-        _check(aligner.align_pairs(t, q), eds, cigars, "W=%d O=%d, table in HBM" % (w, o))
+        _check(aligner_select.align_pairs(t, q), eds, cigars, "W=%d O=%d, table in HBM" % (w, o))
     finally:
-        aligner.params = keep
+        aligner_select.params = keep
 
 
 @pytest.mark.parametrize("w,o", [(64, 33), (64, 40), (64, 60), (33, 2), (32, 17), (2, 1), (48, 24), (17, 9), (63, 32)])
-def test_one_and_two_wavefronts_per_window_agree(aligner, oracle, w, o):
+def test_one_and_two_wavefronts_per_window_agree(aligner, aligner_select, oracle, w, o):
     """The default table (W <= 64, W-O <= 31) exists as one wavefront per 64 pairs (genasm_lane_kernel) and with a window's
     work split over a producer and a consumer wavefront (genasm_lane_split_kernel: what a launch that cannot fill the SIMDs
-    takes by default, i.e. every small batch in this test suite).  reserved[0] = 512 / 1024 force one or the other: both must
+    takes by default, i.e. every small batch in this test suite).  In the test build reserved[0] = 512 / 1024 force one or the other: both must
     give the CPU checker's results — long and short reads, unrelated and low-complexity sequences, ragged and empty inputs
     (a pair of no windows is handed over as first and last at once), more pairs than one wavefront holds (lanes refill from
     the queue while their neighbours are in the middle of a pair)."""
@@ -286,15 +288,16 @@ def test_one_and_two_wavefronts_per_window_agree(aligner, oracle, w, o):
     q += [b"ACGT", b"", b"A" * 10, b"A" * 300, b"TGCA" * 100, b"", b"A"] + [b""] * 70
     eds, cigars, _, _ = oracle.align(t, q, W=w, O=o, threads=8)
     for flags, name in ((512, "two wavefronts per window"), (1024, "one wavefront"), (0, "default")):
-        p = aligner.make_params(W=w, O=o)
+        al = aligner_select if flags else aligner          # (the switches exist in the test build only; the default is the shipped library's)
+        p = al.make_params(W=w, O=o)
         p.reserved[0] = flags
-        keep = aligner.params
-        aligner.params = p
+        keep = al.params
+        al.params = p
         try:
-            _check(aligner.align_pairs(t, q), eds, cigars, "W=%d O=%d, %s" % (w, o, name))
-            _check(aligner.align_pairs(t, q, sort_by_length=0), eds, cigars, "W=%d O=%d, %s, caller order" % (w, o, name))
+            _check(al.align_pairs(t, q), eds, cigars, "W=%d O=%d, %s" % (w, o, name))
+            _check(al.align_pairs(t, q, sort_by_length=0), eds, cigars, "W=%d O=%d, %s, caller order" % (w, o, name))
         finally:
-            aligner.params = keep
+            al.params = keep
 
 
 def test_windows_over_64_limits(aligner):
@@ -307,10 +310,10 @@ def test_windows_over_64_limits(aligner):
 
 
 @pytest.mark.parametrize("lds_rows", [13, 16, 12, 6])
-def test_diagonal_path_on_and_off(aligner, oracle, lds_rows):
+def test_diagonal_path_on_and_off(aligner, aligner_select, oracle, lds_rows):
     """Full W=64 windows with a small distance take the diagonal-major path of the G=8 kernel (carry-chain
     rows, clz traceback), everything else the column-major path; rounds of both kinds interleave inside a
-    pair and share the CIGAR staging ring.  Same results with the path on, off (reserved[0] = 32) and with
+    pair and share the CIGAR staging ring.  Same results with the path on, off (reserved[0] = 32, test build) and with
     row budgets that change how many rows it may use (lds_rows >= 13: 16 compacted rows, else lds_rows)."""
     T, Q = synth.make_pairs(300, 3000, "ont", seed=5)
     a, b = synth.make_pairs(100, 3000, "pacbio15", seed=6)       # many windows beyond 15 edits: fall back mid-pair
@@ -318,14 +321,14 @@ def test_diagonal_path_on_and_off(aligner, oracle, lds_rows):
     T, Q = T + a + c, Q + b + d
     eds, cigars, _, _ = oracle.align(T, Q, threads=8)
     _check(aligner.align_pairs(T, Q, lanes_per_pair=8, lds_rows=lds_rows), eds, cigars, "diag on rows=%d" % lds_rows)
-    p = aligner.make_params(lanes_per_pair=8, lds_rows=lds_rows)
+    p = aligner_select.make_params(lanes_per_pair=8, lds_rows=lds_rows)
     p.reserved[0] = 32
-    keep = aligner.params
-    aligner.params = p
+    keep = aligner_select.params
+    aligner_select.params = p
     try:
-        _check(aligner.align_pairs(T, Q), eds, cigars, "diag off rows=%d" % lds_rows)
+        _check(aligner_select.align_pairs(T, Q), eds, cigars, "diag off rows=%d" % lds_rows)
     finally:
-        aligner.params = keep
+        aligner_select.params = keep
 
 
 def test_array_results_match_object_results(aligner):

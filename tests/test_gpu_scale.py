@@ -378,11 +378,11 @@ def test_bench_two_ranks_dry_run(gather_root, root_share):
     assert j["config"]["rccl_ranks"] == 2
 
 
-def test_full_bench_size_two_algorithms_agree(aligner):
+def test_full_bench_size_two_algorithms_agree(aligner, aligner_select):
     """BASELINE configs[1] at full size (100k x 10 kb ONT-error pairs, generated on the GPU like bench.py):
     the lane-per-pair kernel (difference vectors, the default) and the diagonal-major and column-major window
     paths of the G = 8 kernel (GenASM rows) are three independent formulations of the same table (the lane-per-pair kernel
-    in both of its forms: at this size the library's choice, and one wavefront per 64 pairs forced); every edit
+    in both of its forms: at this size the library's choice — one wavefront per 64 pairs — and two forced, in the test build of the library); every edit
     distance, run count and run must be identical between them, the edit distances must respect the read
     length and error rate, 500 sampled pairs must validate against their sequences — and the first 20 000 pairs are
     compared, run for run, with the reference CPU path itself (oracle/_ref where it was built, else the restatement):
@@ -408,7 +408,12 @@ def test_full_bench_size_two_algorithms_agree(aligner):
         desc = torch.stack([idx * (tw + rw) * 32, torch.full_like(idx, text_len), (idx * (tw + rw) + tw) * 32,
                             torch.full_like(idx, L), idx * cap, torch.full_like(idx, cap)], dim=1).contiguous()
         res = []
-        for lanes, flags in ((1, 0), (1, 1024), (8, 0), (8, 32)):           # 1024: one wavefront per 64 pairs (the default at this size: two); 32: diagonal path off
+        shipped = aligner
+        for lanes, flags in ((1, 0), (1, 512), (8, 0), (8, 32)):           # 512: two wavefronts per 64 pairs (the library's choice at this size: one); 32: diagonal path off
+            # (the selection switches exist in the test build only: the same sources with -DSCRG_SELECT, conftest.aligner_select)
+            aligner = aligner_select if flags else shipped
+            if flags:
+                aligner.set_stream(0)
             p = aligner.make_params(lanes_per_pair=lanes)
             p.reserved[0] = flags
             keep, aligner.params = aligner.params, p
@@ -427,6 +432,7 @@ def test_full_bench_size_two_algorithms_agree(aligner):
                 res.append((ed, nr, st, dense, off))
             finally:
                 aligner.params = keep
+        aligner = shipped
         assert int(bad.item()) == 0
         # a fourth formulation of the output: the kernel's edit streams (one byte per edit), and from them — by the
         # decoder's window replay — the runs again, for all 100 000 pairs
@@ -453,6 +459,7 @@ def test_full_bench_size_two_algorithms_agree(aligner):
         del stream, back
     finally:
         aligner.use_own_stream()
+        aligner_select.use_own_stream()
     for (ed1, nr1, st1, d1, _) in res[1:]:
         assert int(st0.max()) == 0 and int(st1.max()) == 0
         assert torch.equal(ed0, ed1) and torch.equal(nr0, nr1) and torch.equal(d0, d1)
