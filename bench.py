@@ -4,12 +4,17 @@
 One "step" = one pass of the align kernel over one batch of synthetic
 PBSIM2-shaped pairs that is already packed and resident in HBM, followed by
 the run compaction and (N > 1) the RCCL gather of edit distances + CIGARs
-to rank 0, which decodes them to runs inside the timed region.  Workload at
-N=1 = BASELINE.json configs[1]: 100k x 10 kb ONT-error pairs, W=64, O=33.
-N > 1 is weak scaling: a step is N x --pairs pairs (125k per GPU at N = 8 =
-configs[3], 1 M pairs over 8 GPUs), sharded with no data-path collective other
-than the result gather; rank 0, which also decodes every rank's CIGARs, aligns
-a smaller share of the step (--root-share).
+to the step's root, which decodes them to runs inside the timed region.
+Workload at N=1 = BASELINE.json configs[1]: 100k x 10 kb ONT-error pairs,
+W=64, O=33.  N > 1 is weak scaling: a step is N x --pairs pairs (125k per GPU
+at N = 8 = configs[3], 1 M pairs over 8 GPUs), sharded with no data-path
+collective other than the result gather.  The root of step k is rank k mod N
+(--gather-root rotate, the default: every GPU decodes one step in N and every
+xGMI link carries the same) or always rank 0 (--gather-root 0; rank 0 then
+aligns a smaller share of the step, --root-share).  After
+the timed region an N > 1 run measures the other policies, the gather alone and
+every rank's own rate in the same line (`diagnose`, `per_gpu_value`), and a
+rank that stalls is ended by --deadline.
 
     python bench.py --gpus 1 --steps 5 --warmup 1
     python bench.py --gpus 8 --steps 5 --warmup 1          # starts its own 8 ranks (below)
@@ -58,9 +63,12 @@ def parse():
                     help="N > 1: how CIGARs travel to rank 0 — edit streams, 1 byte per edit, written by the align kernel "
                          "itself (default; W-O <= 31) or encoded from its runs (edits-from-runs: any W/O), packed runs "
                          "(1 byte per run, restored on rank 0 inside the timed region) or scrg_run pairs")
-    ap.add_argument("--gather-root", default="0", choices=["rotate", "0"],
-                    help="N > 1, edit streams: the rank a step's results are gathered to and decoded on — always rank 0 (default, "
-                         "SURVEY.md §8e) or step k to rank k mod N (every GPU receives and decodes one step in N)")
+    ap.add_argument("--gather-root", default="rotate", choices=["rotate", "0"],
+                    help="N > 1, edit streams: the rank a step's results are gathered to and decoded on — step k to rank k mod N "
+                         "(default: every GPU receives and decodes one step in N, every xGMI link carries the same, no rank is slower "
+                         "than the others; projected 81 %% of N x one GPU at N = 8, profiles/r05_root_load.json) or always rank 0 "
+                         "(SURVEY.md §8e's literal gather; rank 0 then also decodes every step: 45 %% with equal shards, ~65-73 %% with "
+                         "--root-share auto).  Either way `diagnose` measures both after the timed region")
     ap.add_argument("--root-share", default="auto",
                     help="N > 1 with --gather-root 0 and the decode on: what rank 0 aligns itself, as a fraction of an equal share "
                          "(T / N pairs of the step's T = N x --pairs); the other ranks split the rest.  Rank 0 also decodes all N "
@@ -1678,7 +1686,7 @@ def main():
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": "unstructured pairwise: %d x %d bp %s-error pairs per GPU and step (%s), W=%d O=%d"
                                % (nominal, L, args.profile,
-                                  "BASELINE configs[3]: 1 M pairs over 8 GPUs, results gathered to and decoded on the root" if (world == 8 and nominal == 125000)
+                                  "BASELINE configs[3]: 1 M pairs over 8 GPUs, every step's results gathered to and decoded on its root" if (world == 8 and nominal == 125000)
                                   else ("BASELINE configs[1]" if (world == 1 and n == 100000 and L == 10000) else "%d GPU(s)" % world), p.W, p.O),
                    "pairs_per_gpu": nominal, "pairs_per_step_all_gpus": pairs_per_step_all,
                    "shards": ({"rank_0": n0, "other_ranks": n, "root_share": args.root_share,
@@ -1689,7 +1697,7 @@ def main():
                    "sequence_layout": "lane-interleaved groups of 64 pairs (scrg_pack_planar_groups)" if groups else "contiguous per sequence",
                    "launch": geom, "step": STEP_TEXT[gather_format if dist_on else "local"],
                    "backend": (dist.get_backend() if dist_on else None), "rccl_ranks": (dist.get_world_size() if dist_on else 1),
-                   "gather": ({"format": gather_format, "root": ("step k to rank k mod N" if (edits and args.gather_root == "rotate") else "rank 0"),
+                   "gather": ({"format": gather_format, "root": ("step k to rank k mod N" if (edits and args.gather_root == "rotate" and world > 1) else "rank 0"),
                                "decoded_to_runs_inside_timed_region": bool(decode_on),
                                "bytes_per_rank_and_step": gather.wire if edits else None,
                                "stream_bytes_per_pair": (stream_bytes / n) if stream_bytes is not None else None} if dist_on else None),

@@ -360,6 +360,11 @@ class EditStreamGather:
         # measurement aid (scripts/root_load_probe.sh): a one-rank group decodes its slot `sim` times in the one launch, i.e.
         # does per step what the root of a `sim`-rank job does (the same stream bytes are read, `sim` dense copies written)
         sim = int(os.environ.get("SCRG_GATHER_SIMULATE_SENDERS", "1")) if W == 1 else 1
+        # ... and with SCRG_GATHER_SIMULATE_ROTATE=1 only every `sim`-th step: what EVERY rank of a `sim`-rank job does when the
+        # root rotates (it is the root of one step in `sim`)
+        if sim > 1 and os.environ.get("SCRG_GATHER_SIMULATE_ROTATE") == "1" and k % sim != 0:
+            self._wait(b)
+            return
         if self.dense[b] is None:
             cap_runs = sum(self.run_totals) * sim
             self.dense[b] = torch.zeros(cap_runs * 2 + 64, dtype=torch.uint8, device=self.device)
@@ -413,6 +418,8 @@ class EditStreamGather:
         """-> dict(runs: uint8 [2 * total runs], run_off: int64 [world * n], cnt: int32 [world * n], bad: int32 [1]) of
         step k on its root, pairs in slot order (rank 0's n pairs, rank 1's, ...).  Valid after finish(k)."""
         b = k % self.DEPTH
+        if self.dec[b] is None:
+            return None
         d = dict(self.dec[b])
         d["runs"] = self.dense[b]
         if self.is_cuda:
