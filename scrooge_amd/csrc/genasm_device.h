@@ -121,6 +121,15 @@ __device__ __forceinline__ WindowWords load_window_words(const uint64_t* __restr
     const uint64_t w = (off >> 5) + (uint64_t)(inner >> 5) * stride;
     return WindowWords{seq[w], seq[w + stride], seq[w + 2u * stride], inner & 31u};
 }
+// The same from a sequence's FIRST WORD (a pointer, made once per pair) and the offset of its first base inside that word
+// (0..31): per window one add, one shift, one and, one 64-bit multiply-add and two 64-bit adds — the divisions of the base
+// offset are not repeated for every window.
+__device__ __forceinline__ WindowWords load_window_words_at(const uint64_t* __restrict__ first_word, uint32_t in_word, uint32_t k, uint32_t stride)
+{
+    const uint32_t inner = in_word + k;
+    const uint64_t* const w = first_word + (uint64_t)(inner >> 5) * stride;
+    return WindowWords{w[0], w[stride], w[2u * stride], inner & 31u};
+}
 __device__ __forceinline__ Planes window_planes(const WindowWords& v)
 {
     const uint32_t l0 = (uint32_t)v.a, l1 = (uint32_t)v.b, l2 = (uint32_t)v.c;

@@ -228,7 +228,10 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
     // ---- per-lane pair state ----
     bool has_pair = false;
     uint32_t pair = 0;
-    uint64_t text_off = 0, read_off = 0, cigar_off = 0;
+    const uint64_t* text_w = a.seq;    // the first word of my text / read, and (tr_in: bits 4..0 / 12..8) where in that word they begin
+    const uint64_t* read_w = a.seq;
+    uint32_t tr_in = 0;
+    uint64_t cigar_off = 0;
     uint32_t text_len = 0, read_len = 0, cigar_cap = 0;
     uint32_t ref_idx = 0, read_idx = 0, edits = 0;
     int32_t nr = -1;                   // index of the run in progress (or of the last finished one); n_runs = nr + 1
@@ -345,8 +348,9 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
             if (got) {
                 const scrg_pair_desc pd = a.pairs[idx];
                 pair = idx;
-                text_off = pd.text_off;
-                read_off = pd.read_off;
+                text_w = a.seq + (pd.text_off >> 5);
+                read_w = a.seq + (pd.read_off >> 5);
+                tr_in = ((uint32_t)pd.text_off & 31u) | (((uint32_t)pd.read_off & 31u) << 8);
                 text_len = pd.text_len > 0xffffffffull ? 0xffffffffu : (uint32_t)pd.text_len;
                 read_len = (uint32_t)pd.read_len;
                 cigar_off = pd.cigar_off;
@@ -354,8 +358,8 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
                 ref_idx = read_idx = edits = flushed = pos = mbase = 0;
                 nr = -1;
                 has_pair = true;
-                twords = load_window_words(a.seq, text_off, 0u, a.text_stride);
-                pwords = load_window_words(a.seq, read_off, 0u, a.read_stride);
+                twords = load_window_words_at(text_w, tr_in & 31u, 0u, a.text_stride);
+                pwords = load_window_words_at(read_w, tr_in >> 8, 0u, a.read_stride);
             }
         }
         if (!__any(has_pair)) break;
@@ -454,8 +458,8 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
             // the next window's words, asked for now: the second pass below hides the latency.  (Every lane loads: a
             // pair that is finished reads its padding, a lane without a pair its last pair's, and the registers are
             // not alive across the table that way.)
-            twords = load_window_words(a.seq, text_off, ref_idx, a.text_stride);
-            pwords = load_window_words(a.seq, read_off, read_idx < read_len ? read_idx : 0u, a.read_stride);     // (never past a finished read)
+            twords = load_window_words_at(text_w, tr_in & 31u, ref_idx, a.text_stride);
+            pwords = load_window_words_at(read_w, tr_in >> 8, read_idx < read_len ? read_idx : 0u, a.read_stride);     // (never past a finished read)
 
             // Pass 2.  The next column with an event: an insertion run, then (if B) the run of steps that starts
             // there.  Both words go to the slot after the last committed run; only committing moves on.  (A lane
