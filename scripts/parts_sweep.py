@@ -33,7 +33,7 @@ del rows_a
 runs = torch.empty(n * cap * 2, dtype=torch.uint8, device=dev)
 ed = torch.empty(n, dtype=torch.int64, device=dev); nr = torch.empty(n, dtype=torch.int32, device=dev); st = torch.empty(n, dtype=torch.int32, device=dev)
 out = []
-for W, O in [(160, 81), (192, 97), (224, 113), (256, 129), (128, 20), (128, 1), (200, 100)]:
+for W, O in [(160, 81), (192, 97), (224, 113), (256, 129), (128, 20), (128, 1), (200, 100), (256, 200), (192, 150), (256, 224)]:
     res = {}
     for name, sw in (("parts", 0), ("table_in_hbm", 256)):
         p = al.make_params(W=W, O=O, **kw0)

@@ -119,11 +119,16 @@ hipError_t launch_align_lane_mw(const AlignArgs& a, int grid, size_t lds_bytes, 
 SCRG_HD inline bool lane_wide_serves(int W, int tb_limit) { return W <= 128 && tb_limit >= 32 && tb_limit <= 63; }
 SCRG_HD inline unsigned lane_wide_lds_bytes(int W) { return 64u * (68u + 36u + (W <= 64 ? 40u : 80u)); }
 hipError_t launch_align_lane_wide(const AlignArgs& a, int grid, size_t lds_bytes, hipStream_t s, bool edits = false);
-// genasm_lane_parts_kernel (one pair per lane, 64 <= W-O <= 127, W <= 256: two-word table rows): the table in registers, built
+// genasm_lane_parts_kernel (one pair per lane, W <= 256, 64 <= W-O <= 127 — or W > 128 with any W-O <= 63 —: two-word table rows): the table in registers, built
 // in parts of 16 columns from checkpoints of the difference vectors.  LDS per wavefront and lane: CIGAR ring, 16 insertion-run
 // lengths, the window's Eq words for the four bases and "no match" (NW words each, slots of 16 or 32 bytes), the window's text.
 // HBM per wavefront: 8 checkpoints of 4 NW dwords per lane.
-SCRG_HD inline bool lane_parts_serves(int W, int tb_limit) { return W <= 256 && tb_limit >= 64 && tb_limit <= 127; }
+// (Round 5: also W > 128 with W-O <= 63 — 1 to 4 parts, rows in the first word only — which the two-halves kernel, W <= 128, does
+// not reach; genasm_lane_mw_kernel is left with W-O >= 128: table rows of three and four words.)
+SCRG_HD inline bool lane_parts_serves(int W, int tb_limit)
+{
+    return W <= 256 && ((tb_limit >= 64 && tb_limit <= 127) || (W > 128 && tb_limit >= 1 && tb_limit <= 63));
+}
 SCRG_HD inline unsigned lane_parts_lds_bytes(int W)
 {
     const unsigned nw = ((unsigned)W + 63u) / 64u, slot = nw == 2u ? 16u : 32u;

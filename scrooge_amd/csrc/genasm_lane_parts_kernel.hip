@@ -1,4 +1,4 @@
-// genasm_lane_parts_kernel.hip — the lane-per-pair aligner for 64 <= W-O <= 127 (W <= 256): the formulation of
+// genasm_lane_parts_kernel.hip — the lane-per-pair aligner for 64 <= W-O <= 127 (W <= 256; and W > 128 with W-O <= 63): the formulation of
 // genasm_lane_kernel.hip (every lane aligns its own pair; the window's table holds the differences of the edit-distance
 // matrix behind the GenASM bitvectors, src/genasm_cpu.cpp:210-409 — see the header of that file for why this gives the
 // reference's edit distance and CIGAR bit for bit) with multi-word vectors (NW = ceil(W/64) words of 64 pattern rows,
@@ -257,8 +257,8 @@ __global__ __launch_bounds__(256, 2) void genasm_lane_parts_kernel(AlignArgs a)
     const uint32_t text_b = eq_base + 64u * (EQ_BYTES + NOMATCH_BYTES) + lane * TEXT_BYTES;       // xe / xo of dword d at text_b + 8 d
     const uint32_t swz = NW == 2 ? (lane >> 2) & 3u : (lane >> 1) & 3u;     // lanes that share LDS banks use different slots for the same base
     const uint32_t W = (uint32_t)a.W;
-    const uint32_t TBL = (uint32_t)a.tb_limit;                     // W - O, 64..127
-    const uint32_t P = (TBL + (uint32_t)PT_COLS - 1u) / (uint32_t)PT_COLS;     // parts, 4..8
+    const uint32_t TBL = (uint32_t)a.tb_limit;                     // W - O: 64..127, or 1..63 with W > 128
+    const uint32_t P = (TBL + (uint32_t)PT_COLS - 1u) / (uint32_t)PT_COLS;     // parts, 1..8
     const int32_t ktop = (int32_t)((W + (uint32_t)PT_COLS - 1u) / (uint32_t)PT_COLS) - 1;      // the first chunk of the sweep
     // my wavefront's checkpoints: dword d of checkpoint k at ((k * CP_DWORDS + d) * 64 + lane)
     uint32_t* const cps = a.spill + ((uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6)) * 8u * CP_DWORDS * 64u + lane;

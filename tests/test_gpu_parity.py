@@ -223,7 +223,9 @@ def test_table_in_two_halves(aligner, aligner_select, oracle, w, o):
 
 
 @pytest.mark.parametrize("w,o", [(256, 129), (160, 81), (192, 97), (224, 113), (128, 20), (128, 1), (129, 65), (130, 2), (200, 100), (255, 128),
-                                 (191, 64), (192, 128), (65, 1), (256, 192), (161, 81)])
+                                 (191, 64), (192, 128), (65, 1), (256, 192), (161, 81),
+                                 # W > 128 with W-O <= 63 (the reference's O sweeps at --override_W, scripts/profile.py:88-100): 1 to 4 parts
+                                 (256, 200), (192, 150), (130, 100), (256, 255), (160, 144), (129, 66), (256, 224)])
 def test_table_in_parts(aligner, aligner_select, oracle, w, o):
     """64 <= W-O <= 127 (the reference's large-window sweep points, scripts/profile.py:180-185: W = 160 ... 256 with
     O = W/2 + 1; two-word table rows, src/bitvector.hpp:45-48): genasm_lane_parts_kernel builds the window's table in parts of
