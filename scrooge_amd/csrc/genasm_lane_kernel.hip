@@ -287,13 +287,16 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
 
     // hardware wave slot on my SIMD (HW_ID bits 3:0)
     const uint32_t wave_slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);
+    uint32_t rot = wave_slot;          // priority rotation: one step per round
     for (;;) {
         // The SIMD's arbiter issues oldest-wave-first: left alone, the first wavefront on a SIMD runs at the speed
         // of a lone wave and the last one finishes 2.7x later, with the SIMD half idle at the end of a launch.
-        // Rotating the priorities (set once per round from the clock and the wave slot: a different wavefront is on top
-        // from round to round) lets the wavefronts of a SIMD progress, and finish, together.
+        // Rotating the priorities (one step per round, starting from the wave slot: a different wavefront is on top from
+        // round to round) lets the wavefronts of a SIMD progress, and finish, together.  (Until round 4 the rotation was keyed
+        // on the clock: s_memtime and the wait for it — which is a wait for every LDS operation in flight as well — cost a
+        // wavefront that has its SIMD to itself ~1 000 cycles per round: one launch of 100 k pairs 2.45 -> 2.30 ms without it.)
         if (!SCRG_SW(a, 1)) {
-            const uint32_t pr = ((uint32_t)(__builtin_readcyclecounter() >> 11) + wave_slot) & 3u;
+            const uint32_t pr = rot++ & 3u;
             if (pr == 0) __builtin_amdgcn_s_setprio(0);
             else if (pr == 1) __builtin_amdgcn_s_setprio(1);
             else if (pr == 2) __builtin_amdgcn_s_setprio(2);
@@ -537,38 +540,42 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
                 }
                 mbase += ti;                                   // the next window starts at its column 0
             } else {
-            // The length byte of an insertion run is asked for TWO events before it is used (c0 / c1: the columns of the next
-            // two events, n0 / n1 their bytes): a wavefront that has its SIMD to itself would otherwise wait for LDS once per event.
+            // Two events per trip (c0 / c1: the columns of the next two events; E holds c1 and what comes after it).  The length
+            // bytes of both events' insertion runs are asked for at the TOP of the trip and used at its very end — the two ring
+            // writes of an event come after all its arithmetic — so the loop carries no LDS read from trip to trip (the wait in
+            // front of a carried read would also wait for the writes issued just before the branch) and a wavefront that has its
+            // SIMD to itself waits for LDS less than once per event.
             uint32_t E = SCRG_ABL(a, 4) ? 0u : (B | Im);                  // (ablation, profiling only: no runs)
             uint32_t c0 = ffbh_u32(E);
-            uint32_t n0 = lds8[scr_b + c0];
             E = bitop3<TT_ANDN>(E, 0x80000000u >> (c0 & 31u), 0u);
             uint32_t c1 = ffbh_u32(E);
-            uint32_t n1 = lds8[scr_b + c1];
             uint32_t q = 2u * (uint32_t)nr + 2u;       // byte offset of the next free slot (the run after the last committed one)
-            // one event: column c with its length byte ni; nx = the column of the event after it; E holds nx and the events after it
-            auto event = [&](uint32_t& c, uint32_t& ni, const uint32_t nx) {
+            // one event: column c, its length byte ni; nx = the column of the event after it.  The insertion run goes to the slot
+            // after the last committed run and is committed by its mask bit; the D / X / = run that starts here goes to the slot
+            // after that (the same slot if there is no insertion run: it is written second) and is committed by B.
+            auto event = [&](uint32_t& c, const uint32_t ni, const uint32_t nx) {
                 const uint32_t sh = 31u - c;
-                *reinterpret_cast<uint16_t*>(lds_b + ring_b + (q & 62u)) = (uint16_t)(((uint32_t)'I' << 8) | ni);
+                const uint32_t aI = ring_b + (q & 62u);
                 q = add_twice(q, __builtin_amdgcn_ubfe(Im, sh, 1));
                 // the run's length = min(nx, ti) - c (up to the next event or the end of the walk) = min(nx, ti) + sh - 31; its letter
                 // '=' 0x3D, 'X' 0x58 = '=' + 27, 'D' 0x44 = '=' + 7: two multiply-adds on top of sh and one three-operand add
                 const uint32_t w = add3(mad24(__builtin_amdgcn_ubfe(X, sh, 1), 27u << 8, mad24(__builtin_amdgcn_ubfe(D, sh, 1), 7u << 8, sh)),
                                         min(nx, ti), ((uint32_t)'=' << 8) - 31u);
-                *reinterpret_cast<uint16_t*>(lds_b + ring_b + (q & 62u)) = (uint16_t)w;
+                const uint32_t aS = ring_b + (q & 62u);
                 q = add_twice(q, __builtin_amdgcn_ubfe(B, sh, 1));
-                // the event after nx takes this one's place
-                E = bitop3<TT_ANDN>(E, 0x80000000u >> (nx & 31u), 0u);
+                E = bitop3<TT_ANDN>(E, 0x80000000u >> (nx & 31u), 0u);      // the event after nx takes this one's place
                 c = ffbh_u32(E);
-                ni = lds8[scr_b + c];
+                *reinterpret_cast<uint16_t*>(lds_b + aI) = (uint16_t)(((uint32_t)'I' << 8) | ni);
+                *reinterpret_cast<uint16_t*>(lds_b + aS) = (uint16_t)w;
             };
             // a trip commits at most 4 runs and writes one slot ahead: the 15 left by the regular look + four trips fit the 32-run
             // ring; from the fifth trip on a lane with 27 or more runs pending makes the wavefront look
             uint32_t trips = 0;
             while (__any(c0 < 32u)) {                      // (a lane without events left has c0 = 0xffffffff: it commits nothing)
+                const uint32_t n0 = lds8[scr_b + c0], n1 = lds8[scr_b + c1];
                 if (trips >= 4u) ring_guard((q >> 1) - flushed, 27u);
-                event(c0, n0, c1);                         // two events per trip: half the loop branches, twice the
-                event(c1, n1, c0);                         // independent work in flight
+                event(c0, n0, c1);
+                event(c1, n1, c0);
                 trips++;
             }
             nr = ((int32_t)q >> 1) - 1;
@@ -672,7 +679,7 @@ __global__ __launch_bounds__(512, 2) void genasm_lane_split_kernel(AlignArgs a)
             uint32_t first = 0;
             if (active) {
                 if (!SCRG_SW(a, 1)) {
-                    const uint32_t pr = ((uint32_t)(__builtin_readcyclecounter() >> 11) + wave_slot) & 3u;
+                    const uint32_t pr = (r + wave_slot) & 3u;          // (one step per round: see genasm_lane_kernel)
                     if (pr == 0) __builtin_amdgcn_s_setprio(0);
                     else if (pr == 1) __builtin_amdgcn_s_setprio(1);
                     else if (pr == 2) __builtin_amdgcn_s_setprio(2);

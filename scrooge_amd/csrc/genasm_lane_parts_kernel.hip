@@ -334,10 +334,11 @@ __global__ __launch_bounds__(256, 2) void genasm_lane_parts_kernel(AlignArgs a)
     };
 
     const uint32_t wave_slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);
+    uint32_t rot = wave_slot;          // priority rotation, one step per round (not keyed on the clock: see genasm_lane_kernel)
     for (;;) {
         // (priority rotation: see genasm_lane_kernel)
         if (!SCRG_SW(a, 1)) {
-            const uint32_t pr = ((uint32_t)(__builtin_readcyclecounter() >> 11) + wave_slot) & 3u;
+            const uint32_t pr = rot++ & 3u;
             if (pr == 0) __builtin_amdgcn_s_setprio(0);
             else if (pr == 1) __builtin_amdgcn_s_setprio(1);
             else if (pr == 2) __builtin_amdgcn_s_setprio(2);
