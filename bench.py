@@ -1239,17 +1239,19 @@ def main():
         set_phase("diagnostics: one peer at a time")
         one = []
         for r_ in range(1, world):
-            dist.barrier()
-            torch.cuda.synchronize()
-            t_ = time.perf_counter()
-            if rank == r_:
-                for k_ in range(reps):
-                    dist.send(gather.send[0].cpu() if host_stage else gather.send[0], dst=0)
-            elif rank == 0:
-                buf_ = torch.empty(gather.wire, dtype=torch.uint8) if host_stage else gather.recv[0][r_]
-                for k_ in range(reps):
-                    dist.recv(buf_, src=r_)
-            torch.cuda.synchronize()
+            # (one untimed message first: RCCL sets up the point-to-point connection of a pair of ranks on first use)
+            for timed_ in (False, True):
+                dist.barrier()
+                torch.cuda.synchronize()
+                t_ = time.perf_counter()
+                if rank == r_:
+                    for k_ in range(reps if timed_ else 1):
+                        dist.send(gather.send[0].cpu() if host_stage else gather.send[0], dst=0)
+                elif rank == 0:
+                    buf_ = torch.empty(gather.wire, dtype=torch.uint8) if host_stage else gather.recv[0][r_]
+                    for k_ in range(reps if timed_ else 1):
+                        dist.recv(buf_, src=r_)
+                torch.cuda.synchronize()
             dist.barrier()
             d1 = all_max(time.perf_counter() - t_)
             one.append({"peer": r_, "GBs": gather.wire * reps / d1 / 1e9, "ms_per_message": d1 / reps * 1e3})
