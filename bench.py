@@ -745,12 +745,16 @@ def main():
         def policy(root, shards):
             """the same steps with the results gathered to `root` (0 | "rotate") and the step's pairs split `shards`
             ("equal": every rank aligns --pairs; "auto": root_share_plan) — None if this run's buffers cannot hold it"""
+            scaled = None
             if shards == "equal":
                 real0 = real_other = nominal
             else:
                 real0, real_other = root_share_plan(world, nominal, "auto")
-            if max(real0, real_other) > n:
-                return {"skipped": "the buffers of this run hold %d pairs per rank; this policy needs %d (start with --root-share auto)" % (n, max(real0, real_other))}
+                if real_other > n:
+                    # the buffers of this run hold n pairs per rank (they were sized for another policy): the same split at the
+                    # size that fits — the other ranks align n pairs, rank 0 the same fraction of theirs as in the full plan
+                    scaled = n / real_other
+                    real0, real_other = int(real0 * scaled) // 64 * 64, n // 64 * 64
             mine = real0 if rank == 0 else real_other
             descs_p = []
             for b_ in range(n_lanes):
@@ -776,6 +780,9 @@ def main():
                 dist.all_reduce(ft, op=dist.ReduceOp.MIN)
                 res_["every_slot_decoded"] = bool(int(ft.item()))
                 res_["shards"] = {"rank_0": real0, "other_ranks": real_other}
+                if scaled is not None:
+                    res_["shards"]["note"] = ("the root-share plan of %d pairs per step scaled by %.3f to the %d pairs per rank this run's "
+                                              "buffers hold: same split, smaller step" % (world * nominal, scaled, n))
                 res_["root"] = "rank 0" if root == 0 else "step k to rank k mod N"
             finally:
                 cur.clear()

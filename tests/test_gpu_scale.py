@@ -361,11 +361,11 @@ def test_bench_two_ranks_dry_run(gather_root, root_share):
     # policies, the gather alone, every peer's rate into rank 0, every rank's own N = 1-equivalent rate
     d = j["diagnose"]
     for key in ("root0_equal_shards", "root0_auto_shards", "rotating_root_equal_shards"):
-        assert key in d
-        if "skipped" in d[key]:
-            assert key == "root0_auto_shards" and sh == "equal"         # buffers sized for equal shards cannot hold the larger ones
-        else:
-            assert d[key]["value"] > 0 and d[key]["every_slot_decoded"] is True and d[key]["steps"] >= 2
+        assert d[key]["value"] > 0 and d[key]["every_slot_decoded"] is True and d[key]["steps"] >= 2
+    # the root-share plan at N = 2: rank 0 aligns 0.8 of an equal share; in a run whose buffers were sized for equal shards the
+    # same split runs at the size that fits (the other rank aligns what the buffers hold)
+    a_sh = d["root0_auto_shards"]["shards"]
+    assert a_sh["rank_0"] < a_sh["other_ranks"] <= 7680 and 0.6 < a_sh["rank_0"] / a_sh["other_ranks"] < 0.7
     assert d["root0_equal_shards"]["shards"] == {"rank_0": 6400, "other_ranks": 6400}
     assert d["rotating_root_equal_shards"]["root"] == "step k to rank k mod N"
     assert d["gather_without_decode"] == j["gather_without_decode"] and j["gather_without_decode"]["value"] > 0
