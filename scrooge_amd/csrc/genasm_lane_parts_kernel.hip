@@ -28,6 +28,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "genasm_kernels.h"
 #include "genasm_device.h"
@@ -493,32 +494,76 @@ __global__ __launch_bounds__(256, 2) void genasm_lane_parts_kernel(AlignArgs a)
                 sweep_chunk((int32_t)part, std::true_type{});           // (st: the checkpoint in front of this chunk)
                 if (PREFETCH && part + 1u < P) load_checkpoint(part + 1u, st);
             }
-            // pass 1 (see genasm_lane_kernel): the walk through this part's columns, on 128-bit rows
+            // pass 1 (see genasm_lane_kernel): the walk through this part's columns.  A table row is 128 bits (rows 0..63 in word 0,
+            // 64..127 in word 1), and reading it at an arbitrary row costs a funnel of two 64-bit shifts and two selects per word:
+            // ~45 instructions per column.  But the walk of part k is near row 16 k in EVERY lane, so most parts stay inside one
+            // word for the whole wavefront: then a row access is ONE 64-bit shift (~16 instructions per column).
+            //   MODE 1: every lane that holds a pair starts the part at a row <= 40 — walk on word 0 alone.  Rows past 63 then read
+            //           as "insertion", so a lane that really leaves the word ends the part at a row > 63: the part is walked
+            //           again on the full rows (rare: more than 7 insertions in 16 columns).
+            //   MODE 2: every lane that holds a pair is at a row >= 64 (it can only go up) — walk on word 1 alone.
+            //   MODE 0: the full 128-bit rows.
             const uint32_t j0 = j;
             uint32_t nDm = 0, Xm = 0, nIm = 0;
             const uint64_t stop0 = ((uint64_t)stop[0].y << 32) | stop[0].x, stop1 = ((uint64_t)stop[1].y << 32) | stop[1].x;
+            auto walk_part = [&](auto mode_tag) {
+                constexpr int MODE = decltype(mode_tag)::value;
+                nDm = Xm = nIm = 0;
+                j = j0;
+                if constexpr (MODE == 0) {
 #pragma unroll
-            for (int s = 0; s < PT_COLS; s++) {
-                if ((uint32_t)s >= ncols) continue;                 // (uniform)
-                // not (insertion), or the stop row, from row j on: the run of insertions is its leading zeros (the stop bit ends it)
-                const uint64_t x0 = tab[s][0][0] | ~tab[s][1][0] | stop0, x1 = tab[s][0][1] | ~tab[s][1][1] | stop1;
-                const uint64_t top = pt_from_row(x0, x1, j);
-                const uint64_t nxt = j < 64u ? pt_shl64(x1, j) : 0ull;      // the 64 rows after those (only if the run is that long)
-                const uint32_t ni = (top != 0ull) ? pt_clz64(top) : 64u + pt_clz64(nxt);
-                lds8[scr_b + s] = (uint8_t)ni;
-                nIm = __builtin_amdgcn_alignbit(nIm, (uint32_t)(top >> 32), 31);
-                j += ni;
-                const uint32_t nt1 = (uint32_t)(pt_from_row(tab[s][0][0], tab[s][0][1], j) >> 32);     // sign: not a deletion
-                const uint32_t t0 = (uint32_t)(pt_from_row(tab[s][1][0], tab[s][1][1], j) >> 32);      // sign: substitution
-                nDm = __builtin_amdgcn_alignbit(nDm, nt1, 31);
-                Xm = __builtin_amdgcn_alignbit(Xm, t0, 31);
-                j -= neg_mask(nt1);                                 // j += sign bit of nt1: a deletion (or the stop row) keeps j
+                    for (int s = 0; s < PT_COLS; s++) {
+                        if ((uint32_t)s >= ncols) continue;                 // (uniform)
+                        // not (insertion), or the stop row, from row j on: the run of insertions is its leading zeros (the stop bit ends it)
+                        const uint64_t x0 = tab[s][0][0] | ~tab[s][1][0] | stop0, x1 = tab[s][0][1] | ~tab[s][1][1] | stop1;
+                        const uint64_t top = pt_from_row(x0, x1, j);
+                        const uint64_t nxt = j < 64u ? pt_shl64(x1, j) : 0ull;      // the 64 rows after those (only if the run is that long)
+                        const uint32_t ni = (top != 0ull) ? pt_clz64(top) : 64u + pt_clz64(nxt);
+                        lds8[scr_b + s] = (uint8_t)ni;
+                        nIm = __builtin_amdgcn_alignbit(nIm, (uint32_t)(top >> 32), 31);
+                        j += ni;
+                        const uint32_t nt1 = (uint32_t)(pt_from_row(tab[s][0][0], tab[s][0][1], j) >> 32);     // sign: not a deletion
+                        const uint32_t t0 = (uint32_t)(pt_from_row(tab[s][1][0], tab[s][1][1], j) >> 32);      // sign: substitution
+                        nDm = __builtin_amdgcn_alignbit(nDm, nt1, 31);
+                        Xm = __builtin_amdgcn_alignbit(Xm, t0, 31);
+                        j -= neg_mask(nt1);                                 // j += sign bit of nt1: a deletion (or the stop row) keeps j
+                    }
+                } else {
+                    constexpr int WD = MODE - 1;                            // the word the whole wavefront stays in
+                    const uint64_t stopw = WD == 0 ? stop0 : stop1;
+                    uint32_t jr = j - 64u * (uint32_t)WD;                   // row inside that word
+#pragma unroll
+                    for (int s = 0; s < PT_COLS; s++) {
+                        if ((uint32_t)s >= ncols) continue;                 // (uniform)
+                        const uint64_t x = tab[s][0][WD] | ~tab[s][1][WD] | stopw;
+                        const uint64_t top = pt_shl64(x, jr);               // (rows past the word: zeros = "insertion": see MODE 1 above)
+                        // leading zeros, 64 for 0: the run of insertions
+                        const uint32_t ni = min(pt_ffbh((uint32_t)(top >> 32)), min(pt_ffbh((uint32_t)top), 32u) + 32u);
+                        lds8[scr_b + s] = (uint8_t)ni;
+                        nIm = __builtin_amdgcn_alignbit(nIm, (uint32_t)(top >> 32), 31);
+                        jr += ni;
+                        const uint32_t nt1 = (uint32_t)(pt_shl64(tab[s][0][WD], jr) >> 32);      // sign: not a deletion
+                        const uint32_t t0 = (uint32_t)(pt_shl64(tab[s][1][WD], jr) >> 32);       // sign: substitution
+                        nDm = __builtin_amdgcn_alignbit(nDm, nt1, 31);
+                        Xm = __builtin_amdgcn_alignbit(Xm, t0, 31);
+                        jr -= neg_mask(nt1);
+                    }
+                    j = jr + 64u * (uint32_t)WD;
+                }
+            };
+            if (!__any(has_pair && j0 < 64u)) {
+                walk_part(std::integral_constant<int, 2>{});
+            } else if (!__any(has_pair && j0 > 40u)) {
+                walk_part(std::integral_constant<int, 1>{});
+                if (__any(has_pair && j > 63u)) walk_part(std::integral_constant<int, 0>{});       // some lane left word 0: once more, on the full rows
+            } else {
+                walk_part(std::integral_constant<int, 0>{});
             }
             // column s of the part -> bit 31-s; the lane was alive in the ti columns before the first "deletion and
             // substitution" (the stop row)
             const uint32_t nsh = 32u - ncols;
             const uint32_t Draw = ~(nDm << nsh), Xraw = Xm << nsh;
-            const uint32_t ti = min(pt_ffbh(Draw & Xraw), ncols);
+            const uint32_t ti = has_pair ? min(pt_ffbh(Draw & Xraw), ncols) : 0u;       // (a lane without a pair: the one-word walks read it garbage)
             const uint32_t A = ~(uint32_t)pt_shr64(0xffffffffull, ti);      // the top ti bits (ti = 0..16)
             const uint32_t D = Draw & A, X = Xraw & A;
             const uint32_t Im = ~nIm << nsh;
