@@ -551,7 +551,9 @@ __global__ __launch_bounds__(256, 2) void genasm_lane_parts_kernel(AlignArgs a)
                     j = jr + 64u * (uint32_t)WD;
                 }
             };
-            if (!__any(has_pair && j0 < 64u)) {
+            if (TBL <= 63u) {                                   // (W > 128 with a small W-O: no walk ever reaches row 64 — jlim <= W-O)
+                walk_part(std::integral_constant<int, 1>{});
+            } else if (!__any(has_pair && j0 < 64u)) {
                 walk_part(std::integral_constant<int, 2>{});
             } else if (!__any(has_pair && j0 > 40u)) {
                 walk_part(std::integral_constant<int, 1>{});
