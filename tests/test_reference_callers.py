@@ -149,3 +149,19 @@ def test_third_export_packs_the_references_strings():
     r = subprocess.run([TWOBIT_EXE] + [s or "-" for s in TWOBIT_INPUTS], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert r.stdout.split("\n")[:len(TWOBIT_INPUTS)] == [_twobit_expected(s) for s in TWOBIT_INPUTS]
+
+
+def test_third_export_header_in_two_translation_units(tmp_path):
+    """The compat header defines the kernel (`static`, a kernel cannot be `inline`): a caller made of several translation units
+    that all include it must still link (no duplicate symbols), for gfx950, with hipcc."""
+    scrooge_amd.build_library()
+    libdir = os.path.join(ROOT, "scrooge_amd")
+    a, b = tmp_path / "a.hip", tmp_path / "b.hip"
+    a.write_text('#include "genasm_gpu.hpp"\nvoid launch_b(int, long long*, char**, char**);\n'
+                 'int main() { genasm_gpu::ascii_to_twobit_strings<<<1, 32>>>(0, nullptr, nullptr, nullptr); launch_b(0, nullptr, nullptr, nullptr);'
+                 ' return hipDeviceSynchronize() == hipSuccess ? 0 : 1; }\n')
+    b.write_text('#include "genasm_gpu.hpp"\nvoid launch_b(int n, long long* l, char** x, char** y) { genasm_gpu::ascii_to_twobit_strings<<<4, 64>>>(n, l, x, y); }\n')
+    p = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-std=c++17", "-Wall", "-Werror", "-Wno-unused-result",
+                        "-I" + os.path.join(ROOT, "include", "compat"), "-I" + os.path.join(ROOT, "include"), str(a), str(b),
+                        "-L" + libdir, "-lscrooge_amd", "-Wl,-rpath," + libdir, "-o", str(tmp_path / "two_tu")], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
