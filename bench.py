@@ -94,6 +94,9 @@ def parse():
                          "'auto' root share, rotating root), without the decode, the gather alone (achieved GB/s per peer into rank 0, all "
                          "peers at once and one at a time) and every rank's own N=1-equivalent rate — reported as `diagnose` and "
                          "`per_gpu_value`; auto = on when N > 1")
+    ap.add_argument("--diagnose-budget", type=float, default=240.0,
+                    help="N > 1: seconds the diagnostics may take; after that (or if they raise) rank 0 prints its line with the error in "
+                         "`diagnose` and all ranks leave with exit code 0")
     ap.add_argument("--deadline", type=float, default=1500.0,
                     help="hard limit in seconds for the whole run (0 = none): a rank that is still running then — e.g. stalled in a "
                          "collective — prints where it was and exits with code 124 (the launcher tears the other ranks down); the "
@@ -695,12 +698,22 @@ def main():
     # ---------------- N > 1: the diagnostics of the multi-GPU step, after everything that is timed ----------------
     # One run on a multi-GPU node should answer the open design questions at once: root 0 against a rotating
     # root, equal shards against the root-share plan, what the decode costs, what the links carry, what every GPU does alone.
+    # They run LAST, on every rank, when rank 0 has its whole line ready (guarded_diagnostics, at the end of main): whatever happens
+    # in them — an exception, a collective that never returns on links nobody has used yet — the line is still printed, with the
+    # error in `diagnose`.
     diagnose = None
     per_gpu_value = None
     want_diag = (dist_on and gather_format == "edits" and decode_on and p.lanes_per_pair == 1 and
                  (args.diagnose == "on" or (args.diagnose == "auto" and world > 1)))
-    if want_diag:
+
+    def run_diagnostics():
         set_phase("diagnostics: sizes of the full batches")
+        fault = os.environ.get("SCRG_BENCH_TEST_DIAG")    # test only (tests/test_gpu_scale.py): diagnostics that raise / never return
+        if fault == "raise" and rank == world - 1:
+            raise RuntimeError("test fault (SCRG_BENCH_TEST_DIAG)")
+        if fault == "hang":
+            while True:
+                time.sleep(1.0)
         K = max(2, args.steps)
         gather.finish_all()
         torch.cuda.synchronize()
@@ -881,6 +894,39 @@ def main():
         del dense_local, descs_eq
         torch.cuda.empty_cache()
         set_phase("after the diagnostics")
+        return diagnose, per_gpu_value
+
+    def guarded_diagnostics(line):
+        """Runs the diagnostics under a time budget.  line: rank 0's finished JSON object (None on the other ranks).
+        -> (diagnose, per_gpu_value); if they raise or do not finish within --diagnose-budget seconds, rank 0 prints its line
+        with the error in `diagnose` and every rank leaves with exit code 0: the headline of a multi-GPU run is never lost to
+        its diagnostics (a rank stuck in a collective never returns to Python: a timer thread does this)."""
+        import threading
+        finished = threading.Event()
+
+        def give_up(msg):
+            if line is not None:
+                line["diagnose"] = {"error": msg}
+                print(json.dumps(line), flush=True)
+            print("bench.py: rank %d: %s" % (rank, msg), file=sys.stderr, flush=True)
+            os._exit(0)
+
+        def expire():
+            if not finished.is_set():
+                give_up("the diagnostics did not finish within --diagnose-budget %.0f s (phase: %s); the rest of the line is complete"
+                        % (args.diagnose_budget, PHASE[0]))
+
+        timer = threading.Timer(args.diagnose_budget, expire)
+        timer.daemon = True
+        timer.start()
+        try:
+            res = run_diagnostics()
+        except Exception as e:          # (the other ranks may now wait in a collective this rank never enters: their timers end them)
+            give_up("the diagnostics raised %s: %s (phase: %s); the rest of the line is complete" % (type(e).__name__, e, PHASE[0]))
+        finished.set()
+        timer.cancel()
+        return res
+
     # reference point outside the timed region: the same step on ONE stream (no overlap between launches)
     serial = None
     if n_lanes > 1 and not dist_on and not args.stats:
@@ -943,6 +989,8 @@ def main():
             st["cyc_per_diag_round_" + k] = st["cycles_diag_" + k] / max(1, st["diag_rounds"])
         print("stats(last launch):", st, file=sys.stderr)
     if rank != 0:
+        if want_diag:
+            guarded_diagnostics(None)
         if world > 1:
             dist.destroy_process_group()
         return
@@ -1342,6 +1390,8 @@ def main():
                            "frac": ref_ops * value / world / VALU_PEAK_LANE_OPS, "unit": "int32 lane-ops/s",
                            "note": "per GPU, from the whole-step rate"}
         out["bit_cell_gcups"] = value * dc_cells * 64 / 1e9
+    if want_diag:
+        out["diagnose"], out["per_gpu_value"] = guarded_diagnostics(out)
     print(json.dumps(out))
     if dist_on:
         dist.destroy_process_group()

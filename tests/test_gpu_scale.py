@@ -378,6 +378,30 @@ def test_bench_two_ranks_dry_run(gather_root, root_share):
     assert j["config"]["rccl_ranks"] == 2
 
 
+@pytest.mark.parametrize("fault", ["raise", "hang"])
+def test_bench_line_survives_its_diagnostics(fault):
+    """The diagnostics of an N > 1 run come last and under a budget: if they raise on a rank (the others then wait in a
+    collective that rank never enters) or never return, rank 0 still prints the complete line with the error in `diagnose`
+    and the job ends with exit code 0 (bench.py: guarded_diagnostics).  Two gloo ranks on this GPU, as in the dry run above."""
+    import json, os, subprocess, sys, time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SCRG_BENCH_DRYRUN="1", SCRG_BENCH_TEST_DIAG=fault)
+    env.pop("WORLD_SIZE", None)
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--pairs", "6400",
+                          "--read-len", "2000", "--diagnose-budget", "20"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["value"] > 0 and j["gather_check"] is True and j["roofline"]["hbm"]["achieved"] > 0
+    assert "error" in j["diagnose"] and j["per_gpu_value"] is None
+    if fault == "hang":
+        assert "did not finish within --diagnose-budget" in j["diagnose"]["error"]
+    assert "rest of the line is complete" in j["diagnose"]["error"]
+    assert time.time() - t0 < 300
+
+
 def test_full_bench_size_two_algorithms_agree(aligner, aligner_select):
     """BASELINE configs[1] at full size (100k x 10 kb ONT-error pairs, generated on the GPU like bench.py):
     the lane-per-pair kernel (difference vectors, the default) and the diagonal-major and column-major window
