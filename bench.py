@@ -478,7 +478,8 @@ def main():
                 torch.cuda.synchronize()
                 del t_cnt
             else:
-                bound = int(o["ed"].sum().item()) + n * (L >> 6) + 4 * n + 64
+                # (include/scrooge_amd.h: a byte per edit and per window, streams start at multiples of 4)
+                bound = int(o["ed"].sum().item()) + n * (2 * (L + L // 2) // (p.W - p.O) + 12) + 64
                 tmp = torch.empty(bound, dtype=torch.uint8, device=device)
                 t_off = torch.empty(n, dtype=torch.int64, device=device)
                 t_len = torch.empty(n, dtype=torch.int32, device=device)

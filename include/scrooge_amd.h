@@ -132,7 +132,7 @@ int         scrg_build_flags(void);
  * older header and would shift every later argument.  scrg_abi_version() is what the loaded library was built with; a binding
  * compares it with the SCRG_ABI_VERSION it was compiled against before anything else (include/scrooge_amd.hpp throws,
  * scrooge_amd/api.py raises). */
-#define SCRG_ABI_VERSION 5
+#define SCRG_ABI_VERSION 6
 int         scrg_abi_version(void);
 
 /* ---------------------------------------------------------------------------
@@ -280,8 +280,9 @@ scrg_status scrg_align_device(scrg_ctx *ctx, const scrg_params *params, uint64_t
  * stream goes to its slice — bytes [2 * cigar_off, 2 * cigar_off + 2 * cigar_cap) of d_streams, i.e. the very slice
  * scrg_align_device would fill with runs, so descriptors and buffers can be shared —, d_stream_len[p] is its length
  * in bytes (the bytes up to the next multiple of 4 are zero), d_pair_status[p] is 1 if it did not fit (a stream is
- * never longer than edit distance + read_len / 64 bytes; 2 * cigar_cap >= that always fits).  The kernel does less
- * work than for runs (it visits edits, not run boundaries) and writes a quarter of the bytes.
+ * never longer than edit distance + number of windows + read_len / 63 bytes; a slice sized like the reference's,
+ * cigar_cap = 2 x read length runs, always fits).  The kernel does less
+ * work than for runs (it visits edits, not run boundaries) and writes a third of the bytes.
  * scrg_compact_runs with d_n_runs[p] = (d_stream_len[p] + 3) / 4 * 2 and even d_dense_offset gathers the slices.
  * d_n_runs may be NULL; otherwise d_n_runs[p] = the number of runs of the same alignment (what scrg_align_device
  * reports): sent along with the streams it lets the receiver lay out the decoded runs by a prefix sum and restore them
@@ -309,34 +310,40 @@ scrg_status scrg_compact_runs_packed(scrg_ctx *ctx, const scrg_params *params, u
 scrg_status scrg_unpack_runs(scrg_ctx *ctx, uint64_t n_runs, const uint8_t *d_packed, scrg_run *d_runs);
 
 /* ---- Edit stream: the compact transfer format for CIGARs (multi-GPU gather, D2H) ----
- * The runs of a pair carry the alignment operations AND the places where a window ended; the window breaks are a
- * function of the operations (a window's traceback runs while j < m && i < W-O && j < W-O, genasm_cpu.cpp:307-310,
- * and the next window starts where it stopped, :411-438), so only the operations travel, one byte per EDIT:
+ * The runs of a pair carry the alignment operations AND the places where a window ended (runs are flushed per window,
+ * genasm_cpu.cpp:304-305, 400-403).  One byte per EDIT and one per WINDOW carries both (format version 2, ABI 6):
  *     byte = op << 6 | len     op 1 'X', 2 'I', 3 'D': `len` matches, then that edit;
- *                              op 0: `len + 1` matches, no edit (only inside a stretch of more than 63 matches)
- * in alignment order; the matches after the last edit are implied by the read length.  Canonical form: P matches
- * before an edit = P >> 6 bytes 0x3F, then the edit byte with len = P & 63.  A 10 kb read at 10 % error is ~1.0 KB
- * (2140 runs = 4.3 KB as scrg_run, 2.1 KB packed).  Valid for every W (counts of restored runs are <= W-O <= 255).
+ *                              op 0, len <= 62        : `len` matches, then the window ends (every window of a pair has
+ *                                                       its END byte, the last one too);
+ *                              op 0, len == 63 (0x3F) : 63 matches and nothing else (only W-O > 63 has such stretches)
+ * in alignment order.  Canonical form: P matches before an edit or a window end = P / 63 bytes 0x3F, then the byte with
+ * len = P % 63.  A 10 kb read at 10 % error and W-O = 31 is ~1.3 KB (2140 runs = 4.3 KB as scrg_run, 2.1 KB packed).
+ * Valid for every W (run counts are <= W-O <= 255).  (Version 1 — ABI <= 5 — sent the edits only and the receiver replayed
+ * the window loop: a quarter fewer bytes, three times the decoding work.)
  *
- * scrg_encode_edit_stream: for every pair, the stream of its runs (as scrg_align_device left them in d_runs).
+ * scrg_encode_edit_stream: for every pair, the stream of its runs (as scrg_align_device left them in d_runs; W-O of
+ *   `params` places the window ends).
  *   Streams are placed in d_stream back to back in no particular order, each starting at a multiple of 4:
  *   d_stream_off[p] (bytes; ~0 if the pair did not fit into stream_cap) and d_stream_len[p] say where.
  *   d_total[0] = bytes of d_stream used (the amount to transfer), d_total[1] = pairs that did not fit.
- *   stream_cap >= sum of edit distances + sum of (read_len >> 6) + 4 * n_pairs always suffices.
- * scrg_decode_edit_stream: the inverse (one pair per lane; streams fetched by the wavefront in 64-byte chunks, runs
- *   written in aligned 32-byte pieces).  d_stream holds stream_bytes bytes (16-byte aligned, readable up to the next
+ *   stream_cap >= sum over the pairs of (edit distance + 2 * (read_len + edit distance) / (W-O) + 8) always suffices.
+ * scrg_decode_edit_stream: the inverse (one pair per lane; streams read in aligned 16-byte blocks, runs written in
+ *   aligned 64-byte pieces).  d_stream holds stream_bytes bytes (16-byte aligned, readable up to the next
  *   multiple of 16): a pair whose stream is not inside [0, stream_bytes) — offsets and lengths may come off a wire —
  *   is counted as bad, never read.  Read lengths are taken from d_read_len[p * read_len_stride] (stride 1: a plain
- *   array; 6: &d_pairs[0].read_len; 0: one length for all).
+ *   array; 6: &d_pairs[0].read_len; 0: one length for all).  `params` is not looked at beyond its validity (the window
+ *   ends are in the stream).
  *   With d_dense == NULL it only counts: d_n_runs[p] = runs of pair p.  Otherwise d_n_runs[p] is an input, the size
  *   of pair p's segment at d_dense + d_dense_offset[p] (d_dense 16-byte aligned, room for dense_capacity runs), and the
- *   runs are written there — bit for bit the runs the align kernel produced for W/O of `params`.  Counts and offsets
+ *   runs are written there — bit for bit the runs the align kernel produced.  Counts and offsets
  *   may come off a wire like the streams: a pair whose segment [d_dense_offset[p], + d_n_runs[p]) does not lie inside
  *   [0, dense_capacity) is counted as bad and nothing of it is written.  (scrg_align_device_edits can deliver the
  *   run counts along with the streams, so that the receiver sizes the dense array by a prefix sum and decodes in ONE
- *   pass.)  *d_bad_count is incremented for every pair whose stream is not an alignment of a read of that length,
+ *   pass.)  *d_bad_count is incremented for every pair whose stream is not an alignment of a read of that length
+ *   (it does not end with a window end, places another number of read characters, holds a run longer than 255),
  *   or whose run count differs from d_n_runs[p]. */
-scrg_status scrg_encode_edit_stream(scrg_ctx *ctx, uint64_t n_pairs, const scrg_pair_desc *d_pairs,
+scrg_status scrg_encode_edit_stream(scrg_ctx *ctx, const scrg_params *params, uint64_t n_pairs,
+                                    const scrg_pair_desc *d_pairs,
                                     const scrg_run *d_runs, const uint32_t *d_n_runs,
                                     uint8_t *d_stream, uint64_t stream_cap,
                                     uint64_t *d_stream_off, uint32_t *d_stream_len, uint64_t *d_total);
@@ -347,16 +354,19 @@ scrg_status scrg_decode_edit_stream(scrg_ctx *ctx, const scrg_params *params, ui
                                     const uint64_t *d_dense_offset, scrg_run *d_dense, uint64_t dense_capacity,
                                     uint32_t *d_n_runs, uint32_t *d_bad_count);
 /* The same two conversions for ONE pair on the host (no GPU, no handle): what a receiver without a GPU, or a
- * test, uses.  scrg_edit_stream_to_runs returns SCRG_ERR_INVALID_ARG for a malformed stream and
+ * test, uses.  scrg_edit_stream_to_runs returns SCRG_ERR_INVALID_ARG for a malformed stream — it also checks that
+ * every window ends where the reference's window loop of W/O ends it (genasm_cpu.cpp:307-310) — and
  * SCRG_ERR_CIGAR_OVERFLOW if runs_cap is too small (*n_runs is the number needed either way; runs may be NULL
- * with runs_cap 0 to ask for it).  scrg_runs_to_edit_stream likewise with stream_cap / *n_bytes. */
+ * with runs_cap 0 to ask for it).  scrg_runs_to_edit_stream likewise with stream_cap / *n_bytes; it replays the
+ * window loop of W/O to place the window ends (SCRG_ERR_INVALID_ARG for an operation other than = X I D). */
 scrg_status scrg_edit_stream_to_runs(const scrg_params *params, uint64_t read_len,
                                      const uint8_t *stream, uint64_t n_bytes,
                                      scrg_run *runs, uint64_t runs_cap, uint64_t *n_runs);
-scrg_status scrg_runs_to_edit_stream(const scrg_run *runs, uint64_t n_runs,
+scrg_status scrg_runs_to_edit_stream(const scrg_params *params, const scrg_run *runs, uint64_t n_runs,
                                      uint8_t *stream, uint64_t stream_cap, uint64_t *n_bytes);
 /* scrg_edit_stream_to_runs through the state machine the device decoder runs in every lane (same code, compiled for the
- * host): same arguments, same results; lets a host without a GPU — and the CPU tests — check that form too. */
+ * host): same arguments, same runs; like the device it does not look at the window geometry.  Lets a host without a
+ * GPU — and the CPU tests — check that form too. */
 scrg_status scrg_edit_stream_to_runs_lane(const scrg_params *params, uint64_t read_len,
                                           const uint8_t *stream, uint64_t n_bytes,
                                           scrg_run *runs, uint64_t runs_cap, uint64_t *n_runs);

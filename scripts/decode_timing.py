@@ -101,16 +101,17 @@ def main():
         torch.cuda.synchronize()
         return a.elapsed_time(b) / args.reps
 
+    nocheck = bool(os.environ.get("SCRG_DEC_NOCHECK"))          # (probe builds with parts of the kernel switched off)
     res = {"pairs_per_slot": n, "read_len": L, "slots": S, "stream_bytes_per_pair": sbytes / n, "runs_per_pair": total_runs / n}
     for slots in sorted(set([1, S])):
         m = slots * n
         t_count = timed(lambda: al.decode_edit_stream(m, stream, off_all, len_all, rl, 0, None, None, out_cnt, nbad, **kw))
-        assert torch.equal(out_cnt[:m], cnt_all[:m]) and int(nbad[0].item()) == 0
+        assert nocheck or (torch.equal(out_cnt[:m], cnt_all[:m]) and int(nbad[0].item()) == 0)
         t_dec = timed(lambda: al.decode_edit_stream(m, stream, off_all, len_all, rl, 0, doff_all, dense, cnt_all, nbad, **kw))
         torch.cuda.synchronize()
-        assert int(nbad[0].item()) == 0
+        assert nocheck or int(nbad[0].item()) == 0
         for k in range(slots):
-            assert os.environ.get("SCRG_DEC_NOCHECK") or torch.equal(dense[2 * k * total_runs: 2 * (k + 1) * total_runs], want[: 2 * total_runs]), "slot %d differs" % k
+            assert nocheck or torch.equal(dense[2 * k * total_runs: 2 * (k + 1) * total_runs], want[: 2 * total_runs]), "slot %d differs" % k
         gb = (slots * (sbytes + 2.0 * total_runs)) / 1e9
         res["slots_%d" % slots] = {"count_only_ms": t_count, "decode_ms": t_dec, "decode_ms_per_slot": t_dec / slots,
                                    "decode_M_pairs_per_s": m / t_dec / 1e3, "algorithmic_GB": gb, "GB_per_s": gb / (t_dec * 1e-3)}
@@ -129,8 +130,8 @@ def main():
                 "waves": w, "wave_life_us": v[5] / w / 100.0, "shader_clock_ghz": v[4] / max(1, v[5]) * 0.1,
                 "last_start_us": (v[6] - first) / 100.0, "first_end_us": (((1 << 62) - v[9]) - first) / 100.0,
                 "last_end_us": (v[8] - first) / 100.0,
-                "iterations_per_wave": v[0] / w, "steps_per_wave": 4 * v[0] / w,
-                "cycles_per_step": v[1] / max(1, 4 * v[0]), "flush_cycles_per_iteration": v[2] / max(1, v[0]),
+                "iterations_per_wave": v[0] / w, "steps_per_wave": 16 * v[0] / w,        # (an iteration = the 16 bytes of a block)
+                "cycles_per_step": v[1] / max(1, 16 * v[0]), "flush_cycles_per_iteration": v[2] / max(1, v[0]),
                 "input_cycles_per_iteration": v[3] / max(1, v[0]), "loop_cycles_per_wave": v[4] / w}
     print(json.dumps(res))
 

@@ -18,7 +18,7 @@ SCRG_ERR_NO_DEVICE = 3
 SCRG_ERR_HIP = 4
 SCRG_ERR_OOM = 5
 SCRG_ERR_CIGAR_OVERFLOW = 6
-SCRG_ABI_VERSION = 5          # include/scrooge_amd.h (tests/test_abi.py holds the two equal)
+SCRG_ABI_VERSION = 6          # include/scrooge_amd.h (tests/test_abi.py holds the two equal)
 SEQ_PAD_WORDS = 4
 GROUP = 64                     # rows per group of the lane-interleaved layout
 SEQ_PAD_WORDS_GROUPS = 2 * GROUP + 2
@@ -181,11 +181,11 @@ def load_library(variant=None):
         "scrg_pack_planar_groups": (C.c_int32, [vp, vp, u64, u64, vp, vp]),
         "scrg_compact_runs_packed": (C.c_int32, [vp, vp, u64, vp, vp, vp, vp, vp]),
         "scrg_unpack_runs": (C.c_int32, [vp, u64, vp, vp]),
-        "scrg_encode_edit_stream": (C.c_int32, [vp, u64, vp, vp, vp, vp, u64, vp, vp, vp]),
+        "scrg_encode_edit_stream": (C.c_int32, [vp, C.POINTER(Params), u64, vp, vp, vp, vp, u64, vp, vp, vp]),
         "scrg_decode_edit_stream": (C.c_int32, [vp, vp, u64, vp, u64, vp, vp, vp, u64, vp, vp, u64, vp, vp]),
         "scrg_edit_stream_to_runs": (C.c_int32, [C.POINTER(Params), u64, vp, u64, vp, u64, C.POINTER(u64)]),
         "scrg_edit_stream_to_runs_lane": (C.c_int32, [C.POINTER(Params), u64, vp, u64, vp, u64, C.POINTER(u64)]),
-        "scrg_runs_to_edit_stream": (C.c_int32, [vp, u64, vp, u64, C.POINTER(u64)]),
+        "scrg_runs_to_edit_stream": (C.c_int32, [C.POINTER(Params), vp, u64, vp, u64, C.POINTER(u64)]),
         "scrg_align_device": (C.c_int32, [vp, C.POINTER(Params), u64, vp, vp, vp, vp, vp, vp]),
         "scrg_compact_runs": (C.c_int32, [vp, u64, vp, vp, vp, vp, vp]),
         "scrg_align_device_edits": (C.c_int32, [vp, C.POINTER(Params), u64, vp, vp, vp, vp, vp, vp, vp]),
@@ -223,9 +223,10 @@ EXPORTED_SYMBOLS = [
 
 
 def edit_stream_to_cigar(stream, read_len, W=64, O=33, lane_form=False):
-    """Host-side decoder of ONE pair's edit stream (bytes) -> the CIGAR text the aligner returns for W/O
-    (scrg_edit_stream_to_runs: no GPU involved; lane_form=True: through the state machine the device decoder runs in
-    every lane, scrg_edit_stream_to_runs_lane).  Raises ScroogeError for a malformed stream."""
+    """Host-side decoder of ONE pair's edit stream (bytes, format version 2: window ends on the wire) -> the CIGAR text the
+    aligner returns (scrg_edit_stream_to_runs: no GPU involved; it also holds the window ends to the window loop of W/O.
+    lane_form=True: through the state machine the device decoder runs in every lane, scrg_edit_stream_to_runs_lane, which
+    like the device does not look at the window geometry).  Raises ScroogeError for a malformed stream."""
     lib = load_library()
     fn = lib.scrg_edit_stream_to_runs_lane if lane_form else lib.scrg_edit_stream_to_runs
     p = Params()
@@ -243,10 +244,14 @@ def edit_stream_to_cigar(stream, read_len, W=64, O=33, lane_form=False):
     return "".join("%d%s" % (runs[2 * k], chr(runs[2 * k + 1])) for k in range(n.value))
 
 
-def cigar_to_edit_stream(cigar):
-    """Host-side encoder: CIGAR text (=, X, I, D runs) -> canonical edit stream bytes (scrg_runs_to_edit_stream)."""
+def cigar_to_edit_stream(cigar, W=64, O=33):
+    """Host-side encoder: CIGAR text (=, X, I, D runs) -> canonical edit stream bytes (scrg_runs_to_edit_stream; the window
+    loop of W/O places the window-end bytes)."""
     import re
     lib = load_library()
+    p = Params()
+    lib.scrg_params_default(C.byref(p))
+    p.W, p.O = int(W), int(O)
     items = re.findall(r"(\d+)([=XID])", cigar)
     if "".join(a + b for a, b in items) != cigar:
         raise ValueError("not a CIGAR of =, X, I, D runs: %r" % cigar[:40])
@@ -258,9 +263,9 @@ def cigar_to_edit_stream(cigar):
             c -= 255
     runs = (C.c_uint8 * max(1, len(raw))).from_buffer_copy(bytes(raw) or b"\0")
     n = C.c_uint64(0)
-    lib.scrg_runs_to_edit_stream(runs, len(raw) // 2, None, 0, C.byref(n))
+    lib.scrg_runs_to_edit_stream(C.byref(p), runs, len(raw) // 2, None, 0, C.byref(n))
     out = (C.c_uint8 * max(1, n.value))()
-    st = lib.scrg_runs_to_edit_stream(runs, len(raw) // 2, out, n.value, C.byref(n))
+    st = lib.scrg_runs_to_edit_stream(C.byref(p), runs, len(raw) // 2, out, n.value, C.byref(n))
     if st != SCRG_OK:
         raise ScroogeError(st, "bad runs")
     return bytes(out[: n.value])
@@ -605,16 +610,16 @@ class Aligner:
         """Restores scrg_run pairs (2 bytes each) from packed runs."""
         self._check(self.lib.scrg_unpack_runs(self.h, int(n_runs), _ptr(packed_u8), _ptr(runs_u8)))
 
-    def encode_edit_stream(self, n_pairs, pairs, runs, n_runs, stream_u8, stream_off_i64, stream_len_i32, total_i64):
-        """Runs -> edit stream (one byte per edit, scrooge_amd.h): the transfer format of the RCCL gather.
-        total_i64[0] = bytes of stream_u8 used, total_i64[1] = pairs that did not fit."""
-        self._check(self.lib.scrg_encode_edit_stream(self.h, int(n_pairs), _ptr(pairs), _ptr(runs), _ptr(n_runs),
+    def encode_edit_stream(self, n_pairs, pairs, runs, n_runs, stream_u8, stream_off_i64, stream_len_i32, total_i64, **kw):
+        """Runs -> edit stream (one byte per edit and per window, scrooge_amd.h): the transfer format of the RCCL gather.
+        total_i64[0] = bytes of stream_u8 used, total_i64[1] = pairs that did not fit.  W / O (kw) place the window ends."""
+        self._check(self.lib.scrg_encode_edit_stream(self.h, C.byref(self._params(kw)), int(n_pairs), _ptr(pairs), _ptr(runs), _ptr(n_runs),
                                                      _ptr(stream_u8), int(stream_u8.numel()), _ptr(stream_off_i64),
                                                      _ptr(stream_len_i32), _ptr(total_i64)))
 
     def decode_edit_stream(self, n_pairs, stream_u8, stream_off_i64, stream_len_i32, read_len_i64, read_len_stride,
                            dense_off_i64, dense_u8, n_runs_i32, bad_i32, **kw):
-        """Edit stream -> scrg_run pairs with the window breaks of W/O restored; dense_u8 None: count only."""
+        """Edit stream -> scrg_run pairs, window by window as the stream says; dense_u8 None: count only."""
         self._check(self.lib.scrg_decode_edit_stream(self.h, C.byref(self._params(kw)), int(n_pairs), _ptr(stream_u8),
                                                      int(stream_u8.numel()), _ptr(stream_off_i64), _ptr(stream_len_i32), _ptr(read_len_i64),
                                                      int(read_len_stride),

@@ -1,20 +1,26 @@
-// edit_stream.h — the transfer format for CIGARs ("edit stream") and its window replay.
+// edit_stream.h — the transfer format for CIGARs ("edit stream"), version 2: window ends travel with the edits.
 //
-// A pair's runs (scrg_run, flushed per window, genasm_cpu.cpp:304-305, 400-403) hold two things: the sequence of
-// alignment operations and the places where a window ended.  The second is a pure function of the first: a
-// window's traceback runs `while (j < m && i < W-O && j < W-O)` (genasm_cpu.cpp:307-310) over text index i and
-// pattern index j, m = min(W, read length left) (:415-417), and the next window starts where it stopped.  So only
-// the operations travel, one byte per EDIT:
+// A pair's runs (scrg_run, flushed per window, genasm_cpu.cpp:304-305, 400-403) hold the sequence of alignment
+// operations and the places where a window ended.  One byte per EDIT and one per WINDOW carries both:
 //
-//     byte = op << 6 | len        op 1 'X', 2 'I', 3 'D': `len` matches, then that edit
-//                                 op 0              : `len + 1` matches and no edit (a match stretch > 63)
+//     byte = op << 6 | len        op 1 'X', 2 'I', 3 'D' : `len` matches, then that edit
+//                                 op 0, len <= 62         : `len` matches, then the window ENDS (its run in progress is
+//                                                           flushed, :400-403; the next byte belongs to the next window)
+//                                 op 0, len == 63 (0x3F)  : 63 matches and nothing else (only W-O > 63 has such stretches)
 //
-// in alignment order; the matches after the last edit are implied by the read length.  Canonical form (what
-// the encoders emit): a stretch of P matches before an edit is P >> 6 bytes 0x3F followed by the edit byte
-// with len = P & 63.  A 10 kb read at 10 % error is ~1.0 KB instead of ~2140 runs x 2 bytes.
+// in alignment order; every window of the pair ends with its END byte, the last one too.  Canonical form (what the
+// encoders emit): P matches before an edit or a window end are P / 63 bytes 0x3F followed by the byte with len = P % 63.
+// A 10 kb read at 10 % error and W-O = 31 is ~1.3 KB (968 edits + 323 windows) instead of ~2140 runs x 2 bytes.
 //
-// replay_edit_stream() restores the runs bit for bit, window breaks included (host: scrg_edit_stream_to_runs);
-// decode_lane_step() below is the same replay as a state machine, the form decode_edits_kernel runs per lane.
+// (Version 1, rounds 3-5, sent the edits only — the window ends are a pure function of the operations, :307-310 — and the
+// receiver REPLAYED the window loop: ~90 VALU instructions per byte and per window in every lane of the decoder, 0.31 ms
+// per 100 k pairs.  With the ends on the wire a byte is decoded by itself: what it adds to the run list depends on the
+// byte before it only.)
+//
+// replay_edit_stream() restores the runs bit for bit (host: scrg_edit_stream_to_runs) and, given W-O, also checks that
+// every window ends where the reference's loop ends it; decode_lane_step() is the per-byte state machine
+// decode_edits_kernel runs in every lane; encode_runs() is the way there from a run list (it replays the window loop:
+// the run list does not say where a window ended when the runs on both sides differ).
 #pragma once
 
 #include <stdint.h>
@@ -24,6 +30,8 @@
 namespace scrg {
 
 constexpr uint32_t EDIT_OP_NONE = 0, EDIT_OP_X = 1, EDIT_OP_I = 2, EDIT_OP_D = 3;
+constexpr uint32_t EDIT_MORE = 0x3F;             // 63 matches, nothing else
+constexpr uint32_t EDIT_MORE_MATCHES = 63;
 
 SCRG_HD inline uint32_t edit_code_of_char(uint32_t op)
 {
@@ -33,84 +41,125 @@ SCRG_HD inline uint32_t edit_code_of_char(uint32_t op)
 }
 SCRG_HD inline uint32_t edit_char_of_code(uint32_t code) { return (0x4449583Du >> (8u * code)) & 0xffu; }
 
-// Walks one pair's stream and calls sink(op_char, count) for every run, in order.  Returns the number of runs,
-// or ~0ull if the stream does not describe an alignment of a read of this length (bytes left over, or the
-// read overrun).
+// Walks one pair's stream and calls sink(op_char, count) for every run, in order.  Returns the number of runs, or
+// ~0ull if the stream is not the alignment of a read of this length: it does not end with a window end, the characters
+// it places are not read_len, a run would be longer than 255 — and, with L = W-O > 0, a window does not end exactly
+// where the reference's loop `while (j < m && i < W-O && j < W-O)` (genasm_cpu.cpp:307-310) ends it.  L = 0: the
+// window geometry is not looked at (what the device decoder checks).
 template <typename Sink>
-SCRG_HD inline uint64_t replay_edit_stream(const uint8_t* s, uint64_t n_bytes, uint64_t read_len, uint32_t W, uint32_t O,
-                                           Sink&& sink)
+SCRG_HD inline uint64_t replay_edit_stream(const uint8_t* s, uint64_t n_bytes, uint64_t read_len, uint32_t L, Sink&& sink)
 {
-    const uint64_t limit = W - O;
-    uint64_t ri = 0, k = 0, n_runs = 0;
-    uint64_t pend_m = 0;               // matches still to place
-    uint32_t pend_e = EDIT_OP_NONE;    // the edit after them
-    bool tail = false;                 // stream used up: the rest of the read matches
-    while (ri < read_len) {
-        const uint64_t left = read_len - ri;
-        const uint64_t m = left < W ? left : W;
-        uint64_t i = 0, j = 0;
-        uint32_t cur = 0;
-        uint64_t cur_len = 0;
-        auto push = [&](uint32_t op, uint64_t t) {
-            if (op == cur) {
-                cur_len += t;
-            } else {
-                if (cur_len) { sink(cur, cur_len); n_runs++; }
-                cur = op;
-                cur_len = t;
-            }
-        };
-        while (j < m && i < limit && j < limit) {
-            if (pend_m == 0 && pend_e == EDIT_OP_NONE) {
-                if (k < n_bytes) {
-                    const uint32_t b = s[k++];
-                    pend_e = b >> 6;
-                    pend_m = (b & 63u) + (pend_e == EDIT_OP_NONE ? 1u : 0u);
-                } else {
-                    if (tail) return ~0ull;
-                    tail = true;
-                    pend_m = read_len - ri - j;
-                }
-            }
-            if (pend_m) {
-                uint64_t room = m - j;
-                if (limit - i < room) room = limit - i;
-                if (limit - j < room) room = limit - j;
-                const uint64_t t = pend_m < room ? pend_m : room;
-                push('=', t);
-                i += t; j += t; pend_m -= t;
-            } else {
-                const uint32_t e = pend_e;
-                pend_e = EDIT_OP_NONE;
-                push(edit_char_of_code(e), 1);
-                if (e != EDIT_OP_D) j++;
-                if (e != EDIT_OP_I) i++;
-            }
-        }
+    uint64_t n_runs = 0, placed = 0, pend = 0;
+    uint64_t i = 0, j = 0;             // text / read characters of the window so far
+    uint32_t cur = 0;
+    uint64_t cur_len = 0;
+    bool ended = true;                 // the byte before was a window end (or there was none)
+    bool bad = false;
+    auto flush = [&]() {
         if (cur_len) { sink(cur, cur_len); n_runs++; }
-        ri += j;
-        if (i == 0 && j == 0) return ~0ull;      // cannot happen for W > O; guards the loop
+        cur = 0;
+        cur_len = 0;
+    };
+    auto matches = [&](uint64_t t) {
+        if (!t) return;
+        flush();
+        cur = '=';
+        cur_len = t;
+        if (t > 255) bad = true;
+        if (L && (i + t > L || j + t > L || placed >= read_len)) bad = true;
+        i += t; j += t; placed += t;
+    };
+    for (uint64_t k = 0; k < n_bytes; k++) {
+        const uint32_t b = s[k], op = b >> 6, len = b & 63u;
+        ended = false;
+        if (b == EDIT_MORE) { pend += EDIT_MORE_MATCHES; continue; }
+        matches(pend + len);
+        pend = 0;
+        if (op == EDIT_OP_NONE) {
+            // the window ends: with L given, it must be full (:309-310) or the read used up (:308, j == m)
+            if (L && !(i == L || j == L || placed == read_len)) bad = true;
+            if (i == 0 && j == 0) bad = bad || L != 0;          // (an empty window: padding, never emitted by an encoder)
+            flush();
+            i = j = 0;
+            ended = true;
+            continue;
+        }
+        // an edit: the window must still be open on both sides
+        if (L && (i >= L || j >= L || placed >= read_len)) bad = true;      // (:308: the loop ends with the read, no deletion follows it)
+        const uint32_t c = edit_char_of_code(op);
+        if (c == cur) {
+            if (++cur_len > 255) bad = true;
+        } else {
+            flush();
+            cur = c;
+            cur_len = 1;
+        }
+        if (op != EDIT_OP_D) { j++; placed++; }
+        if (op != EDIT_OP_I) i++;
     }
-    if (k != n_bytes || pend_m != 0 || pend_e != EDIT_OP_NONE) return ~0ull;
+    if (bad || !ended || pend != 0 || placed != read_len) return ~0ull;
     return n_runs;
 }
 
+// The way there: the stream of a run list.  get(r) -> run r as count | op_char << 8; put(byte).  The window loop is
+// replayed (L = W-O: a window ends as soon as it has taken L text or L read characters, or when the runs are used up),
+// so a run may be cut — the align kernels never hand over such a run, a caller's own CIGAR may.  Returns the number of
+// bytes, ~0ull for an operation that is not one of = X I D.
+template <typename Get, typename Put>
+SCRG_HD inline uint64_t encode_runs(uint64_t n_runs, uint32_t L, Get&& get, Put&& put)
+{
+    uint64_t bytes = 0;
+    uint32_t i = 0, j = 0, pend = 0;
+    bool open = false;
+    auto out = [&](uint32_t code) {
+        for (; pend >= EDIT_MORE_MATCHES; pend -= EDIT_MORE_MATCHES) { put((uint8_t)EDIT_MORE); bytes++; }
+        put((uint8_t)(code << 6 | pend));
+        bytes++;
+        pend = 0;
+    };
+    for (uint64_t r = 0; r < n_runs; r++) {
+        const uint32_t run = get(r), op = run >> 8;
+        uint32_t cnt = run & 0xffu;
+        if (op != '=' && op != 'X' && op != 'I' && op != 'D') return ~0ull;
+        while (cnt) {
+            if (op == '=') {
+                uint32_t t = cnt;
+                if (L - i < t) t = L - i;
+                if (L - j < t) t = L - j;
+                pend += t; i += t; j += t; cnt -= t;
+            } else {
+                out(edit_code_of_char(op));
+                if (op != 'D') j++;
+                if (op != 'I') i++;
+                cnt--;
+            }
+            open = true;
+            if (i == L || j == L) {
+                out(EDIT_OP_NONE);
+                i = j = 0;
+                open = false;
+            }
+        }
+    }
+    if (open) out(EDIT_OP_NONE);
+    return bytes;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
-// The same replay as a branch-free STATE MACHINE, one step at a time: what decode_edits_kernel runs in every lane (one
+// The decoder as a branch-free STATE MACHINE, one stream byte per step: what decode_edits_kernel runs in every lane (one
 // pair per lane, 64 pairs per wavefront), compiled for the host too (scrg_edit_stream_to_runs_lane) so that the CPU
-// tests can hold this very code against replay_edit_stream() above on every golden fixture.  Differences in form, not
-// in result:
-//   * one step places the matches of the pending stream byte that fit the window, then its edit if the window is not
-//     full, then closes the window if it is — instead of one event per loop trip;
-//   * bytes with op 0 ("len + 1 matches, no edit") are accumulated into the match count of the next edit byte before
-//     anything is placed, so a match run is never continued by a later step: the only merge left is an edit joining
-//     the run of the same edit directly before it (no match, no window break in between);
+// tests can hold this very code against replay_edit_stream() on every golden fixture.
 //   * runs are handed to `put(k, word)` speculatively: slot k holds run k (count | op << 8) and may be rewritten until
 //     run k + 1 starts (both slots a step might touch are always written: put() must tolerate k = n, a free slot);
 //   * conditions are 0 / ~0 masks and every update is arithmetic on them: the 64 lanes of a wavefront are at 64
-//     different places of their streams, so a branch would be taken by some lane every time — straight-line code issues
-//     at the VALU rate (the first version of this step, with nested conditionals, ran at 24 cycles per instruction).
-// A step consumes at most one stream byte: the caller hands in the byte at `pos` and is told whether it was taken.
+//     different places of their streams, so a branch would be taken by some lane every time;
+//   * a zero byte (a window end after no matches) changes nothing when the byte before it was a window end as well:
+//     the decoder pads a lane's stream with zeros in front and behind.
+//   * the state is kept in the form the GPU wants it: q is the BYTE offset of the next free run slot (2 x the runs started,
+//     plus wherever the caller's ring starts); conditions are 0 / ~0 masks made by arithmetic (a sign bit smeared by
+//     v_ashrrev_i32) and used through v_bitop3_b32 — NOT compare + v_cndmask_b32: a conditional move that reads VCC issues
+//     at a seventh of the rate of the logic and add instructions on gfx950 (profiles/r03_valu_issue_rates.txt: 12.3 against
+//     1.7 cycles at four wavefronts per SIMD).  38 instructions per byte, 32 of them full rate.
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ uint32_t es_neg_mask(uint32_t x)              // ~0 iff (int32)x < 0
 {
@@ -118,117 +167,91 @@ __device__ __forceinline__ uint32_t es_neg_mask(uint32_t x)              // ~0 i
     asm("v_ashrrev_i32 %0, 31, %1" : "=v"(r) : "v"(x));
     return r;
 }
-__device__ __forceinline__ uint32_t es_sel(uint32_t a, uint32_t b, uint32_t m)   // bits of a where m is set, else b
+// truth tables: bit index = a * 4 + b * 2 + c (genasm_device.h: bitop3_table)
+__device__ __forceinline__ uint32_t es_sel(uint32_t a, uint32_t b, uint32_t m) { return __builtin_amdgcn_bitop3_b32(a, b, m, 0xE4); }        // (a & m) | (b & ~m)
+__device__ __forceinline__ uint32_t es_andn(uint32_t a, uint32_t b) { return __builtin_amdgcn_bitop3_b32(a, b, b, 0x30); }                    // a & ~b
+__device__ __forceinline__ uint32_t es_and_or(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0xEA); }      // (a & b) | c
+__device__ __forceinline__ uint32_t es_a_nb_c(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x20); }      // a & ~b & c
+__device__ __forceinline__ uint32_t es_or_xor(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0xF6); }      // a | (b ^ c)
+__device__ __forceinline__ uint32_t es_opw(uint32_t e)
 {
-    return __builtin_amdgcn_bitop3_b32(a, b, m, 0xE4);           // (a & m) | (b & ~m); truth table bit index = a * 4 + b * 2 + m (genasm_device.h: bitop3_table)
+    // byte 1 = byte e of "\0XID", byte 0 = 1: one v_perm_b32 (selector bytes: 0x0C = zero, 4 + e = byte e of the first operand, 0 = byte 0 of the second)
+    return __builtin_amdgcn_perm(0x44495800u, 1u, 0x0C0C0400u + (e << 8));
 }
+__device__ __forceinline__ uint32_t es_bit(uint32_t word, uint32_t at) { return __builtin_amdgcn_ubfe(word, at, 1); }
 #else
-inline uint32_t es_neg_mask(uint32_t x) { return (uint32_t)((int32_t)x >> 31); }
-inline uint32_t es_sel(uint32_t a, uint32_t b, uint32_t m) { return (a & m) | (b & ~m); }
+SCRG_HD inline uint32_t es_neg_mask(uint32_t x) { return (uint32_t)((int32_t)x >> 31); }
+SCRG_HD inline uint32_t es_sel(uint32_t a, uint32_t b, uint32_t m) { return (a & m) | (b & ~m); }
+SCRG_HD inline uint32_t es_andn(uint32_t a, uint32_t b) { return a & ~b; }
+SCRG_HD inline uint32_t es_and_or(uint32_t a, uint32_t b, uint32_t c) { return (a & b) | c; }
+SCRG_HD inline uint32_t es_a_nb_c(uint32_t a, uint32_t b, uint32_t c) { return a & ~b & c; }
+SCRG_HD inline uint32_t es_or_xor(uint32_t a, uint32_t b, uint32_t c) { return a | (b ^ c); }
+SCRG_HD inline uint32_t es_opw(uint32_t e) { return (((0x44495800u >> ((e << 3) & 31u)) & 0xffu) << 8) | 1u; }        // 'X', 'I', 'D' for e = 1, 2, 3
+SCRG_HD inline uint32_t es_bit(uint32_t word, uint32_t at) { return (word >> at) & 1u; }
 #endif
-SCRG_HD inline uint32_t es_nz_mask(uint32_t x) { return es_neg_mask(0u - x); }      // ~0 iff x != 0, for x < 2^31
-SCRG_HD inline uint32_t es_min(uint32_t a, uint32_t b) { return a < b ? a : b; }
+
+constexpr uint32_t DEC_PREV_NONE = 0x40000000u;          // "no edit run to join": no key (below) has this bit (and key ^ prev stays below 2^31: the comparison looks at a sign)
 
 struct DecodeLane {
-    uint32_t L;                 // W - O: a window consumes at most L text and L read characters (genasm_cpu.cpp:309-310)
-    uint32_t pos, end;          // next stream byte, end of the stream
-    uint32_t m, e;              // matches pending, the edit after them (EDIT_OP_NONE: no edit byte has arrived yet)
-    uint32_t tailM;             // mask: stream used up, the rest of the read matches
-    uint32_t R;                 // read characters not placed yet
-    uint32_t ri, rj;            // window: text / read characters it can still take (rj starts at min(R, L))
-    uint32_t cur, prev_e;       // run n - 1 as a word; the edit it consists of if the next edit may join it, else 0
-    uint32_t n;                 // runs started
-    uint32_t aliveM;            // mask: the read is not finished
+    uint32_t pend;              // matches of 0x3F bytes waiting for the byte that closes the stretch
+    uint32_t cur, prev;         // the run started last as a word (count | op << 8); the edit it consists of if the next edit byte may join it, else DEC_PREV_NONE
+    uint32_t q, q0;             // byte offset of the next free run slot; where the pair's first run went
+    uint32_t placed;            // read characters placed so far
+    uint32_t over;              // bits 8.. set: some run was longer than 255
 };
 
-SCRG_HD inline void decode_lane_init(DecodeLane& s, uint32_t W, uint32_t O, uint32_t pos, uint32_t end, uint32_t read_len)
+SCRG_HD inline void decode_lane_init(DecodeLane& s, uint32_t q0)
 {
-    s.L = W - O;
-    s.pos = pos;
-    s.end = end;
-    s.m = s.e = s.tailM = 0;
-    s.R = read_len;
-    s.ri = s.L;
-    s.rj = read_len < s.L ? read_len : s.L;
-    s.cur = s.prev_e = s.n = 0;
-    s.aliveM = read_len != 0 ? ~0u : 0u;
+    s.pend = s.cur = s.placed = s.over = 0;
+    s.prev = DEC_PREV_NONE;
+    s.q = s.q0 = q0;
+}
+SCRG_HD inline uint32_t decode_lane_runs(const DecodeLane& s) { return (s.q - s.q0) >> 1; }
+
+// true when the bytes seen so far are a whole stream for a read of this length (last: the last byte of the stream, 0 for
+// an empty one): the counterpart of replay_edit_stream's last line with L = 0
+SCRG_HD inline bool decode_lane_clean(const DecodeLane& s, uint32_t last, uint32_t read_len)
+{
+    return s.pend == 0 && (last >> 6) == 0 && last != EDIT_MORE && s.placed == read_len && (s.over >> 8) == 0;
 }
 
-// true when the pair is finished: every byte used, nothing pending (the counterpart of replay_edit_stream's last line).
-// (A stream that overruns its read leaves matches or an edit pending, or bytes unused; one that ends early is completed by
-// the tail rule below — the read's remaining characters match — so a lane never waits for input that does not come.)
-SCRG_HD inline bool decode_lane_clean(const DecodeLane& s) { return s.pos == s.end && s.m == 0 && s.e == EDIT_OP_NONE; }
-
-struct DecodeNoTake {
-    SCRG_HD void operator()(uint32_t) const {}
-};
-
-// on_take(takeM) is called as soon as it is known whether the byte at pos is consumed (takeM = ~0) or not (0): the GPU
-// decoder asks for the byte of the NEXT step there, a whole step before it is looked at.
-template <typename Put, typename OnTake = DecodeNoTake>
-SCRG_HD inline uint32_t decode_lane_step(DecodeLane& s, const uint32_t bn0, Put&& put, OnTake&& on_take = OnTake())      // -> 1 if the byte at pos was consumed
+// put(at, word): the run whose slot is at byte offset `at`
+template <typename Put>
+SCRG_HD inline void decode_lane_step(DecodeLane& s, const uint32_t b, Put&& put)
 {
     constexpr uint32_t EQW = (uint32_t)'=' << 8;
-    // ---- the next stream byte, if nothing is pending (an edit byte completes the pending item, an op-0 byte only adds matches)
-    const uint32_t fetchM = ~(es_nz_mask(s.e) | s.tailM) & s.aliveM;
-    const uint32_t hasM = es_neg_mask(s.pos - s.end);                // pos < end
-    const uint32_t takeM = fetchM & hasM;
-    on_take(takeM);
-    const uint32_t e_new = bn0 >> 6;
-    s.m += ((bn0 & 63u) + ((bn0 - 64u) >> 31)) & takeM;              // len, + 1 for op 0
-    s.e = es_sel(e_new, s.e, takeM);
-    s.pos -= takeM;
-    // the stream is used up (once per pair): the matches after the last edit are implied by the read length (op-0 bytes
-    // pending are part of them; more of them than the read has left means the stream overruns the read: m then stays
-    // non-zero to the end and the pair is reported).  From here on m >= R, so the lane ends exactly when its read does.
-    const uint32_t tail_now = fetchM & ~hasM;
-    s.m = es_sel(s.m < s.R ? s.R : s.m, s.m, tail_now);
-    s.tailM |= tail_now;
-    const uint32_t readyM = es_nz_mask(s.e) | s.tailM;
-    // ---- the matches that fit the window: always a new run
-    const uint32_t t = es_min(es_min(s.m, s.ri), s.rj) & readyM;
-    s.m -= t;
-    s.ri -= t;
-    s.rj -= t;
-    s.R -= t;
-    const uint32_t tnzM = es_nz_mask(t);
-    const uint32_t wm = EQW | t;
-    put(s.n, wm);                                                    // (t == 0: a free slot, rewritten by the next run)
-    s.cur = es_sel(wm, s.cur, tnzM);
-    s.n -= tnzM;
-    s.prev_e &= ~tnzM;
-    // ---- the edit, if all its matches are placed and the window is not full
-    const uint32_t doM = es_nz_mask(es_min(es_min(s.e, s.ri), s.rj)) & ~es_nz_mask(s.m);
-    const uint32_t sameM = ~es_nz_mask(s.e ^ s.prev_e);
-    const uint32_t mergeM = doM & sameM, newM = doM & ~sameM;
+    const uint32_t e = b >> 6, len = b & 63u;
+    const uint32_t moreM = es_neg_mask((b ^ EDIT_MORE) - 1u);        // b == 0x3F
+    // ---- the matches in front of the edit / the window end: always a run of their own
+    const uint32_t tot = s.pend + len;
+    s.pend = tot & moreM;
+    const uint32_t t = es_andn(tot, moreM);
+    const uint32_t tnzM = es_neg_mask(0u - t);                       // (t < 2^31)
+    put(s.q, EQW | t);                                               // (t == 0: a free slot, rewritten by the next run)
+    const uint32_t q1 = s.q - tnzM - tnzM;                           // + 2 after a run of matches
+    // ---- the edit: joins the run of the same edit directly before it (no match, no window end in between)
+    const uint32_t key = (t << 2) | e;                               // == prev only for the same edit with no match in front (prev is 1, 2, 3 or DEC_PREV_NONE)
+    const uint32_t sameM = es_neg_mask((key ^ s.prev) - 1u);
+    s.cur = es_sel(s.cur + 1u, es_opw(e), sameM);                    // (no edit: nobody looks at it again — prev becomes none — and it goes to a free slot)
+    put(q1 + sameM + sameM, s.cur);                                  // run n - 1 grows, or run n starts (or a free slot is written)
+    const uint32_t editM = es_neg_mask(63u - b);                     // b >= 64
+    s.q = q1 + es_a_nb_c(editM, sameM, 2u);                          // + 2 after an edit that started a run
+    // a window end (e = 0) closes the run: e - 1 has bit 30 then, and only then; 0x3F leaves things as they are
+    s.prev = es_sel(s.prev, es_and_or(e - 1u, DEC_PREV_NONE, e), moreM);
+    s.placed = s.placed + len + es_bit(6u, e);                       // matches (0x3F: its 63), + the read character of X and I
+    s.over |= t;
+    s.over = es_or_xor(s.over, s.cur - 1u, s.cur);                   // a count of 0 — 256 of the same edit in a row — borrows from the letter
 #if defined(__HIP_DEVICE_COMPILE__)
-    // byte 1 = byte e of "\0XID", byte 0 = 1: one v_perm_b32 (selector bytes: 0x0C = zero, 4 + e = byte e of the first operand, 0 = byte 0 of the second)
-    const uint32_t opw = __builtin_amdgcn_perm(0x44495800u, 1u, 0x0C0C0400u + (s.e << 8));
-#else
-    const uint32_t opw = (((0x44495800u >> ((s.e << 3) & 31u)) & 0xffu) << 8) | 1u;        // 'X', 'I', 'D' for e = 1, 2, 3 (bit field, shift-or)
+    // (the two sums are kept up step by step: left alone, the compiler adds up the sixteen steps of an unrolled block at its
+    // end, in a tree, and keeps every step's len, e and t in registers until then — 150 VGPRs)
+    asm volatile("" : "+v"(s.placed), "+v"(s.over));
 #endif
-    s.cur = es_sel(s.cur + 1u, es_sel(opw, s.cur, newM), mergeM);
-    put(s.n + mergeM, s.cur);                                        // run n - 1 grows, or run n starts (or nothing changes)
-    s.n -= newM;
-    s.prev_e = es_sel(s.e, s.prev_e, doM);
-    s.ri -= s.e & doM & 1u;                                          // X and D consume a text character,
-    const uint32_t jstep = (6u >> s.e) & doM & 1u;                   // X and I a read character
-    s.rj -= jstep;
-    s.R -= jstep;
-    s.e &= ~doM;
-    // ---- the window is full (genasm_cpu.cpp:307-310): the next one starts where it stopped, its run is flushed (:400-403)
-    const uint32_t endM = ~es_nz_mask(es_min(s.ri, s.rj)) & s.aliveM;
-    s.prev_e &= ~endM;
-    s.ri = es_sel(s.L, s.ri, endM);
-    s.rj = es_sel(es_min(s.R, s.L), s.rj, endM);
-    s.aliveM &= es_nz_mask(s.R);                                     // (R = 0 ends the window too: rj <= R)
-    return takeM & 1u;
 }
 
-hipError_t launch_encode_edits(uint64_t n_pairs, const scrg_pair_desc* d_pairs, const uint16_t* d_runs,
+hipError_t launch_encode_edits(uint64_t n_pairs, uint32_t W, uint32_t O, const scrg_pair_desc* d_pairs, const uint16_t* d_runs,
                                const uint32_t* d_n_runs, uint8_t* d_stream, uint64_t stream_cap, uint64_t* d_off,
                                uint32_t* d_len, uint64_t* d_total, hipStream_t s);
-hipError_t launch_decode_edits(uint64_t n_pairs, uint32_t W, uint32_t O, const uint8_t* d_stream, uint64_t stream_bytes,
+hipError_t launch_decode_edits(uint64_t n_pairs, const uint8_t* d_stream, uint64_t stream_bytes,
                                const uint64_t* d_off, const uint32_t* d_len, const uint64_t* d_read_len,
                                uint64_t read_len_stride, const uint64_t* d_dense_off, uint16_t* d_dense, uint64_t dense_cap,
                                uint32_t* d_n_runs, uint32_t* d_bad, void* sort_ws, size_t sort_temp_bytes, hipStream_t s);

@@ -1,26 +1,27 @@
-// edit_stream_decode_kernel.hip — edit streams -> scrg_run pairs with the window breaks restored, on the GPU (gfx950).
+// edit_stream_decode_kernel.hip — edit streams -> scrg_run pairs, on the GPU (gfx950).
 //
-// The receiving side of the multi-GPU gather (rank 0 gets every rank's CIGARs as edit streams) and of a
-// D2H in stream form: what must come out is what the reference delivers, CIGARs with one run list per window
+// The receiving side of the multi-GPU gather (the step's root gets every rank's CIGARs as edit streams) and
+// of a D2H in stream form: what must come out is what the reference delivers, CIGARs with one run list per window
 // (src/genasm_cpu.cpp:304-305, 400-403; host side of src/genasm_gpu.cu:955-968).
 //
-// One pair per LANE, 64 pairs per wavefront, the branch-free state machine of edit_stream.h (decode_lane_step: one
-// stream byte, its matches cut at the window limits, the edit, the window end — O(edits + windows) steps per pair, no
-// per-base work, about 90 VALU instructions per step and no branch: the lanes of a wavefront are at 64 different places
-// of their streams, so every conditional would be taken by some lane every time).  Around it:
-//   in : a lane reads its own stream in aligned 16-byte blocks, all lanes at the same iterations (a block is touched a
-//        whole epoch of 16 steps after its load was issued), into a ring of two blocks per lane in LDS; a step looks at one
-//        byte of it, asked for (ds_read_u8) a whole step earlier — as soon as the step before knows whether it consumes its
-//        own byte.  (Round 3 and the first half of round 4 kept three blocks in registers and fed a 64-bit shift register one
-//        dword at a time through a select tree: 49 of the 383 VALU instructions per four steps.)  A 64-byte sector of the
-//        gathered buffer is asked for four times within ~100 steps and is served by the L2 after the first.
+// One pair per LANE, 64 pairs per wavefront, the branch-free state machine of edit_stream.h (decode_lane_step: one stream
+// byte per step — its matches, its edit or the window end; 30 VALU instructions and no branch: the lanes of a
+// wavefront are at 64 different places of their streams, so every conditional would be taken by some lane every time).
+// (Rounds 3-5 sent the edits without the window ends and replayed the window loop here: 90 instructions per step, a step
+// per byte and per window, the stream bytes through a ring in LDS because a step might not consume its byte.)  Around it:
+//   in : a lane reads its own stream in aligned 16-byte blocks straight into registers, all lanes at the same iterations
+//        (an EPOCH = the 16 steps of one block; the block after it was asked for an epoch earlier); a step takes its byte
+//        from a fixed position of the block.  Bytes of the first and the last block that belong to a neighbour's stream
+//        are replaced by zeros, which the state machine passes over.  A 64-byte sector of the gathered buffer is asked for
+//        four times within ~64 steps and is served by the L2 after the first.
 //   out: runs are staged in a 64-run ring per lane in LDS, indexed by the run's position in the OUTPUT array modulo 64,
 //        and leave as aligned 64-byte pieces (four 16-byte stores per lane); only the first and the last piece of a
 //        pair, which it shares with its neighbours in the dense array, go out run by run.  Pieces are written when ONE
-//        lane's ring is three quarters full, by every lane that has a whole piece: fewer, fuller passes.
-// 10 KB of LDS per wavefront (count-only: 3 KB).  Bound: VALU issue, next to 0.1 GB read + 0.43 GB written per 100 k
+//        lane's ring is half full, by every lane that has a whole piece: fewer, fuller passes.
+// 8 KB of LDS per wavefront (count-only: none).  Bound: VALU issue, next to 0.13 GB read + 0.43 GB written per 100 k
 // 10 kb pairs.
 #include <hipcub/hipcub.hpp>
+#include <stdlib.h>
 
 #include "edit_stream.h"
 
@@ -30,25 +31,21 @@ namespace {
 
 constexpr uint32_t DEC_RING = 64;                     // runs per lane in LDS
 constexpr uint32_t DEC_PIECE = 32;                    // runs per store pass: 64 bytes
-constexpr uint32_t DEC_IN_RING = 32;                   // bytes of the lane's stream in LDS: two aligned 16-byte blocks
-constexpr uint32_t DEC_OUT_STRIDE = 2u * DEC_RING + DEC_IN_RING;      // a lane's row: [64 runs | 32 stream bytes]; 16-byte aligned; 4 wavefronts x 10 KB x 4 workgroups = the CU's 160 KB (they fit: 16 wavefronts per CU)
-constexpr uint32_t DEC_COUNT_STRIDE = DEC_IN_RING + 16u;              // count only: the stream bytes alone
+constexpr uint32_t DEC_OUT_STRIDE = 2u * DEC_RING;            // a lane's row: 64 runs = 128 bytes = one pass over the 32 banks; its 16-byte chunks are swizzled by the lane (below); 4 wavefronts x 8 KB x 4 workgroups: 16 wavefronts per CU
 constexpr uint32_t DEC_WAVE_LDS = 64u * DEC_OUT_STRIDE;
 constexpr uint32_t DEC_FLUSH_AT = 32;                 // final runs in one lane's ring that start a store pass (looked at once per epoch: + <= 32 runs until the next look)
-constexpr int DEC_STEPS_PER_CHECK = 4;                // steps between two looks at the buffers (<= 2 runs and 1 byte per step)
-constexpr uint32_t DEC_EPOCH = 4;                     // iterations between two block moves: 16 steps, at most 16 bytes
+constexpr int DEC_EPOCH_STEPS = 16;                   // steps between two looks at the buffers = bytes of a block (<= 2 runs per step)
 // The output ring is looked at ONCE per epoch.  After a look a lane holds fewer than DEC_FLUSH_AT final runs; until the next
 // look it commits at most 2 runs per step (an '=' run and an edit run: the stream "=X=X=X..." does exactly that), i.e.
-// 2 * DEC_EPOCH * DEC_STEPS_PER_CHECK more, plus the slot the free-running put() writes ahead — all of which must fit the ring, or
-// a put() would overwrite a run that has not been stored yet.  Today that is 32 + 32 = 64 = DEC_RING exactly: no headroom, so the
+// 2 * DEC_EPOCH_STEPS more, plus the slot the free-running put() writes ahead — all of which must fit the ring, or a put()
+// would overwrite a run that has not been stored yet.  Today that is 32 + 32 = 64 = DEC_RING exactly: no headroom, so the
 // constants are tied together here (tests/test_gpu_scale.py::test_decode_two_runs_per_step_fills_the_ring drives the worst case).
-static_assert(DEC_FLUSH_AT + 2u * DEC_EPOCH * (uint32_t)DEC_STEPS_PER_CHECK <= DEC_RING,
+static_assert(DEC_FLUSH_AT + 2u * (uint32_t)DEC_EPOCH_STEPS <= DEC_RING,
               "decoder: runs pending after a look + runs committed until the next look must fit the output ring");
 static_assert(DEC_PIECE <= DEC_FLUSH_AT && DEC_RING % DEC_PIECE == 0u, "decoder: a store pass takes whole pieces of the ring");
 
 struct DecodeArgs {
     uint64_t n_pairs;
-    uint32_t W, O;
     const uint8_t* stream;
     uint64_t stream_bytes;
     const uint64_t* off;
@@ -66,20 +63,33 @@ struct DecodeArgs {
 
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 
+__device__ __forceinline__ uint32_t dec_ffbl(uint32_t v)      // count trailing zeros; 0xffffffff for v == 0
+{
+    uint32_t r;
+    asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+
 }  // namespace
 
 // STORE = false: count only (n_runs[p] is written).  STORE = true: n_runs[p] is the size of pair p's segment of `dense`
 // (nothing is written past it) and a different count is an error.
 template <bool STORE>
-__global__ __launch_bounds__(256) void decode_edits_kernel(DecodeArgs a)
+__global__ __launch_bounds__(256, 4) void decode_edits_kernel(DecodeArgs a)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t lds_all[STORE ? 4 * DEC_WAVE_LDS : 4 * 64 * DEC_COUNT_STRIDE];
+    __shared__ __attribute__((aligned(128))) uint8_t lds_all[STORE ? 4 * DEC_WAVE_LDS : 128];
     const uint32_t lane = threadIdx.x & 63u;
     // On the root of an N > 1 job this kernel shares the SIMDs with the aligner's wavefronts, and its own run time is set by
     // its longest lanes: it goes first.  (The align kernel rotates its priorities 0..3; 3 here is at least a tie.)
     __builtin_amdgcn_s_setprio(3);
-    uint8_t* const out_me = lds_all + (STORE ? (threadIdx.x >> 6) * DEC_WAVE_LDS + lane * DEC_OUT_STRIDE : 0u);
-    uint8_t* const in_me = STORE ? out_me + 2u * DEC_RING : lds_all + threadIdx.x * DEC_COUNT_STRIDE;
+    // LDS, as 32-bit addresses: my row of the wavefront's block (128-byte aligned), and the row with my swizzle in its low bits —
+    // chunk c (16 bytes) of a row sits at chunk c ^ (lane & 7), so that lanes that write the same ring position hit eight
+    // different bank groups; the address of byte offset q of the ring is (q & 126) ^ row_sw, one v_bitop3.
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds_all;      // (an LDS address)
+    const uint32_t wave_row0 = lds0 + (STORE ? (threadIdx.x >> 6) * DEC_WAVE_LDS : 0u);
+    const uint32_t row_sw = (wave_row0 + lane * DEC_OUT_STRIDE) | ((lane & 7u) << 4);
+    typedef __attribute__((address_space(3))) uint16_t lds_u16;
+    typedef __attribute__((address_space(3))) u32x4_t lds_u32x4;
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = tid < a.n_pairs;
     // Longest streams first: the pairs of a wavefront then need about the same number of steps (the wavefront runs until
@@ -110,120 +120,111 @@ __global__ __launch_bounds__(256) void decode_edits_kernel(DecodeArgs a)
             }
         }
     }
-    DecodeLane s;
-    decode_lane_init(s, a.W, a.O, 0u, len, rl);
-    if (!valid) s.aliveM = 0;
 
-    // ---- input: my stream, in aligned 16-byte blocks, through a ring of two blocks in LDS ----
+    // ---- input: my stream, in aligned 16-byte blocks; first / last: my bytes within the blocks, relative to the first block ----
     const uint64_t limit16 = (a.stream_bytes + 15u) & ~15ull;   // whole 16-byte blocks of the buffer may be read
     const uint64_t stream_end = off + len;
-    uint64_t blk = off & ~15ull;                                 // the older block of the ring
+    const uint64_t blk0 = off & ~15ull;
+    const uint32_t first = (uint32_t)off & 15u, last = first + len;
     auto load_block = [&](uint64_t at) -> u32x4_t {
         u32x4_t v = {0u, 0u, 0u, 0u};
         if (at < stream_end && at < limit16) v = *reinterpret_cast<const u32x4_t*>(a.stream + at);
         return v;
     };
-    // The ring holds the block the lane is in and the next one; the one after that is being LOADED into registers.  Blocks
-    // move up (the loaded one into the ring, the next load issued) only every DEC_EPOCH iterations, for all lanes at once: a
-    // block is first touched a whole epoch after its load was issued, so the wait in front of the move costs nothing — issued
-    // lane by lane as blocks run out, some lane's load would be seconds old at every look and the wavefront would wait for
-    // memory each time.  rp = my position relative to the first block; base = the older ring block's.  At a move rp < base + 32
-    // (a lane uses at most 16 bytes per epoch and was inside the older block after the move before), after it rp < base + 16.
-    uint32_t rp = (uint32_t)off & 15u, base = 0;
-    u32x4_t nx2;
-    {
-        const u32x4_t b0 = load_block(blk), b1 = load_block(blk + 16u);
-        nx2 = load_block(blk + 32u);
-        *reinterpret_cast<u32x4_t*>(in_me) = b0;
-        *reinterpret_cast<u32x4_t*>(in_me + 16u) = b1;
-    }
-    auto advance_blocks = [&]() {
-        const bool rot = rp - base >= 16u;
-        if (__any(rot)) {
-            if (rot) {
-                *reinterpret_cast<u32x4_t*>(in_me + (base & 16u)) = nx2;       // over the block that has been used up
-                base += 16u;
-                blk += 16u;
-                nx2 = load_block(blk + 32u);
-            }
-        }
-    };
-    auto byte_at = [&](uint32_t r) -> uint32_t { return in_me[r & (DEC_IN_RING - 1u)]; };
-    uint32_t bn = byte_at(rp);                                   // the byte the next step looks at
+    // the last byte of the stream must be a window end (decode_lane_clean)
+    const uint32_t last_byte = len ? (uint32_t)a.stream[stream_end - 1u] : 0u;
+    u32x4_t cur = load_block(blk0), nxt = load_block(blk0 + 16u);
+    uint32_t at16 = 0;                                           // where `cur` starts, relative to the first block
 
     // ---- output: run k of the pair is element g0 + k of the dense array; ring slot = that index modulo 64 ----
     const uint32_t slot0 = (uint32_t)g0 & (DEC_RING - 1u);
     int32_t kf = -(int32_t)((uint32_t)g0 & (DEC_PIECE - 1u));    // runs below kf are in memory (or not mine); g0 + kf is a multiple of 32
     uint16_t* const dst0 = STORE ? a.dense + g0 : nullptr;
-    auto put = [&](uint32_t k, uint32_t word) {
-        if (STORE) *reinterpret_cast<uint16_t*>(out_me + (((slot0 + k) & (DEC_RING - 1u)) << 1)) = (uint16_t)word;
+    DecodeLane s;
+    decode_lane_init(s, 2u * slot0);                             // (q: byte offset into the ring, taken modulo 128 where it is used)
+    auto put = [&](uint32_t at, uint32_t word) {
+        if (STORE)
+            *reinterpret_cast<lds_u16*>((uintptr_t)__builtin_amdgcn_bitop3_b32(at, 2u * DEC_RING - 2u, row_sw, 0x6A)) = (uint16_t)word;       // (at & 126) ^ row_sw
     };
-    // the 32 runs from kf on: an aligned 64-byte piece of the output; `upto`: runs below this index exist
+    auto n_now = [&]() -> uint32_t { return decode_lane_runs(s); };
+    // chunk c (0..7) of lane l's row, as that lane's swizzle placed it
+    auto chunk_of = [&](uint32_t l, uint32_t c) -> uint32_t { return wave_row0 + l * DEC_OUT_STRIDE + ((c ^ (l & 7u)) << 4); };
+    // the 32 runs from kf on: an aligned 64-byte piece of the output; `upto`: runs below this index exist.  Whole pieces
+    // inside my segment leave as four 16-byte stores; a pair's first and last piece, which it shares with its neighbours
+    // in the dense array, run by run (a loop: twice per pair)
     auto write_piece = [&](uint32_t upto) {
-        const u32x4_t* const src = reinterpret_cast<const u32x4_t*>(out_me + (((slot0 + (uint32_t)kf) & (DEC_RING - 1u)) << 1));
-        u32x4_t w[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) w[k] = src[k];
+        const uint32_t c0 = (((slot0 + (uint32_t)kf) & (DEC_RING - 1u)) << 1) >> 4;              // 0 or 4
         const uint32_t lim = upto < cap ? upto : cap;
         const bool whole = kf >= 0 && (uint32_t)kf + DEC_PIECE <= lim;
         if (whole) {
+            u32x4_t w[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) w[k] = *reinterpret_cast<const lds_u32x4*>((uintptr_t)chunk_of(lane, c0 + (uint32_t)k));
             u32x4_t* const d = reinterpret_cast<u32x4_t*>(dst0 + kf);
 #pragma unroll
             for (int k = 0; k < 4; k++) d[k] = w[k];
         }
         if (__any(!whole)) {
             if (!whole) {
-#pragma unroll
-                for (int k = 0; k < (int)DEC_PIECE; k++) {
-                    const int32_t idx = kf + k;
-                    const uint32_t dw = w[k >> 3][(k >> 1) & 3];
-                    if (idx >= 0 && (uint32_t)idx < lim) dst0[idx] = (uint16_t)(dw >> (16 * (k & 1)));
+#pragma unroll 1
+                for (uint32_t k = 0; k < DEC_PIECE; k++) {
+                    const int32_t idx = kf + (int32_t)k;
+                    if (idx >= 0 && (uint32_t)idx < lim)
+                        dst0[idx] = *reinterpret_cast<const lds_u16*>((uintptr_t)(chunk_of(lane, c0 + (k >> 3)) + 2u * (k & 7u)));
                 }
             }
         }
         kf += (int32_t)DEC_PIECE;
     };
-    // final runs: all but run n - 1, which may still grow while the pair is alive.  A store pass starts when one lane
-    // has DEC_FLUSH_AT of them waiting and takes every lane's whole pieces along.
     // One pass over the lanes' whole pieces, written by the wavefront TOGETHER: four lanes take the four 16-byte quarters of one
     // lane's 64-byte piece (from that lane's ring in LDS; its address and ring position by ds_bpermute), sixteen pieces per store
     // instruction — sixteen fully written 64-byte segments instead of 64 scattered 16-byte ones.  (Every lane storing its own
     // piece, the stores were what eight slots in flight waited for: 2.9 ms with them, 2.1 without.)
-    uint8_t* const wave_out = lds_all + (STORE ? (threadIdx.x >> 6) * DEC_WAVE_LDS : 0u);
     auto write_whole_pieces = [&](bool mine) {            // mine: my piece at kf is whole and inside my segment
-        const uint32_t my_flag = mine ? (((slot0 + (uint32_t)kf) & (DEC_RING - 1u)) << 1) | 1u : 0u;      // ring offset (0 or 64) | valid
+        const uint32_t my_flag = mine ? ((((slot0 + (uint32_t)kf) & (DEC_RING - 1u)) << 1) >> 4) | 8u : 0u;      // first chunk of the piece (0 or 4) | valid
         const uint64_t my_dst = (uint64_t)(uintptr_t)(dst0 + kf);
-        const uint32_t q = lane & 3u;
-        const uint64_t have = __ballot(mine);
+        const uint32_t q4 = lane & 3u;
+        // all twelve cross-lane reads first, then the four LDS reads, then the four stores: two waits for LDS instead of eight
+        uint32_t f[4], lo[4], hi[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            if (((have >> (16 * r)) & 0xffffull) == 0) continue;                 // none of these sixteen lanes has a piece (uniform)
             const int src = 16 * r + (int)(lane >> 2);
-            const uint32_t f = (uint32_t)__shfl((int)my_flag, src, 64);
-            const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)my_dst, src, 64), hi = (uint32_t)__shfl((int)(uint32_t)(my_dst >> 32), src, 64);
-            if (f & 1u) {
-                const u32x4_t v = *reinterpret_cast<const u32x4_t*>(wave_out + (uint32_t)src * DEC_OUT_STRIDE + (f & ~1u) + 16u * q);
-                // (non-temporal: nothing reads the dense array back in this kernel; 2.41 ms where plain stores gave 2.41-2.50)
-                __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t*>((((uint64_t)hi << 32) | lo) + 16u * q));
-            }
+            f[r] = (uint32_t)__shfl((int)my_flag, src, 64);
+            lo[r] = (uint32_t)__shfl((int)(uint32_t)my_dst, src, 64);
+            hi[r] = (uint32_t)__shfl((int)(uint32_t)(my_dst >> 32), src, 64);
+        }
+        u32x4_t v[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const uint32_t src = 16u * (uint32_t)r + (lane >> 2);
+            v[r] = *reinterpret_cast<const lds_u32x4*>((uintptr_t)chunk_of(src, (f[r] & 4u) + q4));       // (a lane without a piece: chunk q4 of its row, not stored)
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            // (non-temporal: nothing reads the dense array back in this kernel; 2.41 ms where plain stores gave 2.41-2.50)
+            if (f[r] & 8u)
+                __builtin_nontemporal_store(v[r], reinterpret_cast<u32x4_t*>((((uint64_t)hi[r] << 32) | lo[r]) + 16u * q4));
         }
     };
+    // final runs: all but run n - 1, which may still grow while the stream has bytes left.  A store pass starts when one lane
+    // has DEC_FLUSH_AT of them waiting and takes every lane's whole pieces along.
     auto flush_pieces = [&]() {
-        const int32_t fin = (int32_t)(s.n - (s.aliveM & 1u));
+        const uint32_t n = n_now();
+        const int32_t fin = (int32_t)(n - (at16 < last ? 1u : 0u));
         if (!__any(fin - kf >= (int32_t)DEC_FLUSH_AT)) return;
         for (;;) {
             const bool need = kf + (int32_t)DEC_PIECE <= fin;
             if (!__any(need)) break;
             if (!a.together) {                            // (uniform) a launch that does not fill the GPU: fewer instructions count for more
-                if (need) write_piece(s.n);
+                if (need) write_piece(n);
                 continue;
             }
-            const uint32_t lim = s.n < cap ? s.n : cap;
+            const uint32_t lim = n < cap ? n : cap;
             const bool whole = need && kf >= 0 && (uint32_t)kf + DEC_PIECE <= lim;
             write_whole_pieces(whole);
             if (whole) kf += (int32_t)DEC_PIECE;
             if (__any(need && !whole)) {                  // a pair's first piece (shared with its neighbour) or one past its segment: run by run
-                if (need && !whole) write_piece(s.n);
+                if (need && !whole) write_piece(n);
             }
         }
     };
@@ -238,38 +239,46 @@ __global__ __launch_bounds__(256) void decode_edits_kernel(DecodeArgs a)
 #define SCRG_DEC_T(var)
 #define SCRG_DEC_ACC(acc, a_, b_)
 #endif
-    for (uint32_t iter = 0;; iter++) {
+    while (__any(at16 < last)) {
         SCRG_DEC_T(t0);
+        // bytes of this block in front of my stream (the first block) or behind it (the last one, and every block after it)
+        // are a neighbour's, or zeros already: they become zeros — a window end after no matches, following a window end
+        const bool edge = at16 < first || (at16 < last && at16 + 16u > last);      // (blocks behind the last one were never loaded: zeros)
+        if (__any(edge)) {
+            if (edge) {
 #pragma unroll
-        for (int it = 0; it < DEC_STEPS_PER_CHECK; it++) {
-            // the blocks move before the LAST step of an epoch asks for its successor's byte: that byte may be the first of
-            // the block that arrives with the move (15 steps since the move before: rp < base + 31, the step's own byte is in
-            // the ring and already on its way)
-            if (it == DEC_STEPS_PER_CHECK - 1 && (iter & (DEC_EPOCH - 1u)) == DEC_EPOCH - 1u) advance_blocks();
-            uint32_t next = 0;
-            (void)decode_lane_step(s, bn, put, [&](uint32_t takeM) {
-                rp -= takeM;
-                next = byte_at(rp);
-                __builtin_amdgcn_sched_barrier(0);       // (left alone, the scheduler sinks the read to its use, a step later: every step then waits for LDS)
-            });
-            bn = next;
+                for (int d = 0; d < 4; d++) {
+                    const int32_t lo = (int32_t)first - (int32_t)(at16 + 4u * (uint32_t)d);       // bytes of this dword below lo are not mine,
+                    const int32_t hi = (int32_t)last - (int32_t)(at16 + 4u * (uint32_t)d);        // nor those from hi on
+                    const uint32_t m_lo = lo <= 0 ? 0xffffffffu : (lo >= 4 ? 0u : 0xffffffffu << (8 * lo));
+                    const uint32_t m_hi = hi >= 4 ? 0xffffffffu : (hi <= 0 ? 0u : 0xffffffffu >> (32 - 8 * hi));
+                    cur[d] &= m_lo & m_hi;
+                }
+            }
         }
         SCRG_DEC_T(t1);
-        // Stores and the waits for stream blocks share one counter (vmcnt), and the wait in front of a block move cannot tell
-        // the stores of a data-dependent pass from the loads it is after: it waits for everything.  So the store passes run in
-        // the FIRST iteration of an epoch and the block move in the LAST (above): a store has three iterations (~2 us) to be
-        // acknowledged before anybody waits (passes in any iteration: the wait of the next move met stores a few hundred
-        // nanoseconds old — 8 slots 2.99 ms with stores against 1.99 ms without; now see DESIGN.md §3.7).
-        if (STORE && (iter & (DEC_EPOCH - 1u)) == 0u) flush_pieces();
+#pragma unroll
+        for (int it = 0; it < DEC_EPOCH_STEPS; it++) {
+            decode_lane_step(s, (cur[it >> 2] >> (8 * (it & 3))) & 0xffu, put);
+            // (left alone, the scheduler interleaves all sixteen steps and keeps their run words and ring addresses alive
+            // side by side: 150 VGPRs, three wavefronts per SIMD instead of four)
+            if ((it & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
         SCRG_DEC_T(t2);
+        // The block after the next is asked for now and looked at an epoch from now.  Stores and loads share one counter
+        // (vmcnt) and the wait in front of the next epoch cannot tell the stores of a data-dependent pass from the load it is
+        // after: the store passes come right behind the load, an epoch (~2 us) before anybody waits.
+        cur = nxt;
+        at16 += 16u;
+        nxt = load_block(blk0 + at16 + 16u);
+        if (STORE) flush_pieces();
         SCRG_DEC_T(t3);
-        SCRG_DEC_ACC(pc_steps, t0, t1);
-        SCRG_DEC_ACC(pc_flush, t1, t2);
-        SCRG_DEC_ACC(pc_input, t2, t3);
+        SCRG_DEC_ACC(pc_input, t0, t1);
+        SCRG_DEC_ACC(pc_steps, t1, t2);
+        SCRG_DEC_ACC(pc_flush, t2, t3);
 #ifdef SCRG_DEC_PROBE
         pc_iter++;
 #endif
-        if (!__any(s.aliveM != 0u)) break;
     }
 #ifdef SCRG_DEC_PROBE
     if (lane == 0) {
@@ -287,17 +296,167 @@ __global__ __launch_bounds__(256) void decode_edits_kernel(DecodeArgs a)
         atomicMax(probe + 9, (unsigned long long)((1ull << 62) - pr_end));            // earliest end
     }
 #endif
-    const bool clean = decode_lane_clean(s) && !bad_input;
+    const bool clean = decode_lane_clean(s, last_byte, rl) && !bad_input;
+    const uint32_t n_end = n_now();
     if (STORE) {
         // what is left in the rings: whole pieces of pairs that ended since the last pass, and every pair's last, partial one
-        while (__any(kf < (int32_t)s.n)) {
-            if (kf < (int32_t)s.n) write_piece(s.n);
+        while (__any(kf < (int32_t)n_end)) {
+            if (kf < (int32_t)n_end) write_piece(n_end);
         }
-        if (valid && (!clean || s.n != cap)) atomicAdd(a.bad, 1u);
+        if (valid && (!clean || n_end != cap)) atomicAdd(a.bad, 1u);
     } else if (valid) {
-        a.n_runs[p] = clean ? s.n : 0xffffffffu;
+        a.n_runs[p] = clean ? n_end : 0xffffffffu;
         if (!clean) atomicAdd(a.bad, 1u);
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same decoding with one pair per WAVEFRONT, 64 stream bytes per iteration, one byte per lane: what a byte adds to the
+// run list depends on the byte before it only (edit_stream.h), so the 64 bytes of a chunk are decoded side by side —
+//   * the byte before comes over DPP (wave_shr:1; lane 0 gets the last byte of the chunk before);
+//   * "this byte starts a run of matches" (Q), "... starts a run of edits" (H = edit and not joined to the byte before, G)
+//     are wavefront masks (v_cmp into an SGPR pair); a run's index in the pair is the number of Q and H bits below the
+//     lane (v_mbcnt) plus the runs of the chunks before (a scalar);
+//   * an edit run's length is the number of G bits directly above its first byte (a 64-bit shift of ~G by the lane and a
+//     count of trailing zeros); the run that reaches the chunk's last byte stays OPEN — its first lane does not store, its
+//     length, index and letter go on as scalars until a later chunk's first byte does not join it;
+//   * bytes 0x3F (63 matches and nothing else: only W-O > 63 has them) take a side path that counts the 0x3F lanes
+//     directly below each lane.
+// Loads are the 64 contiguous bytes of the chunk, stores the chunk's ~106 runs as two 2-byte stores per lane to one
+// contiguous range: no LDS, no sorting by length, nothing for a wavefront to wait for but its own next chunk (asked for a
+// chunk ahead).  Streams shorter than a few chunks leave most lanes idle: launch_decode_edits takes the lane-per-pair
+// kernel above for those.
+template <bool STORE>
+__global__ __launch_bounds__(256) void decode_edits_wave_kernel(DecodeArgs a, uint32_t n_waves)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));
+    // bits below my lane, as two dwords (for the side path)
+    const uint32_t below_lo = lane < 32u ? (1u << lane) - 1u : 0xffffffffu, below_hi = lane < 32u ? 0u : (1u << (lane - 32u)) - 1u;
+    uint32_t n_bad = 0;                                          // (uniform)
+    for (uint64_t p = wave0; p < a.n_pairs; p += n_waves) {
+        // ---- the pair: everything here is the same in all lanes (scalar loads)
+        auto uni32 = [](uint32_t v) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+        auto uni64 = [&](uint64_t v) -> uint64_t { return ((uint64_t)uni32((uint32_t)(v >> 32)) << 32) | uni32((uint32_t)v); };
+        uint64_t off = uni64(a.off[p]);
+        uint32_t len = uni32(a.len[p]);
+        const uint64_t rl64 = uni64(a.read_len[p * a.read_len_stride]);
+        // a stream that is not inside the buffer (offsets and lengths may come off a wire) or a pair marked "did not
+        // fit" by the encoder is reported, never read
+        bool bad = off == ~0ull || off > a.stream_bytes || len > a.stream_bytes - off || len > 0x3fffffffu || rl64 > 0x7fffffffull;
+        const uint32_t rl = bad ? 0u : (uint32_t)rl64;
+        if (bad) { off = 0; len = 0; }
+        uint64_t g0 = 0;
+        uint32_t cap = 0;
+        if (STORE) {
+            g0 = uni64(a.dense_off[p]);
+            cap = uni32(a.n_runs[p]);
+            // run counts and offsets may come off a wire too: a segment that is not inside the dense array is never written
+            if (g0 > a.dense_cap || cap > a.dense_cap - g0) { bad = true; g0 = 0; cap = 0; }
+        }
+        const uint8_t* const src = a.stream + off;
+        uint16_t* const dst = STORE ? a.dense + g0 : nullptr;
+        uint32_t base = 0;                   // runs of the chunks before
+        uint32_t carry_b = 0;                // the last byte of the chunk before (0: a window end)
+        uint32_t carry_more = 0;             // matches of the 0x3F bytes the chunk before ended with
+        uint32_t open_len = 0, open_idx = 0, open_op = 0;       // the edit run that reached the end of the chunk before
+        uint32_t placed = 0, over = 0;       // (per lane) read characters placed; bits 8..: a match run longer than 255
+        // (every lane loads, a lane behind the stream its last byte, and the byte is replaced by 0 — a window end after no matches,
+        // which adds nothing — where it is used: a load under a condition is waited for on the spot)
+        uint32_t b_next = len ? (uint32_t)src[lane < len ? lane : len - 1u] : 0u;
+        for (uint32_t c0 = 0; c0 < len; c0 += 64u) {
+            const uint32_t b = b_next & es_neg_mask(c0 + lane - len);               // (a mask by arithmetic: v_cndmask on VCC issues at a seventh of the rate, edit_stream.h)
+            const uint32_t k_next = c0 + 64u + lane;
+            b_next = (uint32_t)src[k_next < len ? k_next : len - 1u];
+            const uint32_t pb = (uint32_t)__builtin_amdgcn_update_dpp((int)carry_b, (int)b, 0x138, 0xf, 0xf, false);       // wave_shr:1
+            const uint32_t e = b >> 6, ln = b & 63u;
+            const uint64_t M = __ballot(b == EDIT_MORE);
+            const uint64_t E = __ballot(b > 63u);
+            const uint64_t G = __ballot(b == (pb & 0xC0u)) & E;         // the same edit as the byte before, and no match in between
+            uint32_t t = ln;
+            if (M != 0 || carry_more != 0) {
+                // the 0x3F lanes directly below me: from the highest lane below that is not one (none: all of them, and the chunk before's)
+                const uint32_t z_lo = ~(uint32_t)M & below_lo, z_hi = ~(uint32_t)(M >> 32) & below_hi;
+                const bool none = (z_lo | z_hi) == 0u;
+                const uint32_t top = z_hi ? 63u - (uint32_t)__builtin_clz(z_hi) : 31u - (uint32_t)__builtin_clz(z_lo | 1u);
+                const uint32_t cnt = none ? lane : lane - 1u - top;
+                t = ln + EDIT_MORE_MATCHES * cnt + (none ? carry_more : 0u);
+                if (b == EDIT_MORE || c0 + lane >= len) t = 0;                        // (nor do the bytes behind the stream close a stretch)
+                const uint64_t nM = ~M;
+                const uint32_t trailing = nM ? (uint32_t)__builtin_clzll(nM) : 64u;  // 0x3F lanes the chunk ends with
+                carry_more = EDIT_MORE_MATCHES * trailing + (trailing == 64u ? carry_more : 0u);
+                over |= t;
+            }
+            const uint64_t Q = __ballot(t != 0u);
+            const uint64_t H = E & ~G;
+            // ---- the open run of the chunk before: joined by my first lanes, written when it ends
+            const uint64_t nG = ~G;
+            const uint32_t lead = nG ? (uint32_t)__builtin_ctzll(nG) : 64u;           // lanes 0 .. lead-1 join the run before them
+            if (open_len != 0u) {
+                open_len += lead;
+                if (lead < 64u) {
+                    if (open_len > 255u) bad = true;
+                    if (STORE && lane == 0u && open_idx < cap) dst[open_idx] = (uint16_t)(open_op | open_len);
+                    open_len = 0;
+                }
+            }
+            // ---- run indices: the Q and H bits below my lane, on top of the runs of the chunks before
+            const uint32_t eq_idx = __builtin_amdgcn_mbcnt_hi((uint32_t)(H >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)H,
+                                    __builtin_amdgcn_mbcnt_hi((uint32_t)(Q >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)Q, base))));
+            const uint32_t head_idx = eq_idx + (t != 0u ? 1u : 0u);
+            // ---- the edit runs that start here: their lengths
+            const uint64_t y = (nG >> lane) >> 1;                                    // bit j: lane + 1 + j does not join
+            const uint32_t y_lo = (uint32_t)y, y_hi = (uint32_t)(y >> 32);
+            const uint32_t f_lo = dec_ffbl(y_lo), f_hi = min(dec_ffbl(y_hi), 32u) + 32u;          // (v_ffbl_b32: 0xffffffff for 0)
+            const uint32_t above = min(min(f_lo, f_hi), 63u - lane);                 // joined lanes directly above me
+            const uint32_t opw = (((0x44495800u >> ((e << 3) & 31u)) & 0xffu) << 8);
+            // the run that reaches the chunk's last lane stays open: the lanes the chunk ends with that join (tail), and the
+            // edit lane below them (all scalar; a chunk that joined the run before it as a whole has no such lane)
+            const uint32_t tail = nG ? (uint32_t)__builtin_clzll(nG) : 64u;
+            const uint32_t hl = 63u - (tail & 63u);
+            const bool opens = tail < 64u && ((E >> hl) & 1ull);
+            if (opens) {
+                open_len = tail + 1u;
+                open_idx = (uint32_t)__builtin_amdgcn_readlane((int)head_idx, (int)hl);
+                open_op = (uint32_t)__builtin_amdgcn_readlane((int)opw, (int)hl);
+            }
+            if (STORE) {
+                const bool is_head = (H >> lane) & 1ull;
+                const bool stays_open = opens && lane == hl;
+                uint8_t* const d8 = reinterpret_cast<uint8_t*>(dst);
+                if (base + 128u <= cap) {                                             // (uniform: a chunk starts at most 128 runs)
+                    if (t != 0u) *reinterpret_cast<uint16_t*>(d8 + (eq_idx << 1)) = (uint16_t)(((uint32_t)'=' << 8) | t);
+                    if (is_head && !stays_open) *reinterpret_cast<uint16_t*>(d8 + (head_idx << 1)) = (uint16_t)(opw | (above + 1u));
+                } else {
+                    if (t != 0u && eq_idx < cap) *reinterpret_cast<uint16_t*>(d8 + (eq_idx << 1)) = (uint16_t)(((uint32_t)'=' << 8) | t);
+                    if (is_head && !stays_open && head_idx < cap) *reinterpret_cast<uint16_t*>(d8 + (head_idx << 1)) = (uint16_t)(opw | (above + 1u));
+                }
+            }
+            placed += ln + ((6u >> e) & 1u);
+            base += (uint32_t)__popcll(Q) + (uint32_t)__popcll(H);
+            carry_b = (uint32_t)__builtin_amdgcn_readlane((int)b, 63);
+        }
+        // ---- the end of the pair
+        if (open_len != 0u) {              // (a stream that ends in an edit: reported below, its run written all the same)
+            if (STORE && lane == 0u && open_idx < cap) dst[open_idx] = (uint16_t)(open_op | (open_len & 0xffu));
+        }
+        // read characters placed, over all lanes and chunks
+        uint32_t tot = placed, ov = over;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            tot += (uint32_t)__shfl_xor((int)tot, d, 64);
+            ov |= (uint32_t)__shfl_xor((int)ov, d, 64);
+        }
+        const uint32_t last_byte = len ? (uint32_t)src[len - 1u] : 0u;
+        const bool clean = !bad && carry_more == 0u && (last_byte >> 6) == 0u && last_byte != EDIT_MORE && tot == rl && (ov >> 8) == 0u;
+        if (STORE) {
+            if (!clean || base != cap) n_bad++;
+        } else {
+            if (lane == 0u) a.n_runs[p] = clean ? base : 0xffffffffu;
+            if (!clean) n_bad++;
+        }
+    }
+    if (n_bad && lane == 0u) atomicAdd(a.bad, n_bad);
 }
 
 __global__ void iota_kernel(uint32_t* v, uint32_t n)
@@ -319,13 +478,32 @@ size_t decode_sort_temp_bytes(uint64_t n_pairs)
 
 // sort_ws: null (pairs are taken in index order) or a work area of 3 * n_pairs uint32 followed by decode_sort_temp_bytes()
 // bytes (256-byte aligned): the pairs are then taken longest stream first.
-hipError_t launch_decode_edits(uint64_t n_pairs, uint32_t W, uint32_t O, const uint8_t* d_stream, uint64_t stream_bytes,
+hipError_t launch_decode_edits(uint64_t n_pairs, const uint8_t* d_stream, uint64_t stream_bytes,
                                const uint64_t* d_off, const uint32_t* d_len, const uint64_t* d_read_len,
                                uint64_t read_len_stride, const uint64_t* d_dense_off, uint16_t* d_dense, uint64_t dense_cap,
                                uint32_t* d_n_runs, uint32_t* d_bad, void* sort_ws, size_t sort_temp_bytes, hipStream_t s)
 {
     if (n_pairs == 0) return hipSuccess;
+    // Stored together, the pieces cost a third of the write time when launches fill the GPU (8 slots of 100 k pairs: 2.83 -> 2.47 ms,
+    // 4 slots 1.64 -> 1.43) and a few more instructions per pass, which is what a launch of <= 2 wavefronts per SIMD feels
+    // (1 slot: 1.06 -> 1.15 ms): by the size of the launch (200 000 pairs = three wavefronts on every SIMD of an MI355X).
+    const uint32_t together = n_pairs > 200000 ? 1u : 0u;
     const uint32_t* order = nullptr;
+    DecodeArgs a{n_pairs, d_stream, stream_bytes, d_off, d_len, d_read_len, read_len_stride, d_dense_off, d_dense, dense_cap, d_n_runs, d_bad, order, together};
+    // Which kernel (scripts/decode_timing.py, 10 kb reads: one slot of 100 k pairs 0.41 ms by wavefront against 0.82 ms by lane
+    // — 1 563 lane-per-pair wavefronts leave the GPU half empty —, eight slots 2.78 against 2.40 ms): one pair per wavefront for
+    // streams of a few chunks and more (>= 192 bytes on average) in launches that lane-per-pair wavefronts would not fill
+    // four deep.  SCRG_DEC_KERNEL=lane|wave overrides (the tests run both on the same inputs).
+    bool by_wave = stream_bytes / n_pairs >= 192u;
+    if (const char* e = getenv("SCRG_DEC_KERNEL")) by_wave = e[0] == 'w';
+    if (by_wave) {
+        const uint64_t want = n_pairs < 8192u ? (n_pairs + 3u) & ~3ull : 8192u;          // 8 wavefronts on every SIMD of an MI355X
+        const uint32_t n_waves = (uint32_t)want;
+        const dim3 grid(n_waves / 4u), block(256);
+        if (d_dense) hipLaunchKernelGGL(decode_edits_wave_kernel<true>, grid, block, 0, s, a, n_waves);
+        else hipLaunchKernelGGL(decode_edits_wave_kernel<false>, grid, block, 0, s, a, n_waves);
+        return hipGetLastError();
+    }
     if (sort_ws && n_pairs < 0x7fffffffull) {
         uint32_t* const idx = static_cast<uint32_t*>(sort_ws);
         uint32_t* const keys_out = idx + n_pairs;
@@ -338,11 +516,7 @@ hipError_t launch_decode_edits(uint64_t n_pairs, uint32_t W, uint32_t O, const u
         if (e != hipSuccess) return e;
         order = idx_out;
     }
-    // Stored together, the pieces cost a third of the write time when launches fill the GPU (8 slots of 100 k pairs: 2.83 -> 2.47 ms,
-    // 4 slots 1.64 -> 1.43) and a few more instructions per pass, which is what a launch of <= 2 wavefronts per SIMD feels
-    // (1 slot: 1.06 -> 1.15 ms): by the size of the launch (200 000 pairs = three wavefronts on every SIMD of an MI355X).
-    const uint32_t together = n_pairs > 200000 ? 1u : 0u;
-    DecodeArgs a{n_pairs, W, O, d_stream, stream_bytes, d_off, d_len, d_read_len, read_len_stride, d_dense_off, d_dense, dense_cap, d_n_runs, d_bad, order, together};
+    a.order = order;
     const dim3 grid((unsigned)((n_pairs + 255) / 256)), block(256);
     if (d_dense) hipLaunchKernelGGL(decode_edits_kernel<true>, grid, block, 0, s, a);
     else hipLaunchKernelGGL(decode_edits_kernel<false>, grid, block, 0, s, a);

@@ -469,12 +469,12 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
             // that is done computes garbage from column "31", which no mask ever has.)  The length byte of the
             // next insertion run is read one iteration ahead.
             if constexpr (EDITS) {
-                // Pass 2, edit stream.  Only columns with an edit are visited: an insertion run (before the column's
-                // step), then a deletion or substitution.  mbase + c = matches pending when column c is reached;
+                // Pass 2, edit stream (edit_stream.h, version 2).  Only columns with an edit are visited: an insertion run
+                // (before the column's step), then a deletion or substitution.  mbase + c = matches pending when column c
+                // is reached (< W-O <= 31: the window's own matches only, every window closes with its END byte below);
                 // an insertion at c leaves none at c (mbase = -c), a deletion/substitution none at c + 1.  Every byte
-                // goes to the slot after the last committed one; only committing moves on.  Three insertions and 127
-                // pending matches are handled in line, longer runs / stretches on a side path (well under one per cent
-                // of the iterations at 10 % error).
+                // goes to the slot after the last committed one; only committing moves on.  Three insertions are handled
+                // in line, longer runs on a side path (well under one per cent of the iterations at 10 % error).
                 uint32_t E = SCRG_ABL(a, 4) ? 0u : (D | X | Im);
                 // (the runs this window has in the other output format: one per insertion run, one per D / X / = run start)
                 nr += (int32_t)(__builtin_popcount(B) + __builtin_popcount(Im));
@@ -490,9 +490,7 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
                     E = bitop3<TT_ANDN>(E, bit, bit);
                     const uint32_t nx = ffbh_u32(E);
                     const uint32_t step = 0xC0u - 0x80u * xB;                  // 'D' 3 << 6, 'X' 1 << 6
-                    const uint32_t live = iB | dx;                             // (0 only for a lane that is done)
-                    uint32_t k64 = (t >> 6) * live;                            // bytes 0x3F owed before the edit byte
-                    const bool side = max(ni * iB, 2u * k64) > 3u;             // more than 3 insertions or 127 matches pending
+                    const bool side = ni * iB > 3u;                            // more than 3 insertions
                     if (__any(side)) {
                         if (side) {
                             auto emit = [&](uint32_t b) {
@@ -500,36 +498,28 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
                                 pos++;
                                 if (pos - flushed >= 32u) write_piece();
                             };
-                            uint32_t tt = t;
-                            if (iB) {
-                                for (uint32_t q = tt >> 6; q; q--) emit(0x3Fu);
-                                emit(0x80u | (tt & 63u));
-                                for (uint32_t q = 1; q < ni; q++) emit(0x80u);
-                                tt = 0;
-                                mbase = 0u - c;
-                            }
+                            emit(0x80u | t);
+                            for (uint32_t q = 1; q < ni; q++) emit(0x80u);
+                            mbase = 0u - c;
                             if (dx) {
-                                for (uint32_t q = tt >> 6; q; q--) emit(0x3Fu);
-                                emit(step | (tt & 63u));
+                                emit(step);
                                 mbase = ~c;
                             }
-                            iB = dx = k64 = 0;
+                            iB = dx = 0;
                         }
                     }
-                    // in line: one byte 0x3F (64..127 matches pending), up to three insertions, the step
-                    put(pos, 0x3Fu);
-                    pos += k64;
-                    put(pos, 0x80u | (t & 63u));
+                    // in line: up to three insertions, the step
+                    put(pos, 0x80u | t);
                     put(pos + 1u, 0x80u);
                     put(pos + 2u, 0x80u);
-                    pos += iB ? (ni > 3u ? 3u : ni) : 0u;
-                    put(pos, step | ((iB ? 0u : t) & 63u));
+                    pos += iB ? ni : 0u;
+                    put(pos, step | (iB ? 0u : t));
                     pos += dx;
                     mbase = dx ? ~c : (iB ? 0u - c : mbase);
                     ni = lds8[scr_b + nx];
                     c = nx;
                 };
-                // a trip commits at most 2 x 5 bytes and writes 4 more ahead: 31 left by the regular look + two trips fit the
+                // a trip commits at most 2 x 4 bytes and writes 3 more ahead: 31 left by the regular look + two trips fit the
                 // 64-byte ring; from the third trip on a lane with 50 or more bytes pending makes the wavefront look
                 uint32_t trips = 0;
                 while (__any(E != 0u)) {
@@ -538,7 +528,10 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
                     event();
                     trips++;
                 }
-                mbase += ti;                                   // the next window starts at its column 0
+                // the window ends: the matches since its last edit, and the mark (a lane without a pair writes a byte nobody commits)
+                put(pos, mbase + ti);
+                pos += has_pair ? 1u : 0u;
+                mbase = 0;
             } else {
             // Two events per trip (c0 / c1: the columns of the next two events; E holds c1 and what comes after it).  The length
             // bytes of both events' insertion runs are asked for at the TOP of the trip and used at its very end — the two ring

@@ -293,21 +293,29 @@ __global__ __launch_bounds__(64) void genasm_lane_mw_kernel(AlignArgs a)
                         uint32_t t = mbase + c;
                         if (row_test<RW>(Im, c)) {
                             const uint32_t ni = lds8[len_b + c];
-                            for (uint32_t q = t >> 6; q; q--) emit(0x3Fu);
-                            emit(0x80u | (t & 63u));
+                            for (; t >= 63u; t -= 63u) emit(0x3Fu);          // (edit_stream.h: 63 matches and nothing else)
+                            emit(0x80u | t);
                             for (uint32_t q = 1; q < ni; q++) emit(0x80u);
                             t = 0;
                             mbase = 0u - c;
                         }
                         const bool isD = row_test<RW>(D, c), isX = row_test<RW>(X, c);
                         if (isD || isX) {
-                            for (uint32_t q = t >> 6; q; q--) emit(0x3Fu);
-                            emit((isX ? 0x40u : 0xC0u) | (t & 63u));
+                            for (; t >= 63u; t -= 63u) emit(0x3Fu);
+                            emit((isX ? 0x40u : 0xC0u) | t);
                             mbase = ~c;
                         }
                     }
                 }
-                mbase += ti;
+                // the window ends: the matches since its last edit, then the mark (every window of a pair, the last one too)
+                if (__any(has_pair)) {
+                    if (has_pair) {
+                        uint32_t t = mbase + ti;
+                        for (; t >= 63u; t -= 63u) emit(0x3Fu);
+                        emit(t);
+                    }
+                }
+                mbase = 0;
             } else
             while (__any(row_any<RW>(E))) {
                 if (row_any<RW>(E)) {

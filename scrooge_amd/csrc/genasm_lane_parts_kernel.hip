@@ -597,13 +597,14 @@ __global__ __launch_bounds__(256, 2) void genasm_lane_parts_kernel(AlignArgs a)
                     const uint32_t lv = ~c >> 31;
                     uint32_t iB = __builtin_amdgcn_ubfe(Im, sh, lv), dx = __builtin_amdgcn_ubfe(DX, sh, lv);
                     const uint32_t xB = __builtin_amdgcn_ubfe(X, sh, lv);
-                    const uint32_t t = mbase + c;
+                    const uint32_t t = mbase + c;                             // matches pending: the window's own, <= W-O - 1 <= 126
                     E = bitop3<PT_ANDN>(E, bit, bit);
                     const uint32_t nx = pt_ffbh(E);
                     const uint32_t step = 0xC0u - 0x80u * xB;                  // 'D' 3 << 6, 'X' 1 << 6
                     const uint32_t live = iB | dx;                             // (0 only for a lane that is done)
-                    uint32_t k64 = (t >> 6) * live;                            // bytes 0x3F owed before the edit byte
-                    const bool side = max(ni * iB, 2u * k64) > 3u;             // more than 3 insertions or 127 matches pending
+                    uint32_t k63 = ((t >= 63u ? 1u : 0u) + (t >= 126u ? 1u : 0u)) * live;      // bytes 0x3F (63 matches each) owed before the edit byte
+                    const uint32_t r = (t - 63u * k63) & 63u;
+                    const bool side = max(ni * iB, 2u * k63) > 3u;             // more than 3 insertions or 125 matches pending
                     if (__any(side)) {
                         if (side) {
                             auto emit = [&](uint32_t b) {
@@ -611,30 +612,27 @@ __global__ __launch_bounds__(256, 2) void genasm_lane_parts_kernel(AlignArgs a)
                                 pos++;
                                 if (pos - flushed >= 32u) write_piece();
                             };
-                            uint32_t tt = t;
+                            for (uint32_t q = k63; q; q--) emit(0x3Fu);
                             if (iB) {
-                                for (uint32_t q = tt >> 6; q; q--) emit(0x3Fu);
-                                emit(0x80u | (tt & 63u));
+                                emit(0x80u | r);
                                 for (uint32_t q = 1; q < ni; q++) emit(0x80u);
-                                tt = 0;
                                 mbase = 0u - c;
                             }
                             if (dx) {
-                                for (uint32_t q = tt >> 6; q; q--) emit(0x3Fu);
-                                emit(step | (tt & 63u));
+                                emit(step | (iB ? 0u : r));
                                 mbase = ~c;
                             }
-                            iB = dx = k64 = 0;
+                            iB = dx = k63 = 0;
                         }
                     }
-                    // in line: one byte 0x3F (64..127 matches pending), up to three insertions, the step
+                    // in line: one byte 0x3F (63..125 matches pending), up to three insertions, the step
                     put(pos, 0x3Fu);
-                    pos += k64;
-                    put(pos, 0x80u | (t & 63u));
+                    pos += k63;
+                    put(pos, 0x80u | r);
                     put(pos + 1u, 0x80u);
                     put(pos + 2u, 0x80u);
-                    pos += iB ? (ni > 3u ? 3u : ni) : 0u;
-                    put(pos, step | ((iB ? 0u : t) & 63u));
+                    pos += iB ? ni : 0u;
+                    put(pos, step | (iB ? 0u : r));
                     pos += dx;
                     mbase = dx ? ~c : (iB ? 0u - c : mbase);
                     ni = lds8[scr_b + (nx & 15u)];
@@ -692,6 +690,17 @@ __global__ __launch_bounds__(256, 2) void genasm_lane_parts_kernel(AlignArgs a)
             }
         }
         read_idx += j;
+        if constexpr (EDITS) {
+            // the window ends (edit_stream.h): the matches since its last edit (<= W-O <= 127: up to two bytes 0x3F of 63 each), then the mark
+            const uint32_t k63 = has_pair ? (mbase >= 63u ? 1u : 0u) + (mbase >= 126u ? 1u : 0u) : 0u;
+            lds8[ring_b + (pos & 63u)] = (uint8_t)0x3Fu;
+            lds8[ring_b + ((pos + 1u) & 63u)] = (uint8_t)0x3Fu;
+            pos += k63;
+            lds8[ring_b + (pos & 63u)] = (uint8_t)(mbase - 63u * k63);
+            pos += has_pair ? 1u : 0u;
+            mbase = 0;
+            flush_pieces();
+        }
         st_rounds++;
     }
     if (SCRG_TIMING(a) && lane == 0) atomicAdd((unsigned long long*)&a.stats[0], (unsigned long long)st_rounds);

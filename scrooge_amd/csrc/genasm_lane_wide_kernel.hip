@@ -483,11 +483,11 @@ __global__ __launch_bounds__(256, WD_BLOCKS_PER_CU) void genasm_lane_wide_kernel
             if constexpr (EDITS) {
                 // pass 2, edit stream (genasm_lane_kernel<true>): the columns that hold an edit
                 // Only columns with an edit are visited: an insertion run (before the column's step), then a deletion or
-                // substitution.  mbase + c = matches pending when column c is reached; an insertion at c leaves none at c
-                // (mbase = -c), a deletion/substitution none at c + 1.  Every byte goes to the slot after the last
-                // committed one; only committing moves on.  Three insertions and 127 pending matches are handled in line,
-                // longer runs / stretches on a side path.  (A lane that has no event left has c = 0xffffffff and takes its
-                // mask bits with a field width of 0: a half has a column 31.)
+                // substitution.  mbase + c = matches pending when column c is reached (the window's own: < W-O <= 63, its
+                // END byte follows the second half below); an insertion at c leaves none at c (mbase = -c), a
+                // deletion/substitution none at c + 1.  Every byte goes to the slot after the last committed one; only
+                // committing moves on.  Three insertions are handled in line, longer runs on a side path.  (A lane that has no
+                // event left has c = 0xffffffff and takes its mask bits with a field width of 0: a half has a column 31.)
                 uint32_t E = D | X | Im;
                 nr += (int32_t)(__builtin_popcount(B) + __builtin_popcount(Im));
                 uint32_t c = wd_ffbh(E);
@@ -500,13 +500,11 @@ __global__ __launch_bounds__(256, WD_BLOCKS_PER_CU) void genasm_lane_wide_kernel
                     const uint32_t lv = ~c >> 31;
                     uint32_t iB = __builtin_amdgcn_ubfe(Im, sh, lv), dx = __builtin_amdgcn_ubfe(DX, sh, lv);
                     const uint32_t xB = __builtin_amdgcn_ubfe(X, sh, lv);
-                    const uint32_t t = mbase + c;
+                    const uint32_t t = (mbase + c) & 63u;                       // (< 63 wherever a byte is committed)
                     E = bitop3<WT_ANDN>(E, bit, bit);
                     const uint32_t nx = wd_ffbh(E);
                     const uint32_t step = 0xC0u - 0x80u * xB;                  // 'D' 3 << 6, 'X' 1 << 6
-                    const uint32_t live = iB | dx;                             // (0 only for a lane that is done)
-                    uint32_t k64 = (t >> 6) * live;                            // bytes 0x3F owed before the edit byte
-                    const bool side = max(ni * iB, 2u * k64) > 3u;             // more than 3 insertions or 127 matches pending
+                    const bool side = ni * iB > 3u;                            // more than 3 insertions
                     if (__any(side)) {
                         if (side) {
                             auto emit = [&](uint32_t b) {
@@ -514,30 +512,22 @@ __global__ __launch_bounds__(256, WD_BLOCKS_PER_CU) void genasm_lane_wide_kernel
                                 pos++;
                                 if (pos - flushed >= 32u) write_piece();
                             };
-                            uint32_t tt = t;
-                            if (iB) {
-                                for (uint32_t q = tt >> 6; q; q--) emit(0x3Fu);
-                                emit(0x80u | (tt & 63u));
-                                for (uint32_t q = 1; q < ni; q++) emit(0x80u);
-                                tt = 0;
-                                mbase = 0u - c;
-                            }
+                            emit(0x80u | t);
+                            for (uint32_t q = 1; q < ni; q++) emit(0x80u);
+                            mbase = 0u - c;
                             if (dx) {
-                                for (uint32_t q = tt >> 6; q; q--) emit(0x3Fu);
-                                emit(step | (tt & 63u));
+                                emit(step);
                                 mbase = ~c;
                             }
-                            iB = dx = k64 = 0;
+                            iB = dx = 0;
                         }
                     }
-                    // in line: one byte 0x3F (64..127 matches pending), up to three insertions, the step
-                    put(pos, 0x3Fu);
-                    pos += k64;
-                    put(pos, 0x80u | (t & 63u));
+                    // in line: up to three insertions, the step
+                    put(pos, 0x80u | t);
                     put(pos + 1u, 0x80u);
                     put(pos + 2u, 0x80u);
-                    pos += iB ? (ni > 3u ? 3u : ni) : 0u;
-                    put(pos, step | ((iB ? 0u : t) & 63u));
+                    pos += iB ? ni : 0u;
+                    put(pos, step | (iB ? 0u : t));
                     pos += dx;
                     mbase = dx ? ~c : (iB ? 0u - c : mbase);
                     ni = lds8[scr_b + (nx & 31u)];
@@ -547,7 +537,7 @@ __global__ __launch_bounds__(256, WD_BLOCKS_PER_CU) void genasm_lane_wide_kernel
                 while (__any(E != 0u)) {
                     event();
                     event();
-                    if (++trips == 2u) {                       // <= 4 x 5 new bytes between checks + 4 speculative ones: the 64-byte ring cannot wrap
+                    if (++trips == 2u) {                       // <= 4 x 4 new bytes between checks + 3 speculative ones (+ 2 of a window end): the 64-byte ring cannot wrap
                         trips = 0;
                         flush_pieces();
                     }
@@ -596,6 +586,17 @@ __global__ __launch_bounds__(256, WD_BLOCKS_PER_CU) void genasm_lane_wide_kernel
             }
         }
         read_idx += j;
+        if constexpr (EDITS) {
+            // the window ends (edit_stream.h): the matches since its last edit — 63 of them, a whole window of W-O = 63
+            // without an edit, are a byte 0x3F first — and the mark
+            const uint32_t more = mbase >= 63u ? 1u : 0u;
+            lds8[ring_b + (pos & 63u)] = (uint8_t)0x3Fu;
+            pos += has_pair ? more : 0u;
+            lds8[ring_b + (pos & 63u)] = (uint8_t)(mbase - 63u * more);
+            pos += has_pair ? 1u : 0u;
+            mbase = 0;
+            flush_pieces();
+        }
         st_rounds++;
     }
     if (SCRG_TIMING(a) && lane == 0) atomicAdd((unsigned long long*)&a.stats[0], (unsigned long long)st_rounds);

@@ -541,17 +541,19 @@ scrg_status scrg_unpack_runs(scrg_ctx* c, uint64_t n_runs, const uint8_t* d_pack
     return SCRG_OK;
 }
 
-scrg_status scrg_encode_edit_stream(scrg_ctx* c, uint64_t n_pairs, const scrg_pair_desc* d_pairs, const scrg_run* d_runs,
-                                    const uint32_t* d_n_runs, uint8_t* d_stream, uint64_t stream_cap, uint64_t* d_stream_off,
-                                    uint32_t* d_stream_len, uint64_t* d_total)
+scrg_status scrg_encode_edit_stream(scrg_ctx* c, const scrg_params* params, uint64_t n_pairs, const scrg_pair_desc* d_pairs,
+                                    const scrg_run* d_runs, const uint32_t* d_n_runs, uint8_t* d_stream, uint64_t stream_cap,
+                                    uint64_t* d_stream_off, uint32_t* d_stream_len, uint64_t* d_total)
 {
     if (!c) return SCRG_ERR_INVALID_ARG;
+    scrg_params p;
+    if (!resolve_params(params, &p)) return c->fail(SCRG_ERR_INVALID_ARG, "bad scrg_params");
     if (!d_total) return c->fail(SCRG_ERR_INVALID_ARG, "d_total is required");
     if (n_pairs && (!d_pairs || !d_runs || !d_n_runs || !d_stream_off || !d_stream_len || (stream_cap && !d_stream)))
         return c->fail(SCRG_ERR_INVALID_ARG, "null device pointer");
     if (reinterpret_cast<uintptr_t>(d_stream) & 3u) return c->fail(SCRG_ERR_INVALID_ARG, "d_stream needs 4-byte alignment");
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, scrg::launch_encode_edits(n_pairs, d_pairs, reinterpret_cast<const uint16_t*>(d_runs), d_n_runs, d_stream,
+    HIP_TRY(c, scrg::launch_encode_edits(n_pairs, (uint32_t)p.W, (uint32_t)p.O, d_pairs, reinterpret_cast<const uint16_t*>(d_runs), d_n_runs, d_stream,
                                          stream_cap, d_stream_off, d_stream_len, d_total, c->stream));
     return SCRG_OK;
 }
@@ -579,31 +581,31 @@ scrg_status scrg_decode_edit_stream(scrg_ctx* c, const scrg_params* params, uint
         HIP_TRY(c, c->sort_ws.ensure(3 * n_pairs * sizeof(uint32_t) + 256 + temp_bytes));
         ws = c->sort_ws.p;
     }
-    HIP_TRY(c, scrg::launch_decode_edits(n_pairs, (uint32_t)p.W, (uint32_t)p.O, d_stream, stream_bytes, d_stream_off, d_stream_len,
+    HIP_TRY(c, scrg::launch_decode_edits(n_pairs, d_stream, stream_bytes, d_stream_off, d_stream_len,
                                          d_read_len, read_len_stride, d_dense_offset, reinterpret_cast<uint16_t*>(d_dense), dense_capacity,
                                          d_n_runs, d_bad_count, ws, temp_bytes, c->stream));
     return SCRG_OK;
 }
 
 // The device decoder's per-lane state machine (edit_stream.h: decode_lane_step, the code decode_edits_kernel runs in
-// every lane) on the host, for ONE pair: same arguments and results as scrg_edit_stream_to_runs.  Exists so that the
-// state machine can be held against the plain replay without a GPU (tests/test_edit_stream.py).
+// every lane) on the host, for ONE pair: same arguments as scrg_edit_stream_to_runs, same runs; like the device it does
+// not look at the window geometry.  Exists so that the state machine can be checked without a GPU (tests/test_edit_stream.py).
 scrg_status scrg_edit_stream_to_runs_lane(const scrg_params* params, uint64_t read_len, const uint8_t* stream, uint64_t n_bytes,
                                           scrg_run* runs, uint64_t runs_cap, uint64_t* n_runs)
 {
     scrg_params p;
     if (!n_runs || (n_bytes && !stream) || (runs_cap && !runs) || !resolve_params(params, &p)) return SCRG_ERR_INVALID_ARG;
     *n_runs = 0;
-    if (read_len > 0x7fffffffull || n_bytes > 0x7fffffffull) return SCRG_ERR_INVALID_ARG;
+    if (read_len > 0x7fffffffull || n_bytes > 0x3fffffffull) return SCRG_ERR_INVALID_ARG;
     scrg::DecodeLane s;
-    scrg::decode_lane_init(s, (uint32_t)p.W, (uint32_t)p.O, 0u, (uint32_t)n_bytes, (uint32_t)read_len);
-    while (s.aliveM)
-        (void)scrg::decode_lane_step(s, s.pos < n_bytes ? (uint32_t)stream[s.pos] : 0u, [&](uint32_t k, uint32_t word) {
-            if (k < runs_cap) { runs[k].count = (uint8_t)word; runs[k].op = (char)(word >> 8); }
+    scrg::decode_lane_init(s, 0u);
+    for (uint64_t k = 0; k < n_bytes; k++)
+        scrg::decode_lane_step(s, (uint32_t)stream[k], [&](uint32_t at, uint32_t word) {         // at: byte offset of the run's slot
+            if ((at >> 1) < runs_cap) { runs[at >> 1].count = (uint8_t)word; runs[at >> 1].op = (char)(word >> 8); }
         });
-    if (!scrg::decode_lane_clean(s)) return SCRG_ERR_INVALID_ARG;
-    *n_runs = s.n;
-    return s.n > runs_cap ? SCRG_ERR_CIGAR_OVERFLOW : SCRG_OK;
+    if (!scrg::decode_lane_clean(s, n_bytes ? (uint32_t)stream[n_bytes - 1] : 0u, (uint32_t)read_len)) return SCRG_ERR_INVALID_ARG;
+    *n_runs = scrg::decode_lane_runs(s);
+    return *n_runs > runs_cap ? SCRG_ERR_CIGAR_OVERFLOW : SCRG_OK;
 }
 
 scrg_status scrg_edit_stream_to_runs(const scrg_params* params, uint64_t read_len, const uint8_t* stream, uint64_t n_bytes,
@@ -612,7 +614,7 @@ scrg_status scrg_edit_stream_to_runs(const scrg_params* params, uint64_t read_le
     scrg_params p;
     if (!n_runs || (n_bytes && !stream) || (runs_cap && !runs) || !resolve_params(params, &p)) return SCRG_ERR_INVALID_ARG;
     uint64_t k = 0;
-    const uint64_t n = scrg::replay_edit_stream(stream, n_bytes, read_len, (uint32_t)p.W, (uint32_t)p.O,
+    const uint64_t n = scrg::replay_edit_stream(stream, n_bytes, read_len, (uint32_t)(p.W - p.O),
                                                 [&](uint32_t op, uint64_t t) {
                                                     if (k < runs_cap) { runs[k].count = (uint8_t)t; runs[k].op = (char)op; }
                                                     k++;
@@ -622,27 +624,21 @@ scrg_status scrg_edit_stream_to_runs(const scrg_params* params, uint64_t read_le
     return n > runs_cap ? SCRG_ERR_CIGAR_OVERFLOW : SCRG_OK;
 }
 
-scrg_status scrg_runs_to_edit_stream(const scrg_run* runs, uint64_t n_runs, uint8_t* stream, uint64_t stream_cap,
-                                     uint64_t* n_bytes)
+scrg_status scrg_runs_to_edit_stream(const scrg_params* params, const scrg_run* runs, uint64_t n_runs, uint8_t* stream,
+                                     uint64_t stream_cap, uint64_t* n_bytes)
 {
-    if (!n_bytes || (n_runs && !runs) || (stream_cap && !stream)) return SCRG_ERR_INVALID_ARG;
-    uint64_t k = 0, pend = 0;
-    auto put = [&](uint32_t b) {
-        if (k < stream_cap) stream[k] = (uint8_t)b;
-        k++;
-    };
-    for (uint64_t r = 0; r < n_runs; r++) {
-        const uint32_t op = (uint8_t)runs[r].op, cnt = runs[r].count;
-        if (op != '=' && op != 'X' && op != 'I' && op != 'D') return SCRG_ERR_INVALID_ARG;
-        if (op == '=' || cnt == 0) { pend += cnt; continue; }
-        const uint32_t code = scrg::edit_code_of_char(op) << 6;
-        for (uint64_t q = pend >> 6; q; q--) put(0x3F);
-        put(code | (uint32_t)(pend & 63u));
-        for (uint32_t q = 1; q < cnt; q++) put(code);
-        pend = 0;
-    }
-    *n_bytes = k;
-    return k > stream_cap ? SCRG_ERR_CIGAR_OVERFLOW : SCRG_OK;
+    scrg_params p;
+    if (!n_bytes || (n_runs && !runs) || (stream_cap && !stream) || !resolve_params(params, &p)) return SCRG_ERR_INVALID_ARG;
+    uint64_t k = 0;
+    const uint64_t n = scrg::encode_runs(n_runs, (uint32_t)(p.W - p.O),
+                                         [&](uint64_t r) { return (uint32_t)runs[r].count | (uint32_t)(uint8_t)runs[r].op << 8; },
+                                         [&](uint8_t b) {
+                                             if (k < stream_cap) stream[k] = b;
+                                             k++;
+                                         });
+    *n_bytes = n == ~0ull ? 0 : n;
+    if (n == ~0ull) return SCRG_ERR_INVALID_ARG;
+    return n > stream_cap ? SCRG_ERR_CIGAR_OVERFLOW : SCRG_OK;
 }
 
 scrg_status scrg_ascii_to_twobit(scrg_ctx* c, uint64_t count, const uint64_t* d_lens, const uint64_t* d_ascii_off,

@@ -131,8 +131,8 @@ static int lane_tb(const uint64_t *V1, const uint64_t *V0, int m, int TBL, size_
 }
 
 /* The kernel's edit-stream variant of pass 2 (genasm_lane_kernel<true>): the same pass 1, then one visit per column
- * that holds an edit.  mbase + c = matches pending when column c is reached (carried from window to window);
- * an insertion at c leaves none at c, a deletion/substitution none at c + 1. */
+ * that holds an edit.  mbase + c = matches pending when column c is reached (the window's own: every window closes with
+ * its END byte, edit_stream.h); an insertion at c leaves none at c, a deletion/substitution none at c + 1. */
 typedef struct { uint8_t *p; size_t cap, n; uint32_t mbase; } edit_sink;
 static void es_put(edit_sink *o, uint32_t b) { if (o->n < o->cap) o->p[o->n] = (uint8_t)b; o->n++; }
 
@@ -168,19 +168,19 @@ static int lane_tb_edits(const uint64_t *V1, const uint64_t *V0, int m, int TBL,
         uint32_t t = out->mbase + c;
         E &= ~bit;
         if (Im & bit) {
-            for (uint32_t q = t >> 6; q; q--) es_put(out, 0x3F);
-            es_put(out, 0x80u | (t & 63u));
+            es_put(out, 0x80u | t);                        /* (t < W-O <= 31: the window's own matches) */
             for (uint32_t q = 1; q < ilen[c]; q++) es_put(out, 0x80u);
             t = 0;
             out->mbase = 0u - c;
         }
         if ((D | X) & bit) {
-            for (uint32_t q = t >> 6; q; q--) es_put(out, 0x3F);
-            es_put(out, ((X & bit) ? 0x40u : 0xC0u) | (t & 63u));
+            es_put(out, ((X & bit) ? 0x40u : 0xC0u) | t);
             out->mbase = ~c;
         }
     }
-    out->mbase += ti;
+    /* the window ends (format version 2): the matches since its last edit, then the mark */
+    es_put(out, out->mbase + ti);
+    out->mbase = 0;
     *tu = ti; *pu = j;
     return edits;
 }

@@ -32,7 +32,7 @@ CODE[ord("C")], CODE[ord("G")], CODE[ord("T")] = 1, 2, 3
 
 def _run(fn, t, q, head, tail, unit=2):
     tc, qc = CODE[np.frombuffer(t, np.uint8)], CODE[np.frombuffer(q, np.uint8)]
-    cap = len(t) + len(q) + 8
+    cap = 2 * (len(t) + len(q)) + 8          # (runs; as bytes of an edit stream at W-O = 1: one per edit and one per window)
     runs = (C.c_uint8 * (2 * cap))()
     n, ed = C.c_size_t(), C.c_longlong()
     st = fn(tc.ctypes.data_as(C.c_void_p), C.c_size_t(len(tc)), qc.ctypes.data_as(C.c_void_p), C.c_size_t(len(qc)),
@@ -72,7 +72,7 @@ def test_lane_form_matches_oracle(proto, W, O):
 
 @pytest.mark.parametrize("W,O", [(64, 33), (64, 40), (64, 63), (32, 17), (48, 24), (2, 1), (17, 9), (33, 2)])
 def test_lane_edit_stream_form_matches_oracle(proto, oracle, W, O):
-    """The kernel's edit-stream traceback (pending matches carried across windows as mbase + column) produces the
+    """The kernel's edit-stream traceback (pending matches as mbase + column, every window closed by its END byte) produces the
     canonical edit stream of the oracle's CIGAR (tests/test_edit_stream.py: py_encode)."""
     from tests.test_edit_stream import py_encode
     T, Q = _cases(W * 100 + O + 7)
@@ -82,7 +82,7 @@ def test_lane_edit_stream_form_matches_oracle(proto, oracle, W, O):
     ls = LS()
     for t, q, e, c in zip(T, Q, eds, cigars):
         ed, stream = _run(proto.lane_align_edits, t, q, (C.c_int(W), C.c_int(O)), (C.byref(ls),), unit=1)
-        assert ed == e and stream == py_encode(c)
+        assert ed == e and stream == py_encode(c, W, O)
     assert ls.windows > 1000
 
 

@@ -173,7 +173,7 @@ def main():
     ck = out["checks"]
     ck["streams_decode"] = int(nbad.item()) == 0
     ck["run_counts_on_the_wire_are_the_decoded_counts"] = bool(torch.equal(cnt_dec, cnt_w))
-    # edit distance == number of edit bytes of the stream (one byte per edit; 0x3F = 64 matches, no edit)
+    # edit distance == number of edit bytes of the stream (one byte per edit; the bytes with op 0 are window ends)
     is_edit = (recv_slots >= 64).to(torch.int32)
     csum = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(is_edit, 0, dtype=torch.int64)])
     del is_edit

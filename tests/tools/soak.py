@@ -80,7 +80,7 @@ for W, O in ((64, 33), (48, 24), (33, 2), (64, 63), (64, 2), (50, 18), (128, 65)
     torch.cuda.synchronize()
     sl, lh = slices.cpu().numpy(), ln.cpu().tolist()
     assert int(st.max()) == 0 and ed.cpu().tolist() == e2
-    bad = [k for k in range(m) if sl[2 * k * cap: 2 * k * cap + lh[k]].tobytes() != py_encode(c2[k])]
+    bad = [k for k in range(m) if sl[2 * k * cap: 2 * k * cap + lh[k]].tobytes() != py_encode(c2[k], W, O)]
     print("edit streams W=%d O=%d: %d pairs, %d bytes, mismatches: %d %s" % (W, O, m, sum(lh), len(bad), bad[:5]))
     assert not bad
     for k in range(0, m, 97):
