@@ -60,7 +60,7 @@ def parse():
                     help="sequence layout in HBM: linear = every sequence contiguous; groups = lane-interleaved groups of 64 "
                          "pairs (scrg_pack_planar_groups), what the one-pair-per-lane kernel reads best; auto = groups for that kernel")
     ap.add_argument("--gather-format", default="edits", choices=["edits", "edits-from-runs", "packed", "runs"],
-                    help="N > 1: how CIGARs travel to rank 0 — edit streams, 1 byte per edit, written by the align kernel "
+                    help="N > 1: how CIGARs travel to rank 0 — edit streams, 1 byte per edit and per window end, written by the align kernel "
                          "itself (default; W-O <= 31) or encoded from its runs (edits-from-runs: any W/O), packed runs "
                          "(1 byte per run, restored on rank 0 inside the timed region) or scrg_run pairs")
     ap.add_argument("--gather-root", default="rotate", choices=["rotate", "0"],
@@ -262,7 +262,7 @@ def arm_deadline(seconds, rank):
 
 STEP_TEXT = {
     "local": "align kernel + run compaction",
-    "edits": "align kernel writing every CIGAR as an edit stream + its run count (scrg_align_device_edits: one byte per edit, a "
+    "edits": "align kernel writing every CIGAR as an edit stream + its run count (scrg_align_device_edits: one byte per edit and per window end, a "
              "lossless encoding the window breaks are restored from) + compaction of the streams + RCCL gather of scores, run "
              "counts and streams to the step's root (config.gather.root), one collective and one buffer set per pipelined step "
              "(overlaps the next kernels) + on the root, INSIDE the timed region, scrg_decode_edit_stream of every rank's slot "
@@ -460,7 +460,7 @@ def main():
         gather_format = "edits-from-runs"            # only the one-pair-per-lane kernels write edit streams themselves
     edits = gather_format in ("edits", "edits-from-runs")
     if dist_on and edits:
-        # CIGARs travel as edit streams (one byte per edit); rank 0 keeps them in that form
+        # CIGARs travel as edit streams (one byte per edit and per window end); rank 0 keeps them in that form
         from scrooge_amd.distributed import EditStreamGather
         # (sizes are exchanged once: the largest over the lanes' batches; what a step really sends travels in its lengths)
         stream_bytes = 0

@@ -590,7 +590,7 @@ class Aligner:
                                                _ptr(n_runs), _ptr(status)))
 
     def align_device_edits(self, n_pairs, seq, pairs, streams_u8, ed, stream_len, status, n_runs=None, **kw):
-        """Like align_device, but the pairs' slices receive EDIT STREAMS (one byte per edit) and stream_len their
+        """Like align_device, but the pairs' slices receive EDIT STREAMS (one byte per edit and per window end) and stream_len their
         lengths in bytes: the one-pair-per-lane kernels only (lanes_per_pair = 1, the default for every W/O).
         n_runs (optional int32 tensor): the run count of every alignment, for a receiver that decodes in one pass."""
         self._check(self.lib.scrg_align_device_edits(self.h, C.byref(self._params(kw)), int(n_pairs),

@@ -193,7 +193,7 @@ class ResultGather:
 
 
 class EditStreamGather:
-    """Gather of a batch's device results to rank `dst` with the CIGARs as EDIT STREAMS (one byte per edit, ~1.0 KB
+    """Gather of a batch's device results to rank `dst` with the CIGARs as EDIT STREAMS (one byte per edit and per window end, ~1.3 KB
     for a 10 kb read at 10 % error instead of 4.3 KB of scrg_run pairs), so that what a rank produces per second fits
     the one xGMI link it has to `dst`, and their DECODING back to scrg_run pairs on `dst` — what the
     reference delivers is CIGARs on the receiving side (src/genasm_gpu.cu:955-968), so the step is not finished before
