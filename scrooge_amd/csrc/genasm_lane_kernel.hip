@@ -165,7 +165,11 @@ __device__ __forceinline__ void lane_window_table(const Planes tw, const Planes 
         const int f = (b & 1) ? b - 1 : b;                                  // the field's low bit; it goes to bit 9
         const uint32_t u = f >= 9 ? x >> (f - 9) : x << (9 - f);
         const uint32_t a = bitop3<TT_ANDOR>(u, LANE_EQ_FIELD_MASK, eq_b);
-        return (!SHORT_N || (uint32_t)i < n) ? a : nomatch_b;
+        if (!SHORT_N) return a;
+        // column i >= n: the "no character matches" word.  A select by arithmetic (i - n < 0: the column exists): compare +
+        // v_cndmask on VCC costs 15 counted cycles per column against 5 for subtract, smear the sign, v_bitop3
+        // (profiles/r03_valu_issue_rates.txt) — a third of the table's time in the rounds in which some lane's text ends
+        return bitop3<TT_BFI>(a, nomatch_b, neg_mask((uint32_t)i - n));
     };
     uint2 eqw[LANE_EQ_AHEAD];
 #pragma unroll
@@ -450,7 +454,7 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
             const uint32_t Draw = ~notD;
             const uint32_t Im = ~nIm << nsh;
             const uint32_t ti_stopped = (31u - ffbl_u32((notD >> 1) | Im)) & 31u;      // bit 31-c: the lane stopped in column c or later; none: 0
-            ti = j < jlim ? TBc : ti_stopped;
+            ti = bitop3<TT_BFI>(TBc, ti_stopped, neg_mask(j - jlim));          // j < jlim ? TBc : ti_stopped, without a v_cndmask on VCC
             const uint32_t A = ~(0xffffffffu >> ti);
             const uint32_t D = Draw & A, X = Xraw & A;
             const uint32_t B = ((D ^ (D >> 1)) | (X ^ (X >> 1)) | Im | 0x80000000u) & A;    // a D / X / = run starts here
@@ -462,7 +466,7 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
             // pair that is finished reads its padding, a lane without a pair its last pair's, and the registers are
             // not alive across the table that way.)
             twords = load_window_words_at(text_w, tr_in & 31u, ref_idx, a.text_stride);
-            pwords = load_window_words_at(read_w, tr_in >> 8, read_idx < read_len ? read_idx : 0u, a.read_stride);     // (never past a finished read)
+            pwords = load_window_words_at(read_w, tr_in >> 8, read_idx & neg_mask(read_idx - read_len), a.read_stride);     // (never past a finished read: 0 then)
 
             // Pass 2.  The next column with an event: an insertion run, then (if B) the run of steps that starts
             // there.  Both words go to the slot after the last committed run; only committing moves on.  (A lane
@@ -749,7 +753,7 @@ __global__ __launch_bounds__(512, 2) void genasm_lane_split_kernel(AlignArgs a)
                 const uint32_t notD = nDm << nsh, Xraw = Xm << nsh;
                 const uint32_t Im = ~nIm << nsh;
                 const uint32_t ti_stopped = (31u - ffbl_u32((notD >> 1) | Im)) & 31u;
-                const uint32_t ti = j < jlim ? TBc : ti_stopped;
+                const uint32_t ti = bitop3<TT_BFI>(TBc, ti_stopped, neg_mask(j - jlim));       // j < jlim ? TBc : ti_stopped
                 const uint32_t A = ~(0xffffffffu >> ti);
                 const uint32_t D = ~notD & A, X = Xraw & A;
                 edits += j - ti + 2u * (uint32_t)__builtin_popcount(D) + (uint32_t)__builtin_popcount(X);
@@ -757,7 +761,7 @@ __global__ __launch_bounds__(512, 2) void genasm_lane_split_kernel(AlignArgs a)
                 read_idx += j;
                 // the next window's words, asked for now (a pair that is finished reads its padding)
                 twords = load_window_words(a.seq, text_off, ref_idx, a.text_stride);
-                pwords = load_window_words(a.seq, read_off, read_idx < read_len ? read_idx : 0u, a.read_stride);
+                pwords = load_window_words(a.seq, read_off, read_idx & neg_mask(read_idx - read_len), a.read_stride);
                 const uint32_t last = (has_pair && read_idx >= read_len) ? SPLIT_LAST : 0u;
                 lds[rec_w(buf, 0)] = D;
                 lds[rec_w(buf, 1)] = X;

@@ -100,7 +100,11 @@ template <int NW> struct WdWindow {
 // Columns HI .. LO (descending) of the window's table; the columns >= STORE (at most 32 of them: STORE .. STORE + 31)
 // go to tab[column - STORE] as {~(V1 | stop), V0 | stop}; STORE < 0: nothing is kept.
 // SHORT_N as in genasm_lane_kernel: columns >= n read the Eq word "no character matches".
-template <int NW, bool SHORT_N, int HI, int LO, int STORE>
+// SHORT_N: 0 every lane has its text column; 1 columns >= n read "no character matches", selected by compare + v_cndmask; 2 the same
+// selected by arithmetic (subtract, smear the sign, v_bitop3: 5 counted cycles per column instead of 15 — a v_cndmask on VCC issues at
+// a seventh of the rate, profiles/r03_valu_issue_rates.txt — but the compiler keeps the masks: 248 registers for one-word vectors;
+// the edit-stream variant and two-word vectors, which have none to spare, would spill and take form 1)
+template <int NW, int SHORT_N, int HI, int LO, int STORE>
 __device__ __forceinline__ void wd_sweep(WdState<NW>& st, const WdWindow<NW>& w, uint64_t (&tab)[WD_HALF][2],
                                          const uint32_t eq_b, const uint32_t nomatch_b)
 {
@@ -129,7 +133,9 @@ __device__ __forceinline__ void wd_sweep(WdState<NW>& st, const WdWindow<NW>& w,
         const int f = (b & 1) ? b - 1 : b;                                  // the field's low bit; it goes to bit SH
         const uint32_t u = f >= SH ? x >> (f - SH) : x << (SH - f);
         const uint32_t a = bitop3<WT_ANDOR>(u, 3u << SH, eq_b);
-        return (!SHORT_N || (uint32_t)i < w.n) ? a : nomatch_b;
+        if (SHORT_N == 0) return a;
+        if (SHORT_N == 2) return bitop3<WT_BFI>(a, nomatch_b, neg_mask((uint32_t)i - w.n));
+        return (uint32_t)i < w.n ? a : nomatch_b;
     };
     uint2 eqw[WD_EQ_AHEAD][NW];
 #pragma unroll
@@ -407,17 +413,17 @@ __global__ __launch_bounds__(256, WD_BLOCKS_PER_CU) void genasm_lane_wide_kernel
             // they are — Eq = "no match" gives Xh = ~valid, Ph = Mh = 0 — so the sweep starts at the first column a
             // window of W characters can have, rounded up to 16.)
             if (W <= 80u) {
-                if (short_pro) wd_sweep<NW, true, 79, 64, -1>(st0, win, tab, eq_b, nomatch_b);
-                else wd_sweep<NW, false, 79, 64, -1>(st0, win, tab, eq_b, nomatch_b);
+                if (short_pro) wd_sweep<NW, ((EDITS || NW == 2) ? 1 : 2), 79, 64, -1>(st0, win, tab, eq_b, nomatch_b);
+                else wd_sweep<NW, 0, 79, 64, -1>(st0, win, tab, eq_b, nomatch_b);
             } else if (W <= 96u) {
-                if (short_pro) wd_sweep<NW, true, 95, 64, -1>(st0, win, tab, eq_b, nomatch_b);
-                else wd_sweep<NW, false, 95, 64, -1>(st0, win, tab, eq_b, nomatch_b);
+                if (short_pro) wd_sweep<NW, ((EDITS || NW == 2) ? 1 : 2), 95, 64, -1>(st0, win, tab, eq_b, nomatch_b);
+                else wd_sweep<NW, 0, 95, 64, -1>(st0, win, tab, eq_b, nomatch_b);
             } else if (W <= 112u) {
-                if (short_pro) wd_sweep<NW, true, 111, 64, -1>(st0, win, tab, eq_b, nomatch_b);
-                else wd_sweep<NW, false, 111, 64, -1>(st0, win, tab, eq_b, nomatch_b);
+                if (short_pro) wd_sweep<NW, ((EDITS || NW == 2) ? 1 : 2), 111, 64, -1>(st0, win, tab, eq_b, nomatch_b);
+                else wd_sweep<NW, 0, 111, 64, -1>(st0, win, tab, eq_b, nomatch_b);
             } else {
-                if (short_pro) wd_sweep<NW, true, 127, 64, -1>(st0, win, tab, eq_b, nomatch_b);
-                else wd_sweep<NW, false, 127, 64, -1>(st0, win, tab, eq_b, nomatch_b);
+                if (short_pro) wd_sweep<NW, ((EDITS || NW == 2) ? 1 : 2), 127, 64, -1>(st0, win, tab, eq_b, nomatch_b);
+                else wd_sweep<NW, 0, 127, 64, -1>(st0, win, tab, eq_b, nomatch_b);
             }
         }
 
@@ -432,11 +438,11 @@ __global__ __launch_bounds__(256, WD_BLOCKS_PER_CU) void genasm_lane_wide_kernel
             {
                 WdState<NW> st = st0;
                 if (half == 0) {
-                    if (short_n) wd_sweep<NW, true, 63, 0, 0>(st, win, tab, eq_b, nomatch_b);
-                    else wd_sweep<NW, false, 63, 0, 0>(st, win, tab, eq_b, nomatch_b);
+                    if (short_n) wd_sweep<NW, ((EDITS || NW == 2) ? 1 : 2), 63, 0, 0>(st, win, tab, eq_b, nomatch_b);
+                    else wd_sweep<NW, 0, 63, 0, 0>(st, win, tab, eq_b, nomatch_b);
                 } else {
-                    if (short_n) wd_sweep<NW, true, 63, WD_HALF, WD_HALF>(st, win, tab, eq_b, nomatch_b);
-                    else wd_sweep<NW, false, 63, WD_HALF, WD_HALF>(st, win, tab, eq_b, nomatch_b);
+                    if (short_n) wd_sweep<NW, ((EDITS || NW == 2) ? 1 : 2), 63, WD_HALF, WD_HALF>(st, win, tab, eq_b, nomatch_b);
+                    else wd_sweep<NW, 0, 63, WD_HALF, WD_HALF>(st, win, tab, eq_b, nomatch_b);
                 }
             }
             // pass 1 (see genasm_lane_kernel): the walk through this half's columns, on 64-bit rows
