@@ -256,5 +256,6 @@ hipError_t launch_decode_edits(uint64_t n_pairs, const uint8_t* d_stream, uint64
                                uint64_t read_len_stride, const uint64_t* d_dense_off, uint16_t* d_dense, uint64_t dense_cap,
                                uint32_t* d_n_runs, uint32_t* d_bad, void* sort_ws, size_t sort_temp_bytes, hipStream_t s);
 size_t decode_sort_temp_bytes(uint64_t n_pairs);
+bool decode_by_wavefront(uint64_t n_pairs, uint64_t stream_bytes);     // which of the two decoders launch_decode_edits takes
 
 }  // namespace scrg

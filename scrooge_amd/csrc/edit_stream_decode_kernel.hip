@@ -468,6 +468,14 @@ __global__ void iota_kernel(uint32_t* v, uint32_t n)
 // Bits of the stream length the order is made from: 16-byte granularity, lengths up to 1 MB told apart.
 constexpr int DEC_SORT_BEGIN_BIT = 4, DEC_SORT_END_BIT = 20;
 
+// Which decoder a launch takes: one pair per wavefront for streams of a few chunks and more (>= 192 bytes on average), one pair
+// per lane for shorter ones.  SCRG_DEC_KERNEL=lane|wave overrides (the tests run both on the same inputs).
+bool decode_by_wavefront(uint64_t n_pairs, uint64_t stream_bytes)
+{
+    if (const char* e = getenv("SCRG_DEC_KERNEL")) return e[0] == 'w';
+    return n_pairs != 0 && stream_bytes / n_pairs >= 192u;
+}
+
 size_t decode_sort_temp_bytes(uint64_t n_pairs)
 {
     size_t bytes = 0;
@@ -490,13 +498,9 @@ hipError_t launch_decode_edits(uint64_t n_pairs, const uint8_t* d_stream, uint64
     const uint32_t together = n_pairs > 200000 ? 1u : 0u;
     const uint32_t* order = nullptr;
     DecodeArgs a{n_pairs, d_stream, stream_bytes, d_off, d_len, d_read_len, read_len_stride, d_dense_off, d_dense, dense_cap, d_n_runs, d_bad, order, together};
-    // Which kernel (scripts/decode_timing.py, 10 kb reads: one slot of 100 k pairs 0.41 ms by wavefront against 0.82 ms by lane
-    // — 1 563 lane-per-pair wavefronts leave the GPU half empty —, eight slots 2.78 against 2.40 ms): one pair per wavefront for
-    // streams of a few chunks and more (>= 192 bytes on average) in launches that lane-per-pair wavefronts would not fill
-    // four deep.  SCRG_DEC_KERNEL=lane|wave overrides (the tests run both on the same inputs).
-    bool by_wave = stream_bytes / n_pairs >= 192u;
-    if (const char* e = getenv("SCRG_DEC_KERNEL")) by_wave = e[0] == 'w';
-    if (by_wave) {
+    // Which kernel (decode_by_wavefront; scripts/decode_timing.py, 10 kb reads: one slot of 100 k pairs 0.32 ms by wavefront
+    // against 0.82 ms by lane — 1 563 lane-per-pair wavefronts leave the GPU half empty —, eight slots 2.37 against 2.40 ms)
+    if (decode_by_wavefront(n_pairs, stream_bytes)) {
         const uint64_t want = n_pairs < 8192u ? (n_pairs + 3u) & ~3ull : 8192u;          // 8 wavefronts on every SIMD of an MI355X
         const uint32_t n_waves = (uint32_t)want;
         const dim3 grid(n_waves / 4u), block(256);

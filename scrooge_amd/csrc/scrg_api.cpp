@@ -576,7 +576,7 @@ scrg_status scrg_decode_edit_stream(scrg_ctx* c, const scrg_params* params, uint
     // batches that fill the GPU are decoded longest stream first (a wavefront's 64 pairs then finish together)
     void* ws = nullptr;
     size_t temp_bytes = 0;
-    if (n_pairs >= 4096 && n_pairs < 0x7fffffffull) {
+    if (n_pairs >= 4096 && n_pairs < 0x7fffffffull && !scrg::decode_by_wavefront(n_pairs, stream_bytes)) {       // (the lane-per-pair decoder only)
         temp_bytes = scrg::decode_sort_temp_bytes(n_pairs);
         HIP_TRY(c, c->sort_ws.ensure(3 * n_pairs * sizeof(uint32_t) + 256 + temp_bytes));
         ws = c->sort_ws.p;
