@@ -983,9 +983,10 @@ def test_decode_two_runs_per_step_fills_the_ring(aligner, dec_kernel, monkeypatc
     assert want_runs[0] == bytes([1, ord("="), 1, ord("X")]) * 70 and len(want_runs[-1]) == 6
     n0 = len(cases)
     offs, blob = [], bytearray()
-    for st_, _ in cases:
+    for k_, (st_, _) in enumerate(cases):
+        blob += bytes([0xC1] * (k_ % 5))                              # (streams start at any byte offset: the encoder's multiples of 4 are not required; the bytes between streams are not zeros)
         offs.append(len(blob))
-        blob += st_ + bytes((-len(st_)) % 4)
+        blob += st_
     stream = torch.tensor(list(blob) + [0] * 64, dtype=torch.uint8, device=dev)
     s_off = torch.tensor(offs, dtype=torch.int64, device=dev)
     s_len = torch.tensor([len(c[0]) for c in cases], dtype=torch.int32, device=dev)
