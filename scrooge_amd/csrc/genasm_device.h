@@ -140,6 +140,14 @@ __device__ __forceinline__ Planes window_planes(const WindowWords& v)
     return r;
 }
 
+// a - b, 0 if that is negative: one v_sub_u32 with the clamp bit ("a > b ? a - b : 0" would be a compare and a v_cndmask on VCC)
+__device__ __forceinline__ uint32_t sub_sat_u32(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_sub_u32_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // Conditions as 0 / ~0 masks.  Written as asm / intrinsics so that the optimiser cannot turn them
 // back into v_cmp + v_cndmask (both half rate on gfx950; v_ashrrev, v_sub and v_bitop3 are full rate).
 __device__ __forceinline__ uint32_t neg_mask(uint32_t x)      // ~0 iff (int32)x < 0

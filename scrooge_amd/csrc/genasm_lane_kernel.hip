@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
 
         const uint64_t tm1 = timing ? __builtin_readcyclecounter() : 0;
         // ---------------- window setup (genasm_cpu.cpp:417-420) ----------------
-        const uint32_t n = (has_pair && ref_idx < text_len) ? min(W, text_len - ref_idx) : 0u;
+        const uint32_t n = has_pair ? min(W, sub_sat_u32(text_len, ref_idx)) : 0u;      // text characters left, at most a window's
         const uint32_t m = has_pair ? min(W, read_len - read_idx) : 1u;      // >= 1 for live pairs
         // (the words were loaded when the pair was fetched, or before the previous round's second traceback pass.  EVERY lane
         // takes them, not only those that hold a pair: a lane without one computes a table of garbage that its walk never reads —
@@ -466,7 +466,10 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
             // pair that is finished reads its padding, a lane without a pair its last pair's, and the registers are
             // not alive across the table that way.)
             twords = load_window_words_at(text_w, tr_in & 31u, ref_idx, a.text_stride);
-            pwords = load_window_words_at(read_w, tr_in >> 8, read_idx & neg_mask(read_idx - read_len), a.read_stride);     // (never past a finished read: 0 then)
+            // (never past a finished read: index 0 then.  read_idx <= read_len always, so "finished" is "equal": x | -x has its sign
+            // bit set for every x != 0 — exact for any 32-bit length, and no v_cndmask on VCC)
+            const uint32_t left_x = read_idx ^ read_len;
+            pwords = load_window_words_at(read_w, tr_in >> 8, read_idx & neg_mask(left_x | (0u - left_x)), a.read_stride);
 
             // Pass 2.  The next column with an event: an insertion run, then (if B) the run of steps that starts
             // there.  Both words go to the slot after the last committed run; only committing moves on.  (A lane
@@ -761,7 +764,8 @@ __global__ __launch_bounds__(512, 2) void genasm_lane_split_kernel(AlignArgs a)
                 read_idx += j;
                 // the next window's words, asked for now (a pair that is finished reads its padding)
                 twords = load_window_words(a.seq, text_off, ref_idx, a.text_stride);
-                pwords = load_window_words(a.seq, read_off, read_idx & neg_mask(read_idx - read_len), a.read_stride);
+                const uint32_t left_x = read_idx ^ read_len;                     // (see genasm_lane_kernel)
+                pwords = load_window_words(a.seq, read_off, read_idx & neg_mask(left_x | (0u - left_x)), a.read_stride);
                 const uint32_t last = (has_pair && read_idx >= read_len) ? SPLIT_LAST : 0u;
                 lds[rec_w(buf, 0)] = D;
                 lds[rec_w(buf, 1)] = X;
