@@ -263,7 +263,7 @@ def arm_deadline(seconds, rank):
 STEP_TEXT = {
     "local": "align kernel + run compaction",
     "edits": "align kernel writing every CIGAR as an edit stream + its run count (scrg_align_device_edits: one byte per edit and per window end, a "
-             "lossless encoding the window breaks are restored from) + compaction of the streams + RCCL gather of scores, run "
+             "lossless encoding that carries the window ends) + compaction of the streams + RCCL gather of scores, run "
              "counts and streams to the step's root (config.gather.root), one collective and one buffer set per pipelined step "
              "(overlaps the next kernels) + on the root, INSIDE the timed region, scrg_decode_edit_stream of every rank's slot "
              "(one launch for all N x pairs) into one dense scrg_run array: the step ends with the CIGAR runs of all pairs on the root",

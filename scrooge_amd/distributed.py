@@ -370,7 +370,7 @@ class EditStreamGather:
             self.dense[b] = torch.zeros(cap_runs * 2 + 64, dtype=torch.uint8, device=self.device)
             self.dec[b] = {"bad": torch.zeros(1, dtype=torch.int32, device=self.device)}
         # `aligner` may be a list of handles, one per buffer set: a decode launch is bound by its longest streams (a lane
-        # replays its stream sequentially), so the launches of consecutive steps run side by side, each on the stream and
+        # walks its stream sequentially — in the lane-per-pair decoder), so the launches of consecutive steps run side by side, each on the stream and
         # with the handle (sort workspace) of its buffer set
         if isinstance(aligner, (list, tuple)):
             sb = b % len(aligner)

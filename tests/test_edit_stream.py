@@ -1,7 +1,7 @@
 """CPU tests of the edit-stream transfer format (include/scrooge_amd.h, scrooge_amd/csrc/edit_stream.h): the
-host encoder and the window replay of the decoder, against the reference's own CIGARs.
+host encoder (which replays the window loop to place the window-end bytes) and the decoders, against the reference's own CIGARs.
 
-The decoder has to put the window breaks back (runs are flushed per window and never merged,
+What comes out must have the reference's window breaks (runs are flushed per window and never merged,
 genasm_cpu.cpp:304-305, 400-403); these tests pin that to every committed golden fixture — all W/O the
 reference was built with — and to fresh oracle output on random, ragged and degenerate pairs."""
 import glob

@@ -458,8 +458,8 @@ def test_full_bench_size_two_algorithms_agree(aligner, aligner_select):
                 aligner.params = keep
         aligner = shipped
         assert int(bad.item()) == 0
-        # a fourth formulation of the output: the kernel's edit streams (one byte per edit), and from them — by the
-        # decoder's window replay — the runs again, for all 100 000 pairs
+        # a fourth formulation of the output: the kernel's edit streams (one byte per edit and per window end), and from them —
+        # by the decoder — the runs again, for all 100 000 pairs
         (ed0, nr0, st0, d0, off0) = res[0]
         slices = torch.zeros(n * cap * 2, dtype=torch.uint8, device=dev)
         ed_s = torch.empty(n, dtype=torch.int64, device=dev)
@@ -625,9 +625,9 @@ def test_packed_runs_round_trip(aligner, oracle):
 @pytest.mark.parametrize("W,O", [(64, 33), (64, 2), (40, 9), (128, 65), (200, 50), (256, 1), (256, 129), (192, 97), (128, 20)])
 def test_edit_stream_round_trip(aligner, oracle, W, O, dec_kernel, monkeypatch):
     """(Both decoders — one pair per lane, one pair per wavefront: edit_stream_decode_kernel.hip — on the same streams.)
-    scrg_encode_edit_stream (one byte per edit, the RCCL transfer format) against the definition of the format on
-    the oracle's CIGARs, and scrg_decode_edit_stream back to the very runs scrg_compact_runs delivers (window breaks
-    restored); long error-free stretches, empty reads, empty texts, a tiny stream buffer."""
+    scrg_encode_edit_stream (one byte per edit and per window end, the RCCL transfer format) against the definition of the
+    format on the oracle's CIGARs, and scrg_decode_edit_stream back to the very runs scrg_compact_runs delivers; long
+    error-free stretches, empty reads, empty texts, a tiny stream buffer."""
     monkeypatch.setenv("SCRG_DEC_KERNEL", dec_kernel)
     import torch
     import scrooge_amd
