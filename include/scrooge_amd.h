@@ -327,7 +327,7 @@ scrg_status scrg_unpack_runs(scrg_ctx *ctx, uint64_t n_runs, const uint8_t *d_pa
  *   d_stream_off[p] (bytes; ~0 if the pair did not fit into stream_cap) and d_stream_len[p] say where.
  *   d_total[0] = bytes of d_stream used (the amount to transfer), d_total[1] = pairs that did not fit.
  *   stream_cap >= sum over the pairs of (edit distance + 2 * (read_len + edit distance) / (W-O) + 8) always suffices.
- * scrg_decode_edit_stream: the inverse (streams of 192 bytes and more on average: one pair per wavefront, 64 stream bytes side
+ * scrg_decode_edit_stream: the inverse (streams of 64 bytes and more on average: one pair per wavefront, 64 stream bytes side
  *   by side, coalesced loads and stores; shorter ones: one pair per lane, streams read in aligned 16-byte blocks, runs
  *   written in aligned 64-byte pieces — the same runs either way).  d_stream holds stream_bytes bytes (16-byte aligned, readable up to the next
  *   multiple of 16): a pair whose stream is not inside [0, stream_bytes) — offsets and lengths may come off a wire —

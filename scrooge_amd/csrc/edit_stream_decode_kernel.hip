@@ -468,12 +468,16 @@ __global__ void iota_kernel(uint32_t* v, uint32_t n)
 // Bits of the stream length the order is made from: 16-byte granularity, lengths up to 1 MB told apart.
 constexpr int DEC_SORT_BEGIN_BIT = 4, DEC_SORT_END_BIT = 20;
 
-// Which decoder a launch takes: one pair per wavefront for streams of a few chunks and more (>= 192 bytes on average), one pair
-// per lane for shorter ones.  SCRG_DEC_KERNEL=lane|wave overrides (the tests run both on the same inputs).
+// Which decoder a launch takes: one pair per wavefront for streams of 64 bytes and more on average (the size of the buffer over
+// the number of pairs), one pair per lane for shorter ones.  Measured, ms per launch, lane / wavefront (scripts/decode_timing.py
+// --read-len L --pairs n): 2 M x 150 bp (8 bytes per pair) 0.21 / 0.62, 2 M x 300 bp (14) 0.25 / 0.62, 200 k x 500 bp (67)
+// 0.115 / 0.078, 100 k x 1 kb (132) 0.124 / 0.053, 25 k x 4 kb (521) 0.240 / 0.039, 100 k x 10 kb (1 299) 0.82 / 0.32: a
+// wavefront's set-up per pair is ~0.3 ns of the GPU's time, a chunk ~0.05.  SCRG_DEC_KERNEL=lane|wave overrides (the tests run
+// both on the same inputs).
 bool decode_by_wavefront(uint64_t n_pairs, uint64_t stream_bytes)
 {
     if (const char* e = getenv("SCRG_DEC_KERNEL")) return e[0] == 'w';
-    return n_pairs != 0 && stream_bytes / n_pairs >= 192u;
+    return n_pairs != 0 && stream_bytes / n_pairs >= 64u;
 }
 
 size_t decode_sort_temp_bytes(uint64_t n_pairs)
