@@ -472,7 +472,7 @@ constexpr int DEC_SORT_BEGIN_BIT = 4, DEC_SORT_END_BIT = 20;
 // the number of pairs), one pair per lane for shorter ones.  Measured, ms per launch, lane / wavefront (scripts/decode_timing.py
 // --read-len L --pairs n): 2 M x 150 bp (8 bytes per pair) 0.21 / 0.62, 2 M x 300 bp (14) 0.25 / 0.62, 200 k x 500 bp (67)
 // 0.115 / 0.078, 100 k x 1 kb (132) 0.124 / 0.053, 25 k x 4 kb (521) 0.240 / 0.039, 100 k x 10 kb (1 299) 0.82 / 0.32: a
-// wavefront's set-up per pair is ~0.3 ns of the GPU's time, a chunk ~0.05.  SCRG_DEC_KERNEL=lane|wave overrides (the tests run
+// pair of one chunk costs ~0.3 ns of the GPU's time, every further chunk ~0.15.  SCRG_DEC_KERNEL=lane|wave overrides (the tests run
 // both on the same inputs).
 bool decode_by_wavefront(uint64_t n_pairs, uint64_t stream_bytes)
 {
