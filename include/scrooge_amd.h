@@ -128,7 +128,8 @@ int         scrg_device_count(void);
 enum { SCRG_BUILD_STATS = 1, SCRG_BUILD_ABLATE = 2, SCRG_BUILD_SELECT = 4 };
 int         scrg_build_flags(void);
 /* The version of THIS interface.  It goes up whenever an entry point changes its arguments under the same name (version 5:
- * scrg_decode_edit_stream takes the capacity of its output array) — such a change still links against code compiled with the
+ * scrg_decode_edit_stream takes the capacity of its output array; version 6: scrg_encode_edit_stream and
+ * scrg_runs_to_edit_stream take the parameters, and the edit stream itself carries the window ends) — such a change still links against code compiled with the
  * older header and would shift every later argument.  scrg_abi_version() is what the loaded library was built with; a binding
  * compares it with the SCRG_ABI_VERSION it was compiled against before anything else (include/scrooge_amd.hpp throws,
  * scrooge_amd/api.py raises). */
