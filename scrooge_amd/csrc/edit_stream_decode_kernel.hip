@@ -363,11 +363,11 @@ __global__ __launch_bounds__(256) void decode_edits_wave_kernel(DecodeArgs a, ui
         uint32_t placed = 0, over = 0;       // (per lane) read characters placed; bits 8..: a match run longer than 255
         // (every lane loads, a lane behind the stream its last byte, and the byte is replaced by 0 — a window end after no matches,
         // which adds nothing — where it is used: a load under a condition is waited for on the spot)
-        uint32_t b_next = len ? (uint32_t)src[lane < len ? lane : len - 1u] : 0u;
+        uint32_t b_next = len ? (uint32_t)src[min(lane, len - 1u)] : 0u;
         for (uint32_t c0 = 0; c0 < len; c0 += 64u) {
             const uint32_t b = b_next & es_neg_mask(c0 + lane - len);               // (a mask by arithmetic: v_cndmask on VCC issues at a seventh of the rate, edit_stream.h)
             const uint32_t k_next = c0 + 64u + lane;
-            b_next = (uint32_t)src[k_next < len ? k_next : len - 1u];
+            b_next = (uint32_t)src[min(k_next, len - 1u)];                              // (v_min_u32: no compare + conditional move)
             const uint32_t pb = (uint32_t)__builtin_amdgcn_update_dpp((int)carry_b, (int)b, 0x138, 0xf, 0xf, false);       // wave_shr:1
             const uint32_t e = b >> 6, ln = b & 63u;
             const uint64_t M = __ballot(b == EDIT_MORE);
