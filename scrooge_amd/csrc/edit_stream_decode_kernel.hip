@@ -318,8 +318,10 @@ __global__ __launch_bounds__(256, 4) void decode_edits_kernel(DecodeArgs a)
 //     are wavefront masks (v_cmp into an SGPR pair); a run's index in the pair is the number of Q and H bits below the
 //     lane (v_mbcnt) plus the runs of the chunks before (a scalar);
 //   * an edit run's length is the number of G bits directly above its first byte (a 64-bit shift of ~G by the lane and a
-//     count of trailing zeros); the run that reaches the chunk's last byte stays OPEN — its first lane does not store, its
-//     length, index and letter go on as scalars until a later chunk's first byte does not join it;
+//     count of trailing zeros); the run that reaches the chunk's last byte stays OPEN — its first lane does not store it but
+//     keeps its length, index and letter, adds the next chunks' leading G bits and stores when a chunk's first byte does
+//     not join (as three scalars carried by the wavefront, with the scalar unit finding the lane and reading it out, the
+//     same cost 4 % more: the scalar unit is what this kernel waits for);
 //   * bytes 0x3F (63 matches and nothing else: only W-O > 63 has them) take a side path that counts the 0x3F lanes
 //     directly below each lane.
 // Loads are the 64 contiguous bytes of the chunk, stores the chunk's ~106 runs as two 2-byte stores per lane to one
@@ -359,7 +361,9 @@ __global__ __launch_bounds__(256) void decode_edits_wave_kernel(DecodeArgs a, ui
         uint32_t base = 0;                   // runs of the chunks before
         uint32_t carry_b = 0;                // the last byte of the chunk before (0: a window end)
         uint32_t carry_more = 0;             // matches of the 0x3F bytes the chunk before ended with
-        uint32_t open_len = 0, open_idx = 0, open_op = 0;       // the edit run that reached the end of the chunk before
+        // the edit run that reached the last lane of a chunk stays with the lane that started it until a later chunk's first
+        // byte does not join it: its length so far (0: none), its letter word, its index in the pair (per lane; one lane at a time)
+        uint32_t pend_len = 0, pend_opw = 0, pend_idx = 0;
         uint32_t placed = 0, over = 0;       // (per lane) read characters placed; bits 8..: a match run longer than 255
         // (every lane loads, a lane behind the stream its last byte, and the byte is replaced by 0 — a window end after no matches,
         // which adds nothing — where it is used: a load under a condition is waited for on the spot)
@@ -370,9 +374,11 @@ __global__ __launch_bounds__(256) void decode_edits_wave_kernel(DecodeArgs a, ui
             b_next = (uint32_t)src[min(k_next, len - 1u)];                              // (v_min_u32: no compare + conditional move)
             const uint32_t pb = (uint32_t)__builtin_amdgcn_update_dpp((int)carry_b, (int)b, 0x138, 0xf, 0xf, false);       // wave_shr:1
             const uint32_t e = b >> 6, ln = b & 63u;
+            const bool is_edit = b > 63u;
+            const bool joins = is_edit && b == (pb & 0xC0u);             // the same edit as the byte before, and no match in between
             const uint64_t M = __ballot(b == EDIT_MORE);
-            const uint64_t E = __ballot(b > 63u);
-            const uint64_t G = __ballot(b == (pb & 0xC0u)) & E;         // the same edit as the byte before, and no match in between
+            const uint64_t E = __ballot(is_edit);
+            const uint64_t G = __ballot(joins);
             uint32_t t = ln;
             if (M != 0 || carry_more != 0) {
                 // the 0x3F lanes directly below me: from the highest lane below that is not one (none: all of them, and the chunk before's)
@@ -389,15 +395,17 @@ __global__ __launch_bounds__(256) void decode_edits_wave_kernel(DecodeArgs a, ui
             }
             const uint64_t Q = __ballot(t != 0u);
             const uint64_t H = E & ~G;
-            // ---- the open run of the chunk before: joined by my first lanes, written when it ends
+            // ---- the run that stayed open: joined by this chunk's first lanes (lead of them), written by its lane when it ends
             const uint64_t nG = ~G;
-            const uint32_t lead = nG ? (uint32_t)__builtin_ctzll(nG) : 64u;           // lanes 0 .. lead-1 join the run before them
-            if (open_len != 0u) {
-                open_len += lead;
-                if (lead < 64u) {
-                    if (open_len > 255u) bad = true;
-                    if (STORE && lane == 0u && open_idx < cap) dst[open_idx] = (uint16_t)(open_op | open_len);
-                    open_len = 0;
+            if (__any(pend_len != 0u)) {
+                const uint32_t lead = nG ? (uint32_t)__builtin_ctzll(nG) : 64u;       // lanes 0 .. lead-1 join the run before them
+                if (pend_len != 0u) {
+                    pend_len += lead;
+                    if (lead < 64u) {
+                        over |= pend_len;                                             // (more than 255: reported)
+                        if (STORE && pend_idx < cap) dst[pend_idx] = (uint16_t)(pend_opw | (pend_len & 0xffu));
+                        pend_len = 0;
+                    }
                 }
             }
             // ---- run indices: the Q and H bits below my lane, on top of the runs of the chunks before
@@ -410,19 +418,15 @@ __global__ __launch_bounds__(256) void decode_edits_wave_kernel(DecodeArgs a, ui
             const uint32_t f_lo = dec_ffbl(y_lo), f_hi = min(dec_ffbl(y_hi), 32u) + 32u;          // (v_ffbl_b32: 0xffffffff for 0)
             const uint32_t above = min(min(f_lo, f_hi), 63u - lane);                 // joined lanes directly above me
             const uint32_t opw = (((0x44495800u >> ((e << 3) & 31u)) & 0xffu) << 8);
-            // the run that reaches the chunk's last lane stays open: the lanes the chunk ends with that join (tail), and the
-            // edit lane below them (all scalar; a chunk that joined the run before it as a whole has no such lane)
-            const uint32_t tail = nG ? (uint32_t)__builtin_clzll(nG) : 64u;
-            const uint32_t hl = 63u - (tail & 63u);
-            const bool opens = tail < 64u && ((E >> hl) & 1ull);
-            if (opens) {
-                open_len = tail + 1u;
-                open_idx = (uint32_t)__builtin_amdgcn_readlane((int)head_idx, (int)hl);
-                open_op = (uint32_t)__builtin_amdgcn_readlane((int)opw, (int)hl);
+            // the run that reaches the chunk's last lane stays open with the lane that started it (the next chunk may join it)
+            const bool is_head = is_edit && !joins;
+            const bool stays_open = is_head && lane + above == 63u;
+            if (stays_open) {
+                pend_len = above + 1u;
+                pend_opw = opw;
+                pend_idx = head_idx;
             }
             if (STORE) {
-                const bool is_head = (H >> lane) & 1ull;
-                const bool stays_open = opens && lane == hl;
                 uint8_t* const d8 = reinterpret_cast<uint8_t*>(dst);
                 if (base + 128u <= cap) {                                             // (uniform: a chunk starts at most 128 runs)
                     if (t != 0u) *reinterpret_cast<uint16_t*>(d8 + (eq_idx << 1)) = (uint16_t)(((uint32_t)'=' << 8) | t);
@@ -437,8 +441,8 @@ __global__ __launch_bounds__(256) void decode_edits_wave_kernel(DecodeArgs a, ui
             carry_b = (uint32_t)__builtin_amdgcn_readlane((int)b, 63);
         }
         // ---- the end of the pair
-        if (open_len != 0u) {              // (a stream that ends in an edit: reported below, its run written all the same)
-            if (STORE && lane == 0u && open_idx < cap) dst[open_idx] = (uint16_t)(open_op | (open_len & 0xffu));
+        if (pend_len != 0u) {              // (a stream that ends in an edit: reported below, its run written all the same)
+            if (STORE && pend_idx < cap) dst[pend_idx] = (uint16_t)(pend_opw | (pend_len & 0xffu));
         }
         // read characters placed, over all lanes and chunks
         uint32_t tot = placed, ov = over;
@@ -471,7 +475,7 @@ constexpr int DEC_SORT_BEGIN_BIT = 4, DEC_SORT_END_BIT = 20;
 // Which decoder a launch takes: one pair per wavefront for streams of 64 bytes and more on average (the size of the buffer over
 // the number of pairs), one pair per lane for shorter ones.  Measured, ms per launch, lane / wavefront (scripts/decode_timing.py
 // --read-len L --pairs n): 2 M x 150 bp (8 bytes per pair) 0.21 / 0.62, 2 M x 300 bp (14) 0.25 / 0.62, 200 k x 500 bp (67)
-// 0.115 / 0.078, 100 k x 1 kb (132) 0.124 / 0.053, 25 k x 4 kb (521) 0.240 / 0.039, 100 k x 10 kb (1 299) 0.82 / 0.32: a
+// 0.115 / 0.078, 100 k x 1 kb (132) 0.124 / 0.053, 25 k x 4 kb (521) 0.240 / 0.039, 100 k x 10 kb (1 299) 0.82 / 0.30: a
 // pair of one chunk costs ~0.3 ns of the GPU's time, every further chunk ~0.15.  SCRG_DEC_KERNEL=lane|wave overrides (the tests run
 // both on the same inputs).
 bool decode_by_wavefront(uint64_t n_pairs, uint64_t stream_bytes)
@@ -502,8 +506,8 @@ hipError_t launch_decode_edits(uint64_t n_pairs, const uint8_t* d_stream, uint64
     const uint32_t together = n_pairs > 200000 ? 1u : 0u;
     const uint32_t* order = nullptr;
     DecodeArgs a{n_pairs, d_stream, stream_bytes, d_off, d_len, d_read_len, read_len_stride, d_dense_off, d_dense, dense_cap, d_n_runs, d_bad, order, together};
-    // Which kernel (decode_by_wavefront; scripts/decode_timing.py, 10 kb reads: one slot of 100 k pairs 0.32 ms by wavefront
-    // against 0.82 ms by lane — 1 563 lane-per-pair wavefronts leave the GPU half empty —, eight slots 2.37 against 2.40 ms)
+    // Which kernel (decode_by_wavefront; scripts/decode_timing.py, 10 kb reads: one slot of 100 k pairs 0.30 ms by wavefront
+    // against 0.82 ms by lane — 1 563 lane-per-pair wavefronts leave the GPU half empty —, eight slots 2.28 against 2.40 ms)
     if (decode_by_wavefront(n_pairs, stream_bytes)) {
         const uint64_t want = n_pairs < 8192u ? (n_pairs + 3u) & ~3ull : 8192u;          // 8 wavefronts on every SIMD of an MI355X
         const uint32_t n_waves = (uint32_t)want;
