@@ -380,7 +380,7 @@ __global__ __launch_bounds__(256) void decode_edits_wave_kernel(DecodeArgs a, ui
             const uint64_t E = __ballot(is_edit);
             const uint64_t G = __ballot(joins);
             uint32_t t = ln;
-            if (M != 0 || carry_more != 0) {
+            if (((uint32_t)M | (uint32_t)(M >> 32) | carry_more) != 0u) {
                 // the 0x3F lanes directly below me: from the highest lane below that is not one (none: all of them, and the chunk before's)
                 const uint32_t z_lo = ~(uint32_t)M & below_lo, z_hi = ~(uint32_t)(M >> 32) & below_hi;
                 const bool none = (z_lo | z_hi) == 0u;
@@ -427,14 +427,11 @@ __global__ __launch_bounds__(256) void decode_edits_wave_kernel(DecodeArgs a, ui
                 pend_idx = head_idx;
             }
             if (STORE) {
+                // (nothing past the pair's segment: one compare per store — a separate unchecked form for chunks that lie
+                // inside the segment saves the compares and costs more scalar instructions, which are what this kernel is short of)
                 uint8_t* const d8 = reinterpret_cast<uint8_t*>(dst);
-                if (base + 128u <= cap) {                                             // (uniform: a chunk starts at most 128 runs)
-                    if (t != 0u) *reinterpret_cast<uint16_t*>(d8 + (eq_idx << 1)) = (uint16_t)(((uint32_t)'=' << 8) | t);
-                    if (is_head && !stays_open) *reinterpret_cast<uint16_t*>(d8 + (head_idx << 1)) = (uint16_t)(opw | (above + 1u));
-                } else {
-                    if (t != 0u && eq_idx < cap) *reinterpret_cast<uint16_t*>(d8 + (eq_idx << 1)) = (uint16_t)(((uint32_t)'=' << 8) | t);
-                    if (is_head && !stays_open && head_idx < cap) *reinterpret_cast<uint16_t*>(d8 + (head_idx << 1)) = (uint16_t)(opw | (above + 1u));
-                }
+                if (t != 0u && eq_idx < cap) *reinterpret_cast<uint16_t*>(d8 + (eq_idx << 1)) = (uint16_t)(((uint32_t)'=' << 8) | t);
+                if (is_head && !stays_open && head_idx < cap) *reinterpret_cast<uint16_t*>(d8 + (head_idx << 1)) = (uint16_t)(opw | (above + 1u));
             }
             placed += ln + ((6u >> e) & 1u);
             base += (uint32_t)__popcll(Q) + (uint32_t)__popcll(H);
@@ -507,7 +504,7 @@ hipError_t launch_decode_edits(uint64_t n_pairs, const uint8_t* d_stream, uint64
     const uint32_t* order = nullptr;
     DecodeArgs a{n_pairs, d_stream, stream_bytes, d_off, d_len, d_read_len, read_len_stride, d_dense_off, d_dense, dense_cap, d_n_runs, d_bad, order, together};
     // Which kernel (decode_by_wavefront; scripts/decode_timing.py, 10 kb reads: one slot of 100 k pairs 0.30 ms by wavefront
-    // against 0.82 ms by lane — 1 563 lane-per-pair wavefronts leave the GPU half empty —, eight slots 2.28 against 2.40 ms)
+    // against 0.82 ms by lane — 1 563 lane-per-pair wavefronts leave the GPU half empty —, eight slots 2.26 against 2.40 ms)
     if (decode_by_wavefront(n_pairs, stream_bytes)) {
         const uint64_t want = n_pairs < 8192u ? (n_pairs + 3u) & ~3ull : 8192u;          // 8 wavefronts on every SIMD of an MI355X
         const uint32_t n_waves = (uint32_t)want;
