@@ -26,7 +26,8 @@ d, slots = sys.argv[1], int(sys.argv[2])
 acc = collections.defaultdict(list)
 for f in glob.glob(d + "/p*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "decode_edits_kernelILb1" in r.get("Kernel_Name", "") or "decode_edits_kernel<true>" in r.get("Kernel_Name", ""):
+        kn = r.get("Kernel_Name", "")
+        if ("decode_edits" in kn) and ("<true>" in kn or "ILb1" in kn):          # the storing form of whichever decoder the launches took
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 # the timed launches of the N-slot decode are the ones with the largest values; the one-slot launches the smallest
 out = {k: {"largest_launches_mean": sum(sorted(v)[-2:]) / 2, "smallest_launches_mean": sum(sorted(v)[:2]) / 2, "n": len(v)} for k, v in acc.items()}
