@@ -479,12 +479,12 @@ def main():
                 del t_cnt
             else:
                 # (include/scrooge_amd.h: a byte per edit and per window, streams start at multiples of 4)
-                bound = int(o["ed"].sum().item()) + n * (2 * (L + L // 2) // (p.W - p.O) + 12) + 64
+                bound = int(o["ed"].sum().item()) + n * (2 * (L + L // 2) // (p.W - p.O) + L // 63 + 12) + 64
                 tmp = torch.empty(bound, dtype=torch.uint8, device=device)
                 t_off = torch.empty(n, dtype=torch.int64, device=device)
                 t_len = torch.empty(n, dtype=torch.int32, device=device)
                 t_tot = torch.zeros(2, dtype=torch.int64, device=device)
-                al.encode_edit_stream(n, descs[b_], o["runs"], o["n_runs"], tmp, t_off, t_len, t_tot)
+                al.encode_edit_stream(n, descs[b_], o["runs"], o["n_runs"], tmp, t_off, t_len, t_tot, W=p.W, O=p.O)
                 torch.cuda.synchronize()
                 assert int(t_tot[1].item()) == 0
                 stream_bytes = max(stream_bytes, int(t_tot[0].item()))
@@ -569,7 +569,7 @@ def main():
                 # the same with the streams encoded from the kernel's runs (any W/O, any kernel)
                 gather_.finish(j)
                 g = gather_.buffers(j)
-                aligners[b].encode_edit_stream(n, descs_[b], o["runs"], o["n_runs"], g["stream"], g["off"], g["len"], g["total"])
+                aligners[b].encode_edit_stream(n, descs_[b], o["runs"], o["n_runs"], g["stream"], g["off"], g["len"], g["total"], W=p.W, O=p.O)
                 gather_.start(j, o["ed"])
                 return
             cnt64 = o["n_runs"].to(torch.int64)

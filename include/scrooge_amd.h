@@ -327,7 +327,8 @@ scrg_status scrg_unpack_runs(scrg_ctx *ctx, uint64_t n_runs, const uint8_t *d_pa
  *   Streams are placed in d_stream back to back in no particular order, each starting at a multiple of 4:
  *   d_stream_off[p] (bytes; ~0 if the pair did not fit into stream_cap) and d_stream_len[p] say where.
  *   d_total[0] = bytes of d_stream used (the amount to transfer), d_total[1] = pairs that did not fit.
- *   stream_cap >= sum over the pairs of (edit distance + 2 * (read_len + edit distance) / (W-O) + 8) always suffices.
+ *   stream_cap >= sum over the pairs of (edit distance + 2 * (read_len + edit distance) / (W-O) + read_len / 63 + 8) always
+ *   suffices (the read_len / 63 term is the 0x3F bytes, one per 63 matches in a row: only W-O > 63 has any).
  * scrg_decode_edit_stream: the inverse (streams of 64 bytes and more on average: one pair per wavefront, 64 stream bytes side
  *   by side, coalesced loads and stores; shorter ones: one pair per lane, streams read in aligned 16-byte blocks, runs
  *   written in aligned 64-byte pieces — the same runs either way).  d_stream holds stream_bytes bytes (16-byte aligned, readable up to the next

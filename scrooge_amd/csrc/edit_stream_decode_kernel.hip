@@ -460,6 +460,391 @@ __global__ __launch_bounds__(256) void decode_edits_wave_kernel(DecodeArgs a, ui
     if (n_bad && lane == 0u) atomicAdd(a.bad, n_bad);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// decode_edits_quad_kernel (round 6) — one pair per wavefront, FOUR stream bytes per lane: a trip takes 256 bytes.
+//
+// decode_edits_wave_kernel above is bound by the scalar unit (34 scalar instructions per 64-byte chunk — ballots, popcounts, the
+// open run, the loop — one scalar unit per CU: profiles/r05_decode_timing.json) and stores its ~106 runs per chunk as two
+// scattered 2-byte stores per lane.  Here
+//   * a lane's four bytes are classified side by side in its dword (SWAR: "has matches", "is an edit", "is the same edit as the
+//     byte before and has no match in front" are bit 7 of each byte), the byte before a lane's first comes over DPP;
+//   * the runs a lane starts (0..8) are counted by two shift-adds, their indices in the pair come from ONE wavefront scan
+//     (six DPP adds) on top of a scalar — no ballot, no popcount;
+//   * every run is WRITTEN ONCE into a ring of 32-bit slots in LDS (1024 per wavefront, slot = the run's index in the dense
+//     output array modulo 1024): a stretch of matches by its byte, an edit run by its LAST byte — the one the byte after does
+//     not join — whose position in the run is the run's length: a segmented count over the lane's four bytes (two shift-adds)
+//     plus, where the run began in the lane before, that lane's count (DPP; a lane whose four bytes ALL join takes the other
+//     path, so the hand-over never chains).  The last byte of a trip writes as far as it knows; if the next trip's first bytes
+//     join that run, their last one writes the slot again.  A byte that writes nothing writes to a per-lane slot nobody reads
+//     (an address select by v_bitop3, no predication, no branch);
+//   * the ring leaves in aligned 16-byte UNITS of eight runs, one unit per lane and trip (two ds_read_b128, four v_perm to pack,
+//     ONE 16-byte store instruction per trip, 1 KB per wavefront, fully coalesced — a fixed number of memory instructions per
+//     trip, so the wait for the next trip's dword does not wait for this trip's stores); only the last run stays behind (the
+//     next trip may still write it), and the units a pair shares with its neighbours in the dense array (its first and its
+//     last) go out run by run at the end of the pair.
+// (First version of this kernel, measured and not kept: every byte ADDED its contribution to its run's slot with ds_add_u32 — no
+// run lengths to compute at all — and the slots were zeroed behind the units: the LDS atomics alone cost 0.074 ms of 0.25 ms per
+// 100 k pairs, the zeroing 0.024: gpurun_out/r06_dec_probe.txt.)
+// What the side-by-side form cannot do takes the per-byte form for that trip (four sub-chunks of 64 bytes, one byte per lane,
+// ballots and v_mbcnt as in the wave kernel; there a joining byte ADDS 1 to its run's slot): a 0x3F byte in the trip or pending
+// from the one before (only W-O > 63 writes them), a lane whose four bytes all join the run before them (five equal edits in a
+// row with no match between them, dword-aligned: ~1e-4 of the trips at 10 % error) — which is also where a run longer than 255
+// is noticed, by counting the bytes in a row that join (`chain`).  tests/tools/quad_decoder_model.py is this arithmetic lane by
+// lane in numpy; tests/test_quad_decoder_model.py holds it to the format's definition on the CPU.
+constexpr uint32_t QD_RING = 1024;                      // run slots (dwords) per wavefront: <= 7 waiting for their unit + the last run + 512 a trip
+constexpr uint32_t QD_RING_BYTES = 4u * QD_RING;
+constexpr uint32_t QD_WAVE_LDS = QD_RING_BYTES + 256u;  // + a slot per lane for the bytes that write nothing
+
+template <int SH>
+__device__ __forceinline__ uint32_t qd_lshl_add_t(uint32_t a, uint32_t c)
+{
+    uint32_t r;
+    asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "n"(SH), "v"(c));
+    return r;
+}
+#define qd_lshl_add(a, sh, c) qd_lshl_add_t<sh>(a, c)
+template <int SH>
+__device__ __forceinline__ uint32_t qd_lshl_or_t(uint32_t a, uint32_t c)
+{
+    uint32_t r;
+    asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "n"(SH), "v"(c));
+    return r;
+}
+#define qd_lshl_or(a, sh, c) qd_lshl_or_t<sh>(a, c)
+// truth tables: bit index = a * 4 + b * 2 + c (genasm_device.h: bitop3_table)
+__device__ __forceinline__ uint32_t qd_or_and(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0xA8); }      // (a | b) & c
+__device__ __forceinline__ uint32_t qd_xor_and(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x78); }     // a ^ (b & c)
+
+// inclusive prefix sum over the 64 lanes (values small enough not to overflow)
+__device__ __forceinline__ uint32_t qd_wave_scan(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);       // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);       // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);       // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);       // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);       // row_bcast:15 -> rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);       // row_bcast:31 -> rows 2 and 3
+    return v;
+}
+__device__ __forceinline__ uint32_t qd_total(uint32_t v)         // the sum over the 64 lanes, in every lane (uniform)
+{
+    return (uint32_t)__builtin_amdgcn_readlane((int)qd_wave_scan(v), 63);
+}
+
+template <bool STORE>
+__global__ __launch_bounds__(256) void decode_edits_quad_kernel(DecodeArgs a, uint32_t n_waves)
+{
+    __shared__ __attribute__((aligned(4096))) uint32_t ring_all[STORE ? 4 * (QD_WAVE_LDS / 4u) : 32];      // (a slot's address is slot offset | ring base: the four rings first)
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    typedef __attribute__((address_space(3))) u32x4_t lds_u32x4;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t wave0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + wave));
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)ring_all;
+    const uint32_t ring_b = lds0 + (STORE ? wave * QD_RING_BYTES : 0u);
+    const uint32_t dump_b = lds0 + (STORE ? 4u * QD_RING_BYTES + wave * 256u + lane * 4u : 0u);
+    auto uni32 = [](uint32_t v) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+    auto uni64 = [&](uint64_t v) -> uint64_t { return ((uint64_t)uni32((uint32_t)(v >> 32)) << 32) | uni32((uint32_t)v); };
+    // LDS address of run slot `slot4 / 4` (slot4: 4 x the run's index in the dense array; any value, taken modulo the ring)
+    auto slot_addr = [&](uint32_t slot4) -> uint32_t { return __builtin_amdgcn_bitop3_b32(slot4, QD_RING_BYTES - 4u, ring_b, 0xEA); };      // (slot4 & mask) | ring_b
+    // `value` to that slot where bit `BIT` of `flags` is set, to the lane's own dump slot where it is not
+    auto ring_put = [&](uint32_t slot4, uint32_t value, uint32_t flags, auto bit_tag) {
+        constexpr int BIT = decltype(bit_tag)::value;
+        const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)flags, BIT, 1);                       // 0 / ~0
+        *(lds_u32*)(uintptr_t)__builtin_amdgcn_bitop3_b32(slot_addr(slot4), dump_b, m, 0xE4) = value;  // (a & m) | (b & ~m)
+    };
+    uint32_t n_bad = 0;                                          // (uniform)
+    // A pair's five numbers (every lane loads the same addresses; made scalars where they are used) are asked for while the pair
+    // before it is decoded: a wavefront's pairs are a chain of dependent loads otherwise — numbers, first dwords, trips — and a
+    // 10 kb pair is only five trips long.
+    struct PairMeta { uint64_t off, rl, g0; uint32_t len, cap; };
+    auto load_meta = [&](uint64_t p) -> PairMeta {
+        PairMeta m = {0, 0, 0, 0, 0};
+        if (p < a.n_pairs) {                                     // (uniform)
+            m.off = a.off[p];
+            m.len = a.len[p];
+            m.rl = a.read_len[p * a.read_len_stride];
+            if (STORE) {
+                m.g0 = a.dense_off[p];
+                m.cap = a.n_runs[p];
+            }
+        }
+        return m;
+    };
+    PairMeta next_meta = load_meta(wave0);
+    for (uint64_t p = wave0; p < a.n_pairs; p += n_waves) {
+        // ---- the pair: everything here is the same in all lanes
+        const PairMeta meta = next_meta;
+        next_meta = load_meta(p + n_waves);
+        uint64_t off = uni64(meta.off);
+        uint32_t len = uni32(meta.len);
+        const uint64_t rl64 = uni64(meta.rl);
+        // a stream that is not inside the buffer (offsets and lengths may come off a wire) or a pair marked "did not
+        // fit" by the encoder is reported, never read
+        bool bad = off == ~0ull || off > a.stream_bytes || len > a.stream_bytes - off || len > 0x3fffffffu || rl64 > 0x7fffffffull;
+        const uint32_t rl = bad ? 0u : (uint32_t)rl64;
+        if (bad) { off = 0; len = 0; }
+        uint64_t g0 = 0;
+        uint32_t cap = 0;
+        if (STORE) {
+            g0 = uni64(meta.g0);
+            cap = uni32(meta.cap);
+            // run counts and offsets may come off a wire too: a segment that is not inside the dense array is never written
+            if (g0 > a.dense_cap || cap > a.dense_cap - g0) { bad = true; g0 = 0; cap = 0; }
+        }
+        // ---- input: dwords of the stream from its 4-byte aligned start; a stream that starts off a dword boundary takes two
+        // loads per lane and one v_alignbit.  Every lane loads — a lane behind the stream the last dword that holds a stream
+        // byte (inside the buffer: it is readable up to the next multiple of 16) — and the bytes behind the stream become zeros
+        // where they are used: a window end after no matches, which writes nothing.
+        const uint32_t delta = (uint32_t)off & 3u;
+        const uint8_t* const src4 = a.stream + (off - delta);
+        const uint32_t last_dw = len ? (delta + len - 1u) & ~3u : 0u;
+        uint32_t base = 0;                   // runs so far
+        uint32_t carry_x = 0;                // the dword in front of the trip's first (its top byte: the byte before lane 0's first)
+        uint32_t carry_rp = 0;               // x 0x01010101: the length so far of the edit run that reaches the end of the trip before (0: none does)
+        uint32_t carry_more = 0;             // matches of the 0x3F bytes the trip before ended with
+        uint32_t chain = 0;                  // bytes in a row, up to the end of the trip before, that join the edit run before them (+ last_jn's)
+        uint32_t last_jn = 0;                // Jn of the last lane of a side-by-side trip (its top bytes continue the chain)
+        uint32_t force_other = 0;            // 0x3F matches pending, or a chain that is getting long: the next trip takes the per-byte path
+        uint32_t over_s = 0;                 // (uniform) an edit run longer than 255
+        uint32_t placed = 0, over = 0;       // (per lane) read characters placed; bits 8..: a run of matches longer than 255
+        uint32_t cnt_acc = 0;                // (per lane, count only) runs started
+        uint32_t x_last = 0;                 // the last trip's dwords (the stream's last byte is looked at when the pair ends)
+        // Units of eight runs (16 bytes of the dense array).  Positions are counted from the start of the unit that holds the pair's
+        // first run: run r of the pair is at position h + r, h = g0 % 8; unit u covers positions 8u .. 8u + 7; units below `uf` have
+        // left the ring.  (32-bit arithmetic; 64 bits only where an address is formed.)
+        const uint32_t g0l = (uint32_t)g0;                                  // (slot arithmetic is modulo the ring: the low bits do)
+        const uint32_t h = g0l & 7u;
+        const uint32_t unit0 = (uint32_t)(g0 >> 3);                         // (modulo 2^32: the ring only looks at its low bits)
+        uint16_t* const dense_u = STORE ? a.dense + (g0 - h) : nullptr;     // position 0
+        uint32_t uf = 0;
+        uint32_t head_w = 0;                                                // (lanes 0..7) the slots of the pair's first unit, if the pair starts inside one: stored when the pair ends
+        bool head_kept = false;                                             // (uniform)
+        auto read_unit = [&](uint32_t u) -> u32x4_t {
+            const uint32_t rd = ring_b + (((unit0 + u) & (QD_RING / 8u - 1u)) << 5);
+            const u32x4_t w0 = *(const lds_u32x4*)(uintptr_t)rd, w1 = *(const lds_u32x4*)(uintptr_t)(rd + 16u);
+            u32x4_t o;
+            o.x = __builtin_amdgcn_perm(w0.y, w0.x, 0x05040100u);                             // low halves of two slots
+            o.y = __builtin_amdgcn_perm(w0.w, w0.z, 0x05040100u);
+            o.z = __builtin_amdgcn_perm(w1.y, w1.x, 0x05040100u);
+            o.w = __builtin_amdgcn_perm(w1.w, w1.z, 0x05040100u);
+            return o;
+        };
+        // The trip loop asks for the next trip's dwords at its top and stores this trip's units at its bottom.  Loads and stores
+        // share one counter (vmcnt) and complete in order; the compiler, which cannot know whether the (predicated) store of a
+        // trip was issued, would wait for the counter to reach 0 in front of the next trip — i.e. for the store it has just
+        // issued.  So both are issued where the compiler does not count them (inline assembly: exactly one or two loads, then
+        // exactly ONE store instruction per trip — issued under an EXEC mask, possibly with no lane, never skipped), and the wait
+        // at the trip's bottom is written out: vmcnt(1) — the loads have landed, the store may still be on its way.  (Memory
+        // operations the compiler does not know about can only make ITS waits longer: completion is in order.)
+        auto load_x_async = [&](uint32_t c0) -> uint32_t {                                             // (complete after qd_wait_loads)
+            const uint32_t at = min(c0 + 4u * lane, last_dw);
+            uint32_t w0;
+            asm volatile("global_load_dword %0, %1, %2" : "=v"(w0) : "v"(at), "s"(src4));
+            if (delta == 0u) return w0;                                                                // (uniform)
+            const uint32_t at1 = min(at + 4u, last_dw);
+            uint32_t w1;
+            asm volatile("global_load_dword %0, %1, %2" : "=v"(w1) : "v"(at1), "s"(src4));
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(w0), "+v"(w1));                                  // (streams off a dword boundary: the plain way)
+            return __builtin_amdgcn_alignbit(w1, w0, 8u * delta);
+        };
+        // (the first trip's dwords the same way: a load the compiler counts would make it wait — for everything — at the loop's top)
+        uint32_t x = 0;
+        if (len) {                                                                                     // (uniform)
+            x = load_x_async(0u);
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(x));
+        }
+        for (uint32_t c0 = 0; c0 < len; c0 += 256u) {
+            if (c0 + 256u > len) {                                                                      // (uniform) the last trip: zeros behind the stream
+                const int32_t rem = (int32_t)len - (int32_t)(c0 + 4u * lane);
+                const uint32_t keep = rem >= 4 ? 0xffffffffu : (rem <= 0 ? 0u : (0xffffffffu >> (32 - 8 * rem)));
+                x &= keep;
+            }
+            uint32_t x_next = load_x_async(c0 + 256u);                                                  // (behind the stream: its last dword again — never used)
+            x_last = x;
+            // ---- the four bytes side by side.  Bit 7 of byte k of ...
+            const uint32_t px = (uint32_t)__builtin_amdgcn_update_dpp((int)carry_x, (int)x, 0x138, 0xf, 0xf, false);    // wave_shr:1; lane 0: the trip before
+            const uint32_t pv = __builtin_amdgcn_alignbit(x, px, 24);                               // byte k: the byte before byte k
+            const uint32_t T = x & 0x3F3F3F3Fu;                                                     // the matches in front
+            const uint32_t Em = (T + 0x7F7F7F7Fu) & 0x80808080u;                                    // ... Em: there are matches (a run of '=')
+            const uint32_t OPB = x & 0xC0C0C0C0u;
+            const uint32_t Ed = qd_or_and(OPB, OPB << 1, 0x80808080u);                              // ... Ed: an edit
+            const uint32_t D = qd_xor_and(x, pv, 0xC0C0C0C0u);                                      // 0 where the byte is the edit before it, bare
+            const uint32_t nz = ((D & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | D;                              // bit 7: the byte of D is not 0
+            const uint32_t Hd = nz & Ed;                                                            // ... Hd: an edit that starts a run
+            const uint32_t Jn = es_andn(Ed, nz);                                                    // ... Jn: an edit that joins the run before it
+            const uint32_t More = es_a_nb_c(T + 0x41414141u, Ed, 0x80808080u);                      // ... More: the byte is 0x3F
+            const uint64_t trigger = __ballot(More != 0u) | __ballot(Jn == 0x80808080u);
+            if (trigger != 0ull || force_other != 0u) {
+                // ---- one byte per lane, four times (see the head of the kernel)
+                uint32_t carry_b = carry_x >> 24;
+                // (after a side-by-side trip the chain is what joins at that trip's very end: the top bytes of its last lane's Jn)
+                chain += (uint32_t)__builtin_clz(~(last_jn | 0x7F7F7F7Fu) | 1u) >> 3;
+                last_jn = 0;
+                uint32_t b = 0;
+#pragma unroll 1
+                for (uint32_t sub = 0; sub < 4u; sub++) {
+                    const uint32_t xs = (uint32_t)__shfl((int)x, (int)(sub * 16u + (lane >> 2)), 64);
+                    b = (xs >> (8u * (lane & 3u))) & 0xffu;
+                    const uint32_t pb = (uint32_t)__builtin_amdgcn_update_dpp((int)carry_b, (int)b, 0x138, 0xf, 0xf, false);
+                    const uint32_t e = b >> 6, ln = b & 63u;
+                    const bool is_edit = b > 63u;
+                    const bool joins = is_edit && b == (pb & 0xC0u);
+                    const uint64_t M = __ballot(b == EDIT_MORE);
+                    const uint64_t G = __ballot(joins);
+                    uint32_t t = ln;
+                    if (M != 0ull || carry_more != 0u) {
+                        // the 0x3F lanes directly below me: from the highest lane below that is not one (none: all of them, and the trip before's)
+                        const uint64_t below = (1ull << lane) - 1ull;
+                        const uint64_t z = ~M & below;
+                        const bool none = z == 0ull;
+                        const uint32_t top = none ? 0u : 63u - (uint32_t)__builtin_clzll(z);
+                        const uint32_t cnt = none ? lane : lane - 1u - top;
+                        t = ln + EDIT_MORE_MATCHES * cnt + (none ? carry_more : 0u);
+                        if (b == EDIT_MORE || c0 + 64u * sub + lane >= len) t = 0;                    // (nor do the bytes behind the stream close a stretch)
+                        const uint64_t nM = ~M;
+                        const uint32_t trailing = nM ? (uint32_t)__builtin_clzll(nM) : 64u;          // 0x3F lanes the sub-chunk ends with
+                        carry_more = EDIT_MORE_MATCHES * trailing + (trailing == 64u ? carry_more : 0u);
+                        over |= t;
+                    }
+                    const uint64_t Q = __ballot(t != 0u);
+                    const uint64_t H = __ballot(is_edit && !joins);
+                    // the bytes in a row that join: 255 of them make a run of 256
+                    const uint64_t nG = ~G;
+                    if (nG == 0ull) {
+                        chain += 64u;
+                    } else {
+                        if (chain + (uint32_t)__builtin_ctzll(nG) >= 255u) over_s = 1u;
+                        chain = (uint32_t)__builtin_clzll(nG);
+                    }
+                    if (chain >= 255u) over_s = 1u;
+                    if (STORE) {
+                        const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(H >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)H,
+                                                __builtin_amdgcn_mbcnt_hi((uint32_t)(Q >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)Q, g0l + base))));
+                        const uint32_t q1 = t != 0u ? 1u : 0u, h1 = (is_edit && !joins) ? 1u : 0u;
+                        const uint32_t opw = ((0x44495800u >> ((e << 3) & 31u)) & 0xffu) << 8;
+                        // matches and heads are written, then the joining bytes add 1 each (LDS operations of a wavefront run in order)
+                        if (q1) *(lds_u32*)(uintptr_t)slot_addr(before << 2) = ((uint32_t)'=' << 8) | t;
+                        if (h1) *(lds_u32*)(uintptr_t)slot_addr((before + q1) << 2) = opw | 1u;
+                        asm volatile("" ::: "memory");
+                        if (joins) (void)__hip_atomic_fetch_add((lds_u32*)(uintptr_t)slot_addr((before - 1u) << 2), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    placed += ln + ((6u >> e) & 1u);
+                    base += (uint32_t)__popcll(Q) + (uint32_t)__popcll(H);
+                    carry_b = (uint32_t)__builtin_amdgcn_readlane((int)b, 63);
+                }
+                force_other = carry_more | (chain >= 248u ? 1u : 0u);
+                // what the next side-by-side trip's first lane is handed: the length so far of the edit run that reaches this trip's end
+                carry_rp = carry_b > 63u ? ((chain + 1u) & 0xffu) * 0x01010101u : 0u;
+            } else {
+                // ---- runs started per byte (0..2), their inclusive prefix over the lane's bytes (<= 8 in the top byte), the lanes' prefix
+                const uint32_t e7 = Em >> 7;
+                const uint32_t R = e7 + (Hd >> 7);
+                const uint32_t P1 = qd_lshl_add(R, 8, R);                                                               // (as written: the optimiser makes
+                const uint32_t P = qd_lshl_add(P1, 16, P1);                                                             //  a quarter-rate v_mul_lo_u32 of the two)
+                const uint32_t c = P >> 24;
+                if (STORE) {
+                    const uint32_t incl = qd_wave_scan(c);
+                    // 4 x (index in the dense array of the first run this lane starts); 4 x the prefix within the lane, byte by byte
+                    const uint32_t i4 = (incl - c + (g0l + base)) << 2;
+                    const uint32_t P4 = P << 2;
+                    // ---- an edit byte's position in its run: a segmented count over the lane's bytes (byte k: E_k, + the count of byte
+                    // k - 1 if byte k joins, in two doubling steps), plus what the lane before hands over where bytes 0..k all join
+                    const uint32_t E1 = Ed >> 7;
+                    const uint32_t Jm = Jn | (Jn - (Jn >> 7));                                                          // 0xFF in the bytes that join
+                    const uint32_t v1 = qd_lshl_add(E1 & (Jm >> 8), 8, E1);
+                    const uint32_t f1 = Jm & (Jm << 8);
+                    const uint32_t v2 = qd_lshl_add(v1 & (f1 >> 16), 16, v1);
+                    const uint32_t g1 = Jm & qd_lshl_or(Jm, 8, 0xFFu);
+                    const uint32_t F = g1 & qd_lshl_or(g1, 16, 0xFFFFu);                                                // bytes 0..k all join
+                    const uint32_t B = __builtin_amdgcn_perm(v2, v2, 0x03030303u);                                      // the count of the lane's last byte, in all four
+                    const uint32_t prB = (uint32_t)__builtin_amdgcn_update_dpp((int)carry_rp, (int)B, 0x138, 0xf, 0xf, false);       // wave_shr:1
+                    const uint32_t RP = v2 + (F & prB);
+                    // an edit byte is the last of its run unless the byte after it joins (the last lane's last byte: as far as it knows)
+                    const uint32_t Jnx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)Jn, 0x130, 0xf, 0xf, false);       // wave_shl:1
+                    const uint32_t Tl = es_andn(Ed, __builtin_amdgcn_alignbit(Jnx, Jn, 8));
+                    // what the bytes write: matches '=' << 8 | t, the last byte of an edit run letter << 8 | its position
+                    const uint32_t EQL = qd_or_and(Em - e7, Em, 0x3D3D3D3Du);                                            // '=' in the bytes that have matches
+                    const uint32_t LET = __builtin_amdgcn_perm(0u, 0x44495800u, (x >> 6) & 0x03030303u);                 // "\0XID"[code]
+                    const uint32_t p0 = P4 & 0xffu, p1 = (P4 >> 8) & 0xffu, p2 = (P4 >> 16) & 0xffu, p3 = P4 >> 24;
+                    ring_put(i4, __builtin_amdgcn_perm(EQL, T, 0x0C0C0400u), Em, std::integral_constant<int, 7>{});
+                    ring_put(i4 + p0 - 4u, __builtin_amdgcn_perm(LET, RP, 0x0C0C0400u), Tl, std::integral_constant<int, 7>{});
+                    ring_put(i4 + p0, __builtin_amdgcn_perm(EQL, T, 0x0C0C0501u), Em, std::integral_constant<int, 15>{});
+                    ring_put(i4 + p1 - 4u, __builtin_amdgcn_perm(LET, RP, 0x0C0C0501u), Tl, std::integral_constant<int, 15>{});
+                    ring_put(i4 + p1, __builtin_amdgcn_perm(EQL, T, 0x0C0C0602u), Em, std::integral_constant<int, 23>{});
+                    ring_put(i4 + p2 - 4u, __builtin_amdgcn_perm(LET, RP, 0x0C0C0602u), Tl, std::integral_constant<int, 23>{});
+                    ring_put(i4 + p2, __builtin_amdgcn_perm(EQL, T, 0x0C0C0703u), Em, std::integral_constant<int, 31>{});
+                    ring_put(i4 + p3 - 4u, __builtin_amdgcn_perm(LET, RP, 0x0C0C0703u), Tl, std::integral_constant<int, 31>{});
+                    base += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                    carry_rp = ((uint32_t)__builtin_amdgcn_readlane((int)RP, 63) >> 24) * 0x01010101u;
+                } else {
+                    cnt_acc += c;
+                }
+                // read characters placed: the matches, and one per X or I (edit codes 1 and 2: bits 7 and 6 differ)
+                placed = __builtin_amdgcn_sad_u8(T, 0u, placed);
+                placed += (uint32_t)__builtin_popcount(((x >> 1) ^ x) & 0x40404040u);
+                // the bytes at the trip's end that join the run before them (never all four of lane 63: that is the other path) are
+                // counted when the other path is next entered; a chain that came in ended in this trip
+                last_jn = (uint32_t)__builtin_amdgcn_readlane((int)Jn, 63);
+                chain = 0;
+            }
+            carry_x = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+            if (STORE) {
+                // Every unit below the last run — which the next trip may still write — is final: at most 64 of them (7 + 512 runs), one
+                // per lane, ONE store instruction.  A unit that sticks out of the segment is not stored here: the pair's first unit is kept
+                // by lanes 0..7 (a slot each) for the end of the pair; a unit past a segment that is too small (the pair is reported) is dropped.
+                asm volatile("" ::: "memory");
+                const uint32_t u_lim = base != 0u ? (h + base - 1u) >> 3 : 0u;
+                const uint32_t lim = h + min(base, cap);
+                const uint32_t u = uf + lane;
+                const u32x4_t o = read_unit(u);
+                const uint64_t inside = __ballot(u < u_lim && 8u * u + 8u <= lim && 8u * u >= h);
+                uint16_t* const dst = dense_u + 8ull * u;
+                uint64_t exec_keep;
+                asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %1\n\tglobal_store_dwordx4 %2, %3, off nt\n\ts_mov_b64 exec, %0"
+                             : "=&s"(exec_keep) : "s"(inside), "v"(dst), "v"(o) : "memory", "scc");       // (s_and_b64 writes SCC)
+                if (uf == 0u && u_lim != 0u && h != 0u) {                                               // (uniform) unit 0 leaves the ring now
+                    head_w = *(const lds_u32*)(uintptr_t)slot_addr((8u * unit0 + (lane & 7u)) << 2);
+                    head_kept = true;
+                }
+                uf = max(uf, u_lim);
+                asm volatile("s_waitcnt vmcnt(1)" : "+v"(x_next));
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(x_next));
+            }
+            x = x_next;
+        }
+        // ---- the end of the pair
+        if (!STORE) base += qd_total(cnt_acc);
+        if (STORE) {
+            asm volatile("" ::: "memory");
+            // what has not left the ring goes out run by run, one run per lane: the pair's first unit where it was kept (lanes 0..7),
+            // and the at most two units from `uf` on — the last run's and the one before it (lanes 0..15)
+            const uint32_t lim = h + min(base, cap);
+            if (head_kept) {                                                                            // (uniform)
+                if (lane < 8u && lane >= h && lane < lim) dense_u[lane] = (uint16_t)head_w;
+            }
+            const uint32_t at = 8u * uf + lane;
+            if (lane < 16u && at >= h && at < lim)
+                dense_u[at] = (uint16_t)*(const lds_u32*)(uintptr_t)slot_addr((8u * unit0 + at) << 2);
+        }
+        // read characters placed, over all lanes (64 bits: a lane's share stays below 2^30, their sum may not)
+        const uint64_t tot = __any((placed >> 24) != 0u) ? (uint64_t)qd_total(placed & 0xffffu) + ((uint64_t)qd_total(placed >> 16) << 16)
+                                                         : (uint64_t)qd_total(placed);            // (64 lanes below 2^24: no overflow)
+        const bool ov = __any((over >> 8) != 0u) || over_s != 0u;
+        // the stream's last byte must be a window end: it sits in the last trip's dwords
+        const uint32_t last_byte = len ? ((uint32_t)__builtin_amdgcn_readlane((int)x_last, (int)(((len - 1u) & 255u) >> 2)) >> (8u * ((len - 1u) & 3u))) & 0xffu : 0u;
+        const bool clean = !bad && carry_more == 0u && (last_byte >> 6) == 0u && last_byte != EDIT_MORE && tot == (uint64_t)rl && !ov;
+        if (STORE) {
+            if (!clean || base != cap) n_bad++;
+        } else {
+            if (lane == 0u) a.n_runs[p] = clean ? base : 0xffffffffu;
+            if (!clean) n_bad++;
+        }
+    }
+    if (n_bad && lane == 0u) atomicAdd(a.bad, n_bad);
+}
+
 __global__ void iota_kernel(uint32_t* v, uint32_t n)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -469,17 +854,22 @@ __global__ void iota_kernel(uint32_t* v, uint32_t n)
 // Bits of the stream length the order is made from: 16-byte granularity, lengths up to 1 MB told apart.
 constexpr int DEC_SORT_BEGIN_BIT = 4, DEC_SORT_END_BIT = 20;
 
-// Which decoder a launch takes: one pair per wavefront for streams of 64 bytes and more on average (the size of the buffer over
-// the number of pairs), one pair per lane for shorter ones.  Measured, ms per launch, lane / wavefront (scripts/decode_timing.py
-// --read-len L --pairs n): 2 M x 150 bp (8 bytes per pair) 0.21 / 0.62, 2 M x 300 bp (14) 0.25 / 0.62, 200 k x 500 bp (67)
-// 0.115 / 0.078, 100 k x 1 kb (132) 0.124 / 0.053, 25 k x 4 kb (521) 0.240 / 0.039, 100 k x 10 kb (1 299) 0.82 / 0.30: a
-// pair of one chunk costs ~0.3 ns of the GPU's time, every further chunk ~0.15.  SCRG_DEC_KERNEL=lane|wave overrides (the tests run
-// both on the same inputs).
-bool decode_by_wavefront(uint64_t n_pairs, uint64_t stream_bytes)
+// Which decoder a launch takes: one pair per wavefront (decode_edits_quad_kernel, four bytes per lane) for streams of 64 bytes and
+// more on average (the size of the buffer over the number of pairs), one pair per lane for shorter ones.  Measured, ms per launch,
+// lane / wavefront-per-pair with one byte per lane (round 5; scripts/decode_timing.py --read-len L --pairs n): 2 M x 150 bp (8 bytes
+// per pair) 0.21 / 0.62, 2 M x 300 bp (14) 0.25 / 0.62, 200 k x 500 bp (67) 0.115 / 0.078, 100 k x 1 kb (132) 0.124 / 0.053,
+// 25 k x 4 kb (521) 0.240 / 0.039, 100 k x 10 kb (1 299) 0.82 / 0.30.  SCRG_DEC_KERNEL=lane|wave|quad overrides (the tests run all
+// three on the same inputs; `wave` is round 5's one-byte-per-lane kernel, kept as the independent formulation).
+int decode_kernel_choice(uint64_t n_pairs, uint64_t stream_bytes)          // 0: lane, 1: wave, 2: quad
 {
-    if (const char* e = getenv("SCRG_DEC_KERNEL")) return e[0] == 'w';
-    return n_pairs != 0 && stream_bytes / n_pairs >= 64u;
+    if (const char* e = getenv("SCRG_DEC_KERNEL")) {
+        if (e[0] == 'l') return 0;
+        if (e[0] == 'w') return 1;
+        if (e[0] == 'q') return 2;
+    }
+    return n_pairs != 0 && stream_bytes / n_pairs >= 64u ? 2 : 0;
 }
+bool decode_by_wavefront(uint64_t n_pairs, uint64_t stream_bytes) { return decode_kernel_choice(n_pairs, stream_bytes) != 0; }
 
 size_t decode_sort_temp_bytes(uint64_t n_pairs)
 {
@@ -505,12 +895,18 @@ hipError_t launch_decode_edits(uint64_t n_pairs, const uint8_t* d_stream, uint64
     DecodeArgs a{n_pairs, d_stream, stream_bytes, d_off, d_len, d_read_len, read_len_stride, d_dense_off, d_dense, dense_cap, d_n_runs, d_bad, order, together};
     // Which kernel (decode_by_wavefront; scripts/decode_timing.py, 10 kb reads: one slot of 100 k pairs 0.30 ms by wavefront
     // against 0.82 ms by lane — 1 563 lane-per-pair wavefronts leave the GPU half empty —, eight slots 2.26 against 2.40 ms)
-    if (decode_by_wavefront(n_pairs, stream_bytes)) {
+    const int choice = decode_kernel_choice(n_pairs, stream_bytes);
+    if (choice != 0) {
         const uint64_t want = n_pairs < 8192u ? (n_pairs + 3u) & ~3ull : 8192u;          // 8 wavefronts on every SIMD of an MI355X
         const uint32_t n_waves = (uint32_t)want;
         const dim3 grid(n_waves / 4u), block(256);
-        if (d_dense) hipLaunchKernelGGL(decode_edits_wave_kernel<true>, grid, block, 0, s, a, n_waves);
-        else hipLaunchKernelGGL(decode_edits_wave_kernel<false>, grid, block, 0, s, a, n_waves);
+        if (choice == 2) {
+            if (d_dense) hipLaunchKernelGGL(decode_edits_quad_kernel<true>, grid, block, 0, s, a, n_waves);
+            else hipLaunchKernelGGL(decode_edits_quad_kernel<false>, grid, block, 0, s, a, n_waves);
+        } else {
+            if (d_dense) hipLaunchKernelGGL(decode_edits_wave_kernel<true>, grid, block, 0, s, a, n_waves);
+            else hipLaunchKernelGGL(decode_edits_wave_kernel<false>, grid, block, 0, s, a, n_waves);
+        }
         return hipGetLastError();
     }
     if (sort_ws && n_pairs < 0x7fffffffull) {

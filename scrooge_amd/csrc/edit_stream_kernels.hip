@@ -69,7 +69,9 @@ __global__ __launch_bounds__(256) void encode_edits_kernel(uint64_t n_pairs, uin
     base = __shfl(base, 0, 64);
     if (!valid) return;
     const uint64_t at = base + incl - mine;
-    const bool fits = !bad_op && bytes <= stream_cap && at <= stream_cap - mine;
+    // (`mine`, not `bytes`, is what walk 2 stores — whole dwords — and what is subtracted: with a capacity that is not a multiple of 4 and
+    // bytes in (cap - 3, cap] the difference stream_cap - mine would wrap and the pair "fit" anywhere)
+    const bool fits = !bad_op && mine <= stream_cap && at <= stream_cap - mine;
     off[p] = fits ? at : ~0ull;
     len[p] = bytes > 0xffffffffull ? 0xffffffffu : (uint32_t)bytes;
     if (!fits) atomicAdd(reinterpret_cast<unsigned long long*>(total + 1), 1ull);

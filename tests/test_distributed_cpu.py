@@ -355,3 +355,150 @@ def test_bench_self_launch_ends_a_stalled_job():
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 124 and 30 < time.time() - t0 < 150
     assert "did not finish within --deadline 2 s (+30): ending its process group" in out.stderr
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Rehearsal at world sizes 4 and 8 (round 6): the first execution of this logic on eight ranks must not be the driver's run
+# on hardware.  Same classes, same calls as bench.py's N > 1 step; gloo through the host.
+
+def _spawn(world, target, extra=(), timeout=170):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port, q) + tuple(extra)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        got = [q.get(timeout=timeout) for _ in range(world)]
+    finally:
+        for p in procs:
+            p.join(60)
+    assert [p.exitcode for p in procs] == [0] * world
+    return dict(got)
+
+
+def _rank_streams(rank, k, n):
+    """What rank `rank` "aligned" in step k: n streams of lengths that differ by rank, step and pair (some empty); the bytes say
+    who wrote them."""
+    lens = [(7 * rank + 3 * k + 5 * i) % 23 for i in range(n)]
+    return [bytes(((rank << 4) | ((k + i + j) & 15)) for j in range(l)) for i, l in enumerate(lens)]
+
+
+def _worker_wide(rank, world, port, q, dst, depth, steps):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = 5
+        cap = n * 24
+        g = sd.EditStreamGather(n, cap, torch.device("cpu"), dst=dst, depth=depth, ordered=True, total_runs=n * 40)
+        assert g.DEPTH == depth
+        seen = {}
+
+        def look(k):
+            if g.root_of(k) != rank:
+                return
+            per = []
+            for r in range(world):
+                v = g.results(k, r)
+                raw = bytes(v["stream"].tolist())
+                per.append((v["ed"].tolist(), [raw[o: o + l] for o, l in zip(v["off"].tolist(), v["len"].tolist())], v["cnt"].tolist()))
+            seen[k] = per
+
+        for k in range(steps):
+            if k >= depth:
+                g.finish(k)                                 # the buffers of step k - depth are free again ...
+            else:
+                g.finish(k)
+            v = g.buffers(k)
+            at = 0
+            for i, s in enumerate(_rank_streams(rank, k, n)):
+                v["len"][i] = len(s)
+                v["cnt"][i] = len(s) + rank
+                if s:
+                    v["stream"][at: at + len(s)] = torch.frombuffer(bytearray(s), dtype=torch.uint8)
+                at += (len(s) + 3) // 4 * 4
+            g.start(k, torch.tensor([1000 * rank + 10 * k + i for i in range(n)], dtype=torch.int64))
+            if k >= depth - 1:
+                g.finish(k + 1)                             # ... which is when step k - depth + 1's results are complete and still there
+                look(k - depth + 1)
+        g.finish_all()
+        for k in range(max(0, steps - depth + 1), steps):
+            look(k)
+        q.put((rank, seen))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(240)
+@pytest.mark.parametrize("world,dst,depth", [(8, "rotate", 2), (8, "rotate", 4), (8, 0, 4), (4, "rotate", 4), (4, 0, 2)])
+def test_edit_stream_gather_at_four_and_eight_ranks(world, dst, depth):
+    """EditStreamGather as bench.py drives it — `depth` steps in flight, root fixed or rotating — on 4 and 8 ranks: every step's
+    root ends up with every rank's scores, stream lengths, run counts and stream bytes of THAT step (ragged, some empty), looked
+    at when the step's buffers are the oldest still alive, exactly as the decode of bench.py does."""
+    steps = 2 * world + 3
+    got = _spawn(world, _worker_wide, (dst, depth, steps))
+    n = 5
+    checked = 0
+    for k in range(steps):
+        root = k % world if dst == "rotate" else 0
+        for rank in range(world):
+            if rank != root:
+                assert k not in got[rank], (rank, k)
+        per = got[root][k]
+        for r in range(world):
+            ed, streams, cnt = per[r]
+            want = _rank_streams(r, k, n)
+            assert ed == [1000 * r + 10 * k + i for i in range(n)] and streams == want and cnt == [len(s) + r for s in want], (k, r)
+            checked += 1
+    assert checked == steps * world
+
+
+def _worker_sharded_wide(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        T, Q = _batch()
+        T, Q = T * 3, Q * 3                                  # 33 pairs over 8 ranks: shards of 5 and 4, ragged lengths, empty reads
+        res = sd.align_pairs_sharded(OracleAligner(), T, Q, dst=0)
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(240)
+def test_eight_rank_gather_restores_input_order():
+    got = _spawn(8, _worker_sharded_wide)
+    T, Q = _batch()
+    want = OracleAligner().align_pairs(T * 3, Q * 3)
+    assert got[0] == want and all(got[r] is None for r in range(1, 8))
+
+
+def test_shard_plan_unequal_at_eight():
+    rng = np.random.Generator(np.random.PCG64(3))
+    lens = rng.integers(0, 20000, 1003).tolist()
+    plan = sd.shard_plan(lens, 8)
+    assert sorted(int(i) for p in plan for i in p) == list(range(1003))
+    sizes = [len(p) for p in plan]
+    assert max(sizes) - min(sizes) <= 1                       # round-robin after the length sort
+    sums = [sum(lens[int(i)] for i in p) for p in plan]
+    assert max(sums) - min(sums) <= max(lens)
+
+
+@pytest.mark.timeout(300)
+def test_bench_eight_ranks_stalled_job_ends_within_the_deadline():
+    """`python bench.py --gpus 8` whose eight ranks stall: every rank's watchdog ends it with code 124 and the job ends well inside
+    deadline + 30 s — on eight ranks as on two (the driver's 8-GPU run has a budget; a hang must not consume it)."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SCRG_BENCH_DRYRUN="1", SCRG_BENCH_TEST_STALL="1")
+    env.pop("WORLD_SIZE", None)
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--no-build", "--deadline", "6"], env=env, cwd=root,
+                         capture_output=True, text=True, timeout=280)
+    assert out.returncode != 0 and time.time() - t0 < 150
+    assert out.stderr.count("still running after --deadline 6 s") >= 1
+    assert not [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]

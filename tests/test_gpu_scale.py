@@ -621,7 +621,7 @@ def test_packed_runs_round_trip(aligner, oracle):
         aligner.use_own_stream()
 
 
-@pytest.mark.parametrize("dec_kernel", ["lane", "wave"])
+@pytest.mark.parametrize("dec_kernel", ["lane", "wave", "quad"])
 @pytest.mark.parametrize("W,O", [(64, 33), (64, 2), (40, 9), (128, 65), (200, 50), (256, 1), (256, 129), (192, 97), (128, 20)])
 def test_edit_stream_round_trip(aligner, oracle, W, O, dec_kernel, monkeypatch):
     """(Both decoders — one pair per lane, one pair per wavefront: edit_stream_decode_kernel.hip — on the same streams.)
@@ -762,6 +762,19 @@ def test_edit_stream_round_trip(aligner, oracle, W, O, dec_kernel, monkeypatch):
         assert missing > 0 and sum(1 for o in oh2 if o == -1) == missing and s_len.cpu().tolist() == lh
         sm = small.cpu().numpy().tobytes()
         assert all(sm[o: o + l] == w for o, l, w in zip(oh2, lh, want) if o != -1)
+        # capacities that are not multiples of 4: a stream is stored as whole dwords, so a pair whose bytes
+        # fit but whose dwords do not is "did not fit" — and nothing is ever written past the capacity handed over
+        k0 = max(range(n), key=lambda k: lh[k])
+        for capb in [c for c in range(max(lh[k0] - 5, 1), lh[k0] + 6) if c % 4]:
+            guard = torch.full((capb + 4096 + 64,), 0xAB, dtype=torch.uint8, device=dev)
+            aligner.encode_edit_stream(1, desc[k0:k0 + 1].contiguous(), runs, nr[k0:k0 + 1].contiguous(), guard[:capb], s_off, s_len, tot, W=W, O=O)
+            torch.cuda.synchronize()
+            gh = guard.cpu().numpy().tobytes()
+            assert gh[capb:] == b"\xab" * (4096 + 64), capb
+            fits = (lh[k0] + 3) // 4 * 4 <= capb
+            assert (int(s_off[0].item()) == 0) == fits and int(tot[1].item()) == (0 if fits else 1), capb
+            if fits:
+                assert gh[:lh[k0]] == want[k0], capb
     finally:
         aligner.use_own_stream()
 
@@ -879,7 +892,7 @@ def test_host_results_grow_while_chunks_arrive(aligner, oracle, order):
         assert "".join("%d%s" % (int(c), chr(int(o))) for c, o in runs[ro[i]:ro[i + 1]]) == cigars[i]
 
 
-@pytest.mark.parametrize("dec_kernel", ["lane", "wave"])
+@pytest.mark.parametrize("dec_kernel", ["lane", "wave", "quad"])
 def test_decode_large_launch_stores_pieces_together(aligner, dec_kernel, monkeypatch):
     """(dec_kernel: lane — the store form this test is named after — and wave: the decoder such a launch takes by itself,
     every wavefront a queue of pairs.)
@@ -948,7 +961,7 @@ def test_decode_large_launch_stores_pieces_together(aligner, dec_kernel, monkeyp
         aligner.use_own_stream()
 
 
-@pytest.mark.parametrize("dec_kernel", ["lane", "wave"])
+@pytest.mark.parametrize("dec_kernel", ["lane", "wave", "quad"])
 def test_decode_two_runs_per_step_fills_the_ring(aligner, dec_kernel, monkeypatch):
     """(dec_kernel: the lane-per-pair decoder, whose ring this is about, and the wavefront-per-pair one, for which the same
     streams are runs of up to 64 heads per chunk and edit runs that stay open over many chunks.)
