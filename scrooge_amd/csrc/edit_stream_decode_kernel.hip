@@ -600,12 +600,15 @@ __global__ __launch_bounds__(256) void decode_edits_quad_kernel(DecodeArgs a, ui
         const uint8_t* const src4 = a.stream + (off - delta);
         const uint32_t last_dw = len ? (delta + len - 1u) & ~3u : 0u;
         uint32_t base = 0;                   // runs so far
-        uint32_t carry_x = 0;                // the dword in front of the trip's first (its top byte: the byte before lane 0's first)
-        uint32_t carry_rp = 0;               // x 0x01010101: the length so far of the edit run that reaches the end of the trip before (0: none does)
+        // what a trip hands to the next one stays in VECTOR registers (lane 0 holds what the trip's last lane had: one DPP
+        // wave_ror:1, and it is the `old` operand of the next trip's wave_shr:1): a scalar round trip (v_readlane, s_mul, v_mov)
+        // costs the scalar unit, which all of a CU's wavefronts share
+        uint32_t cx_v = 0;                   // (lane 0) the dword in front of the trip's first (its top byte: the byte before lane 0's first)
+        uint32_t crp_v = 0;                  // (lane 0) x 0x01010101: the length so far of the edit run that reaches the end of the trip before (0: none does)
+        uint32_t jn_prev = 0;                // Jn of the side-by-side trip before (its last lane's top bytes continue the chain); 0 after a per-byte trip
         uint32_t carry_more = 0;             // matches of the 0x3F bytes the trip before ended with
-        uint32_t chain = 0;                  // bytes in a row, up to the end of the trip before, that join the edit run before them (+ last_jn's)
-        uint32_t last_jn = 0;                // Jn of the last lane of a side-by-side trip (its top bytes continue the chain)
-        uint32_t force_other = 0;            // 0x3F matches pending, or a chain that is getting long: the next trip takes the per-byte path
+        uint32_t chain = 0;                  // bytes in a row, up to the end of the trip before, that join the edit run before them (+ jn_prev's)
+        uint64_t force_other = 0;            // (0 / ~0) 0x3F matches pending, or a chain that is getting long: the next trip takes the per-byte path
         uint32_t over_s = 0;                 // (uniform) an edit run longer than 255
         uint32_t placed = 0, over = 0;       // (per lane) read characters placed; bits 8..: a run of matches longer than 255
         uint32_t cnt_acc = 0;                // (per lane, count only) runs started
@@ -619,7 +622,8 @@ __global__ __launch_bounds__(256) void decode_edits_quad_kernel(DecodeArgs a, ui
         uint16_t* const dense_u = STORE ? a.dense + (g0 - h) : nullptr;     // position 0
         uint32_t uf = 0;
         uint32_t head_w = 0;                                                // (lanes 0..7) the slots of the pair's first unit, if the pair starts inside one: stored when the pair ends
-        bool head_kept = false;                                             // (uniform)
+        bool head_kept = false, head_pending = h != 0u;                     // (uniform)
+        const uint32_t unit_first = h != 0u ? 1u : 0u, unit_stop = (h + cap) >> 3;
         auto read_unit = [&](uint32_t u) -> u32x4_t {
             const uint32_t rd = ring_b + (((unit0 + u) & (QD_RING / 8u - 1u)) << 5);
             const u32x4_t w0 = *(const lds_u32x4*)(uintptr_t)rd, w1 = *(const lds_u32x4*)(uintptr_t)(rd + 16u);
@@ -663,7 +667,7 @@ __global__ __launch_bounds__(256) void decode_edits_quad_kernel(DecodeArgs a, ui
             uint32_t x_next = load_x_async(c0 + 256u);                                                  // (behind the stream: its last dword again — never used)
             x_last = x;
             // ---- the four bytes side by side.  Bit 7 of byte k of ...
-            const uint32_t px = (uint32_t)__builtin_amdgcn_update_dpp((int)carry_x, (int)x, 0x138, 0xf, 0xf, false);    // wave_shr:1; lane 0: the trip before
+            const uint32_t px = (uint32_t)__builtin_amdgcn_update_dpp((int)cx_v, (int)x, 0x138, 0xf, 0xf, false);       // wave_shr:1; lane 0: the trip before
             const uint32_t pv = __builtin_amdgcn_alignbit(x, px, 24);                               // byte k: the byte before byte k
             const uint32_t T = x & 0x3F3F3F3Fu;                                                     // the matches in front
             const uint32_t Em = (T + 0x7F7F7F7Fu) & 0x80808080u;                                    // ... Em: there are matches (a run of '=')
@@ -674,13 +678,13 @@ __global__ __launch_bounds__(256) void decode_edits_quad_kernel(DecodeArgs a, ui
             const uint32_t Hd = nz & Ed;                                                            // ... Hd: an edit that starts a run
             const uint32_t Jn = es_andn(Ed, nz);                                                    // ... Jn: an edit that joins the run before it
             const uint32_t More = es_a_nb_c(T + 0x41414141u, Ed, 0x80808080u);                      // ... More: the byte is 0x3F
-            const uint64_t trigger = __ballot(More != 0u) | __ballot(Jn == 0x80808080u);
-            if (trigger != 0ull || force_other != 0u) {
+            const uint64_t trigger = __ballot(More != 0u) | __ballot(Jn == 0x80808080u) | force_other;
+            if (trigger != 0ull) {
                 // ---- one byte per lane, four times (see the head of the kernel)
-                uint32_t carry_b = carry_x >> 24;
+                uint32_t carry_b = (uint32_t)__builtin_amdgcn_readfirstlane((int)cx_v) >> 24;
                 // (after a side-by-side trip the chain is what joins at that trip's very end: the top bytes of its last lane's Jn)
-                chain += (uint32_t)__builtin_clz(~(last_jn | 0x7F7F7F7Fu) | 1u) >> 3;
-                last_jn = 0;
+                chain += (uint32_t)__builtin_clz(~((uint32_t)__builtin_amdgcn_readlane((int)jn_prev, 63) | 0x7F7F7F7Fu) | 1u) >> 3;
+                jn_prev = 0;
                 uint32_t b = 0;
 #pragma unroll 1
                 for (uint32_t sub = 0; sub < 4u; sub++) {
@@ -733,9 +737,9 @@ __global__ __launch_bounds__(256) void decode_edits_quad_kernel(DecodeArgs a, ui
                     base += (uint32_t)__popcll(Q) + (uint32_t)__popcll(H);
                     carry_b = (uint32_t)__builtin_amdgcn_readlane((int)b, 63);
                 }
-                force_other = carry_more | (chain >= 248u ? 1u : 0u);
+                force_other = (carry_more != 0u || chain >= 248u) ? ~0ull : 0ull;
                 // what the next side-by-side trip's first lane is handed: the length so far of the edit run that reaches this trip's end
-                carry_rp = carry_b > 63u ? ((chain + 1u) & 0xffu) * 0x01010101u : 0u;
+                crp_v = carry_b > 63u ? ((chain + 1u) & 0xffu) * 0x01010101u : 0u;
             } else {
                 // ---- runs started per byte (0..2), their inclusive prefix over the lane's bytes (<= 8 in the top byte), the lanes' prefix
                 const uint32_t e7 = Em >> 7;
@@ -758,7 +762,7 @@ __global__ __launch_bounds__(256) void decode_edits_quad_kernel(DecodeArgs a, ui
                     const uint32_t g1 = Jm & qd_lshl_or(Jm, 8, 0xFFu);
                     const uint32_t F = g1 & qd_lshl_or(g1, 16, 0xFFFFu);                                                // bytes 0..k all join
                     const uint32_t B = __builtin_amdgcn_perm(v2, v2, 0x03030303u);                                      // the count of the lane's last byte, in all four
-                    const uint32_t prB = (uint32_t)__builtin_amdgcn_update_dpp((int)carry_rp, (int)B, 0x138, 0xf, 0xf, false);       // wave_shr:1
+                    const uint32_t prB = (uint32_t)__builtin_amdgcn_update_dpp((int)crp_v, (int)B, 0x138, 0xf, 0xf, false);          // wave_shr:1; lane 0: the trip before
                     const uint32_t RP = v2 + (F & prB);
                     // an edit byte is the last of its run unless the byte after it joins (the last lane's last byte: as far as it knows)
                     const uint32_t Jnx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)Jn, 0x130, 0xf, 0xf, false);       // wave_shl:1
@@ -776,7 +780,7 @@ __global__ __launch_bounds__(256) void decode_edits_quad_kernel(DecodeArgs a, ui
                     ring_put(i4 + p2, __builtin_amdgcn_perm(EQL, T, 0x0C0C0703u), Em, std::integral_constant<int, 31>{});
                     ring_put(i4 + p3 - 4u, __builtin_amdgcn_perm(LET, RP, 0x0C0C0703u), Tl, std::integral_constant<int, 31>{});
                     base += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                    carry_rp = ((uint32_t)__builtin_amdgcn_readlane((int)RP, 63) >> 24) * 0x01010101u;
+                    crp_v = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)B, 0x13C, 0xf, 0xf, false);                              // wave_ror:1: lane 0 <- the last lane
                 } else {
                     cnt_acc += c;
                 }
@@ -785,29 +789,34 @@ __global__ __launch_bounds__(256) void decode_edits_quad_kernel(DecodeArgs a, ui
                 placed += (uint32_t)__builtin_popcount(((x >> 1) ^ x) & 0x40404040u);
                 // the bytes at the trip's end that join the run before them (never all four of lane 63: that is the other path) are
                 // counted when the other path is next entered; a chain that came in ended in this trip
-                last_jn = (uint32_t)__builtin_amdgcn_readlane((int)Jn, 63);
+                jn_prev = Jn;
                 chain = 0;
             }
-            carry_x = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+            cx_v = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x13C, 0xf, 0xf, false);                                        // wave_ror:1: lane 0 <- the last lane
             if (STORE) {
                 // Every unit below the last run — which the next trip may still write — is final: at most 64 of them (7 + 512 runs), one
                 // per lane, ONE store instruction.  A unit that sticks out of the segment is not stored here: the pair's first unit is kept
                 // by lanes 0..7 (a slot each) for the end of the pair; a unit past a segment that is too small (the pair is reported) is dropped.
                 asm volatile("" ::: "memory");
-                const uint32_t u_lim = base != 0u ? (h + base - 1u) >> 3 : 0u;
-                const uint32_t lim = h + min(base, cap);
+                // (signed: no run yet and h = 0 make u_lim -1; units [u_first, u_stop) are stored: from the first unit that lies wholly in
+                // the segment — unit 1 when the pair starts inside unit 0 — to the last unit wholly below the segment's end)
+                const int32_t u_lim = (int32_t)(h + base - 1u) >> 3;
                 const uint32_t u = uf + lane;
                 const u32x4_t o = read_unit(u);
-                const uint64_t inside = __ballot(u < u_lim && 8u * u + 8u <= lim && 8u * u >= h);
+                const int32_t u_first = max((int32_t)uf, (int32_t)unit_first), u_stop = min(u_lim, (int32_t)unit_stop);
+                const uint64_t inside = __ballot(u - (uint32_t)u_first < (uint32_t)max(u_stop - u_first, 0));
                 uint16_t* const dst = dense_u + 8ull * u;
                 uint64_t exec_keep;
                 asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %1\n\tglobal_store_dwordx4 %2, %3, off nt\n\ts_mov_b64 exec, %0"
                              : "=&s"(exec_keep) : "s"(inside), "v"(dst), "v"(o) : "memory", "scc");       // (s_and_b64 writes SCC)
-                if (uf == 0u && u_lim != 0u && h != 0u) {                                               // (uniform) unit 0 leaves the ring now
-                    head_w = *(const lds_u32*)(uintptr_t)slot_addr((8u * unit0 + (lane & 7u)) << 2);
-                    head_kept = true;
+                if (head_pending) {                                                                     // (uniform) the pair starts inside unit 0 ...
+                    if (u_lim > 0) {                                                                    // ... which leaves the ring now
+                        head_w = *(const lds_u32*)(uintptr_t)slot_addr((8u * unit0 + (lane & 7u)) << 2);
+                        head_kept = true;
+                        head_pending = false;
+                    }
                 }
-                uf = max(uf, u_lim);
+                uf = (uint32_t)max((int32_t)uf, u_lim);
                 asm volatile("s_waitcnt vmcnt(1)" : "+v"(x_next));
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" : "+v"(x_next));
