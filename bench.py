@@ -80,6 +80,10 @@ def parse():
     ap.add_argument("--sustained-steps", type=int, default=600,
                     help="N = 1: after the timed region, time this many more pipelined steps for the 'sustained' field (0 = skip)")
     ap.add_argument("--streams", type=int, default=4, help="pipeline depth: consecutive steps rotate over this many streams/handles")
+    ap.add_argument("--gather-depth", type=int, default=8,
+                    help="N > 1: buffer sets of the gather (a step's send / receive buffers are reused this many steps later: by then its "
+                         "transfer and, on its root, the decoding must be over; at 4 — the number of align lanes — a step waited for the "
+                         "transfer of the step four before it)")
     ap.add_argument("--other-configs", default="auto", choices=["auto", "on", "off"],
                     help="after the timed region, also measure BASELINE configs[0] (4 M x 150 bp), configs[2] (read mapping, 1 M reads x 4 "
                          "candidates on a 100 Mbp chromosome) and configs[4] (40 k x 50 kb PacBio-error pairs), each with an oracle-checked sample; "
@@ -335,6 +339,7 @@ def main():
     al.set_stream(torch.cuda.current_stream().cuda_stream)
     stats_pipelined = args.stats and os.environ.get("SCRG_BENCH_STATS_PIPELINED") == "1"     # counters of one launch among overlapping ones
     n_lanes = 1 if (args.serial or (args.stats and not stats_pipelined) or args.ablate) else max(1, args.streams)      # software pipeline depth over streams
+    gather_depth = max(2, n_lanes, args.gather_depth)
     kw = {}
     if args.lanes:
         kw["lanes_per_pair"] = args.lanes
@@ -491,14 +496,14 @@ def main():
                 del tmp, t_off
             del t_len
         gather = EditStreamGather(n, stream_bytes, device, dst="rotate" if args.gather_root == "rotate" else 0,
-                                  depth=max(2, n_lanes), ordered=gather_format == "edits",
+                                  depth=gather_depth, ordered=gather_format == "edits",
                                   total_runs=max(totals) if gather_format == "edits" else None)
         gather.prime()                               # (set-up: connections to every root exist before anything is timed)
         # the root's decoder: a handle of its own (its stream is the gather's decode stream), one read length for all pairs
         decode_on = gather_format == "edits" and not args.no_decode
         if decode_on:
             # (one handle per buffer set of the gather: the decode launches of consecutive steps run side by side)
-            decoders = [scrooge_amd.Aligner(local_rank) for _ in range(max(2, n_lanes))]
+            decoders = [scrooge_amd.Aligner(local_rank) for _ in range(gather_depth)]
             for d_ in decoders:
                 d_.params = al.params
             decode_args = (decoders, rl_all, 1, dict(kw)) if share_on else (decoders, torch.tensor([L], dtype=torch.int64, device=device), 0, dict(kw))
@@ -779,7 +784,7 @@ def main():
             rl_p = torch.zeros((world, n), dtype=torch.int64, device=device)
             rl_p[0, :real0] = L
             rl_p[1:, :real_other] = L
-            g_ = EditStreamGather(n, sb_full, device, dst=root, depth=max(2, n_lanes), ordered=True, total_runs=rt_full)
+            g_ = EditStreamGather(n, sb_full, device, dst=root, depth=gather_depth, ordered=True, total_runs=rt_full)
             g_.prime()
             keep = dict(cur)
             cur.update(fmt="edits", gather=g_, descs=descs_p, decode_args=(decoders, rl_p.reshape(-1), 1, dict(kw)))

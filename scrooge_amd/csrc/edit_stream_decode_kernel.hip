@@ -470,14 +470,14 @@ __global__ __launch_bounds__(256) void decode_edits_wave_kernel(DecodeArgs a, ui
 //     byte before and has no match in front" are bit 7 of each byte), the byte before a lane's first comes over DPP;
 //   * the runs a lane starts (0..8) are counted by two shift-adds, their indices in the pair come from ONE wavefront scan
 //     (six DPP adds) on top of a scalar — no ballot, no popcount;
-//   * every run is WRITTEN ONCE into a ring of 32-bit slots in LDS (1024 per wavefront, slot = the run's index in the dense
+//   * every run is WRITTEN ONCE into a ring of 16-bit slots in LDS (1024 per wavefront, slot = the run's index in the dense
 //     output array modulo 1024): a stretch of matches by its byte, an edit run by its LAST byte — the one the byte after does
 //     not join — whose position in the run is the run's length: a segmented count over the lane's four bytes (two shift-adds)
 //     plus, where the run began in the lane before, that lane's count (DPP; a lane whose four bytes ALL join takes the other
 //     path, so the hand-over never chains).  The last byte of a trip writes as far as it knows; if the next trip's first bytes
 //     join that run, their last one writes the slot again.  A byte that writes nothing writes to a per-lane slot nobody reads
 //     (an address select by v_bitop3, no predication, no branch);
-//   * the ring leaves in aligned 16-byte UNITS of eight runs, one unit per lane and trip (two ds_read_b128, four v_perm to pack,
+//   * the ring leaves in aligned 16-byte UNITS of eight runs, one unit per lane and trip (one ds_read_b128,
 //     ONE 16-byte store instruction per trip, 1 KB per wavefront, fully coalesced — a fixed number of memory instructions per
 //     trip, so the wait for the next trip's dword does not wait for this trip's stores); only the last run stays behind (the
 //     next trip may still write it), and the units a pair shares with its neighbours in the dense array (its first and its
@@ -491,9 +491,12 @@ __global__ __launch_bounds__(256) void decode_edits_wave_kernel(DecodeArgs a, ui
 // row with no match between them, dword-aligned: ~1e-4 of the trips at 10 % error) — which is also where a run longer than 255
 // is noticed, by counting the bytes in a row that join (`chain`).  tests/tools/quad_decoder_model.py is this arithmetic lane by
 // lane in numpy; tests/test_quad_decoder_model.py holds it to the format's definition on the CPU.
-constexpr uint32_t QD_RING = 1024;                      // run slots (dwords) per wavefront: <= 7 waiting for their unit + the last run + 512 a trip
-constexpr uint32_t QD_RING_BYTES = 4u * QD_RING;
-constexpr uint32_t QD_WAVE_LDS = QD_RING_BYTES + 256u;  // + a slot per lane for the bytes that write nothing
+constexpr uint32_t QD_RING = 1024;                      // run slots (16 bits: a scrg_run) per wavefront: <= 7 waiting for their unit + the last run + 512 a trip
+constexpr uint32_t QD_RING_BYTES = 2u * QD_RING;
+constexpr uint32_t QD_WAVE_LDS = QD_RING_BYTES + 256u;  // + a dword per lane for the bytes that write nothing
+// (9 KB per workgroup of four wavefronts: on the root of an N > 1 job this kernel runs beside the align kernel, whose four workgroups
+// per CU hold 147 of the CU's 160 KB — a decoder workgroup of 17 KB, as with 32-bit slots, only started where an align workgroup
+// had ended, and the two kernels took turns instead of sharing the CUs)
 
 template <int SH>
 __device__ __forceinline__ uint32_t qd_lshl_add_t(uint32_t a, uint32_t c)
@@ -534,8 +537,9 @@ __device__ __forceinline__ uint32_t qd_total(uint32_t v)         // the sum over
 template <bool STORE>
 __global__ __launch_bounds__(256) void decode_edits_quad_kernel(DecodeArgs a, uint32_t n_waves)
 {
-    __shared__ __attribute__((aligned(4096))) uint32_t ring_all[STORE ? 4 * (QD_WAVE_LDS / 4u) : 32];      // (a slot's address is slot offset | ring base: the four rings first)
+    __shared__ __attribute__((aligned(4 * QD_RING_BYTES))) uint32_t ring_all[STORE ? 4 * (QD_WAVE_LDS / 4u) : 32];      // (a slot's address is slot offset | ring base: the four rings first)
     typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    typedef __attribute__((address_space(3))) uint16_t lds_u16;
     typedef __attribute__((address_space(3))) u32x4_t lds_u32x4;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
@@ -545,13 +549,13 @@ __global__ __launch_bounds__(256) void decode_edits_quad_kernel(DecodeArgs a, ui
     const uint32_t dump_b = lds0 + (STORE ? 4u * QD_RING_BYTES + wave * 256u + lane * 4u : 0u);
     auto uni32 = [](uint32_t v) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
     auto uni64 = [&](uint64_t v) -> uint64_t { return ((uint64_t)uni32((uint32_t)(v >> 32)) << 32) | uni32((uint32_t)v); };
-    // LDS address of run slot `slot4 / 4` (slot4: 4 x the run's index in the dense array; any value, taken modulo the ring)
-    auto slot_addr = [&](uint32_t slot4) -> uint32_t { return __builtin_amdgcn_bitop3_b32(slot4, QD_RING_BYTES - 4u, ring_b, 0xEA); };      // (slot4 & mask) | ring_b
+    // LDS address of run slot `slot2 / 2` (slot2: 2 x the run's index in the dense array; any value, taken modulo the ring)
+    auto slot_addr = [&](uint32_t slot2) -> uint32_t { return __builtin_amdgcn_bitop3_b32(slot2, QD_RING_BYTES - 2u, ring_b, 0xEA); };      // (slot2 & mask) | ring_b
     // `value` to that slot where bit `BIT` of `flags` is set, to the lane's own dump slot where it is not
-    auto ring_put = [&](uint32_t slot4, uint32_t value, uint32_t flags, auto bit_tag) {
+    auto ring_put = [&](uint32_t slot2, uint32_t value, uint32_t flags, auto bit_tag) {
         constexpr int BIT = decltype(bit_tag)::value;
         const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)flags, BIT, 1);                       // 0 / ~0
-        *(lds_u32*)(uintptr_t)__builtin_amdgcn_bitop3_b32(slot_addr(slot4), dump_b, m, 0xE4) = value;  // (a & m) | (b & ~m)
+        *(lds_u16*)(uintptr_t)__builtin_amdgcn_bitop3_b32(slot_addr(slot2), dump_b, m, 0xE4) = (uint16_t)value;  // (a & m) | (b & ~m)
     };
     uint32_t n_bad = 0;                                          // (uniform)
     // A pair's five numbers (every lane loads the same addresses; made scalars where they are used) are asked for while the pair
@@ -625,14 +629,7 @@ __global__ __launch_bounds__(256) void decode_edits_quad_kernel(DecodeArgs a, ui
         bool head_kept = false, head_pending = h != 0u;                     // (uniform)
         const uint32_t unit_first = h != 0u ? 1u : 0u, unit_stop = (h + cap) >> 3;
         auto read_unit = [&](uint32_t u) -> u32x4_t {
-            const uint32_t rd = ring_b + (((unit0 + u) & (QD_RING / 8u - 1u)) << 5);
-            const u32x4_t w0 = *(const lds_u32x4*)(uintptr_t)rd, w1 = *(const lds_u32x4*)(uintptr_t)(rd + 16u);
-            u32x4_t o;
-            o.x = __builtin_amdgcn_perm(w0.y, w0.x, 0x05040100u);                             // low halves of two slots
-            o.y = __builtin_amdgcn_perm(w0.w, w0.z, 0x05040100u);
-            o.z = __builtin_amdgcn_perm(w1.y, w1.x, 0x05040100u);
-            o.w = __builtin_amdgcn_perm(w1.w, w1.z, 0x05040100u);
-            return o;
+            return *(const lds_u32x4*)(uintptr_t)(ring_b + (((unit0 + u) & (QD_RING / 8u - 1u)) << 4));
         };
         // The trip loop asks for the next trip's dwords at its top and stores this trip's units at its bottom.  Loads and stores
         // share one counter (vmcnt) and complete in order; the compiler, which cannot know whether the (predicated) store of a
@@ -728,10 +725,13 @@ __global__ __launch_bounds__(256) void decode_edits_quad_kernel(DecodeArgs a, ui
                         const uint32_t q1 = t != 0u ? 1u : 0u, h1 = (is_edit && !joins) ? 1u : 0u;
                         const uint32_t opw = ((0x44495800u >> ((e << 3) & 31u)) & 0xffu) << 8;
                         // matches and heads are written, then the joining bytes add 1 each (LDS operations of a wavefront run in order)
-                        if (q1) *(lds_u32*)(uintptr_t)slot_addr(before << 2) = ((uint32_t)'=' << 8) | t;
-                        if (h1) *(lds_u32*)(uintptr_t)slot_addr((before + q1) << 2) = opw | 1u;
+                        if (q1) *(lds_u16*)(uintptr_t)slot_addr(before << 1) = (uint16_t)(((uint32_t)'=' << 8) | t);
+                        if (h1) *(lds_u16*)(uintptr_t)slot_addr((before + q1) << 1) = (uint16_t)(opw | 1u);
                         asm volatile("" ::: "memory");
-                        if (joins) (void)__hip_atomic_fetch_add((lds_u32*)(uintptr_t)slot_addr((before - 1u) << 2), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (joins) {                               // (the slot's dword, 1 in the slot's half: a count never carries — 256 is reported)
+                            const uint32_t at = slot_addr((before - 1u) << 1);
+                            (void)__hip_atomic_fetch_add((lds_u32*)(uintptr_t)(at & ~3u), 1u << ((at & 2u) << 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
                     }
                     placed += ln + ((6u >> e) & 1u);
                     base += (uint32_t)__popcll(Q) + (uint32_t)__popcll(H);
@@ -749,9 +749,9 @@ __global__ __launch_bounds__(256) void decode_edits_quad_kernel(DecodeArgs a, ui
                 const uint32_t c = P >> 24;
                 if (STORE) {
                     const uint32_t incl = qd_wave_scan(c);
-                    // 4 x (index in the dense array of the first run this lane starts); 4 x the prefix within the lane, byte by byte
-                    const uint32_t i4 = (incl - c + (g0l + base)) << 2;
-                    const uint32_t P4 = P << 2;
+                    // 2 x (index in the dense array of the first run this lane starts); 2 x the prefix within the lane, byte by byte
+                    const uint32_t i2 = (incl - c + (g0l + base)) << 1;
+                    const uint32_t P2 = P << 1;
                     // ---- an edit byte's position in its run: a segmented count over the lane's bytes (byte k: E_k, + the count of byte
                     // k - 1 if byte k joins, in two doubling steps), plus what the lane before hands over where bytes 0..k all join
                     const uint32_t E1 = Ed >> 7;
@@ -770,15 +770,15 @@ __global__ __launch_bounds__(256) void decode_edits_quad_kernel(DecodeArgs a, ui
                     // what the bytes write: matches '=' << 8 | t, the last byte of an edit run letter << 8 | its position
                     const uint32_t EQL = qd_or_and(Em - e7, Em, 0x3D3D3D3Du);                                            // '=' in the bytes that have matches
                     const uint32_t LET = __builtin_amdgcn_perm(0u, 0x44495800u, (x >> 6) & 0x03030303u);                 // "\0XID"[code]
-                    const uint32_t p0 = P4 & 0xffu, p1 = (P4 >> 8) & 0xffu, p2 = (P4 >> 16) & 0xffu, p3 = P4 >> 24;
-                    ring_put(i4, __builtin_amdgcn_perm(EQL, T, 0x0C0C0400u), Em, std::integral_constant<int, 7>{});
-                    ring_put(i4 + p0 - 4u, __builtin_amdgcn_perm(LET, RP, 0x0C0C0400u), Tl, std::integral_constant<int, 7>{});
-                    ring_put(i4 + p0, __builtin_amdgcn_perm(EQL, T, 0x0C0C0501u), Em, std::integral_constant<int, 15>{});
-                    ring_put(i4 + p1 - 4u, __builtin_amdgcn_perm(LET, RP, 0x0C0C0501u), Tl, std::integral_constant<int, 15>{});
-                    ring_put(i4 + p1, __builtin_amdgcn_perm(EQL, T, 0x0C0C0602u), Em, std::integral_constant<int, 23>{});
-                    ring_put(i4 + p2 - 4u, __builtin_amdgcn_perm(LET, RP, 0x0C0C0602u), Tl, std::integral_constant<int, 23>{});
-                    ring_put(i4 + p2, __builtin_amdgcn_perm(EQL, T, 0x0C0C0703u), Em, std::integral_constant<int, 31>{});
-                    ring_put(i4 + p3 - 4u, __builtin_amdgcn_perm(LET, RP, 0x0C0C0703u), Tl, std::integral_constant<int, 31>{});
+                    const uint32_t p0 = P2 & 0xffu, p1 = (P2 >> 8) & 0xffu, p2 = (P2 >> 16) & 0xffu, p3 = P2 >> 24;
+                    ring_put(i2, __builtin_amdgcn_perm(EQL, T, 0x0C0C0400u), Em, std::integral_constant<int, 7>{});
+                    ring_put(i2 + p0 - 2u, __builtin_amdgcn_perm(LET, RP, 0x0C0C0400u), Tl, std::integral_constant<int, 7>{});
+                    ring_put(i2 + p0, __builtin_amdgcn_perm(EQL, T, 0x0C0C0501u), Em, std::integral_constant<int, 15>{});
+                    ring_put(i2 + p1 - 2u, __builtin_amdgcn_perm(LET, RP, 0x0C0C0501u), Tl, std::integral_constant<int, 15>{});
+                    ring_put(i2 + p1, __builtin_amdgcn_perm(EQL, T, 0x0C0C0602u), Em, std::integral_constant<int, 23>{});
+                    ring_put(i2 + p2 - 2u, __builtin_amdgcn_perm(LET, RP, 0x0C0C0602u), Tl, std::integral_constant<int, 23>{});
+                    ring_put(i2 + p2, __builtin_amdgcn_perm(EQL, T, 0x0C0C0703u), Em, std::integral_constant<int, 31>{});
+                    ring_put(i2 + p3 - 2u, __builtin_amdgcn_perm(LET, RP, 0x0C0C0703u), Tl, std::integral_constant<int, 31>{});
                     base += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
                     crp_v = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)B, 0x13C, 0xf, 0xf, false);                              // wave_ror:1: lane 0 <- the last lane
                 } else {
@@ -811,7 +811,7 @@ __global__ __launch_bounds__(256) void decode_edits_quad_kernel(DecodeArgs a, ui
                              : "=&s"(exec_keep) : "s"(inside), "v"(dst), "v"(o) : "memory", "scc");       // (s_and_b64 writes SCC)
                 if (head_pending) {                                                                     // (uniform) the pair starts inside unit 0 ...
                     if (u_lim > 0) {                                                                    // ... which leaves the ring now
-                        head_w = *(const lds_u32*)(uintptr_t)slot_addr((8u * unit0 + (lane & 7u)) << 2);
+                        head_w = *(const lds_u16*)(uintptr_t)slot_addr((8u * unit0 + (lane & 7u)) << 1);
                         head_kept = true;
                         head_pending = false;
                     }
@@ -835,7 +835,7 @@ __global__ __launch_bounds__(256) void decode_edits_quad_kernel(DecodeArgs a, ui
             }
             const uint32_t at = 8u * uf + lane;
             if (lane < 16u && at >= h && at < lim)
-                dense_u[at] = (uint16_t)*(const lds_u32*)(uintptr_t)slot_addr((8u * unit0 + at) << 2);
+                dense_u[at] = *(const lds_u16*)(uintptr_t)slot_addr((8u * unit0 + at) << 1);
         }
         // read characters placed, over all lanes (64 bits: a lane's share stays below 2^30, their sum may not)
         const uint64_t tot = __any((placed >> 24) != 0u) ? (uint64_t)qd_total(placed & 0xffffu) + ((uint64_t)qd_total(placed >> 16) << 16)

@@ -258,6 +258,12 @@ class EditStreamGather:
             self.recv = [[ra[r * self.wire: (r + 1) * self.wire] for r in range(self.world)] for ra in self.recv_all]
         self.pending = [None] * d
         self.host_stage = dist.get_backend(group) == "gloo" and self.is_cuda
+        # How a step travels.  "p2p" (default): the step's root produces its own slot IN PLACE (buffers(k) hands out views of its
+        # receive buffer) and posts one receive per peer, every other rank posts one send: nothing of the root's own 130 MB per step
+        # goes through a collective — ncclGather copies the root's contribution to itself with a copy kernel, which on a one-rank
+        # group is the whole "transfer" and cost 0.25 ms per step (scripts/r06_step_probe.sh).  "gather": one dist.gather per step,
+        # as until round 5 (SCRG_GATHER_COLLECTIVE=gather; also what the host-staged gloo dry run of bench.py uses).
+        self.p2p = os.environ.get("SCRG_GATHER_COLLECTIVE", "p2p") != "gather" and not self.host_stage
         # decoding on the receiving rank: one dense array, offsets, counts and an error counter per buffer set
         self.dense = [None] * d
         self.dec = [None] * d
@@ -275,7 +281,11 @@ class EditStreamGather:
         if self.host_stage or os.environ.get("SCRG_BENCH_NOCOLL") == "1":
             return
         for dst in (range(self.world) if self.rotate else [self.dst]):
-            dist.gather(self.send[0], self.recv[0] if self.rank == dst else None, dst=dst, group=self.group)
+            if self.p2p:
+                for w in self._post(0, dst):
+                    w.wait()
+            else:
+                dist.gather(self.send[0], self.recv[0] if self.rank == dst else None, dst=dst, group=self.group)
         if self.send[0].is_cuda:
             torch.cuda.synchronize()
 
@@ -289,9 +299,23 @@ class EditStreamGather:
             v["off"] = buf[self.o_off: self.o_off + 8 * n].view(torch.int64)
         return v
 
+    def _post(self, b, dst):
+        """The point-to-point form of the gather of buffer set b to rank dst: -> the work handles (none in a one-rank group)."""
+        if self.rank == dst:
+            ops = [dist.P2POp(dist.irecv, self.recv[b][r], r, self.group, b) for r in range(self.world) if r != dst]
+        else:
+            ops = [dist.P2POp(dist.isend, self.send[b], dst, self.group, b)]
+        return dist.batch_isend_irecv(ops) if ops else []
+
+    def _slot(self, k):
+        """Where this rank's contribution to step k is produced: its send buffer, or — as the step's root in p2p mode — its own
+        slot of the receive buffer."""
+        b = k % self.DEPTH
+        return self.recv[b][self.rank] if (self.p2p and self.rank == self.root_of(k)) else self.send[b]
+
     def buffers(self, k):
         b = k % self.DEPTH
-        v = self._views(self.send[b])
+        v = self._views(self._slot(k))
         v["total"] = self.total[b]
         if self.ordered:
             v["off"] = self.off_scratch[b]
@@ -306,7 +330,7 @@ class EditStreamGather:
         for all when it is 0."""
         b = k % self.DEPTH
         dst = self.root_of(k)
-        self._views(self.send[b])["ed"].copy_(ed)            # (int64 -> int32)
+        self._views(self._slot(k))["ed"].copy_(ed)           # (int64 -> int32)
         if self.host_stage:
             torch.cuda.current_stream().synchronize()
             host = [torch.empty(self.wire, dtype=torch.uint8) for _ in range(self.world)] if self.rank == dst else None
@@ -316,6 +340,8 @@ class EditStreamGather:
                     self.recv[b][r].copy_(host[r])
         elif os.environ.get("SCRG_BENCH_NOCOLL") == "1":      # experiment: everything but the collective
             pass
+        elif self.p2p:
+            self.pending[b] = self._post(b, dst) or None
         else:
             self.pending[b] = dist.gather(self.send[b], self.recv[b] if self.rank == dst else None, dst=dst, group=self.group,
                                           async_op=True)
@@ -324,7 +350,8 @@ class EditStreamGather:
 
     def _wait(self, b):
         if self.pending[b] is not None:
-            self.pending[b].wait()                            # the CURRENT stream waits for the collective
+            for w in (self.pending[b] if isinstance(self.pending[b], (list, tuple)) else [self.pending[b]]):
+                w.wait()                                      # the CURRENT stream waits for the collective
             self.pending[b] = None
 
     def finish(self, k):
@@ -405,8 +432,9 @@ class EditStreamGather:
             if self.is_cuda:
                 aligner.set_stream(dec_stream.cuda_stream)
             try:
-                aligner.decode_edit_stream(W * n * sim, self.recv_all[b], d["off"], ln, read_len, read_len_stride, doff, self.dense[b],
-                                           cnt, d["bad"], **(params or {}))
+                if os.environ.get("SCRG_GATHER_PROBE") != "no-decode-kernel":      # (measurement aid: everything of the step but the decode launch)
+                    aligner.decode_edit_stream(W * n * sim, self.recv_all[b], d["off"], ln, read_len, read_len_stride, doff, self.dense[b],
+                                               cnt, d["bad"], **(params or {}))
             finally:
                 if self.is_cuda:
                     aligner.restore_stream(saved)

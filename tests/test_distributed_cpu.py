@@ -431,11 +431,16 @@ def _worker_wide(rank, world, port, q, dst, depth, steps):
 
 
 @pytest.mark.timeout(240)
+@pytest.mark.parametrize("mode", ["p2p", "gather"])
 @pytest.mark.parametrize("world,dst,depth", [(8, "rotate", 2), (8, "rotate", 4), (8, 0, 4), (4, "rotate", 4), (4, 0, 2)])
-def test_edit_stream_gather_at_four_and_eight_ranks(world, dst, depth):
+def test_edit_stream_gather_at_four_and_eight_ranks(world, dst, depth, mode, monkeypatch):
     """EditStreamGather as bench.py drives it — `depth` steps in flight, root fixed or rotating — on 4 and 8 ranks: every step's
     root ends up with every rank's scores, stream lengths, run counts and stream bytes of THAT step (ragged, some empty), looked
     at when the step's buffers are the oldest still alive, exactly as the decode of bench.py does."""
+    # (mode: the step as point-to-point sends with the root's own slot produced in place — the default — and as one dist.gather)
+    if mode == "gather" and (world, depth) not in ((8, 4), (4, 2)):
+        pytest.skip("the collective form: two of the five shapes")
+    monkeypatch.setenv("SCRG_GATHER_COLLECTIVE", mode)
     steps = 2 * world + 3
     got = _spawn(world, _worker_wide, (dst, depth, steps))
     n = 5
