@@ -82,7 +82,13 @@ typedef struct scrg_params {
                                 uninitialised struct cannot silently change anything.  (Other BUILDS of the same sources
                                 give them a meaning — the test build, -DSCRG_SELECT, selects between formulations that give
                                 identical results; profiling builds add counters and ablations: see scrg_debug_stats.)   */
+    int32_t stranded;        /* device-pointer entry points (ABI 7): 1 = bit 63 of scrg_pair_desc.read_off (SCRG_READ_REVCOMP) marks
+                                a pair whose read is aligned as its REVERSE COMPLEMENT, taken from the one packed copy of the read
+                                (a read-mapping candidate on the minus strand; the reference drops those, src/tests.cu:346-355).
+                                Served by the default kernel geometry — lanes_per_pair = 1, W <= 64, W-O <= 31 —,
+                                SCRG_ERR_INVALID_ARG for any other.  0 (default): bit 63 must be clear                    */
 } scrg_params;
+#define SCRG_READ_REVCOMP (1ull << 63)
 
 enum { SCRG_OUT_ALL = 0, SCRG_OUT_TEXT = 1, SCRG_OUT_RUNS = 2 };
 
@@ -133,7 +139,7 @@ int         scrg_build_flags(void);
  * older header and would shift every later argument.  scrg_abi_version() is what the loaded library was built with; a binding
  * compares it with the SCRG_ABI_VERSION it was compiled against before anything else (include/scrooge_amd.hpp throws,
  * scrooge_amd/api.py raises). */
-#define SCRG_ABI_VERSION 6
+#define SCRG_ABI_VERSION 7
 int         scrg_abi_version(void);
 
 /* ---------------------------------------------------------------------------
@@ -263,7 +269,7 @@ scrg_status scrg_pack_planar_host(const char *ascii, uint64_t n_bases, uint64_t 
 typedef struct scrg_pair_desc {
     uint64_t text_off;
     uint64_t text_len;
-    uint64_t read_off;
+    uint64_t read_off;    /* (| SCRG_READ_REVCOMP with scrg_params.stranded: the read's reverse complement is aligned) */
     uint64_t read_len;
     uint64_t cigar_off;   /* first run of this pair's slice, in scrg_run units; multiple of 16 */
     uint64_t cigar_cap;   /* slice capacity in runs; multiple of 16 (runs leave the GPU in

@@ -18,7 +18,7 @@ SCRG_ERR_NO_DEVICE = 3
 SCRG_ERR_HIP = 4
 SCRG_ERR_OOM = 5
 SCRG_ERR_CIGAR_OVERFLOW = 6
-SCRG_ABI_VERSION = 6          # include/scrooge_amd.h (tests/test_abi.py holds the two equal)
+SCRG_ABI_VERSION = 7          # include/scrooge_amd.h (tests/test_abi.py holds the two equal)
 SEQ_PAD_WORDS = 4
 GROUP = 64                     # rows per group of the lane-interleaved layout
 SEQ_PAD_WORDS_GROUPS = 2 * GROUP + 2
@@ -34,7 +34,10 @@ class Params(C.Structure):
     _fields_ = [("W", C.c_int32), ("O", C.c_int32), ("lanes_per_pair", C.c_int32),
                 ("lds_rows", C.c_int32), ("waves_per_cu", C.c_int32),
                 ("sort_by_length", C.c_int32), ("text_stride_words", C.c_int32), ("read_stride_words", C.c_int32),
-                ("outputs", C.c_int32), ("reserved", C.c_int32 * 2)]
+                ("outputs", C.c_int32), ("reserved", C.c_int32 * 2), ("stranded", C.c_int32)]
+
+
+READ_REVCOMP = 1 << 63            # include/scrooge_amd.h: SCRG_READ_REVCOMP
 
 
 class PairDesc(C.Structure):

@@ -33,6 +33,7 @@ struct AlignArgs {
     uint32_t read_stride;         //   64 = lane-interleaved groups, scrg_pack_planar_groups; lane kernel only)
     uint64_t* stats;              // profiling builds (-DSCRG_STATS) only: counters, may be null; never read by the shipped kernels
     int32_t debug;                // params.reserved[0] (always 0 in the shipped build): see SCRG_SEL / SCRG_SW / SCRG_ABL below
+    uint32_t stranded;            // params.stranded: bit 63 of a pair's read_off = align the read's reverse complement (genasm_lane_kernel only)
 };
 
 // scrg_params.reserved[0] / reserved[1].  The SHIPPED library accepts neither: scrg_params_resolve() rejects every bit.
@@ -127,7 +128,7 @@ hipError_t launch_align_lane_wide(const AlignArgs& a, int grid, size_t lds_bytes
 // not reach; genasm_lane_mw_kernel is left with W-O >= 128: table rows of three and four words.)
 SCRG_HD inline bool lane_parts_serves(int W, int tb_limit)
 {
-    return W <= 256 && ((tb_limit >= 64 && tb_limit <= 127) || (W > 128 && tb_limit >= 1 && tb_limit <= 63));
+    return W > 64 && W <= 256 && ((tb_limit >= 64 && tb_limit <= 127) || (W > 128 && tb_limit >= 1 && tb_limit <= 63));      // (W = 64, O = 0: genasm_lane_mw_kernel)
 }
 SCRG_HD inline unsigned lane_parts_lds_bytes(int W)
 {

@@ -119,6 +119,32 @@ __device__ __forceinline__ uint32_t ffbl_u32(uint32_t v)      // count trailing 
     return r;
 }
 
+// ---- reads taken as their REVERSE COMPLEMENT (scrg_params.stranded, bit 63 of scrg_pair_desc.read_off: SURVEY.md §8 f4 — the
+// reference drops reverse-strand candidates, src/tests.cu:346-355) — from the ONE packed copy of the read.  Character k of the
+// window at read_idx of the reverse complement r' is the complement of read[len-1-read_idx-k]; complement = both planes inverted
+// (A0 C1 G2 T3).  The table wants the pattern reversed and left-aligned (bit 63-k <-> pattern[k]): for a forward read that is the
+// bit reversal of the 64 bases from read_idx; for r' it is simply the INVERTED 64 bases that END at len - read_idx — bit 63-k of
+// that window is read[len-read_idx-1-k] — so a reverse-strand window costs no bit reversal at all: a window that starts 64
+// before the place where the forward window would end, shifted up when fewer than 64 bases are left (the bits below the
+// pattern are masked by the table anyway).
+// lane_read_offset: the first base the window's words are loaded from (forward: read_idx; reverse: len - read_idx - 64, not below 0)
+__device__ __forceinline__ uint32_t lane_read_offset(uint32_t fwd_offset, uint32_t read_idx, uint32_t read_len, uint32_t revm)
+{
+    return bitop3<TT_BFI>(sub_sat_u32(read_len - read_idx, 64u), fwd_offset, revm);      // (a finished read: 0 either way)
+}
+// lane_pattern_rev: the window's planes as loaded -> reversed and left-aligned, per lane by its strand (revm: 0 / ~0)
+__device__ __forceinline__ void lane_pattern_rev(const Planes pw, uint32_t left, uint32_t revm, bool any_rev, uint64_t& rlo, uint64_t& rhi)
+{
+    rlo = brev64(pw.lo);
+    rhi = brev64(pw.hi);
+    if (any_rev) {                                     // (uniform: a wavefront of forward pairs pays one scalar branch)
+        const uint32_t sh = sub_sat_u32(64u, left);  // `left` = read characters from read_idx on: fewer than 64 -> the window was loaded from base 0
+        const uint64_t flo = ~(pw.lo << sh), fhi = ~(pw.hi << sh);
+        rlo = ((uint64_t)bitop3<TT_BFI>((uint32_t)(flo >> 32), (uint32_t)(rlo >> 32), revm) << 32) | bitop3<TT_BFI>((uint32_t)flo, (uint32_t)rlo, revm);
+        rhi = ((uint64_t)bitop3<TT_BFI>((uint32_t)(fhi >> 32), (uint32_t)(rhi >> 32), revm) << 32) | bitop3<TT_BFI>((uint32_t)fhi, (uint32_t)rhi, revm);
+    }
+}
+
 // SHORT_N = false: every lane of the wave has a full text window (n = 64); true: any n <= 64 per lane (the text ends
 // inside the window): columns >= n read the Eq word "no character matches", which leaves the boundary column
 // D[n][j] = m-j (genasm_cpu.cpp:239-245) as it is and gives table words that say "insertion" in every row — what the
@@ -133,15 +159,15 @@ __device__ __forceinline__ uint32_t ffbl_u32(uint32_t v)      // count trailing 
 // (slot-major, LANE_EQ_SLOT_STRIDE above), and a column reads the one its text character selects — address =
 // lane's column of the region | 512 * character from one shift and one v_bitop3_b32, the ds_read_b64 itself does not occupy
 // the VALU.  (Computing Eq per column costs 2 v_bfe_i32 + 2 v_xor + 2 v_bitop3; the reads are issued LANE_EQ_AHEAD columns early.)
+// rlo / rhi: the two planes of the window's pattern REVERSED and left-aligned (bit 63-k <-> pattern character k): lane_pattern_rev.
 template <bool SHORT_N>
-__device__ __forceinline__ void lane_window_table(const Planes tw, const Planes pw, const uint32_t n, const uint32_t m,
+__device__ __forceinline__ void lane_window_table(const Planes tw, const uint64_t rlo, const uint64_t rhi, const uint32_t n, const uint32_t m,
                                                   const uint32_t stop, uint64_t (&tab)[LANE_TB_COLS],
                                                   const uint32_t eq_b, const uint32_t nomatch_b)
 {
     // tab[i] = ~(V1 | stop) in the upper dword, V0 in the lower one (a register pair: the traceback shifts both with one
     // 64-bit shift): stop has the one bit of the row at which this lane's walk ends (jlim), so a finished lane reads
     // "deletion" there — it stays put without a test; how many columns it was alive in follows from the masks (below)
-    const uint64_t rlo = brev64(pw.lo), rhi = brev64(pw.hi);
     const uint64_t valid = ~0ull << (64u - m);                    // (m >= 1)
     const uint32_t rl0 = (uint32_t)rlo, rl1 = (uint32_t)(rlo >> 32), rh0 = (uint32_t)rhi, rh1 = (uint32_t)(rhi >> 32);
     const uint32_t iv0 = ~(uint32_t)valid, iv1 = ~(uint32_t)(valid >> 32);
@@ -238,6 +264,7 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
     uint64_t cigar_off = 0;
     uint32_t text_len = 0, read_len = 0, cigar_cap = 0;
     uint32_t ref_idx = 0, read_idx = 0, edits = 0;
+    uint32_t revm = 0;                 // ~0: my pair's read is aligned as its reverse complement (a.stranded and bit 63 of read_off)
     int32_t nr = -1;                   // index of the run in progress (or of the last finished one); n_runs = nr + 1
     uint32_t flushed = 0;              // runs below this index are in HBM (a multiple of 16); EDITS: bytes, a multiple of 32
     uint32_t pos = 0;                  // EDITS: bytes of the pair's stream so far
@@ -356,8 +383,10 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
                 const scrg_pair_desc pd = a.pairs[idx];
                 pair = idx;
                 text_w = a.seq + (pd.text_off >> 5);
-                read_w = a.seq + (pd.read_off >> 5);
-                tr_in = ((uint32_t)pd.text_off & 31u) | (((uint32_t)pd.read_off & 31u) << 8);
+                const uint64_t r_off = a.stranded ? pd.read_off & ~SCRG_READ_REVCOMP : pd.read_off;
+                revm = (a.stranded && (pd.read_off & SCRG_READ_REVCOMP)) ? 0xffffffffu : 0u;
+                read_w = a.seq + (r_off >> 5);
+                tr_in = ((uint32_t)pd.text_off & 31u) | (((uint32_t)r_off & 31u) << 8);
                 text_len = pd.text_len > 0xffffffffull ? 0xffffffffu : (uint32_t)pd.text_len;
                 read_len = (uint32_t)pd.read_len;
                 cigar_off = pd.cigar_off;
@@ -366,10 +395,11 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
                 nr = -1;
                 has_pair = true;
                 twords = load_window_words_at(text_w, tr_in & 31u, 0u, a.text_stride);
-                pwords = load_window_words_at(read_w, tr_in >> 8, 0u, a.read_stride);
+                pwords = load_window_words_at(read_w, tr_in >> 8, lane_read_offset(0u, 0u, read_len, revm), a.read_stride);
             }
         }
         if (!__any(has_pair)) break;
+        const bool wave_rev = a.stranded && __any(has_pair && revm != 0u);       // (uniform) some lane aligns a reverse complement
 
         const uint64_t tm1 = timing ? __builtin_readcyclecounter() : 0;
         // ---------------- window setup (genasm_cpu.cpp:417-420) ----------------
@@ -392,14 +422,16 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
         const uint32_t jlim = has_pair ? min(m, TBL) : 0u;          // the walk ends when j gets here (:301, :310)
         const uint32_t stop = 0x80000000u >> jlim;
         const bool short_n = __any(has_pair && n != 64u);
+        uint64_t rlo, rhi;
+        lane_pattern_rev(pw, read_len - read_idx, revm, wave_rev, rlo, rhi);
         if (SCRG_ABL(a, 2)) {                       // ablation (profiling only): no table computation
 #pragma unroll
             for (int i = 0; i < LANE_TB_COLS; i++) tab[i] = ((uint64_t)~stop << 32) | (((uint32_t)tw.lo * (uint32_t)(i + 1)) | stop);
         } else if (short_n) {
-            lane_window_table<true>(tw, pw, n, m, stop, tab, eq_b, nomatch_b);
+            lane_window_table<true>(tw, rlo, rhi, n, m, stop, tab, eq_b, nomatch_b);
             st_gen++;
         } else {
-            lane_window_table<false>(tw, pw, n, m, stop, tab, eq_b, nomatch_b);
+            lane_window_table<false>(tw, rlo, rhi, n, m, stop, tab, eq_b, nomatch_b);
         }
         const uint64_t tm3 = timing ? __builtin_readcyclecounter() : 0;
 
@@ -469,7 +501,8 @@ __global__ __launch_bounds__(256, 4) void genasm_lane_kernel(AlignArgs a)
             // (never past a finished read: index 0 then.  read_idx <= read_len always, so "finished" is "equal": x | -x has its sign
             // bit set for every x != 0 — exact for any 32-bit length, and no v_cndmask on VCC)
             const uint32_t left_x = read_idx ^ read_len;
-            pwords = load_window_words_at(read_w, tr_in >> 8, read_idx & neg_mask(left_x | (0u - left_x)), a.read_stride);
+            const uint32_t fwd_at = read_idx & neg_mask(left_x | (0u - left_x));
+            pwords = load_window_words_at(read_w, tr_in >> 8, wave_rev ? lane_read_offset(fwd_at, read_idx, read_len, revm) : fwd_at, a.read_stride);
 
             // Pass 2.  The next column with an event: an insertion run, then (if B) the run of steps that starts
             // there.  Both words go to the slot after the last committed run; only committing moves on.  (A lane
@@ -670,6 +703,7 @@ __global__ __launch_bounds__(512, 2) void genasm_lane_split_kernel(AlignArgs a)
         uint64_t text_off = 0, read_off = 0;
         uint32_t text_len = 0, read_len = 0;
         uint32_t ref_idx = 0, read_idx = 0, edits = 0;
+        uint32_t revm = 0;                 // (see genasm_lane_kernel)
         WindowWords twords = {0, 0, 0, 0}, pwords = {0, 0, 0, 0};
         bool queue_empty = false;          // wave-uniform
         uint32_t st_rounds = 0;
@@ -702,14 +736,15 @@ __global__ __launch_bounds__(512, 2) void genasm_lane_split_kernel(AlignArgs a)
                         const scrg_pair_desc pd = a.pairs[idx];
                         pair = idx;
                         text_off = pd.text_off;
-                        read_off = pd.read_off;
+                        read_off = a.stranded ? pd.read_off & ~SCRG_READ_REVCOMP : pd.read_off;
+                        revm = (a.stranded && (pd.read_off & SCRG_READ_REVCOMP)) ? 0xffffffffu : 0u;
                         text_len = pd.text_len > 0xffffffffull ? 0xffffffffu : (uint32_t)pd.text_len;
                         read_len = (uint32_t)pd.read_len;
                         ref_idx = read_idx = edits = 0;
                         has_pair = true;
                         first = SPLIT_FIRST;
                         twords = load_window_words(a.seq, text_off, 0u, a.text_stride);
-                        pwords = load_window_words(a.seq, read_off, 0u, a.read_stride);
+                        pwords = load_window_words(a.seq, read_off, lane_read_offset(0u, 0u, read_len, revm), a.read_stride);
                     }
                     // (an empty read is a pair of no windows: it is handed over as first and last at once, below)
                 }
@@ -729,8 +764,11 @@ __global__ __launch_bounds__(512, 2) void genasm_lane_split_kernel(AlignArgs a)
                 const uint32_t jlim = live ? min(m, TBL) : 0u;
                 const uint32_t stop = 0x80000000u >> jlim;
                 const bool short_n = __any(live && n != 64u);
-                if (short_n) lane_window_table<true>(tw, pw, n, m, stop, tab, eq_b, nomatch_b);
-                else lane_window_table<false>(tw, pw, n, m, stop, tab, eq_b, nomatch_b);
+                const bool wave_rev = a.stranded && __any(live && revm != 0u);
+                uint64_t rlo, rhi;
+                lane_pattern_rev(pw, read_len - read_idx, revm, wave_rev, rlo, rhi);
+                if (short_n) lane_window_table<true>(tw, rlo, rhi, n, m, stop, tab, eq_b, nomatch_b);
+                else lane_window_table<false>(tw, rlo, rhi, n, m, stop, tab, eq_b, nomatch_b);
                 // ---------------- traceback pass 1 (genasm_cpu.cpp:290-409; see genasm_lane_kernel) ----------------
                 uint32_t j = 0, nDm = 0, Xm = 0, nIm = 0;
                 const uint32_t lb = len_b(buf);
@@ -765,7 +803,7 @@ __global__ __launch_bounds__(512, 2) void genasm_lane_split_kernel(AlignArgs a)
                 // the next window's words, asked for now (a pair that is finished reads its padding)
                 twords = load_window_words(a.seq, text_off, ref_idx, a.text_stride);
                 const uint32_t left_x = read_idx ^ read_len;                     // (see genasm_lane_kernel)
-                pwords = load_window_words(a.seq, read_off, read_idx & neg_mask(left_x | (0u - left_x)), a.read_stride);
+                pwords = load_window_words(a.seq, read_off, lane_read_offset(read_idx & neg_mask(left_x | (0u - left_x)), read_idx, read_len, revm), a.read_stride);
                 const uint32_t last = (has_pair && read_idx >= read_len) ? SPLIT_LAST : 0u;
                 lds[rec_w(buf, 0)] = D;
                 lds[rec_w(buf, 1)] = X;

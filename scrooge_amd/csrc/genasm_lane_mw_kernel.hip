@@ -209,8 +209,11 @@ __global__ __launch_bounds__(64) void genasm_lane_mw_kernel(AlignArgs a)
                     if (i < TBL) {
 #pragma unroll
                         for (int r = 0; r < RW; r++) {
-                            tab[((uint64_t)(i * 2u) * RW + r) * 64u] = ~((pv[r] | ph[r]) | stop.w[r]);
-                            tab[((uint64_t)(i * 2u + 1u) * RW + r) * 64u] = (pv[r] | ~(ph[r] | xh[r])) | stop.w[r];
+                            // (O = 0 at W = 64, 128, 256: the stop row W is the first bit of a word the vectors do not have —
+                            // RW = NW + 1 — which holds nothing but that bit)
+                            const uint64_t pvr = r < NW ? pv[r < NW ? r : 0] : 0ull, phr = r < NW ? ph[r < NW ? r : 0] : 0ull, xhr = r < NW ? xh[r < NW ? r : 0] : ~0ull;
+                            tab[((uint64_t)(i * 2u) * RW + r) * 64u] = ~((pvr | phr) | stop.w[r]);
+                            tab[((uint64_t)(i * 2u + 1u) * RW + r) * 64u] = (pvr | ~(phr | xhr)) | stop.w[r];
                         }
                     }
                 }
@@ -345,6 +348,9 @@ hipError_t launch_align_lane_mw(const AlignArgs& a, int grid, size_t lds_bytes, 
 {
     const int nw = a.W <= 64 ? 1 : (a.W <= 128 ? 2 : 4), rw = a.tb_limit / 64 + 1;
     if (nw == 1 && rw == 1) return launch_mw<1, 1>(a, grid, lds_bytes, s, edits);
+    if (nw == 1 && rw == 2) return launch_mw<1, 2>(a, grid, lds_bytes, s, edits);       // (W = 64, O = 0: the stop bit is row 64)
+    if (nw == 2 && rw == 3) return launch_mw<2, 3>(a, grid, lds_bytes, s, edits);       // (W = 128, O = 0)
+    if (nw == 4 && rw == 5) return launch_mw<4, 5>(a, grid, lds_bytes, s, edits);       // (W = 256, O = 0)
     if (nw == 2 && rw == 1) return launch_mw<2, 1>(a, grid, lds_bytes, s, edits);
     if (nw == 2 && rw == 2) return launch_mw<2, 2>(a, grid, lds_bytes, s, edits);
     if (nw == 4 && rw == 1) return launch_mw<4, 1>(a, grid, lds_bytes, s, edits);

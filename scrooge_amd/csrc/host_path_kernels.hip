@@ -21,8 +21,10 @@ __global__ __launch_bounds__(256) void build_desc_kernel(HostDescArgs a)
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
     scrg_pair_desc d;
-    const uint64_t row = a.row ? a.row[i] : i;
+    const uint32_t row_word = a.row ? a.row[i] : 0u;
+    const uint64_t row = a.row ? row_word & 0x7fffffffu : i;              // (bit 31 of a mapping pair's row: the read's reverse complement is aligned)
     d.read_off = a.linear ? 32ull * (a.read_base + row * a.read_words) : 32ull * (a.read_base + (row >> 6) * a.read_words * 64ull + (row & 63ull));
+    if (row_word & 0x80000000u) d.read_off |= SCRG_READ_REVCOMP;
     d.read_len = a.read_len[i];
     if (a.start) {
         const uint64_t st = a.start[i];

@@ -253,7 +253,9 @@ static bool resolve_params(const scrg_params* in, scrg_params* p)
         p->outputs = in->outputs;
         p->reserved[0] = in->reserved[0];      // ablation switches and profiling counters travel with the parameters
         p->reserved[1] = in->reserved[1];
+        p->stranded = in->stranded;
     }
+    if (p->stranded != 0 && p->stranded != 1) return false;
     // experiment switches: only those that leave the results intact, unless this is an ablation build (genasm_kernels.h)
     if (p->reserved[0] & ~scrg::SCRG_ALLOWED_SWITCHES) return false;
     if (p->reserved[1] && !scrg::SCRG_HAVE_STATS) return false;       // the kernels' counters exist in -DSCRG_STATS builds only
@@ -263,7 +265,12 @@ static bool resolve_params(const scrg_params* in, scrg_params* p)
     if (p->text_stride_words < 1 || p->read_stride_words < 1) return false;
     if (p->W < 2 || p->W > 256) return false;
     const int tbl = p->W - p->O;
-    if (tbl < 1 || p->O < 1) return false;   // O = 0 (no overlap) would let the traceback read the boundary column
+    // O = 0 (no overlap: the reference's special case src/genasm_cpu.cpp:104-110, reached by its O sweep for W < 32,
+    // scripts/profile.py:92-93): a window's traceback may consume all W characters.  The one-pair-per-lane kernels serve it
+    // (a table column holds the steps OUT of it, so column W-1 needs nothing of the boundary column); the GenASM-row
+    // mappings, whose traceback reads R[i+1], do not.
+    if (tbl < 1 || p->O < 0) return false;
+    if (p->O == 0 && p->lanes_per_pair > 1) return false;
     const size_t row_bytes = (size_t)scrg::stored_row_dwords(p->W, tbl) * 4;
     if (p->W > 64) {
         // one pair per lane here too (genasm_lane_mw_kernel.hip: multi-word difference vectors, the table in HBM); the
@@ -291,6 +298,8 @@ static bool resolve_params(const scrg_params* in, scrg_params* p)
     // every CU for kernels of other streams (RCCL's gather in bench.py --gpus N).  The LDS footprint caps it.
     if (p->waves_per_cu == 0) p->waves_per_cu = p->lanes_per_pair == 1 ? 16 : 11;
     const int g = p->lanes_per_pair;
+    // reverse-strand pairs from one packed copy of the read: genasm_lane_kernel (and its two-wavefront form) only
+    if (p->stranded && !(g == 1 && p->W <= 64 && tbl <= 31 && !SCRG_SEL(p->reserved[0], scrg::SCRG_SWITCH_MW_TABLE))) return false;
     if (g == 1) return p->waves_per_cu >= 1 && p->waves_per_cu <= 32;      // no table in LDS: lds_rows is not used
     if (p->text_stride_words != 1 || p->read_stride_words != 1) return false;   // strided sequences: lane kernel only
     if (!(g == 4 || g == 8 || g == 16 || g == 32 || g == 64)) return false;
@@ -436,6 +445,7 @@ static scrg_status align_device_impl(scrg_ctx* c, const scrg_params* params, uin
     a.text_stride = (uint32_t)p.text_stride_words;
     a.read_stride = (uint32_t)p.read_stride_words;
     a.debug = p.reserved[0];
+    a.stranded = (uint32_t)p.stranded;
     a.stats = nullptr;
     if (params && params->reserved[1]) {
         HIP_TRY(c, c->stats.ensure(12 * sizeof(uint64_t)));

@@ -423,7 +423,11 @@ scrg_status stage1(DeviceState* ds, Slot& sl, Call& c, uint64_t chunk)
     const int64_t t0 = now_ns();
     HTRY(ds, hipSetDevice(ds->device));
 
-    // ---- layout of the chunk's sequences: read rows (mapping: one row per run of pairs with the same read and strand), text rows
+    // ---- layout of the chunk's sequences: read rows (mapping: one row per run of pairs with the same read), text rows.
+    // Reverse-strand candidates (cand_reverse): with the default kernel geometry the DEVICE takes the read's reverse complement
+    // from the one packed copy (scrg_params.stranded: the pair's descriptor carries the strand), so both strands of a read share
+    // a row; the other kernels get a row of their own, packed reverse-complemented here.
+    const bool dev_strand = b.mapping && b.cand_reverse && c.p.lanes_per_pair == 1 && c.p.W <= 64 && c.p.W - c.p.O <= 31 && !c.p.reserved[0];
     std::vector<uint32_t> row(b.mapping ? n : 0);
     std::vector<uint64_t> row_pair;                  // a pair that owns each row (its read is the row's content)
     uint64_t max_read = 0, max_text = 0;
@@ -434,7 +438,8 @@ scrg_status stage1(DeviceState* ds, Slot& sl, Call& c, uint64_t chunk)
         auto starts_row = [&](uint64_t i) -> bool {
             if (i == 0) return true;
             const uint64_t p = c.order[first + i], q = c.order[first + i - 1];
-            return !(b.pair_read[q] == b.pair_read[p] && (b.cand_reverse && b.cand_reverse[q]) == (b.cand_reverse && b.cand_reverse[p]));
+            return !(b.pair_read[q] == b.pair_read[p] &&
+                     (dev_strand || (b.cand_reverse && b.cand_reverse[q]) == (b.cand_reverse && b.cand_reverse[p])));
         };
         parallel_for(nb, [&](uint64_t k) {
             uint64_t cnt = 0, mr = 0, mt = 0;
@@ -509,7 +514,7 @@ scrg_status stage1(DeviceState* ds, Slot& sl, Call& c, uint64_t chunk)
                 const uint64_t p = row_pair[r], rd = b.pair_read[p];
                 rsrc[l] = b.reads[rd];
                 rlen[l] = b.read_lens[rd];
-                rrev[l] = b.cand_reverse && b.cand_reverse[p];
+                rrev[l] = !dev_strand && b.cand_reverse && b.cand_reverse[p];
             } else {
                 const uint64_t p = c.order[first + r];
                 rsrc[l] = b.reads[p];
@@ -552,7 +557,7 @@ scrg_status stage1(DeviceState* ds, Slot& sl, Call& c, uint64_t chunk)
         const uint64_t p = c.order[first + i];
         if (b.mapping) {
             m_rl[i] = (uint32_t)b.read_lens[b.pair_read[p]];
-            m_tl[i] = row[i];
+            m_tl[i] = row[i] | ((dev_strand && b.cand_reverse[p]) ? 0x80000000u : 0u);      // (bit 31: the reverse complement of the row's read)
             m_st[i] = b.cand_start[p];
         } else {
             m_rl[i] = (uint32_t)b.read_lens[p];
@@ -606,6 +611,7 @@ scrg_status stage1(DeviceState* ds, Slot& sl, Call& c, uint64_t chunk)
     scrg_params pp = c.p;
     pp.read_stride_words = (int32_t)rstride;
     pp.text_stride_words = b.mapping ? 1 : (int32_t)rstride;
+    pp.stranded = dev_strand ? 1 : 0;
     scrg_status s = scrg_align_device(sl.ctx, &pp, n, d_seq, sl.d_desc.as<scrg_pair_desc>(), sl.d_slices.as<scrg_run>(), d_ed,
                                       sl.d_nruns.as<uint32_t>(), d_status);
     if (s != SCRG_OK) {

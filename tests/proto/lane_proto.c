@@ -188,7 +188,7 @@ static int lane_tb_edits(const uint64_t *V1, const uint64_t *V0, int m, int TBL,
 int lane_align_edits(const uint8_t *text, size_t text_len, const uint8_t *read, size_t read_len, int W, int O,
                      uint8_t *stream, size_t cap, size_t *n_bytes, long long *edit_distance, lane_stats *ls)
 {
-    if (W < 2 || W > 64 || O < 1 || O >= W || W - O > 31) return GO_ERR_PARAMS;
+    if (W < 2 || W > 64 || O < 0 || O >= W || W - O > 31) return GO_ERR_PARAMS;
     edit_sink out = { stream, cap, 0, 0 };
     size_t ti = 0, ri = 0; long long total = 0;
     const int TBL = W - O;
@@ -234,7 +234,7 @@ static int lane_tb_wide(const uint64_t *V1, const uint64_t *V0, int m, int TBL, 
 int lane_align_codes(const uint8_t *text, size_t text_len, const uint8_t *read, size_t read_len, int W, int O,
                      go_run *runs, size_t cap, size_t *n_runs, long long *edit_distance, lane_stats *ls)
 {
-    if (W < 2 || W > 64 || O < 1 || O >= W) return GO_ERR_PARAMS;
+    if (W < 2 || W > 64 || O < 0 || O >= W) return GO_ERR_PARAMS;
     run_sink out = { runs, cap, 0, 0 };
     size_t ti = 0, ri = 0; long long total = 0;
     const int TBL = W - O;

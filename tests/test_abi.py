@@ -73,7 +73,7 @@ def test_struct_layouts():
     import ctypes as C
     assert C.sizeof(api.Run) == 2        # CigarEntry_t, src/util.hpp:43-46
     assert C.sizeof(api.PairDesc) == 48
-    assert C.sizeof(api.Params) == 44    # 11 x int32 (scrooge_amd.h: scrg_params)
+    assert C.sizeof(api.Params) == 48    # 12 x int32 (scrooge_amd.h: scrg_params; `stranded` since ABI 7)
 
 
 def test_status_strings(lib):

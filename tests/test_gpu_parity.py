@@ -148,6 +148,28 @@ def test_long_reads_10kb(aligner, oracle):
     _check(aligner.align_pairs(t, q, lanes_per_pair=64), eds, cigars, "10kb g64")
 
 
+@pytest.mark.parametrize("name", ["pairs_w16_o0.json", "pairs_w24_o0.json", "pairs_w40_o0.json", "pairs_w64_o0.json", "pairs_w128_o0.json"])
+def test_golden_no_overlap(aligner, oracle, name):
+    """O = 0 (the reference's special case src/genasm_cpu.cpp:104-110; its O sweep reaches it for W < 32, scripts/profile.py:92-93):
+    fixtures from the reference built with -DCLI_O=0.  W <= 31: the default kernel; 32..63: the two-halves kernel; 64, 128: the
+    kernel with the table in HBM (the stop bit is row W).  Runs and edit streams; 256/0 and a mixed batch against the oracle; the
+    GenASM-row mappings refuse O = 0."""
+    import scrooge_amd
+    from tests.conftest import load_golden
+    g = load_golden(name)
+    cases = g["cases"]
+    T, Q = [c["text"] for c in cases], [c["read"] for c in cases]
+    alns = aligner.align_pairs(T, Q, W=g["W"], O=0)
+    _check(alns, [c["ed"] for c in cases], [c["cigar"] for c in cases], name)
+    with pytest.raises(scrooge_amd.ScroogeError):
+        aligner.align_pairs(T[:4], Q[:4], W=g["W"], O=0, lanes_per_pair=64 if g["W"] > 64 else 8)
+    if name == "pairs_w128_o0.json":
+        t, q = synth.make_pairs(60, 1500, "ont", seed=5)
+        for W in (256, 31, 63, 100):
+            eds, cigars, _, _ = oracle.align(t, q, W=W, O=0, threads=8)
+            _check(aligner.align_pairs(t, q, W=W, O=0), eds, cigars, "W=%d O=0" % W)
+
+
 @pytest.mark.parametrize("name", ["pairs_w128_o65.json", "pairs_w96_o49.json", "pairs_w256_o129.json",
                                   "pairs_w192_o97.json", "pairs_w128_o20.json", "pairs_w200_o50.json"])
 @pytest.mark.parametrize("g", [1, 32, 64])

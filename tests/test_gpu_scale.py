@@ -378,6 +378,38 @@ def test_bench_two_ranks_dry_run(gather_root, root_share):
     assert j["config"]["rccl_ranks"] == 2
 
 
+@pytest.mark.parametrize("gather_root", ["rotate", "0"])
+def test_bench_eight_ranks_dry_run(gather_root):
+    """`python bench.py --gpus 8` as the driver starts it on an 8-GPU node, rehearsed on this one GPU (SCRG_BENCH_DRYRUN: all
+    eight ranks on GPU 0, gloo through the host): the rotating root with eight buffer sets — every rank is the root of steps,
+    produces its own slot in place and decodes all eight —, the fixed root with the root-share plan of N = 8 (rank 0 only collects
+    and decodes), every slot decoded to its own kernel's runs, one line from rank 0 with the diagnostics of an N > 1 run in it."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SCRG_BENCH_DRYRUN="1")
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "17", "--warmup", "3", "--pairs", "1280",
+                          "--read-len", "1500", "--gather-root", gather_root, "--diagnose-budget", "200", "--deadline", "500"],
+                         env=env, cwd=root, capture_output=True, text=True, timeout=700)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["steps"] == 17 and j["value"] > 0 and j["scaling"] == "weak" and j["gather_check"] is True
+    assert j["config"]["rccl_ranks"] == 8 and j["config"]["gather"]["format"] == "edits"
+    assert j["config"]["gather"]["root"] == ("rank 0" if gather_root == "0" else "step k to rank k mod N")
+    if gather_root == "rotate":
+        assert j["config"]["shards"] == "equal" and j["config"]["pairs_per_step_all_gpus"] == 8 * 1280
+    else:
+        assert j["config"]["shards"]["rank_0"] == 0                  # 'auto' at N = 8: the root only collects and decodes
+    d = j["diagnose"]
+    assert "error" not in d, d
+    for key in ("root0_equal_shards", "root0_auto_shards", "rotating_root_equal_shards"):
+        assert d[key]["value"] > 0 and d[key]["every_slot_decoded"] is True
+    assert [x["peer"] for x in d["links"]["one_peer_at_a_time"]] == list(range(1, 8))
+    assert len(j["per_gpu_value"]["per_rank"]) == 8 and j["per_gpu_value"]["min"] > 0
+
+
 @pytest.mark.parametrize("fault", ["raise", "hang"])
 def test_bench_line_survives_its_diagnostics(fault):
     """The diagnostics of an N > 1 run come last and under a budget: if they raise on a rank (the others then wait in a
@@ -524,6 +556,101 @@ def _device_align(aligner, torch, seq, desc, n, cap, **kw):
         seg = h[2 * k * cap: 2 * (k * cap + cnt[k])]
         cig.append("".join("%d%s" % (seg[2 * j], chr(seg[2 * j + 1])) for j in range(cnt[k])))
     return ed.cpu().tolist(), cig, st.cpu().tolist()
+
+
+def _revcomp(b):
+    return b.translate(bytes.maketrans(b"ACGTacgt", b"TGCAtgca"))[::-1]
+
+
+@pytest.mark.parametrize("form", ["runs, small launch (two wavefronts per window)", "runs, one wavefront per window", "edit streams"])
+@pytest.mark.parametrize("W,O", [(64, 33), (32, 17), (50, 25)])
+def test_reverse_strand_on_the_device(aligner, oracle, form, W, O):
+    """SURVEY.md §8 f4 on the device-pointer layer (scrg_params.stranded, SCRG_READ_REVCOMP in scrg_pair_desc.read_off): pairs
+    whose read is aligned as its reverse complement FROM THE ONE PACKED COPY of the read — forward and reverse candidates of the
+    same read share its words — against the reference algorithm on the reverse-complemented string (the reference itself drops
+    such candidates, src/tests.cu:346-355).  Ragged and empty reads, reads shorter than a window, both sequence layouts, runs
+    (both forms of the kernel) and edit streams."""
+    import torch
+    import scrooge_amd
+    dev = torch.device("cuda", 0)
+    rng = np.random.Generator(np.random.PCG64(W * 7 + O))
+    n_reads = 333
+    t, q = synth.make_pairs(n_reads, 900, "ont", seed=400 + W)
+    for k in range(0, n_reads, 4):
+        q[k] = q[k][: int(rng.integers(0, 900))]
+    q[5], q[9], q[13] = b"", q[9][:1], q[13][:63]
+    # every read twice: as it is against its text, and flagged "reverse complement" against a text made from its reverse complement
+    texts, reads, want_reads, rev = [], [], [], []
+    for k in range(n_reads):
+        texts.append(t[k]); reads.append(k); want_reads.append(q[k]); rev.append(0)
+        rc = _revcomp(q[k])
+        t_rc = synth.BASES[synth.mutate(np.searchsorted(synth.BASES, np.frombuffer(rc + b"ACGT" * 30, dtype=np.uint8)).astype(np.uint8), 0.08, (23, 31, 46), rng)].tobytes()
+        texts.append(t_rc); reads.append(k); want_reads.append(rc); rev.append(1)
+    n = len(texts)
+    eds, cigars, _, _ = oracle.align(texts, want_reads, W=W, O=O, threads=8)
+    tw, rw = (max(len(x) for x in texts) + 31) // 32 + 1, (900 + 31) // 32
+    cap = (2 * 900 + 8 + 15) // 16 * 16
+    G = scrooge_amd.api.GROUP
+    bad = torch.zeros(1, dtype=torch.int32, device=dev)
+    kw = dict(W=W, O=O, stranded=1)
+    if form.startswith("runs, one"):
+        kw["waves_per_cu"] = 16
+    aligner.set_stream(0)
+    try:
+        for layout in ("linear", "groups"):
+            t_rows = np.zeros((n, tw * 32), dtype=np.uint8)
+            r_rows = np.zeros((n_reads, rw * 32), dtype=np.uint8)
+            for k in range(n):
+                t_rows[k, :len(texts[k])] = np.frombuffer(texts[k], dtype=np.uint8)
+            for k in range(n_reads):
+                r_rows[k, :len(q[k])] = np.frombuffer(q[k], dtype=np.uint8)
+            idx = torch.arange(n, dtype=torch.int64, device=dev)
+            ridx = torch.tensor(reads, dtype=torch.int64, device=dev)
+            flag = torch.tensor(rev, dtype=torch.int64, device=dev) << 63
+            tl = torch.tensor([len(x) for x in texts], dtype=torch.int64, device=dev)
+            ql = torch.tensor([len(q[k]) for k in reads], dtype=torch.int64, device=dev)
+            if layout == "linear":
+                seq = torch.zeros(n * tw + n_reads * rw + scrooge_amd.api.SEQ_PAD_WORDS, dtype=torch.int64, device=dev)
+                aligner.pack_planar(torch.from_numpy(t_rows).to(dev).view(-1), seq[: n * tw], bad)
+                aligner.pack_planar(torch.from_numpy(r_rows).to(dev).view(-1), seq[n * tw:], bad)
+                t_off, r_off = idx * tw * 32, (n * tw + ridx * rw) * 32
+                lay = {}
+            else:
+                tg, rg = (n + G - 1) // G, (n_reads + G - 1) // G
+                seq = torch.zeros(tg * G * tw + rg * G * rw + scrooge_amd.api.SEQ_PAD_WORDS_GROUPS, dtype=torch.int64, device=dev)
+                aligner.pack_planar_groups(torch.from_numpy(t_rows).to(dev).view(-1), n, tw, seq[: tg * G * tw], bad)
+                aligner.pack_planar_groups(torch.from_numpy(r_rows).to(dev).view(-1), n_reads, rw, seq[tg * G * tw:], bad)
+                t_off = ((idx // G) * tw * G + idx % G) * 32
+                r_off = (tg * G * tw + (ridx // G) * rw * G + ridx % G) * 32
+                lay = dict(text_stride_words=G, read_stride_words=G)
+            desc = torch.stack([t_off, tl, r_off | flag, ql, idx * cap, torch.full_like(idx, cap)], dim=1).contiguous()
+            assert int(bad.item()) == 0
+            if form == "edit streams":
+                slices = torch.zeros(n * cap * 2, dtype=torch.uint8, device=dev)
+                ed = torch.empty(n, dtype=torch.int64, device=dev)
+                ln = torch.empty(n, dtype=torch.int32, device=dev)
+                st = torch.empty(n, dtype=torch.int32, device=dev)
+                aligner.align_device_edits(n, seq, desc, slices, ed, ln, st, **kw, **lay)
+                torch.cuda.synchronize()
+                assert ed.cpu().tolist() == eds and int(st.max().item()) == 0, layout
+                sl, lh = slices.cpu().numpy(), ln.cpu().tolist()
+                for k in range(n):
+                    stream = sl[2 * k * cap: 2 * k * cap + lh[k]].tobytes()
+                    assert scrooge_amd.api.edit_stream_to_cigar(stream, len(want_reads[k]), W=W, O=O) == cigars[k], (layout, k, rev[k])
+            else:
+                got = _device_align(aligner, torch, seq, desc, n, cap, **kw, **lay)
+                bad_k = [k for k in range(n) if (got[0][k], got[1][k]) != (eds[k], cigars[k])]
+                assert not bad_k, (layout, bad_k[:10], [rev[k] for k in bad_k[:10]], [len(want_reads[k]) for k in bad_k[:10]])
+                assert got[2] == [0] * n
+        # the flag without the parameter is a (huge) offset, not a strand; geometries the other kernels serve refuse the parameter
+        with pytest.raises(scrooge_amd.ScroogeError):
+            _device_align(aligner, torch, seq, desc, n, cap, W=64, O=2, stranded=1)
+        with pytest.raises(scrooge_amd.ScroogeError):
+            _device_align(aligner, torch, seq, desc, n, cap, W=128, O=65, stranded=1)
+        with pytest.raises(scrooge_amd.ScroogeError):
+            _device_align(aligner, torch, seq, desc, n, cap, lanes_per_pair=8, stranded=1)
+    finally:
+        aligner.use_own_stream()
 
 
 @pytest.mark.parametrize("n", [1, 63, 64, 65, 1000])

@@ -59,7 +59,8 @@ def _cases(seed):
     return T, Q
 
 
-@pytest.mark.parametrize("W,O", [(64, 33), (64, 40), (64, 50), (64, 63), (32, 17), (48, 24), (33, 2), (2, 1), (17, 9), (64, 2), (64, 20), (50, 1)])
+@pytest.mark.parametrize("W,O", [(64, 33), (64, 40), (64, 50), (64, 63), (32, 17), (48, 24), (33, 2), (2, 1), (17, 9), (64, 2), (64, 20), (50, 1),
+                                 (16, 0), (31, 0), (24, 0), (40, 0), (63, 0), (64, 0)])           # O = 0: a window's traceback takes all W characters
 def test_lane_form_matches_oracle(proto, W, O):
     T, Q = _cases(W * 100 + O)
     ls = LS()
@@ -70,7 +71,7 @@ def test_lane_form_matches_oracle(proto, W, O):
     assert ls.windows > 1000
 
 
-@pytest.mark.parametrize("W,O", [(64, 33), (64, 40), (64, 63), (32, 17), (48, 24), (2, 1), (17, 9), (33, 2)])
+@pytest.mark.parametrize("W,O", [(64, 33), (64, 40), (64, 63), (32, 17), (48, 24), (2, 1), (17, 9), (33, 2), (16, 0), (31, 0)])
 def test_lane_edit_stream_form_matches_oracle(proto, oracle, W, O):
     """The kernel's edit-stream traceback (pending matches as mbase + column, every window closed by its END byte) produces the
     canonical edit stream of the oracle's CIGAR (tests/test_edit_stream.py: py_encode)."""

@@ -36,7 +36,8 @@ def test_oracle_matches_golden_pairs(oracle, golden_pairs):
 @pytest.mark.parametrize("name", ["pairs_w32_o17.json", "pairs_w64_o2.json", "pairs_w48_o24.json", "pairs_w64_o40.json",
                                   "pairs_w128_o65.json", "pairs_w96_o49.json",
                                   "pairs_w256_o129.json", "pairs_w192_o97.json", "pairs_w128_o20.json",
-                                  "pairs_w200_o50.json"])
+                                  "pairs_w200_o50.json",
+                                  "pairs_w16_o0.json", "pairs_w24_o0.json", "pairs_w40_o0.json", "pairs_w64_o0.json", "pairs_w128_o0.json"])
 def test_oracle_matches_golden_other_knobs(oracle, name):
     """Fixtures from the reference built with its own -DCLI_W/-DCLI_K/-DCLI_O switches."""
     from tests.conftest import load_golden
