@@ -111,11 +111,18 @@ def parse():
                     help="never rebuild the library (profiling: nothing may fork a compiler under rocprofv3)")
     ap.add_argument("--stats", action="store_true", help="profiling only: print kernel round/step counters")
     ap.add_argument("--ablate", type=int, default=0, help="profiling only: 1 = no TB table reads, 2 = no DC sweep")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="profiling: nothing but set-up, warm-up and the timed region (no CPU leg, no serial / sustained / inclusive / "
+                         "edit-stream / other-config / host-API legs): the LAST --steps launches of the align kernel in a rocprofv3 "
+                         "kernel trace of this command are the timed ones (scripts/headline_trace.sh)")
     ap.add_argument("--serial", action="store_true",
                     help="one stream: every step waits for the previous one to finish (default: consecutive steps "
                          "alternate between two streams and two handles, so the next step's wavefronts fill the "
                          "GPU while the previous step's last pairs finish)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.headline_only:
+        args.cpu_seconds, args.sustained_steps, args.other_configs, args.host_api = 0.0, 0, "off", "off"
+    return args
 
 
 def usable_cores():
@@ -935,7 +942,7 @@ def main():
 
     # reference point outside the timed region: the same step on ONE stream (no overlap between launches)
     serial = None
-    if n_lanes > 1 and not dist_on and not args.stats:
+    if n_lanes > 1 and not dist_on and not args.stats and not args.headline_only:
         sev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(3)]
         o = outs[0]
         torch.cuda.synchronize()
@@ -965,6 +972,39 @@ def main():
         sdt = time.perf_counter() - ts
         sustained = {"steps": args.sustained_steps, "value": n * args.sustained_steps / sdt, "unit": "pairs/s",
                      "ms_per_step": sdt / args.sustained_steps * 1e3}
+        last = (step.count - 1) % n_lanes
+        ed, n_runs, dense = outs[last]["ed"], outs[last]["n_runs"], denses[last]
+    # Reference point outside the timed region: the same pipelined step INCLUDING the packing of the sequences — ASCII in HBM ->
+    # runs: scrg_pack_planar_groups of the batch's 21.5 KB per pair, then the align kernel and the compaction, every step.  The
+    # headline excludes the packing, as the reference's timed region does (src/genasm_gpu.cu:939-944: its 2-bit conversion runs
+    # before the clock starts); a caller whose sequences arrive as text pays this rate.
+    incl_pack = None
+    if (n_lanes > 1 and not dist_on and not args.stats and not args.ablate and groups and not same_batch
+            and all(a_ is not None for a_ in ascii_keep)):
+        row_words_ = tw + rw
+
+        def step_incl_pack():
+            j = step.count
+            step.count += 1
+            b = j % n_lanes
+            o = outs[b]
+            with torch.cuda.stream(streams[b]):
+                aligners[b].pack_planar_groups(ascii_keep[b].view(-1), n, row_words_, seqs[b], bad)
+                aligners[b].align_device(n, seqs[b], descs[b], o["runs"], o["ed"], o["n_runs"], o["status"], **kw)
+                cnt64 = o["n_runs"].to(torch.int64)
+                aligners[b].compact_runs(n, descs[b], o["runs"], o["n_runs"], torch.cumsum(cnt64, 0) - cnt64, denses[b])
+        for _ in range(n_lanes):
+            step_incl_pack()
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        for _ in range(args.steps):
+            step_incl_pack()
+        torch.cuda.synchronize()
+        idt = time.perf_counter() - ts
+        assert int(bad.item()) == 0
+        incl_pack = {"value": n * args.steps / idt, "unit": "pairs/s", "steps": args.steps, "ms_per_step": idt / args.steps * 1e3,
+                     "includes": "ASCII in HBM -> lane-interleaved 2-bit planes (scrg_pack_planar_groups, %.1f KB of text per pair) + align kernel + "
+                                 "run compaction, pipelined over the same %d streams as the headline" % (row_words_ * 32 / 1e3, n_lanes)}
         last = (step.count - 1) % n_lanes
         ed, n_runs, dense = outs[last]["ed"], outs[last]["n_runs"], denses[last]
     # duration of one align launch for the roofline line: events around a launch that has the GPU to itself.
@@ -1095,7 +1135,7 @@ def main():
     # scaling figure the same step — align kernel with edit-stream output + compaction of the streams, pipelined
     # over the same streams, no collective — is timed here on one GPU, after everything above (it reuses the slices).
     edit_stream_step = None
-    if not dist_on and n_lanes > 1 and not args.ablate and not args.stats and p.lanes_per_pair == 1:
+    if not dist_on and n_lanes > 1 and not args.ablate and not args.stats and p.lanes_per_pair == 1 and not args.headline_only:
         lens = [torch.empty(n, dtype=torch.int32, device=device) for _ in range(n_lanes)]
         sbytes_lane = []
         for b_ in range(n_lanes):
@@ -1306,6 +1346,28 @@ def main():
                             "this same run compares every pair of every timed batch (edit distances, run counts, all runs) byte for byte "
                             "with the reference CPU path (`parity`)",
                     "hbm": hbm}
+        if windows is not None and p.lanes_per_pair == 1 and p.W <= 64 and p.W - p.O <= 31:
+            # USEFUL work of the formulation this kernel really runs, per pair and at each lane's own counts — not
+            # the maximum over a wavefront's 64 lanes, not the instructions of idle lanes, fetches, set-up or stores:
+            #   the table     19 VALU per text column x 64 columns per window (all 64 rows and every distance at once)
+            #   pass 1        10 VALU per traceback column x (W-O) columns per window (the walk, branch-free)
+            #   pass 2        20.5 VALU per event (41 per trip of two) x the pair's events: one per run that starts in a window =
+            #                 the pair's runs (insertion runs and D / X / = runs are separate events)
+            # windows per pair: the CPU checker's count on this batch; runs per pair: this launch's own output.
+            USEFUL_TABLE, USEFUL_PASS1, USEFUL_PASS2 = 19.0 * 64.0, 10.0 * (p.W - p.O), 20.5
+            useful_pair = windows * (USEFUL_TABLE + USEFUL_PASS1) + runs_per_pair * USEFUL_PASS2
+            useful_launch = useful_pair * n_real
+            roofline["useful_lane_ops"] = {
+                "lane_ops_per_pair": useful_pair, "windows_per_pair": windows, "runs_per_pair": runs_per_pair,
+                "formula": "windows x (19 x 64 table + 10 x (W-O) pass 1) + runs x 20.5 pass 2, per lane at its own counts (DESIGN.md §3.1)",
+                "useful_over_issued": useful_launch / lane_ops_launch,
+                "frac_useful": useful_launch / (kernel_ms * 1e-3) / VALU_PEAK_LANE_OPS,
+                "frac_useful_at_step_rate": (useful_launch / (dt / args.steps) / VALU_PEAK_LANE_OPS) if not dist_on else None,
+                "frac_useful_sustained": (useful_launch / (sustained["ms_per_step"] * 1e-3) / VALU_PEAK_LANE_OPS) if sustained else None,
+                "note": "what a regression shows in: `frac` (issued / peak) goes UP if the kernel is padded with instructions and does not "
+                        "move if lanes idle more; `frac_useful` (this) only moves with time per pair; `frac_reference_ops` prices the "
+                        "reference's per-distance recurrence, which this kernel does not run"}
+            roofline["frac_useful"] = roofline["useful_lane_ops"]["frac_useful_at_step_rate"] or roofline["useful_lane_ops"]["frac_useful"]
         if dc_cells is not None:
             # what SURVEY.md §8(d) asks `achieved` to be computed from: 14 int32 lane-ops per GenASM-DC cell + ~13 per traceback step
             ref_lane_ops_pair = 14.0 * dc_cells + 13.0 * (tb_steps or 0)
@@ -1356,6 +1418,7 @@ def main():
         "kernel_ms_events_in_timed_region": events_ms,   # pipelined launches: includes waiting for the previous launch's wavefronts to retire
         "serial": serial,              # the same step without overlap between launches, measured after the timed region
         "sustained": sustained,        # the same pipelined step over many more steps (fill and drain amortised), after the timed region
+        "value_incl_pack": incl_pack,  # the same pipelined step with the packing of the sequences inside it (ASCII in HBM -> runs), after the timed region
         "other_configs": other_configs,   # BASELINE configs[0], [2], [4], Cfg2b, mixed lengths, two knob-sweep points on this GPU, measured after the timed region, each with an oracle-checked sample
         "host_api": host_api,             # the host-pointer entry points (PCIe-inclusive; never `value`), after the timed region
         "edit_stream_step": edit_stream_step,   # the N > 1 step (CIGARs as edit streams) on this one GPU, without the collective
