@@ -215,6 +215,10 @@ SCRG_HD inline bool decode_lane_clean(const DecodeLane& s, uint32_t last, uint32
     return s.pend == 0 && (last >> 6) == 0 && last != EDIT_MORE && s.placed == read_len && (s.over >> 8) == 0;
 }
 
+// Streams off a wire may be long enough to wrap the 32-bit count of placed characters (64 per byte, 2^30 bytes): a count that
+// has passed 2^31 — no read is that long — marks the pair for good.  The device decoder calls this once per 16-byte block.
+SCRG_HD inline void decode_lane_guard(DecodeLane& s) { s.over |= (s.placed >> 31) << 8; }
+
 // put(at, word): the run whose slot is at byte offset `at`
 template <typename Put>
 SCRG_HD inline void decode_lane_step(DecodeLane& s, const uint32_t b, Put&& put)
@@ -239,7 +243,10 @@ SCRG_HD inline void decode_lane_step(DecodeLane& s, const uint32_t b, Put&& put)
     // a window end (e = 0) closes the run: e - 1 has bit 30 then, and only then; 0x3F leaves things as they are
     s.prev = es_sel(s.prev, es_and_or(e - 1u, DEC_PREV_NONE, e), moreM);
     s.placed = s.placed + len + es_bit(6u, e);                       // matches (0x3F: its 63), + the read character of X and I
-    s.over |= t;
+    // (`tot`, not `t`: a stretch of 0x3F bytes that has grown past 255 is reported at once and for good — the sum it becomes
+    // when the stretch closes can only be larger — so a stream long enough to wrap the 32-bit `pend` cannot pass as clean.
+    // `placed` grows by at most 64 per byte: decode_lane_guard(), called at least every 2^24 steps, catches it above 2^31.)
+    s.over |= tot;
     s.over = es_or_xor(s.over, s.cur - 1u, s.cur);                   // a count of 0 — 256 of the same edit in a row — borrows from the letter
 #if defined(__HIP_DEVICE_COMPILE__)
     // (the two sums are kept up step by step: left alone, the compiler adds up the sixteen steps of an unrolled block at its

@@ -264,6 +264,7 @@ __global__ __launch_bounds__(256, 4) void decode_edits_kernel(DecodeArgs a)
             // side by side: 150 VGPRs, three wavefronts per SIMD instead of four)
             if ((it & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
+        decode_lane_guard(s);
         SCRG_DEC_T(t2);
         // The block after the next is asked for now and looked at an epoch from now.  Stores and loads share one counter
         // (vmcnt) and the wait in front of the next epoch cannot tell the stores of a data-dependent pass from the load it is

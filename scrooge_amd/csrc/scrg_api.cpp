@@ -609,10 +609,13 @@ scrg_status scrg_edit_stream_to_runs_lane(const scrg_params* params, uint64_t re
     if (read_len > 0x7fffffffull || n_bytes > 0x3fffffffull) return SCRG_ERR_INVALID_ARG;
     scrg::DecodeLane s;
     scrg::decode_lane_init(s, 0u);
-    for (uint64_t k = 0; k < n_bytes; k++)
+    for (uint64_t k = 0; k < n_bytes; k++) {
         scrg::decode_lane_step(s, (uint32_t)stream[k], [&](uint32_t at, uint32_t word) {         // at: byte offset of the run's slot
             if ((at >> 1) < runs_cap) { runs[at >> 1].count = (uint8_t)word; runs[at >> 1].op = (char)(word >> 8); }
         });
+        if ((k & 15u) == 15u) scrg::decode_lane_guard(s);
+    }
+    if (read_len > 0x7fffffffull) return SCRG_ERR_INVALID_ARG;
     if (!scrg::decode_lane_clean(s, n_bytes ? (uint32_t)stream[n_bytes - 1] : 0u, (uint32_t)read_len)) return SCRG_ERR_INVALID_ARG;
     *n_runs = scrg::decode_lane_runs(s);
     return *n_runs > runs_cap ? SCRG_ERR_CIGAR_OVERFLOW : SCRG_OK;

@@ -542,3 +542,113 @@ int lane_align_codes_band(const uint8_t *text, size_t text_len, const uint8_t *r
     *n_runs = out.n; *edit_distance = total;
     return out.overflow ? GO_ERR_CAPACITY : GO_OK;
 }
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Round 6 experiment: the window's table computed in a 32-ROW BAND around the main diagonal (W = 64, W-O <= 31).
+ * The traceback keeps d == D[i][j] and only ever asks whether a neighbour's value is d - 1; every cell it visits or
+ * asks about lies within d_w of the main diagonal (d_w = D[0][0], the window's distance) and its best completion
+ * deviates by no more than its own value, so if d_w <= B all of it happens inside |i - j| <= B.  A band-restricted
+ * computation gives over-estimates outside and the exact values inside (an over-estimate can only turn a true
+ * "== d - 1" into a miss, never invent one), and its D[0][0] is itself an over-estimate: d_band <= B proves the window
+ * safe.  Column i (swept 63 .. 0) keeps rows i - 15 .. i + 16 as ONE dword (bit 31 <-> row i - 15): the band moves up
+ * one row per column, so the two shifts of the full recurrence become one (Hyyro's diagonal form), the 64-bit add a
+ * 32-bit add, and every v_bitop3 pair a single one: 10 instead of 19 instructions per column.  Eq of the column is the
+ * 64-bit word of the text character shifted to the band (a compile-time shift in the unrolled kernel).
+ * d_band = 64 - (number of columns whose main-diagonal step is free), read from bit 17 of Xh | Mv in every column.
+ * Windows with n < 64 or m < 64 (a pair's last) and windows with d_band > BAND32_SAFE take the full table.
+ * ---------------------------------------------------------------------------------------------------------- */
+#define BAND32_UP 15            /* rows above the diagonal (j < i) */
+#define BAND32_DOWN 16          /* rows below it */
+#define BAND32_SAFE 14
+
+typedef struct lane_stats_band32 { uint64_t windows, banded, escapes, mismatching_safe_windows; uint64_t hist[66]; } lane_stats_band32;
+
+/* -> d_band; V1[i], V0[i] (i < TBL) in the full 64-bit row alignment of lane_dc, zero outside the band */
+static int lane_dc_band32(const uint8_t *t, const uint8_t *q, int TBL, uint64_t *V1, uint64_t *V0)
+{
+    uint64_t Tlo = 0, Thi = 0, Plo = 0, Phi = 0;
+    for (int k = 0; k < 64; k++) {
+        Tlo |= (uint64_t)(t[k] & 1) << k; Thi |= (uint64_t)(t[k] >> 1) << k;
+        Plo |= (uint64_t)(q[k] & 1) << k; Phi |= (uint64_t)(q[k] >> 1) << k;
+    }
+    const uint64_t Rlo = lp_brev64(Plo), Rhi = lp_brev64(Phi);
+    /* band of column c (c = 64 is the boundary column): full-word bits s_c .. s_c + 31, s_c = 63 - c - BAND32_DOWN;
+     * bits below bit 0 (rows > 63) are neutral — Eq = 1, Pv = Mv = 0, like the bits below a short pattern */
+    uint32_t pv, mv = 0;
+    {   /* boundary column 64: rows 49 .. 63 exist (+1 each), rows 64 .. 80 do not */
+        const int s = 63 - 64 - BAND32_DOWN;                        /* -17 */
+        pv = (uint32_t)(~0ull << (-s));                             /* full word of ones, moved up by 17 */
+    }
+    int free_diagonals = 0;
+    for (int i = 63; i >= 0; i--) {
+        const uint64_t sl = 0ull - ((Tlo >> i) & 1), sh = 0ull - ((Thi >> i) & 1);
+        const uint64_t Eq64 = ~((Rlo ^ sl) | (Rhi ^ sh));
+        const int s_old = 63 - (i + 1) - BAND32_DOWN;               /* the band of column i + 1: where pv / mv live */
+        uint32_t eq;
+        if (s_old >= 0) eq = (uint32_t)(Eq64 >> s_old);
+        else eq = (uint32_t)((Eq64 << (-s_old)) | ((1ull << (-s_old)) - 1ull));     /* rows past 63: Eq = 1 */
+        const uint32_t xv = eq | mv;
+        const uint32_t xh = (((eq & pv) + pv) ^ pv) | eq;
+        const uint32_t ph = mv | ~(xh | pv);
+        const uint32_t mh = pv & xh;
+        /* the main diagonal's step (i + 1, i + 1) -> (i, i): row i sits BAND32_UP + 1 rows below the old band's top row i + 1 - 15 ... */
+        free_diagonals += (int)(((xh | mv) >> (31 - (BAND32_UP - 1))) & 1u);     /* row i of the old band: bit 31 - (i - (i + 1 - 15)) = 17 */
+        const uint32_t xvs = xv >> 1;
+        const uint32_t pvn = mh | ~(xvs | ph);
+        const uint32_t mvn = ph & xvs;
+        if (i < TBL) {
+            /* table words in the NEW band's coordinates (one bit down from the old one's): Ph, Xh of row j sit one bit lower there */
+            const uint32_t v1 = pvn | (ph >> 1) , v0 = pvn | ~((ph | xh) >> 1);
+            const int s_new = 63 - i - BAND32_DOWN;                  /* >= 17 for i <= 30 */
+            V1[i] = (uint64_t)v1 << s_new;
+            V0[i] = (uint64_t)(v0 & ~0u) << s_new;
+            /* rows below the band (bits under s_new) read "match", rows above it were shifted out */
+        }
+        pv = pvn; mv = mvn;
+    }
+    return 64 - free_diagonals;
+}
+
+int lane_align_codes_band32(const uint8_t *text, size_t text_len, const uint8_t *read, size_t read_len, int W, int O,
+                            go_run *runs, size_t cap, size_t *n_runs, long long *edit_distance, lane_stats_band32 *ls)
+{
+    if (W != 64 || O < 33 || O >= W) return GO_ERR_PARAMS;
+    run_sink out = { runs, cap, 0, 0 };
+    size_t ti = 0, ri = 0; long long total = 0;
+    const int TBL = W - O;
+    uint64_t V1[64], V0[64], B1[64], B0[64];
+    lane_stats dummy = {0, 0, 0};
+    while (ri < read_len) {
+        size_t n = text_len - ti < (size_t)W ? text_len - ti : (size_t)W;
+        size_t m = read_len - ri < (size_t)W ? read_len - ri : (size_t)W;
+        size_t tu, pu;
+        int banded = 0;
+        ls->windows++;
+        if (n == 64 && m == 64) {
+            const int d_band = lane_dc_band32(text + ti, read + ri, TBL, B1, B0);
+            ls->hist[d_band < 0 ? 0 : (d_band > 65 ? 65 : d_band)]++;
+            if (d_band <= BAND32_SAFE) banded = 1; else ls->escapes++;
+        }
+        if (banded) {
+            /* (the proto also runs the full table and counts the safe windows on which the two walks differ: must stay 0) */
+            run_sink o1 = { runs + out.n, cap > out.n ? cap - out.n : 0, 0, 0 };
+            size_t tu2, pu2;
+            lane_dc(text + ti, (int)n, read + ri, (int)m, TBL, V1, V0, &dummy);
+            go_run tmp[80]; run_sink o2 = { tmp, 80, 0, 0 };
+            const int e2 = lane_tb(V1, V0, (int)m, TBL, &tu2, &pu2, &o2, &dummy);
+            const int e1 = lane_tb(B1, B0, (int)m, TBL, &tu, &pu, &o1, &dummy);
+            int same = e1 == e2 && tu == tu2 && pu == pu2 && o1.n == o2.n;
+            for (size_t k = 0; same && k < o1.n && k < o1.cap; k++) same = runs[out.n + k].count == tmp[k].count && runs[out.n + k].op == tmp[k].op;
+            if (!same) ls->mismatching_safe_windows++;
+            out.n += o1.n; out.overflow |= o1.overflow;
+            total += e1;
+            ls->banded++;
+        } else {
+            lane_dc(text + ti, (int)n, read + ri, (int)m, TBL, V1, V0, &dummy);
+            total += lane_tb(V1, V0, (int)m, TBL, &tu, &pu, &out, &dummy);
+        }
+        ti += tu; ri += pu;
+    }
+    *n_runs = out.n; *edit_distance = total;
+    return out.overflow ? GO_ERR_CAPACITY : GO_OK;
+}

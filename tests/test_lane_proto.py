@@ -131,3 +131,34 @@ def test_lane_band_form_matches_oracle(proto, W, O):
         assert related.escapes <= related.windows // 200, (related.escapes, related.windows)
     elif (W, O) in ((64, 2), (64, 1)):        # ... and here it does not
         assert related.escapes > related.windows // 300, (related.escapes, related.windows)
+
+
+class LSB32(C.Structure):
+    _fields_ = [("windows", C.c_uint64), ("banded", C.c_uint64), ("escapes", C.c_uint64), ("mismatching_safe_windows", C.c_uint64),
+                ("hist", C.c_uint64 * 66)]
+
+
+def test_band32_table_is_exact_where_it_claims_and_escapes_too_often(proto):
+    """Round 6's step-change experiment on the default kernel, prototyped and NOT adopted: the window's table computed in a 32-row
+    band around the main diagonal (one dword per vector: 10 instead of 19 instructions per column; tests/proto/lane_proto.c,
+    lane_dc_band32).  The band's own D[0][0] <= 14 proves a window safe, and on every safe window the banded table gives the walk
+    of the full one (checked here: 0 differences) — but 1.6 % of the WINDOWS of 10 % ONT-error reads are not safe (the window
+    distance has a long tail: mean 7.3, 1 in 60 above 14), and a wavefront redoes its round on the full table when ANY of its 64
+    lanes is not: 65 % of the rounds (PacBio 15 %: 7.4 % of the windows, 99 % of the rounds).  A band wide enough for 1 % of the
+    rounds needs |i - j| <= 20: 41 rows, two dwords again."""
+    ls = LSB32()
+    T, Q = synth.make_pairs(120, 4000, "ont", seed=77)
+    t2, q2 = synth.make_pairs(40, 4000, "pacbio15", seed=78)
+    n_ont_windows = None
+    for k, (t, q) in enumerate(zip(T + t2, Q + q2)):
+        if k == 120:
+            n_ont_windows, ont_escapes = ls.windows, ls.escapes
+        got = _run(proto.lane_align_codes_band32, t, q, (C.c_int(64), C.c_int(33)), (C.byref(ls),))
+        want = _run(proto.go_align_codes, t, q, (C.c_int(64), C.c_int(33)), (None,))
+        assert got == want, k
+    assert ls.mismatching_safe_windows == 0 and ls.banded > 40000
+    p_ont = ont_escapes / n_ont_windows
+    assert 0.008 < p_ont < 0.03                                  # ~1.6 % of the windows ...
+    assert 1 - (1 - p_ont) ** 64 > 0.4                           # ... i.e. most rounds of a wavefront of 64 lanes
+    p_pb = (ls.escapes - ont_escapes) / (ls.windows - n_ont_windows)
+    assert p_pb > 0.04
