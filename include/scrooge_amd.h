@@ -335,9 +335,9 @@ scrg_status scrg_unpack_runs(scrg_ctx *ctx, uint64_t n_runs, const uint8_t *d_pa
  *   d_total[0] = bytes of d_stream used (the amount to transfer), d_total[1] = pairs that did not fit.
  *   stream_cap >= sum over the pairs of (edit distance + 2 * (read_len + edit distance) / (W-O) + read_len / 63 + 8) always
  *   suffices (the read_len / 63 term is the 0x3F bytes, one per 63 matches in a row: only W-O > 63 has any).
- * scrg_decode_edit_stream: the inverse (streams of 64 bytes and more on average: one pair per wavefront, 64 stream bytes side
- *   by side, coalesced loads and stores; shorter ones: one pair per lane, streams read in aligned 16-byte blocks, runs
- *   written in aligned 64-byte pieces — the same runs either way).  d_stream holds stream_bytes bytes (16-byte aligned, readable up to the next
+ * scrg_decode_edit_stream: the inverse (streams of 64 bytes and more on average: one pair per wavefront, four stream bytes per
+ *   lane side by side, runs staged in LDS and stored in aligned 16-byte units; shorter ones: one pair per lane, streams read in
+ *   aligned 16-byte blocks, runs written in aligned 64-byte pieces — the same runs either way).  d_stream holds stream_bytes bytes (16-byte aligned, readable up to the next
  *   multiple of 16): a pair whose stream is not inside [0, stream_bytes) — offsets and lengths may come off a wire —
  *   is counted as bad, never read.  Read lengths are taken from d_read_len[p * read_len_stride] (stride 1: a plain
  *   array; 6: &d_pairs[0].read_len; 0: one length for all).  `params` is not looked at beyond its validity (the window

@@ -65,7 +65,21 @@ def test_defaults_match_reference_knobs(lib):
     p.lanes_per_pair = 0
     p.W, p.O = 257, 129
     assert lib.scrg_params_resolve(p, r) != 0
-    p.W, p.O = 64, 0
+    p.W, p.O = 64, 0                     # (O = 0: the reference's no-overlap special case, src/genasm_cpu.cpp:104-110 — one pair per lane only)
+    assert lib.scrg_params_resolve(p, r) == 0 and (r.W, r.O, r.lanes_per_pair) == (64, 0, 1)
+    p.lanes_per_pair = 8
+    assert lib.scrg_params_resolve(p, r) != 0
+    p.lanes_per_pair = 0
+    p.W, p.O = 64, 64
+    assert lib.scrg_params_resolve(p, r) != 0
+    p.W, p.O = 64, -1
+    assert lib.scrg_params_resolve(p, r) != 0
+    p.W, p.O = 64, 33
+    p.stranded = 1                       # minus-strand pairs from one packed copy of the read: the default geometry only
+    assert lib.scrg_params_resolve(p, r) == 0 and r.stranded == 1
+    p.O = 2
+    assert lib.scrg_params_resolve(p, r) != 0
+    p.O, p.stranded = 33, 2
     assert lib.scrg_params_resolve(p, r) != 0
 
 
