@@ -1155,6 +1155,81 @@ def test_decode_two_runs_per_step_fills_the_ring(aligner, dec_kernel, monkeypatc
         aligner.use_own_stream()
 
 
+def test_decoders_agree_on_arbitrary_streams(aligner, monkeypatch):
+    """All three device decoders on byte strings that mostly are NOT alignments (random bytes, long runs of one edit — 300 deletions
+    in a row —, 0x3F stretches, streams that start at any byte offset): the verdict (clean or not), the run count and the runs of
+    every clean stream must be those of the format's definition (tests/test_edit_stream.py: py_decode), nothing is written outside
+    a pair's segment, and a segment that is one run short is reported and not overrun."""
+    import re
+    import torch
+    from tests.test_edit_stream import py_decode
+    dev = torch.device("cuda", 0)
+    rng = np.random.Generator(np.random.PCG64(99))
+    streams, rls = [], []
+    for k in range(1500):
+        n = int(rng.integers(0, 1200))
+        kind = k % 5
+        if kind == 0:
+            b = rng.integers(0, 256, n, dtype=np.uint8)
+        elif kind == 1:
+            b = rng.choice(np.array([0x40, 0x80, 0xC0, 0x00, 0x41, 0x3F], dtype=np.uint8), n, p=[.3, .2, .3, .05, .1, .05])
+        elif kind == 2:
+            b = rng.choice(np.array([0x40, 0x80, 0xC0], dtype=np.uint8), n, p=[.1, .1, .8])
+        elif kind == 3:
+            b = rng.integers(0, 64, n, dtype=np.uint8)
+        else:
+            b = np.frombuffer(bytes([0x41]) * int(rng.integers(0, 300)) + bytes([0xC0]) * int(rng.integers(250, 262)) + b"\x02", dtype=np.uint8)
+        st = bytes(b) + (b"\0" if rng.integers(0, 4) else b"")
+        placed = sum((x & 63) + (1 if (x >> 6) in (1, 2) else 0) for x in st)
+        streams.append(st)
+        rls.append(placed if rng.integers(0, 8) else placed + 1)
+    want = [py_decode(s_, r_) for s_, r_ in zip(streams, rls)]
+    n = len(streams)
+    assert 100 < sum(w is not None for w in want) < n - 100
+    offs, blob = [], bytearray()
+    for k, st in enumerate(streams):
+        blob += bytes([0xC1] * (k % 7))                  # (any byte offset; what lies between the streams is not zeros)
+        offs.append(len(blob))
+        blob += st
+    stream = torch.tensor(list(blob) + [0xC1] * 64, dtype=torch.uint8, device=dev)
+    s_off = torch.tensor(offs, dtype=torch.int64, device=dev)
+    s_len = torch.tensor([len(x) for x in streams], dtype=torch.int32, device=dev)
+    rl = torch.tensor(rls, dtype=torch.int64, device=dev)
+    runs_of = lambda c: [int(a) | (ord(o) << 8) for a, o in re.findall(r"(\d+)([=XID])", c)]
+    aligner.set_stream(0)
+    try:
+        for dec in ("quad", "wave", "lane"):
+            monkeypatch.setenv("SCRG_DEC_KERNEL", dec)
+            counted = torch.zeros(n, dtype=torch.int32, device=dev)
+            nbad = torch.zeros(1, dtype=torch.int32, device=dev)
+            aligner.decode_edit_stream(n, stream, s_off, s_len, rl, 1, None, None, counted, nbad)
+            torch.cuda.synchronize()
+            ch = counted.cpu().numpy().astype(np.int64)
+            assert int(nbad.item()) == sum(w is None for w in want), dec
+            for k in range(n):
+                assert (ch[k] == 0xffffffff - (1 << 32) or ch[k] == -1) == (want[k] is None), (dec, k)
+                if want[k] is not None:
+                    assert ch[k] == len(runs_of(want[k])), (dec, k)
+            # the runs: every pair gets the segment its count asks for (a stream that is not clean: 40 runs), one in ten a run short
+            seg = np.array([len(runs_of(w)) if w is not None else 40 for w in want], dtype=np.int64)
+            short = (np.arange(n) % 10 == 3) & (seg > 0)
+            seg_cap = seg - short
+            off = np.cumsum(seg + 3) - (seg + 3)               # three guard runs behind every segment
+            dense = torch.full((int(off[-1] + seg[-1] + 3) * 2 + 64,), 0xEE, dtype=torch.uint8, device=dev)
+            nbad.zero_()
+            aligner.decode_edit_stream(n, stream, s_off, s_len, rl, 1, torch.from_numpy(off).to(dev), dense,
+                                       torch.from_numpy(seg_cap.astype(np.int32)).to(dev), nbad)
+            torch.cuda.synchronize()
+            dh = dense.cpu().numpy().view(np.uint16)
+            assert int(nbad.item()) == sum(1 for k in range(n) if want[k] is None or short[k]), dec
+            for k in range(n):
+                assert (dh[off[k] + seg_cap[k]: off[k] + seg[k] + 3] == 0xEEEE).all(), (dec, k)      # nothing past the segment
+                if want[k] is not None:
+                    assert dh[off[k]: off[k] + seg_cap[k]].tolist() == runs_of(want[k])[: seg_cap[k]], (dec, k)
+    finally:
+        aligner.use_own_stream()
+
+
 def _run_tool(args, timeout):
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
