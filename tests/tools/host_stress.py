@@ -10,6 +10,9 @@ from oracle.pyoracle import Oracle
 
 
 
+RC = bytes.maketrans(b"ACGTacgt", b"TGCAtgca")
+
+
 def run(calls=150, seed=1, verbose=True):
     rng = np.random.Generator(np.random.PCG64(seed))
     orc = Oracle()
@@ -21,7 +24,8 @@ def run(calls=150, seed=1, verbose=True):
     t0 = time.time()
     for it in range(calls):
         kind = int(rng.integers(0, 4))
-        W, O = [(64, 33), (64, 33), (64, 2), (128, 65), (48, 24), (64, 40), (96, 49), (192, 97), (256, 129)][int(rng.integers(0, 9))]
+        W, O = [(64, 33), (64, 33), (64, 33), (64, 2), (128, 65), (48, 24), (64, 40), (96, 49), (192, 97), (256, 129),
+                (16, 0), (31, 0), (40, 0), (64, 0)][int(rng.integers(0, 14))]            # (O = 0: the reference's no-overlap build)
         outputs = int(rng.integers(0, 3))
         devices = [None, None, [0, 0], [0, 0, 0]][int(rng.integers(0, 4))]
         sort = int(rng.integers(0, 2))
@@ -48,13 +52,19 @@ def run(calls=150, seed=1, verbose=True):
             starts = rng.integers(0, len(genome) - 400, nr)
             reads = [genome[int(s):int(s) + 150] for s in starts]
             cands = [[int(s), max(0, int(s) - 2), int(rng.integers(0, len(genome) - 10))] for s in starts]
+            # (two calls in three carry minus-strand candidates: the read's reverse complement is aligned — on the device from the one
+            # packed copy of the read when the geometry is the default one, from a reverse-complemented row otherwise)
+            revs = [[int(rng.integers(0, 2)) for _ in cs] for cs in cands] if rng.integers(0, 3) else None
             T = [genome[c:c + 400] for cs in cands for c in cs]
-            Q = [reads[i] for i, cs in enumerate(cands) for _ in cs]
+            Q = [(reads[i] if not (revs and revs[i][k]) else reads[i].translate(RC)[::-1]) for i, cs in enumerate(cands) for k in range(len(cs))]
             eds, cigars, _, _ = orc.align(T, Q, W=W, O=O, threads=16)
+            kw_rev = {"reverse": revs} if revs else {}
+            if revs and not devices:
+                devices = [0]                  # (the binding passes strands through the device-list entry point)
             if devices:
-                r = a.align_mapping_multi(devices, genome, reads, cands, arrays=True, W=W, O=O, outputs=outputs, sort_by_length=sort)
+                r = a.align_mapping_multi(devices, genome, reads, cands, arrays=True, W=W, O=O, outputs=outputs, sort_by_length=sort, **kw_rev)
             else:
-                r = a.align_mapping(genome, reads, cands, arrays=True, W=W, O=O, outputs=outputs, sort_by_length=sort)
+                r = a.align_mapping(genome, reads, cands, arrays=True, W=W, O=O, outputs=outputs, sort_by_length=sort, **kw_rev)
         n = len(eds)
         assert (r["edit_distance"] == np.array(eds)).all(), (it, "edit distances")
         assert not r["status"].any()
