@@ -85,8 +85,8 @@ typedef struct scrg_params {
     int32_t stranded;        /* device-pointer entry points (ABI 7): 1 = bit 63 of scrg_pair_desc.read_off (SCRG_READ_REVCOMP) marks
                                 a pair whose read is aligned as its REVERSE COMPLEMENT, taken from the one packed copy of the read
                                 (a read-mapping candidate on the minus strand; the reference drops those, src/tests.cu:346-355).
-                                Served by the default kernel geometry — lanes_per_pair = 1, W <= 64, W-O <= 31 —,
-                                SCRG_ERR_INVALID_ARG for any other.  0 (default): bit 63 must be clear                    */
+                                Served by the one-pair-per-lane kernels (lanes_per_pair = 1, the default, at every W and O);
+                                SCRG_ERR_INVALID_ARG for the GenASM-row mappings.  0 (default): bit 63 must be clear      */
 } scrg_params;
 #define SCRG_READ_REVCOMP (1ull << 63)
 

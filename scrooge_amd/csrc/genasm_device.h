@@ -112,6 +112,24 @@ __device__ __forceinline__ Planes load_window_strided(const uint64_t* __restrict
     return r;
 }
 
+// Minus-strand pairs (scrg_params.stranded, SCRG_READ_REVCOMP): the 64-bit word `w` (characters 64 w .. 64 w + 63) of the window at
+// read_idx of a read's REVERSE COMPLEMENT, already REVERSED and left-aligned (bit 63-k <-> character 64 w + k) as the tables want
+// it, from the read's one packed (forward) copy: the inverted 64 bases that END at len - read_idx - 64 w — complement = both
+// planes inverted, and reading the bases backwards IS the reversal — moved up when fewer than 64 are left (what is below the
+// pattern is masked by the caller's `valid` word).  A word beyond the pattern returns garbage the caller never looks at.
+__device__ __forceinline__ Planes revcomp_pattern_word(const uint64_t* __restrict__ seq, uint64_t read_off, uint32_t read_len, uint32_t read_idx,
+                                                       uint32_t w, uint32_t stride)
+{
+    const uint32_t left = read_len - read_idx;
+    const uint32_t end = left > 64u * w ? left - 64u * w : 0u;          // the word's forward window ends here (exclusive)
+    const uint32_t at = end > 64u ? end - 64u : 0u, sh = (end >= 64u ? 0u : 64u - end) & 63u;
+    const Planes f = load_window_strided(seq, read_off, at, stride);
+    Planes r;
+    r.lo = ~(f.lo << sh);
+    r.hi = ~(f.hi << sh);
+    return r;
+}
+
 // The same in two steps, so that the loads can be issued long before the words are needed: the three words a window
 // can touch, then the funnel shifts.
 struct WindowWords { uint64_t a, b, c; uint32_t s; };

@@ -33,7 +33,7 @@ struct AlignArgs {
     uint32_t read_stride;         //   64 = lane-interleaved groups, scrg_pack_planar_groups; lane kernel only)
     uint64_t* stats;              // profiling builds (-DSCRG_STATS) only: counters, may be null; never read by the shipped kernels
     int32_t debug;                // params.reserved[0] (always 0 in the shipped build): see SCRG_SEL / SCRG_SW / SCRG_ABL below
-    uint32_t stranded;            // params.stranded: bit 63 of a pair's read_off = align the read's reverse complement (genasm_lane_kernel only)
+    uint32_t stranded;            // params.stranded: bit 63 of a pair's read_off = align the read's reverse complement (the one-pair-per-lane kernels)
 };
 
 // scrg_params.reserved[0] / reserved[1].  The SHIPPED library accepts neither: scrg_params_resolve() rejects every bit.

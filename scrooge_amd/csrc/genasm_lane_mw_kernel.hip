@@ -51,6 +51,7 @@ __global__ __launch_bounds__(64) void genasm_lane_mw_kernel(AlignArgs a)
     bool has_pair = false;
     uint32_t pair = 0;
     uint64_t text_off = 0, read_off = 0, cigar_off = 0;
+    bool rev = false;                  // my pair's read is aligned as its reverse complement (genasm_device.h: revcomp_pattern_word)
     uint32_t text_len = 0, read_len = 0, cigar_cap = 0;
     uint32_t ref_idx = 0, read_idx = 0, edits = 0;
     int32_t nr = -1;                   // index of the last committed run; n_runs = nr + 1
@@ -139,7 +140,8 @@ __global__ __launch_bounds__(64) void genasm_lane_mw_kernel(AlignArgs a)
                 const scrg_pair_desc pd = a.pairs[idx];
                 pair = idx;
                 text_off = pd.text_off;
-                read_off = pd.read_off;
+                read_off = a.stranded ? pd.read_off & ~SCRG_READ_REVCOMP : pd.read_off;
+                rev = a.stranded && (pd.read_off & SCRG_READ_REVCOMP) != 0;
                 text_len = pd.text_len > 0xffffffffull ? 0xffffffffu : (uint32_t)pd.text_len;
                 read_len = (uint32_t)pd.read_len;
                 cigar_off = pd.cigar_off;
@@ -164,6 +166,10 @@ __global__ __launch_bounds__(64) void genasm_lane_mw_kernel(AlignArgs a)
             thi[w] = t.hi;
             rlo[w] = brev64(p.lo);                       // reversed: bit 63-k <-> pattern character 64 w + k
             rhi[w] = brev64(p.hi);
+            if (a.stranded && __any(has_pair && rev)) {  // (uniform)
+                const Planes rv = revcomp_pattern_word(a.seq, read_off, read_len, has_pair ? read_idx : read_len, (uint32_t)w, a.read_stride);
+                if (has_pair && rev) { rlo[w] = rv.lo; rhi[w] = rv.hi; }
+            }
             const uint32_t lo = 64u * (uint32_t)w;
             valid[w] = m >= lo + 64u ? ~0ull : (m <= lo ? 0ull : ~0ull << (64u - (m - lo)));
         }

@@ -268,6 +268,7 @@ __global__ __launch_bounds__(256, 2) void genasm_lane_parts_kernel(AlignArgs a)
     bool has_pair = false;
     uint32_t pair = 0;
     uint64_t text_off = 0, read_off = 0, cigar_off = 0;
+    bool rev = false;                  // my pair's read is aligned as its reverse complement (genasm_device.h: revcomp_pattern_word)
     uint32_t text_len = 0, read_len = 0, cigar_cap = 0;
     uint32_t ref_idx = 0, read_idx = 0, edits = 0;
     int32_t nr = -1;                   // index of the last committed run; n_runs = nr + 1
@@ -391,7 +392,8 @@ __global__ __launch_bounds__(256, 2) void genasm_lane_parts_kernel(AlignArgs a)
                 const scrg_pair_desc pd = a.pairs[idx];
                 pair = idx;
                 text_off = pd.text_off;
-                read_off = pd.read_off;
+                read_off = a.stranded ? pd.read_off & ~SCRG_READ_REVCOMP : pd.read_off;
+                rev = a.stranded && (pd.read_off & SCRG_READ_REVCOMP) != 0;
                 text_len = pd.text_len > 0xffffffffull ? 0xffffffffu : (uint32_t)pd.text_len;
                 read_len = (uint32_t)pd.read_len;
                 cigar_off = pd.cigar_off;
@@ -429,8 +431,15 @@ __global__ __launch_bounds__(256, 2) void genasm_lane_parts_kernel(AlignArgs a)
 #pragma unroll
             for (int q = 0; q < NW; q++) {
                 // word q: characters 64 q .. 64 q + 63 = plane dwords 2q (-> high dword, reversed) and 2q + 1 (-> low dword)
-                const uint32_t rl1 = __builtin_bitreverse32(plo[2 * q]), rl0 = __builtin_bitreverse32(plo[2 * q + 1]);
-                const uint32_t rh1 = __builtin_bitreverse32(phi[2 * q]), rh0 = __builtin_bitreverse32(phi[2 * q + 1]);
+                uint32_t rl1 = __builtin_bitreverse32(plo[2 * q]), rl0 = __builtin_bitreverse32(plo[2 * q + 1]);
+                uint32_t rh1 = __builtin_bitreverse32(phi[2 * q]), rh0 = __builtin_bitreverse32(phi[2 * q + 1]);
+                if (a.stranded && __any(has_pair && rev)) {       // (uniform) minus-strand pairs: the word comes reversed from the read's forward copy
+                    const Planes rv = revcomp_pattern_word(a.seq, read_off, read_len, has_pair ? read_idx : read_len, (uint32_t)q, a.read_stride);
+                    if (has_pair && rev) {
+                        rl1 = (uint32_t)(rv.lo >> 32); rl0 = (uint32_t)rv.lo;
+                        rh1 = (uint32_t)(rv.hi >> 32); rh0 = (uint32_t)rv.hi;
+                    }
+                }
                 const uint32_t lo_chars = 64u * (uint32_t)q;
                 const uint64_t valid = m >= lo_chars + 64u ? ~0ull : (m <= lo_chars ? 0ull : ~0ull << (64u - (m - lo_chars)));
                 const uint32_t iv0 = ~(uint32_t)valid, iv1 = ~(uint32_t)(valid >> 32);

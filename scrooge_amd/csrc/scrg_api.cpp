@@ -298,8 +298,8 @@ static bool resolve_params(const scrg_params* in, scrg_params* p)
     // every CU for kernels of other streams (RCCL's gather in bench.py --gpus N).  The LDS footprint caps it.
     if (p->waves_per_cu == 0) p->waves_per_cu = p->lanes_per_pair == 1 ? 16 : 11;
     const int g = p->lanes_per_pair;
-    // reverse-strand pairs from one packed copy of the read: genasm_lane_kernel (and its two-wavefront form) only
-    if (p->stranded && !(g == 1 && p->W <= 64 && tbl <= 31 && !SCRG_SEL(p->reserved[0], scrg::SCRG_SWITCH_MW_TABLE))) return false;
+    // reverse-strand pairs from one packed copy of the read: the one-pair-per-lane kernels (every W / O)
+    if (p->stranded && g != 1) return false;
     if (g == 1) return p->waves_per_cu >= 1 && p->waves_per_cu <= 32;      // no table in LDS: lds_rows is not used
     if (p->text_stride_words != 1 || p->read_stride_words != 1) return false;   // strided sequences: lane kernel only
     if (!(g == 4 || g == 8 || g == 16 || g == 32 || g == 64)) return false;

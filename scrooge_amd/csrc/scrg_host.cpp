@@ -424,10 +424,10 @@ scrg_status stage1(DeviceState* ds, Slot& sl, Call& c, uint64_t chunk)
     HTRY(ds, hipSetDevice(ds->device));
 
     // ---- layout of the chunk's sequences: read rows (mapping: one row per run of pairs with the same read), text rows.
-    // Reverse-strand candidates (cand_reverse): with the default kernel geometry the DEVICE takes the read's reverse complement
+    // Reverse-strand candidates (cand_reverse): the one-pair-per-lane kernels take the read's reverse complement on the DEVICE
     // from the one packed copy (scrg_params.stranded: the pair's descriptor carries the strand), so both strands of a read share
-    // a row; the other kernels get a row of their own, packed reverse-complemented here.
-    const bool dev_strand = b.mapping && b.cand_reverse && c.p.lanes_per_pair == 1 && c.p.W <= 64 && c.p.W - c.p.O <= 31 && !c.p.reserved[0];
+    // a row; the GenASM-row mappings get a row of their own, packed reverse-complemented here.
+    const bool dev_strand = b.mapping && b.cand_reverse && c.p.lanes_per_pair == 1;
     std::vector<uint32_t> row(b.mapping ? n : 0);
     std::vector<uint64_t> row_pair;                  // a pair that owns each row (its read is the row's content)
     uint64_t max_read = 0, max_text = 0;

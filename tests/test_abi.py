@@ -75,10 +75,13 @@ def test_defaults_match_reference_knobs(lib):
     p.W, p.O = 64, -1
     assert lib.scrg_params_resolve(p, r) != 0
     p.W, p.O = 64, 33
-    p.stranded = 1                       # minus-strand pairs from one packed copy of the read: the default geometry only
+    p.stranded = 1                       # minus-strand pairs from one packed copy of the read: the one-pair-per-lane kernels
     assert lib.scrg_params_resolve(p, r) == 0 and r.stranded == 1
     p.O = 2
+    assert lib.scrg_params_resolve(p, r) == 0
+    p.lanes_per_pair = 8
     assert lib.scrg_params_resolve(p, r) != 0
+    p.lanes_per_pair = 0
     p.O, p.stranded = 33, 2
     assert lib.scrg_params_resolve(p, r) != 0
 
