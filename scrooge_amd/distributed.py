@@ -12,6 +12,7 @@ Partitioning follows what the reference's callers do for load balance
 them round-robin so every rank sees the same length mix.
 """
 import os
+import sys
 
 import numpy as np
 import torch
@@ -280,11 +281,27 @@ class EditStreamGather:
         use, and with a rotating root the first `world` steps would otherwise each pay for seven new ones."""
         if self.host_stage or os.environ.get("SCRG_BENCH_NOCOLL") == "1":
             return
+        if self.p2p and self.world > 1:
+            # (a rank on which the point-to-point form raises — a backend without grouped send / receive — takes every rank back to
+            # the one-collective form: the verdict is agreed on with an all_reduce, outside any timed region)
+            ok = 1
+            try:
+                for dst in (range(self.world) if self.rotate else [self.dst]):
+                    for w in self._post(0, dst):
+                        w.wait()
+            except Exception as e:                            # noqa: BLE001
+                ok = 0
+                print("EditStreamGather: point-to-point form failed on rank %d (%s: %s); using dist.gather" % (self.rank, type(e).__name__, e),
+                      file=sys.stderr)
+            flag = torch.tensor([ok], dtype=torch.int32, device=self.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            if int(flag.item()) == 1:
+                if self.send[0].is_cuda:
+                    torch.cuda.synchronize()
+                return
+            self.p2p = False
         for dst in (range(self.world) if self.rotate else [self.dst]):
-            if self.p2p:
-                for w in self._post(0, dst):
-                    w.wait()
-            else:
+            if not self.p2p:
                 dist.gather(self.send[0], self.recv[0] if self.rank == dst else None, dst=dst, group=self.group)
         if self.send[0].is_cuda:
             torch.cuda.synchronize()

@@ -393,6 +393,8 @@ def _worker_wide(rank, world, port, q, dst, depth, steps):
         cap = n * 24
         g = sd.EditStreamGather(n, cap, torch.device("cpu"), dst=dst, depth=depth, ordered=True, total_runs=n * 40)
         assert g.DEPTH == depth
+        g.prime()                                           # (as bench.py does before anything is timed: a full-size exchange with every root)
+        assert g.p2p == (os.environ.get("SCRG_GATHER_COLLECTIVE", "p2p") != "gather")
         seen = {}
 
         def look(k):
