@@ -1,3 +1,7 @@
+# usage (GPU box): scripts/r06_slots_ab.sh   — the N > 1 step with 16-bit against 32-bit ring slots in decode_edits_quad_kernel.
+# ab_libs/lib_slots32.so = the library with edit_stream_decode_kernel.hip as of commit 5f3bd08~1 ("Quad decoder: every run written
+# once ...": 32-bit slots, 17 KB of LDS per workgroup), built in the container with scripts/ab.sh-style hipcc; result in
+# profiles/r06_root_load.json ("ring_slots_ab"): no difference in the step.
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 export SCRG_BENCH_FORCE_GATHER=1
 run() { echo "$1: $(env $2 python3 $root/bench.py --no-build --cpu-seconds 0 --pairs 100000 --steps 40 --warmup 8 --other-configs off $3 2>/dev/null | python3 -c "
