@@ -652,6 +652,43 @@ def test_reverse_strand_on_the_device(aligner, oracle, form, W, O):
         aligner.use_own_stream()
 
 
+@pytest.mark.parametrize("wpr", [1, 2, 3, 7, 22, 673])
+@pytest.mark.parametrize("n", [1, 63, 65, 300])
+def test_group_packer_against_the_linear_one(aligner, n, wpr):
+    """scrg_pack_planar_groups (a thread packs two words of a row: odd and even row widths, a last group that is not full) gives the
+    words of scrg_pack_planar, re-arranged; padding rows and words are zero; bytes that are no base are counted by both."""
+    import torch
+    import scrooge_amd
+    dev = torch.device("cuda", 0)
+    G = scrooge_amd.api.GROUP
+    rng = np.random.Generator(np.random.PCG64(n * 1000 + wpr))
+    rows = rng.choice(np.frombuffer(b"ACGTacgt", np.uint8), (n, wpr * 32))
+    for k in range(0, n, 2):                                   # ragged rows: zero padding
+        rows[k, int(rng.integers(0, wpr * 32 + 1)):] = 0
+    n_bad = min(5, n)
+    for k in range(n_bad):                                     # one byte that is no base in each of the first rows
+        rows[k, int(rng.integers(0, wpr * 32))] = ord("N")
+    ascii_t = torch.from_numpy(rows).to(dev).view(-1)
+    ng = (n + G - 1) // G
+    lin = torch.zeros(n * wpr, dtype=torch.int64, device=dev)
+    grp = torch.full((ng * G * wpr,), -1, dtype=torch.int64, device=dev)
+    bad_l = torch.zeros(1, dtype=torch.int32, device=dev)
+    bad_g = torch.zeros(1, dtype=torch.int32, device=dev)
+    aligner.set_stream(0)
+    try:
+        aligner.pack_planar(ascii_t, lin, bad_l)
+        aligner.pack_planar_groups(ascii_t, n, wpr, grp, bad_g)
+        torch.cuda.synchronize()
+    finally:
+        aligner.use_own_stream()
+    want = np.zeros((ng, wpr, G), dtype=np.int64)
+    L = lin.cpu().numpy().reshape(n, wpr)
+    for r in range(n):
+        want[r // G, :, r % G] = L[r]
+    assert np.array_equal(grp.cpu().numpy().reshape(ng, wpr, G), want)
+    assert int(bad_l.item()) == n_bad and int(bad_g.item()) == n_bad
+
+
 @pytest.mark.parametrize("n", [1, 63, 64, 65, 1000])
 def test_lane_interleaved_layout(aligner, oracle, n):
     """scrg_pack_planar_groups + word strides of 64 (the layout bench.py times): ragged texts and reads, a pair
