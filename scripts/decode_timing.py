@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--busy", type=int, default=60, help="align launches enqueued in front of every timed series (clock warm-up)")
     ap.add_argument("--probe", action="store_true", help="library built with -DSCRG_DEC_PROBE: print the kernel's cycle counters")
+    ap.add_argument("--buffer-per-pair", type=int, default=0, help="make the stream buffer at least this many bytes per pair (a capacity-sized buffer)")
     ap.add_argument("--W", type=int, default=64)
     ap.add_argument("--O", type=int, default=33)
     args = ap.parse_args()
@@ -73,7 +74,7 @@ def main():
     sbytes = int(r4.sum().item())
     slot_bytes = (sbytes + 63) // 64 * 64
     S = args.slots
-    stream = torch.zeros(S * slot_bytes + 64, dtype=torch.uint8, device=dev)
+    stream = torch.zeros(max(S * slot_bytes, S * n * args.buffer_per_pair) + 64, dtype=torch.uint8, device=dev)
     al.compact_runs(n, desc, slices, (r4 >> 1).to(torch.int32), boff >> 1, stream)
     for k in range(1, S):
         stream[k * slot_bytes: k * slot_bytes + sbytes].copy_(stream[:sbytes])
@@ -102,7 +103,8 @@ def main():
         return a.elapsed_time(b) / args.reps
 
     nocheck = bool(os.environ.get("SCRG_DEC_NOCHECK"))          # (probe builds with parts of the kernel switched off)
-    res = {"pairs_per_slot": n, "read_len": L, "slots": S, "stream_bytes_per_pair": sbytes / n, "runs_per_pair": total_runs / n}
+    res = {"pairs_per_slot": n, "read_len": L, "slots": S, "stream_bytes_per_pair": sbytes / n, "runs_per_pair": total_runs / n,
+           "buffer_bytes_per_pair": stream.numel() / (S * n), "SCRG_DEC_KERNEL": os.environ.get("SCRG_DEC_KERNEL")}
     for slots in sorted(set([1, S])):
         m = slots * n
         t_count = timed(lambda: al.decode_edit_stream(m, stream, off_all, len_all, rl, 0, None, None, out_cnt, nbad, **kw))

@@ -59,6 +59,7 @@ struct DecodeArgs {
     uint32_t* bad;
     const uint32_t* order;      // optional: thread t takes pair order[t] (pairs sorted by stream length, longest first)
     uint32_t together;          // whole pieces are stored by the wavefront together (write_whole_pieces); 0: every lane its own
+    uint32_t gate;              // 1: the one-pair-per-wavefront kernel looks at the lengths first and takes short streams lane by lane (dec_sample_long); 2: it does so anyway
 };
 
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
@@ -70,6 +71,85 @@ __device__ __forceinline__ uint32_t dec_ffbl(uint32_t v)      // count trailing 
     return r;
 }
 
+// Which decoding the streams are for, decided where their lengths are known (the host sees only the size of the buffer, and a
+// capacity-sized buffer of short streams is not a buffer of long streams): the mean length of 256 evenly spaced pairs against
+// DEC_LONG_STREAM bytes.  Every wavefront of a launch computes the same answer from the same 256 dwords.
+constexpr uint32_t DEC_LONG_STREAM = 64;
+constexpr uint32_t DEC_PLAIN_BELOW = 16;          // below this mean: every run stored on its own (decode_pairs_plain), no staging
+__device__ __forceinline__ uint64_t dec_sample_mean256(const DecodeArgs& a)       // 256 x the mean length of the sample
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t sum = 0, fine = 0;                                  // (in units of 256 bytes and of one: no overflow)
+#pragma unroll
+    for (uint32_t j = 0; j < 4; j++) {
+        const uint32_t v = a.len[((uint64_t)(lane + 64u * j) * a.n_pairs) >> 8];       // (n_pairs < 2^56)
+        sum += v >> 8;
+        fine += v & 255u;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        sum += (uint32_t)__shfl_xor((int)sum, d);
+        fine += (uint32_t)__shfl_xor((int)fine, d);
+    }
+    return (uint64_t)sum * 256u + fine;
+}
+__device__ __forceinline__ bool dec_sample_long(const DecodeArgs& a) { return dec_sample_mean256(a) >= 256ull * DEC_LONG_STREAM; }
+
+// Short streams — in a buffer sized for long ones (the quad kernel's launch, dec_sample_long says "short"), or so short that
+// staging their few runs costs more than it saves (the lane kernel's launch, mean below DEC_PLAIN_BELOW bytes): one pair per
+// lane, the shared state machine (edit_stream.h: decode_lane_step) byte by byte, every run stored where it belongs as soon as it
+// is made — no staging, no sorting: at 8-14 bytes per pair (150 bp reads) a wavefront per pair would spend its time on the
+// per-pair overhead (2 M pairs: 0.83 ms, this loop: scripts/r06_gate_probe.sh).  Same checks and verdicts as decode_edits_kernel.
+template <bool STORE>
+__device__ __forceinline__ void decode_pairs_plain(const DecodeArgs& a, uint64_t first_pair, uint64_t stride)
+{
+#pragma unroll 1
+    for (uint64_t p = first_pair; p < a.n_pairs; p += stride) {
+        uint64_t off = a.off[p], g0 = 0;
+        uint32_t len = a.len[p], cap = 0;
+        const uint64_t rl64 = a.read_len[p * a.read_len_stride];
+        bool bad_input = off == ~0ull || off > a.stream_bytes || len > a.stream_bytes - off || len > 0x3fffffffu || rl64 > 0x7fffffffull;
+        const uint32_t rl = bad_input ? 0u : (uint32_t)rl64;
+        if (bad_input) { off = 0; len = 0; }
+        if (STORE) {
+            g0 = a.dense_off[p];
+            cap = a.n_runs[p];
+            if (g0 > a.dense_cap || cap > a.dense_cap - g0) {
+                bad_input = true;
+                g0 = 0;
+                cap = 0;
+            }
+        }
+        uint16_t* const dst0 = STORE ? a.dense + g0 : nullptr;
+        DecodeLane s;
+        decode_lane_init(s, 0u);
+        auto put = [&](uint32_t at, uint32_t word) {
+            if (STORE && (at >> 1) < cap) dst0[at >> 1] = (uint16_t)word;         // (slot n, the free one, is rewritten by run n or lies past the segment)
+        };
+        const uint64_t end = off + len;
+        const uint32_t last_byte = len ? (uint32_t)a.stream[end - 1u] : 0u;
+        uint32_t steps = 0;
+#pragma unroll 1
+        for (uint64_t at = off & ~3ull; at < end; at += 4u) {   // aligned dwords (whole 16-byte blocks of the buffer may be read); bytes that are not mine become zeros
+            uint32_t w = *reinterpret_cast<const uint32_t*>(a.stream + at);
+            const uint32_t lo = at < off ? (uint32_t)(off - at) : 0u, hi = end - at < 4u ? (uint32_t)(end - at) : 4u;
+            w &= (0xffffffffu << (8u * lo)) & (0xffffffffu >> (32u - 8u * hi));
+#pragma unroll
+            for (int k = 0; k < 4; k++) decode_lane_step(s, (w >> (8 * k)) & 0xffu, put);
+            if ((++steps & 0xfffffu) == 0u) decode_lane_guard(s);
+        }
+        decode_lane_guard(s);
+        const bool clean = decode_lane_clean(s, last_byte, rl) && !bad_input;
+        const uint32_t n_end = decode_lane_runs(s);
+        if (STORE) {
+            if (!clean || n_end != cap) atomicAdd(a.bad, 1u);
+        } else {
+            a.n_runs[p] = clean ? n_end : 0xffffffffu;
+            if (!clean) atomicAdd(a.bad, 1u);
+        }
+    }
+}
+
 }  // namespace
 
 // STORE = false: count only (n_runs[p] is written).  STORE = true: n_runs[p] is the size of pair p's segment of `dense`
@@ -79,6 +159,10 @@ __global__ __launch_bounds__(256, 4) void decode_edits_kernel(DecodeArgs a)
 {
     __shared__ __attribute__((aligned(128))) uint8_t lds_all[STORE ? 4 * DEC_WAVE_LDS : 128];
     const uint32_t lane = threadIdx.x & 63u;
+    if (a.gate == 2u || (a.gate == 1u && dec_sample_mean256(a) < 256u * DEC_PLAIN_BELOW)) {       // (uniform over the launch)
+        decode_pairs_plain<STORE>(a, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, (uint64_t)gridDim.x * blockDim.x);
+        return;
+    }
     // On the root of an N > 1 job this kernel shares the SIMDs with the aligner's wavefronts, and its own run time is set by
     // its longest lanes: it goes first.  (The align kernel rotates its priorities 0..3; 3 here is at least a tie.)
     __builtin_amdgcn_s_setprio(3);
@@ -576,7 +660,11 @@ __global__ __launch_bounds__(256) void decode_edits_quad_kernel(DecodeArgs a, ui
         }
         return m;
     };
-    PairMeta next_meta = load_meta(wave0);
+    PairMeta next_meta = load_meta(wave0);                       // (asked for before the sample of the lengths is waited for)
+    if (a.gate == 2u || (a.gate == 1u && !dec_sample_long(a))) {        // (uniform over the launch)
+        decode_pairs_plain<STORE>(a, (uint64_t)wave0 * 64u + lane, (uint64_t)n_waves * 64u);
+        return;
+    }
     for (uint64_t p = wave0; p < a.n_pairs; p += n_waves) {
         // ---- the pair: everything here is the same in all lanes
         const PairMeta meta = next_meta;
@@ -864,20 +952,24 @@ __global__ void iota_kernel(uint32_t* v, uint32_t n)
 // Bits of the stream length the order is made from: 16-byte granularity, lengths up to 1 MB told apart.
 constexpr int DEC_SORT_BEGIN_BIT = 4, DEC_SORT_END_BIT = 20;
 
-// Which decoder a launch takes: one pair per wavefront (decode_edits_quad_kernel, four bytes per lane) for streams of 64 bytes and
-// more on average (the size of the buffer over the number of pairs), one pair per lane for shorter ones.  Measured, ms per launch,
-// lane / wavefront-per-pair with one byte per lane (round 5; scripts/decode_timing.py --read-len L --pairs n): 2 M x 150 bp (8 bytes
-// per pair) 0.21 / 0.62, 2 M x 300 bp (14) 0.25 / 0.62, 200 k x 500 bp (67) 0.115 / 0.078, 100 k x 1 kb (132) 0.124 / 0.053,
-// 25 k x 4 kb (521) 0.240 / 0.039, 100 k x 10 kb (1 299) 0.82 / 0.30.  SCRG_DEC_KERNEL=lane|wave|quad overrides (the tests run all
-// three on the same inputs; `wave` is round 5's one-byte-per-lane kernel, kept as the independent formulation).
+// Which decoding a launch takes, in two steps.  The HOST picks the launch from the size of the buffer over the number of pairs —
+// all it can see: one pair per wavefront (decode_edits_quad_kernel) at 64 bytes per pair and more, one pair per lane below.  The
+// DEVICE then looks at the lengths themselves (dec_sample_mean256): the quad launch takes streams that turn out short lane by lane
+// (a capacity-sized buffer of 150 bp reads' streams), and the lane launch drops its staging below 16 bytes per pair.  Measured, ms
+// per launch, scripts/r06_gate_sweep.sh (profiles/r06_decoder_choice.json), plain / lane / quad: 2 M x 150 bp at 8 bytes per pair
+// 0.043 / 0.12 / 0.83; 1 M x 300 bp ONT (41) 0.36 / 0.16 / 0.42; 600 k x 500 bp (67) 0.36 / 0.25 / 0.25; 300 k x 1 kb (132)
+// 0.41 / 0.21 / 0.13; 75 k x 4 kb (521) 0.74 / 0.29 / 0.065; 100 k x 10 kb (1 299) 2.1 / 0.81 / 0.15.
+// SCRG_DEC_KERNEL=lane|wave|quad|plain overrides (the tests run them on the same inputs; `wave` is round 5's one-byte-per-lane
+// kernel, kept as the independent formulation).
+static int decode_kernel_forced()                                          // -1: no override (read per call: the tests switch it)
+{
+    const char* e = getenv("SCRG_DEC_KERNEL");
+    return !e ? -1 : e[0] == 'l' ? 0 : e[0] == 'w' ? 1 : e[0] == 'q' ? 2 : e[0] == 'p' ? 3 : -1;          // (p: the quad kernel's launch, every stream lane by lane)
+}
 int decode_kernel_choice(uint64_t n_pairs, uint64_t stream_bytes)          // 0: lane, 1: wave, 2: quad
 {
-    if (const char* e = getenv("SCRG_DEC_KERNEL")) {
-        if (e[0] == 'l') return 0;
-        if (e[0] == 'w') return 1;
-        if (e[0] == 'q') return 2;
-    }
-    return n_pairs != 0 && stream_bytes / n_pairs >= 64u ? 2 : 0;
+    if (decode_kernel_forced() >= 0) return decode_kernel_forced();
+    return n_pairs != 0 && stream_bytes / n_pairs >= DEC_LONG_STREAM ? 2 : 0;
 }
 bool decode_by_wavefront(uint64_t n_pairs, uint64_t stream_bytes) { return decode_kernel_choice(n_pairs, stream_bytes) != 0; }
 
@@ -902,7 +994,7 @@ hipError_t launch_decode_edits(uint64_t n_pairs, const uint8_t* d_stream, uint64
     // (1 slot: 1.06 -> 1.15 ms): by the size of the launch (200 000 pairs = three wavefronts on every SIMD of an MI355X).
     const uint32_t together = n_pairs > 200000 ? 1u : 0u;
     const uint32_t* order = nullptr;
-    DecodeArgs a{n_pairs, d_stream, stream_bytes, d_off, d_len, d_read_len, read_len_stride, d_dense_off, d_dense, dense_cap, d_n_runs, d_bad, order, together};
+    DecodeArgs a{n_pairs, d_stream, stream_bytes, d_off, d_len, d_read_len, read_len_stride, d_dense_off, d_dense, dense_cap, d_n_runs, d_bad, order, together, 0u};
     // Which kernel (decode_by_wavefront; scripts/decode_timing.py, 10 kb reads: one slot of 100 k pairs 0.30 ms by wavefront
     // against 0.82 ms by lane — 1 563 lane-per-pair wavefronts leave the GPU half empty —, eight slots 2.26 against 2.40 ms)
     const int choice = decode_kernel_choice(n_pairs, stream_bytes);
@@ -910,7 +1002,11 @@ hipError_t launch_decode_edits(uint64_t n_pairs, const uint8_t* d_stream, uint64
         const uint64_t want = n_pairs < 8192u ? (n_pairs + 3u) & ~3ull : 8192u;          // 8 wavefronts on every SIMD of an MI355X
         const uint32_t n_waves = (uint32_t)want;
         const dim3 grid(n_waves / 4u), block(256);
-        if (choice == 2) {
+        if (choice >= 2) {
+            // The buffer is large enough for long streams; whether the streams ARE long only the device knows (a capacity-sized
+            // buffer of 150 bp reads' streams — 8-14 bytes a pair — is no case for a wavefront per pair): the kernel looks at a
+            // sample of the lengths first (a.gate) and takes short streams one pair per lane.
+            a.gate = decode_kernel_forced() < 0 ? 1u : decode_kernel_forced() == 3 ? 2u : 0u;
             if (d_dense) hipLaunchKernelGGL(decode_edits_quad_kernel<true>, grid, block, 0, s, a, n_waves);
             else hipLaunchKernelGGL(decode_edits_quad_kernel<false>, grid, block, 0, s, a, n_waves);
         } else {
@@ -919,7 +1015,10 @@ hipError_t launch_decode_edits(uint64_t n_pairs, const uint8_t* d_stream, uint64
         }
         return hipGetLastError();
     }
-    if (sort_ws && n_pairs < 0x7fffffffull) {
+    // Longest first pays for streams long enough to differ by many steps — which this kernel only sees when it is asked for by
+    // name (long streams go to the other kernel).  On the short streams it is chosen for, the sort cost more than the decoding
+    // (profiles/r06_decoder_choice.json: 1 M x 300 bp 0.30 ms sorted, 0.16 not; 2 M x 150 bp 0.21 / 0.12).
+    if (sort_ws && n_pairs < 0x7fffffffull && (stream_bytes / n_pairs >= DEC_LONG_STREAM || getenv("SCRG_DEC_SORT"))) {
         uint32_t* const idx = static_cast<uint32_t*>(sort_ws);
         uint32_t* const keys_out = idx + n_pairs;
         uint32_t* const idx_out = keys_out + n_pairs;
@@ -932,6 +1031,7 @@ hipError_t launch_decode_edits(uint64_t n_pairs, const uint8_t* d_stream, uint64
         order = idx_out;
     }
     a.order = order;
+    a.gate = decode_kernel_forced() < 0 ? 1u : 0u;
     const dim3 grid((unsigned)((n_pairs + 255) / 256)), block(256);
     if (d_dense) hipLaunchKernelGGL(decode_edits_kernel<true>, grid, block, 0, s, a);
     else hipLaunchKernelGGL(decode_edits_kernel<false>, grid, block, 0, s, a);

@@ -1195,16 +1195,26 @@ def test_decoders_agree_on_arbitrary_streams(aligner, monkeypatch):
     """All three device decoders on byte strings that mostly are NOT alignments (random bytes, long runs of one edit — 300 deletions
     in a row —, 0x3F stretches, streams that start at any byte offset): the verdict (clean or not), the run count and the runs of
     every clean stream must be those of the format's definition (tests/test_edit_stream.py: py_decode), nothing is written outside
-    a pair's segment, and a segment that is one run short is reported and not overrun."""
+    a pair's segment, and a segment that is one run short is reported and not overrun.  "auto" is the library's own choice, made on
+    the device from a sample of the lengths (dec_sample_long): long streams, and short ones in a buffer sized for long ones."""
     import re
     import torch
     from tests.test_edit_stream import py_decode
     dev = torch.device("cuda", 0)
     rng = np.random.Generator(np.random.PCG64(99))
+    aligner.set_stream(0)
+    try:
+        for decs, longest, pad in ((("quad", "wave", "lane", "auto"), 1200, 0), (("auto",), 40, 200)):
+            _decoders_case(aligner, monkeypatch, torch, dev, rng, py_decode, re, decs, longest, pad)
+    finally:
+        aligner.use_own_stream()
+
+
+def _decoders_case(aligner, monkeypatch, torch, dev, rng, py_decode, re, decs, longest, pad):
     streams, rls = [], []
     for k in range(1500):
-        n = int(rng.integers(0, 1200))
-        kind = k % 5
+        n = int(rng.integers(0, longest))
+        kind = k % 5 if longest > 300 else k % 4
         if kind == 0:
             b = rng.integers(0, 256, n, dtype=np.uint8)
         elif kind == 1:
@@ -1224,7 +1234,7 @@ def test_decoders_agree_on_arbitrary_streams(aligner, monkeypatch):
     assert 100 < sum(w is not None for w in want) < n - 100
     offs, blob = [], bytearray()
     for k, st in enumerate(streams):
-        blob += bytes([0xC1] * (k % 7))                  # (any byte offset; what lies between the streams is not zeros)
+        blob += bytes([0xC1] * (k % 7 + pad))            # (any byte offset; what lies between the streams is not zeros)
         offs.append(len(blob))
         blob += st
     stream = torch.tensor(list(blob) + [0xC1] * 64, dtype=torch.uint8, device=dev)
@@ -1232,10 +1242,12 @@ def test_decoders_agree_on_arbitrary_streams(aligner, monkeypatch):
     s_len = torch.tensor([len(x) for x in streams], dtype=torch.int32, device=dev)
     rl = torch.tensor(rls, dtype=torch.int64, device=dev)
     runs_of = lambda c: [int(a) | (ord(o) << 8) for a, o in re.findall(r"(\d+)([=XID])", c)]
-    aligner.set_stream(0)
-    try:
-        for dec in ("quad", "wave", "lane"):
-            monkeypatch.setenv("SCRG_DEC_KERNEL", dec)
+    if True:
+        for dec in decs:
+            if dec == "auto":
+                monkeypatch.delenv("SCRG_DEC_KERNEL", raising=False)
+            else:
+                monkeypatch.setenv("SCRG_DEC_KERNEL", dec)
             counted = torch.zeros(n, dtype=torch.int32, device=dev)
             nbad = torch.zeros(1, dtype=torch.int32, device=dev)
             aligner.decode_edit_stream(n, stream, s_off, s_len, rl, 1, None, None, counted, nbad)
@@ -1262,8 +1274,6 @@ def test_decoders_agree_on_arbitrary_streams(aligner, monkeypatch):
                 assert (dh[off[k] + seg_cap[k]: off[k] + seg[k] + 3] == 0xEEEE).all(), (dec, k)      # nothing past the segment
                 if want[k] is not None:
                     assert dh[off[k]: off[k] + seg_cap[k]].tolist() == runs_of(want[k])[: seg_cap[k]], (dec, k)
-    finally:
-        aligner.use_own_stream()
 
 
 def _run_tool(args, timeout):
