@@ -337,7 +337,9 @@ scrg_status scrg_unpack_runs(scrg_ctx *ctx, uint64_t n_runs, const uint8_t *d_pa
  *   suffices (the read_len / 63 term is the 0x3F bytes, one per 63 matches in a row: only W-O > 63 has any).
  * scrg_decode_edit_stream: the inverse (streams of 64 bytes and more on average: one pair per wavefront, four stream bytes per
  *   lane side by side, runs staged in LDS and stored in aligned 16-byte units; shorter ones: one pair per lane, streams read in
- *   aligned 16-byte blocks, runs written in aligned 64-byte pieces — the same runs either way).  d_stream holds stream_bytes bytes (16-byte aligned, readable up to the next
+ *   aligned 16-byte blocks, runs written in aligned 64-byte pieces — the same runs either way; the launch follows
+ *   stream_bytes / n_pairs, the kernel then looks at a sample of d_stream_len itself, so a buffer sized for the worst case
+ *   costs nothing).  d_stream holds stream_bytes bytes (16-byte aligned, readable up to the next
  *   multiple of 16): a pair whose stream is not inside [0, stream_bytes) — offsets and lengths may come off a wire —
  *   is counted as bad, never read.  Read lengths are taken from d_read_len[p * read_len_stride] (stride 1: a plain
  *   array; 6: &d_pairs[0].read_len; 0: one length for all).  `params` is not looked at beyond its validity (the window
