@@ -324,6 +324,40 @@ def test_one_and_two_wavefronts_per_window_agree(aligner, aligner_select, oracle
             al.params = keep
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_window_settings_drawn_at_random(aligner, oracle, seed):
+    """The whole (W, O) plane, not the hand-picked points of the tests above: 40 settings per seed with 2 <= W <= 256 and 0 <= O < W
+    (runtime parameters here; compile-time macros in the reference, src/genasm_cpu.cpp:22-35, 104-110), a third of them next to the
+    borders between the kernels (W-O = 31/32, 63/64, 127/128; W = 64/65, 128/129), on related, unrelated, low-complexity, ragged and
+    empty pairs — edit distance and CIGAR of the one-pair-per-lane kernels against the oracle."""
+    rng = np.random.Generator(np.random.PCG64(1000 + seed))
+    settings = []
+    while len(settings) < 40:
+        if len(settings) % 3 == 0:
+            tb = int(rng.choice([31, 32, 33, 63, 64, 65, 127, 128, 129, 1, 2]))       # W - O
+            W = int(rng.choice([64, 65, 128, 129, 256, 63, 127, 255, int(rng.integers(2, 257))]))
+            O = W - tb
+        else:
+            W = int(rng.integers(2, 257))
+            O = int(rng.integers(0, W))
+        if 2 <= W <= 256 and 0 <= O < W and (W, O) not in settings:
+            settings.append((W, O))
+    t, q = synth.make_pairs(24, 700, "ont", seed=seed)
+    t2, q2 = synth.make_pairs(12, 500, "pacbio15", seed=seed + 50)
+    t, q = t + t2, q + q2
+    for _ in range(16):
+        t.append(synth.random_seq(int(rng.integers(0, 300)), rng))
+        q.append(synth.random_seq(int(rng.integers(0, 300)), rng))
+    for _ in range(8):
+        t.append(bytes(rng.choice(np.frombuffer(b"AC", np.uint8), int(rng.integers(1, 400)))))
+        q.append(bytes(rng.choice(np.frombuffer(b"AC", np.uint8), int(rng.integers(1, 400)))))
+    t += [b"", b"ACGT", b"A" * 300]
+    q += [b"ACGT", b"", b"A" * 290]
+    for W, O in settings:
+        eds, cigars, _, _ = oracle.align(t, q, W=W, O=O, threads=8)
+        _check(aligner.align_pairs(t, q, W=W, O=O), eds, cigars, "W=%d O=%d" % (W, O))
+
+
 def test_windows_over_64_limits(aligner):
     import scrooge_amd
     with pytest.raises(scrooge_amd.ScroogeError):
