@@ -329,7 +329,7 @@ def test_window_settings_drawn_at_random(aligner, oracle, seed):
     """The whole (W, O) plane, not the hand-picked points of the tests above: 40 settings per seed with 2 <= W <= 256 and 0 <= O < W
     (runtime parameters here; compile-time macros in the reference, src/genasm_cpu.cpp:22-35, 104-110), a third of them next to the
     borders between the kernels (W-O = 31/32, 63/64, 127/128; W = 64/65, 128/129), on related, unrelated, low-complexity, ragged and
-    empty pairs — edit distance and CIGAR of the one-pair-per-lane kernels against the oracle."""
+    empty pairs — edit distance and CIGAR of the one-pair-per-lane kernels and of two GenASM-row mappings against the oracle."""
     rng = np.random.Generator(np.random.PCG64(1000 + seed))
     settings = []
     while len(settings) < 40:
@@ -356,6 +356,9 @@ def test_window_settings_drawn_at_random(aligner, oracle, seed):
     for W, O in settings:
         eds, cigars, _, _ = oracle.align(t, q, W=W, O=O, threads=8)
         _check(aligner.align_pairs(t, q, W=W, O=O), eds, cigars, "W=%d O=%d" % (W, O))
+        if O >= 1:                                   # the GenASM-row mappings (they refuse O = 0: their traceback reads R[i + 1])
+            for g in ((8, 64) if W <= 64 else (32, 64)):
+                _check(aligner.align_pairs(t, q, W=W, O=O, lanes_per_pair=g), eds, cigars, "W=%d O=%d g%d" % (W, O, g))
 
 
 def test_windows_over_64_limits(aligner):
