@@ -1210,7 +1210,7 @@ def test_decode_two_runs_per_step_fills_the_ring(aligner, dec_kernel, monkeypatc
 
 
 def test_decoders_agree_on_arbitrary_streams(aligner, monkeypatch):
-    """All three device decoders on byte strings that mostly are NOT alignments (random bytes, long runs of one edit — 300 deletions
+    """All device decoders (and the two loops of each launch) on byte strings that mostly are NOT alignments (random bytes, long runs of one edit — 300 deletions
     in a row —, 0x3F stretches, streams that start at any byte offset): the verdict (clean or not), the run count and the runs of
     every clean stream must be those of the format's definition (tests/test_edit_stream.py: py_decode), nothing is written outside
     a pair's segment, and a segment that is one run short is reported and not overrun.  "auto" is the library's own choice, made on
@@ -1222,7 +1222,7 @@ def test_decoders_agree_on_arbitrary_streams(aligner, monkeypatch):
     rng = np.random.Generator(np.random.PCG64(99))
     aligner.set_stream(0)
     try:
-        for decs, longest, pad in ((("quad", "wave", "lane", "auto"), 1200, 0), (("auto",), 40, 200)):
+        for decs, longest, pad in ((("quad", "wave", "lane", "plain", "auto"), 1200, 0), (("auto", "plain", "lane"), 40, 200)):
             _decoders_case(aligner, monkeypatch, torch, dev, rng, py_decode, re, decs, longest, pad)
     finally:
         aligner.use_own_stream()
