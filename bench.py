@@ -584,8 +584,18 @@ def main():
                 aligners[b].encode_edit_stream(n, descs_[b], o["runs"], o["n_runs"], g["stream"], g["off"], g["len"], g["total"], W=p.W, O=p.O)
                 gather_.start(j, o["ed"])
                 return
+            probe = os.environ.get("SCRG_BENCH_PROBE")                  # measuring aids (scripts/r06_chain_probe.sh): results unchecked
+            if probe == "no-chain":                                    # the step without its scan and compaction
+                return
+            if probe == "no-scan" and b in step.cached_off:            # the offsets of the same batch from an earlier step
+                aligners[b].compact_runs(n, descs_[b], o["runs"], o["n_runs"], step.cached_off[b], cur["denses"][b])
+                return
             cnt64 = o["n_runs"].to(torch.int64)
             dense_off = torch.cumsum(cnt64, 0) - cnt64
+            if probe == "no-scan":
+                step.cached_off[b] = dense_off
+            if probe == "no-compact":                                  # the scan alone
+                return
             if fmt in ("packed", "runs"):
                 # the same with the runs themselves (--gather-format runs | packed)
                 gather_.finish(j)                       # buffers of step j-DEPTH are free again
@@ -598,6 +608,7 @@ def main():
                 aligners[b].compact_runs(n, descs_[b], o["runs"], o["n_runs"], dense_off, cur["denses"][b])
 
     step.count = 0
+    step.cached_off = {}
     step.decode = decode_on
     set_phase("warm-up steps")
     for _ in range(args.warmup):

@@ -416,6 +416,7 @@ __global__ __launch_bounds__(256, 4) void decode_edits_kernel(DecodeArgs a)
 template <bool STORE>
 __global__ __launch_bounds__(256) void decode_edits_wave_kernel(DecodeArgs a, uint32_t n_waves)
 {
+    __builtin_amdgcn_s_setprio(3);      // (a helper between align launches: it goes first, see compact_runs_kernel)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));
     // bits below my lane, as two dwords (for the side path)
@@ -622,6 +623,7 @@ __device__ __forceinline__ uint32_t qd_total(uint32_t v)         // the sum over
 template <bool STORE>
 __global__ __launch_bounds__(256) void decode_edits_quad_kernel(DecodeArgs a, uint32_t n_waves)
 {
+    __builtin_amdgcn_s_setprio(3);      // (a helper between align launches: it goes first, see compact_runs_kernel)
     __shared__ __attribute__((aligned(4 * QD_RING_BYTES))) uint32_t ring_all[STORE ? 4 * (QD_WAVE_LDS / 4u) : 32];      // (a slot's address is slot offset | ring base: the four rings first)
     typedef __attribute__((address_space(3))) uint32_t lds_u32;
     typedef __attribute__((address_space(3))) uint16_t lds_u16;

@@ -20,6 +20,7 @@ __global__ __launch_bounds__(256) void encode_edits_kernel(uint64_t n_pairs, uin
                                                            uint64_t stream_cap, uint64_t* __restrict__ off,
                                                            uint32_t* __restrict__ len, uint64_t* __restrict__ total)
 {
+    __builtin_amdgcn_s_setprio(3);      // (a helper between align launches: it goes first, see compact_runs_kernel)
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = p < n_pairs;

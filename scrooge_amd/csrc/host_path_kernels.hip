@@ -18,6 +18,7 @@ namespace scrg {
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void build_desc_kernel(HostDescArgs a)
 {
+    __builtin_amdgcn_s_setprio(3);      // (a helper between align launches: it goes first, see compact_runs_kernel)
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
     scrg_pair_desc d;
@@ -54,6 +55,7 @@ __global__ __launch_bounds__(256) void text_len_kernel(uint64_t n, const scrg_pa
                                                        uint64_t* __restrict__ cnt64, uint64_t* __restrict__ len64, int want_text,
                                                        uint32_t split)
 {
+    __builtin_amdgcn_s_setprio(3);      // (a helper between align launches: it goes first, see compact_runs_kernel)
     // pairs are taken 64 at a time; `split` wavefronts share a group of 64 (each takes every split-th pair of it), so
     // that a batch of few, long alignments still fills the GPU
     const uint32_t lane = threadIdx.x & 63u;
@@ -108,6 +110,7 @@ __global__ __launch_bounds__(256) void wire_totals_kernel(uint64_t n, const int6
                                                           const uint64_t* __restrict__ len64, const uint64_t* __restrict__ text_off,
                                                           uint64_t* __restrict__ totals, uint32_t* __restrict__ wire, int want_text)
 {
+    __builtin_amdgcn_s_setprio(3);      // (a helper between align launches: it goes first, see compact_runs_kernel)
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) {
         totals[0] = n ? run_off[n - 1] + cnt64[n - 1] : 0;
@@ -142,6 +145,7 @@ __global__ __launch_bounds__(256) void render_text_kernel(uint64_t n, const uint
                                                           const uint64_t* __restrict__ run_off, const uint64_t* __restrict__ cnt64,
                                                           const uint64_t* __restrict__ text_off, uint8_t* __restrict__ text, uint32_t split)
 {
+    __builtin_amdgcn_s_setprio(3);      // (a helper between align launches: it goes first, see compact_runs_kernel)
     __shared__ __attribute__((aligned(16))) uint8_t tile_all[4][TEXT_TILE_BYTES];
     const uint32_t lane = threadIdx.x & 63u;
     uint8_t* const tile = tile_all[threadIdx.x >> 6];

@@ -36,6 +36,7 @@ __device__ __forceinline__ void pack4(uint32_t v, uint32_t& lo, uint32_t& hi, ui
 __global__ __launch_bounds__(256) void pack_planar_kernel(const uint4* __restrict__ ascii, uint64_t n_words,
                                                           uint64_t* __restrict__ planar, uint32_t* __restrict__ bad_count)
 {
+    __builtin_amdgcn_s_setprio(3);      // (a helper between align launches: it goes first, see compact_runs_kernel)
     uint32_t bad = 0;
     for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words;
          w += (uint64_t)gridDim.x * blockDim.x) {
@@ -63,6 +64,7 @@ __global__ __launch_bounds__(256) void pack_planar_groups_kernel(const uint4* __
                                                                  uint64_t words_per_row, uint64_t* __restrict__ planar,
                                                                  uint32_t* __restrict__ bad_count)
 {
+    __builtin_amdgcn_s_setprio(3);      // (a helper between align launches: it goes first, see compact_runs_kernel)
     uint32_t bad = 0;
     const uint64_t pairs_per_row = (words_per_row + 1) / 2;
     const uint64_t n_out = ((n_rows + 63) / 64) * 64 * pairs_per_row;
@@ -145,6 +147,11 @@ __global__ __launch_bounds__(256) void compact_runs_kernel(uint64_t n_pairs, con
     // (v_alignbit by 16).  The bulk moves 16 bytes per lane with 16-byte aligned stores.
     // Pairs are taken 64 at a time; `split` wavefronts share a group of 64 (each takes every split-th long alignment), so
     // that a batch of few, long alignments still fills the GPU.
+    // This kernel sits between two align launches of its stream and shares the SIMDs with the align wavefronts of the other
+    // streams (which rotate their priorities 0..3): it goes first.  Its instructions are ~1 % of a step's; at priority 0 it
+    // took 1.2 ms of the stream's chain while overlapped, and the headline 57.2 -> 59-60 M pairs/s with it in front
+    // (scripts/r06_chain_probe.sh, profiles/r06_chain_probe.txt).
+    __builtin_amdgcn_s_setprio(3);
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t wave_all = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t wave = wave_all / split, n_waves = (((uint64_t)gridDim.x * blockDim.x) >> 6) / split;
@@ -239,6 +246,7 @@ __global__ __launch_bounds__(256) void compact_runs_packed_kernel(uint64_t n_pai
                                                                   const uint64_t* __restrict__ dense_off,
                                                                   uint8_t* __restrict__ dense)
 {
+    __builtin_amdgcn_s_setprio(3);      // (a helper between align launches: it goes first, see compact_runs_kernel)
     // one wavefront per pair; a lane converts four runs (8 bytes in, 4 bytes out) per iteration once the
     // destination is dword aligned
     const uint32_t lane = threadIdx.x & 63;
@@ -267,6 +275,7 @@ __global__ __launch_bounds__(256) void compact_runs_packed_kernel(uint64_t n_pai
 
 __global__ __launch_bounds__(256) void unpack_runs_kernel(uint64_t n, const uint8_t* __restrict__ packed, uint16_t* __restrict__ runs)
 {
+    __builtin_amdgcn_s_setprio(3);      // (a helper between align launches: it goes first, see compact_runs_kernel)
     // n runs; a thread restores four at a time where both sides are aligned (callers pass 4-byte aligned buffers)
     const uint64_t quads = n >> 2;
     const uint32_t* const p32 = reinterpret_cast<const uint32_t*>(packed);
