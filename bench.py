@@ -584,7 +584,7 @@ def main():
                 aligners[b].encode_edit_stream(n, descs_[b], o["runs"], o["n_runs"], g["stream"], g["off"], g["len"], g["total"], W=p.W, O=p.O)
                 gather_.start(j, o["ed"])
                 return
-            probe = os.environ.get("SCRG_BENCH_PROBE")                  # measuring aids (scripts/r06_chain_probe.sh): results unchecked
+            probe = os.environ.get("SCRG_BENCH_PROBE") if args.headline_only else None      # measuring aids (scripts/r06_chain_probe.sh; --headline-only: nothing is checked there); the line's metric says INVALID
             if probe == "no-chain":                                    # the step without its scan and compaction
                 return
             if probe == "no-scan" and b in step.cached_off:            # the offsets of the same batch from an earlier step
@@ -1395,8 +1395,11 @@ def main():
         roofline = {"bound": "valu-issue", "achieved": None, "peak": VALU_PEAK_LANE_OPS / 1e12, "unit": "T int32 lane-ops/s", "frac": None,
                     "traffic": traffic, "kernel": kernel_name, "window_rounds_per_launch": rounds_live,
                     "note": "no instruction count for this build: " + str(instr_src), "hbm": hbm}
+    probe_env = os.environ.get("SCRG_BENCH_PROBE")
     out = {
-        "metric": "aligned pairs/s (+ GCUPS) at W=64, 10kb reads; 1/2/4/8 MI355X",
+        # (a line made with a measuring aid that leaves work out of the step says so in its metric: it is not a measurement of the path)
+        "metric": "aligned pairs/s (+ GCUPS) at W=64, 10kb reads; 1/2/4/8 MI355X" if not probe_env
+                  else "INVALID AS A RESULT: ablation SCRG_BENCH_PROBE=%s (scripts/r06_chain_probe.sh)" % probe_env,
         "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
