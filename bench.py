@@ -1395,7 +1395,7 @@ def main():
         roofline = {"bound": "valu-issue", "achieved": None, "peak": VALU_PEAK_LANE_OPS / 1e12, "unit": "T int32 lane-ops/s", "frac": None,
                     "traffic": traffic, "kernel": kernel_name, "window_rounds_per_launch": rounds_live,
                     "note": "no instruction count for this build: " + str(instr_src), "hbm": hbm}
-    probe_env = os.environ.get("SCRG_BENCH_PROBE")
+    probe_env = os.environ.get("SCRG_BENCH_PROBE") if args.headline_only else None
     out = {
         # (a line made with a measuring aid that leaves work out of the step says so in its metric: it is not a measurement of the path)
         "metric": "aligned pairs/s (+ GCUPS) at W=64, 10kb reads; 1/2/4/8 MI355X" if not probe_env
